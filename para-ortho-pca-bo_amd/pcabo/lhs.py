@@ -1,0 +1,24 @@
+"""Latin-hypercube design, `criterion="center"`, as the reference draws it.
+
+The reference calls pyDOE 0.3.8 `lhs(n=dim, samples=m, criterion="center", iterations=...)`
+(reference: Algorithms/BayesianOptimization/AbstractBayesianOptimizer.py:40-45), which is not
+installed here.  pyDOE's centred variant consumes the *legacy global* numpy RNG as
+`rand(m, dim)` (drawn, unused) followed by one `permutation` of the bin centres per column.
+Pinned by the first n_DoE rows of all 120 runs in the reference's committed .dat files
+(tests/golden/doe_f15_f20_dim5.npz).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+__all__ = ["lhs_center"]
+
+
+def lhs_center(dim: int, samples: int) -> np.ndarray:
+    cut = np.linspace(0, 1, samples + 1)
+    np.random.rand(samples, dim)              # pyDOE draws this and then ignores it for "center"
+    centres = (cut[:samples] + cut[1:samples + 1]) / 2
+    h = np.empty((samples, dim))
+    for j in range(dim):
+        h[:, j] = np.random.permutation(centres)
+    return h

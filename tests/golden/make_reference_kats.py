@@ -1,0 +1,64 @@
+"""Extract the known answers the reference ships into small committed fixtures.
+
+Run in the build container (the only place /root/reference exists):
+    python tests/golden/make_reference_kats.py
+Outputs tests/golden/ref_kats_dim5.json holding DATA only (inputs + expected outputs):
+  * "doe":  for each of the 120 committed runs (pca/vanilla x f15/f20 x 30 instances, d=5,
+            n_DoE=10) the seed and the 10 DoE rows (x printed to 1e-6 by the IOH logger)
+            -> pins seed formula (ExperimentRunner.py:146) + LHS "center" draw.
+  * "f15_doe": raw_y of the f15 DoE rows (x exact: bin centres) -> pins BBOB f15 to ~1e-12.
+  * "f15_best": full-precision best x / y per run from the two f15 .json files
+            -> pins BBOB f15 on off-grid points to ~1e-13.
+  * "f15_bo_rows": a sample of BO-phase rows (x printed to 1e-6) -> pins f15 to ~1e-5.
+Source files: /root/reference/{pca,vanilla}-experiment/data_f*/IOHprofiler_f*_DIM5.dat and
+/root/reference/{pca,vanilla}-experiment/IOHprofiler_f15_RastriginRotated.json
+"""
+import json
+import os
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_kats_dim5.json")
+
+
+def read_runs(path):
+    runs, cur = [], None
+    for line in open(path):
+        t = line.split()
+        if not t:
+            continue
+        if t[0] == "evaluations":
+            cur = []
+            runs.append(cur)
+        else:
+            cur.append([float(v) for v in t])
+    return runs
+
+
+def main():
+    out = {"doe": [], "f15_doe": [], "f15_best": [], "f15_bo_rows": []}
+    for alg in ("pca", "vanilla"):
+        for fid, name in ((15, "RastriginRotated"), (20, "Schwefel")):
+            meta = json.load(open(f"{REF}/{alg}-experiment/IOHprofiler_f{fid}_{name}.json"))
+            insts = [r["instance"] for r in meta["scenarios"][0]["runs"]]
+            runs = read_runs(f"{REF}/{alg}-experiment/data_f{fid}_{name}/IOHprofiler_f{fid}_DIM5.dat")
+            # the .dat holds one block per run in instance order 0..29 (the .json may list fewer)
+            for inst, run in enumerate(runs):
+                first = run[0][0]
+                doe = [r for r in run[:10]]
+                out["doe"].append({"alg": alg, "fid": fid, "dim": 5, "instance": inst,
+                                   "seed": 1000 * fid + 10 * 5 + inst, "first_eval_index": first,
+                                   "x": [r[3:] for r in doe]})
+                if fid == 15:
+                    out["f15_doe"].append({"alg": alg, "instance": inst, "raw_y": [r[1] for r in doe]})
+                    for r in run[10::13]:
+                        out["f15_bo_rows"].append({"instance": inst, "x": r[3:], "raw_y": r[1]})
+            if fid == 15:
+                for r in meta["scenarios"][0]["runs"]:
+                    out["f15_best"].append({"alg": alg, "instance": r["instance"],
+                                            "x": r["best"]["x"], "y": r["best"]["y"]})
+    json.dump(out, open(OUT, "w"))
+    print(OUT, os.path.getsize(OUT), "bytes;", {k: len(v) for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,146 @@
+/*
+ * pcabo.h - C ABI of libpcabo.so: the MI355X (gfx950) implementation of the PCA_BO inner loop.
+ *
+ * The reference (IvanBanny/para-ortho-pca-bo) is pure Python and has no FFI; the four places
+ * where its hot loop hands arithmetic to third-party CPU libraries are the boundary this
+ * library replaces.  Each entry point below names the reference call
+ * site (file:line under /root/reference) whose work it performs.
+ *
+ * Conventions
+ *   - fp64 everywhere, row-major, caller owns every buffer passed in.
+ *   - Pointers are HOST pointers unless the context is switched with pcabo_set_pointer_mode()
+ *     to PCABO_PTR_DEVICE, in which case the bulk inputs/outputs (marked [bulk]) are device
+ *     pointers on the context's device (e.g. torch tensor .data_ptr()); small scalar/vector
+ *     results (marked [host]) are always written to host memory.
+ *   - Every call returns 0 on success or a negative pcabo_status; nothing throws across the ABI.
+ *     pcabo_last_error() returns a human-readable message for the last failure on a context.
+ *   - A context owns one HIP stream plus all workspaces, sized at creation for (max_n, max_d,
+ *     max_q).  A context is single-threaded; distinct contexts are independent (one per
+ *     concurrent BO run; ctypes releases the GIL around calls).
+ *   - There is NO CPU fallback: without a usable HIP device pcabo_ctx_create() fails with
+ *     PCABO_ERR_HIP.
+ */
+#ifndef PCABO_H
+#define PCABO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pcabo_ctx pcabo_ctx;
+
+typedef enum {
+  PCABO_OK = 0,
+  PCABO_ERR_ARG = -1,      /* bad argument / size exceeds context capacity / call order */
+  PCABO_ERR_NOT_PD = -2,   /* K + s2 I not positive definite after the jitter retries */
+  PCABO_ERR_HIP = -3,      /* HIP runtime error (message in pcabo_last_error) */
+  PCABO_ERR_NAN = -4,      /* NaN met in an acquisition gradient (botorch raises here) */
+  PCABO_ERR_TIMEOUT = -5   /* device did not answer within the watchdog interval */
+} pcabo_status;
+
+enum { PCABO_KERNEL_MATERN52 = 0, PCABO_KERNEL_RBF = 1 };
+enum { PCABO_ACQ_LOG_EI = 0, PCABO_ACQ_PI = 1 };
+enum { PCABO_PTR_HOST = 0, PCABO_PTR_DEVICE = 1 };
+
+/* ABI version of this header (checked by the Python loader). */
+int pcabo_abi_version(void);
+
+/* Number of HIP devices visible (0 when none; never fails). */
+int pcabo_device_count(void);
+
+/* Create / destroy a per-run context on `device`.
+ * max_n: largest number of evaluated points (budget); max_d: ambient dimension;
+ * max_q: largest number of query points per pcabo_acq_eval call (>= raw_samples). */
+int pcabo_ctx_create(int device, int max_n, int max_d, int max_q, pcabo_ctx** out);
+int pcabo_ctx_destroy(pcabo_ctx* ctx);
+int pcabo_set_pointer_mode(pcabo_ctx* ctx, int mode);
+int pcabo_last_error(pcabo_ctx* ctx, char* buf, int buflen);
+
+/* Rows A-C (+D,J): rank-weighted PCA of the evaluated points.
+ * Replaces PCA_BO._calculate_weights + _transform_points_to_reduced_space
+ * (Algorithms/BayesianOptimization/PCA_BO.py:316-408), i.e. numpy + sklearn PCA().fit/transform.
+ *   X[n*d]      [bulk] evaluated points
+ *   f[n]        [bulk] objective values; used only when ranks == NULL (device ranking, ties
+ *               broken by index)
+ *   ranks[n]    [bulk] 1-based ranks (best = 1) as numpy's argsort(argsort(.))+1 gives them, or NULL
+ *   noise[n*d]  [bulk] the N(0,1e-8) draw of PCA_BO.py:376 (numpy global RNG), or NULL for none
+ *   n_components > 0 fixes k; otherwise k = #(cumsum(evr) <= var_threshold) + 1 clamped to [1, min(n,d)]
+ * Outputs (any may be NULL):
+ *   data_mean[d], pca_mean[d] [host]; comps[r*d] [host] all r=min(n,d) components (sklearn
+ *   components_, rows sorted by decreasing variance, sign: max-|.| entry of each row positive);
+ *   evr[r] [host]; *k [host]; Z[n*k] [bulk] reduced coordinates (PCA_BO.py:407).
+ * The context keeps X-mean, the k leading components and Z on the device for the calls below. */
+int pcabo_wpca(pcabo_ctx* ctx, const double* X, const double* f, const int64_t* ranks, int n, int d,
+               int maximize, double var_threshold, int n_components, const double* noise,
+               double* data_mean, double* pca_mean, double* comps, double* evr, int* k, double* Z);
+
+/* Rows D-H: condition the exact GP on (Z, y).
+ * Replaces PCA_BO._initialize_model (PCA_BO.py:502-545: SingleTaskGP(MaternKernel(2.5),
+ * Standardize, Normalize)) and the lazy Gram/Cholesky/alpha/root-inverse that gpytorch performs
+ * on the first posterior call inside optimize_acqf (PCA_BO.py:607).
+ *   Z[n*k]           [bulk] reduced points, or NULL to use the Z of the last pcabo_wpca call
+ *   y[n]             [bulk] objective values (un-standardised)
+ *   norm_bounds[2*k] [host] Normalize bounds (lo row, hi row) or NULL for PCA_BO.py:514-518
+ *   lengthscale, noise: model constants (reference values: ln 2 and exp(-5)); kernel: PCABO_KERNEL_*
+ * On Cholesky breakdown jitter 1e-8, 1e-7, 1e-6 is added (psd_safe_cholesky) before PCABO_ERR_NOT_PD. */
+int pcabo_gp_condition(pcabo_ctx* ctx, const double* Z, const double* y, int n, int k,
+                       const double* norm_bounds, double lengthscale, double noise, int kernel);
+
+/* Row J: search box of the acquisition optimiser, PCA_BO.py:558-573. bounds[2*k] [host] (lo row, hi row). */
+int pcabo_acq_bounds(pcabo_ctx* ctx, double* bounds);
+
+/* Row I: batched acquisition value (+ gradient) at q query points of the reduced space.
+ * Replaces LogExpectedImprovement / ProbabilityOfImprovement .forward + torch autograd as driven
+ * by botorch (PCA_BO.py:199-203, 607-614).
+ *   Xq[q*k] [bulk]; best_f as the reference passes it (current_best; it is rounded to float32
+ *   like torch.as_tensor(python float) does); val[q] [bulk]; grad[q*k] [bulk] or NULL. */
+int pcabo_acq_eval(pcabo_ctx* ctx, const double* Xq, int q, double best_f, int maximize, int acq,
+                   double* val, double* grad);
+/* Name suggested by SURVEY.md 8b; identical to pcabo_acq_eval(..., PCABO_ACQ_LOG_EI, ...). */
+int pcabo_logei(pcabo_ctx* ctx, const double* Xq, int q, double best_f, int maximize,
+                double* val, double* grad);
+
+/* Rows M-N: multi-start L-BFGS-B over the acquisition (botorch gen_candidates_scipy semantics:
+ * restarts are optimised jointly in groups of `batch_limit`, objective -sum_j acq(x_j), scipy
+ * L-BFGS-B defaults m=10, factr=1e7 (ftol 2.22e-9), pgtol=1e-5, maxls=20, maxfun=15000).
+ * Replaces botorch.optim.optimize_acqf's optimisation stage (PCA_BO.py:607-614).
+ *   ics[num_restarts*k] [host] initial conditions; bounds[2*k] [host];
+ *   cand[num_restarts*k] [host] clamped final points; vals[num_restarts] [host] acquisition there;
+ *   info[4*ngroups] [host] or NULL: per group {iterations, function evaluations, warnflag, task};
+ *   returns PCABO_OK; *failed (may be NULL) is set to 1 when a group ended abnormally (the case in
+ *   which botorch re-draws initial conditions and retries once). */
+int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int batch_limit,
+                        const double* bounds, int maxiter, double best_f, int maximize, int acq,
+                        double* cand, double* vals, int* info, int* failed);
+
+/* Row O: x = z Ck + pca_mean + data_mean (PCA_BO.py:410-434). z[k] [host] -> x[d] [host]. */
+int pcabo_inverse_map(pcabo_ctx* ctx, const double* z, double* x);
+
+/* Introspection used by the parity tests (all [host] outputs, row-major n x n / vectors). */
+int pcabo_get_gp_state(pcabo_ctx* ctx, double* K_chol /*n*n lower*/, double* Rinv /*n*n lower*/,
+                       double* alpha /*n*/, double* y_mean_std /*2*/, double* norm_bounds /*2*k*/);
+int pcabo_get_gram(pcabo_ctx* ctx, double* K /*n*n, symmetric, incl. noise*/);
+
+/* Host-only L-BFGS-B (no device work): minimise a callback objective with box bounds, same
+ * algorithm and defaults as scipy.optimize.minimize(method="L-BFGS-B").  Used by the CPU tests
+ * to pin this library's optimiser against scipy itself.
+ *   fg(x, g, user) returns f and fills g.  Returns warnflag (0 converged, 1 limit, 2 abnormal). */
+typedef double (*pcabo_fg_callback)(const double* x, double* g, void* user);
+int pcabo_lbfgsb_minimize(int nvar, double* x, const double* lower, const double* upper,
+                          pcabo_fg_callback fg, void* user, int m, double factr, double pgtol,
+                          int maxiter, int maxfun, int maxls, double* f_out, int* nit, int* nfev,
+                          int* task_out);
+
+/* Device-time accounting: accumulated HIP-event time (ms) and launch count of the kernel groups
+ * since the last reset.  which: 0 wpca, 1 gram, 2 cholesky, 3 root-inverse+alpha, 4 acq partial,
+ * 5 acq combine.  Enabled by pcabo_set_profiling(ctx, 1) (adds an event pair per launch). */
+int pcabo_set_profiling(pcabo_ctx* ctx, int enabled);
+int pcabo_get_profile(pcabo_ctx* ctx, int which, double* ms, int64_t* launches);
+int pcabo_reset_profile(pcabo_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCABO_H */

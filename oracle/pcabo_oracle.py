@@ -168,7 +168,9 @@ def weighted_pca(X: np.ndarray, f_evals, maximization: bool, var_threshold: floa
     comps, evr, pmean = pca_fit(wx, use_sklearn)                # :380-387
     k = select_components(evr, var_threshold, n_components)
     ck = comps[:k]                                              # :399
-    Z = (xc - pmean) @ ck.T                                     # :407 (sklearn _base.py transform)
+    # :407 -> sklearn _base.py `_transform(X, x_is_centered=False)`: X @ C^T - mean @ C^T
+    Z = xc @ ck.T
+    Z -= pmean.reshape(1, -1) @ ck.T
     return WPCAResult(data_mean, pmean, comps, evr, k, Z, weights)
 
 

@@ -1,0 +1,316 @@
+"""PCA-assisted Bayesian optimisation on MI355X.
+
+Same call surface as the reference's `PCA_BO`
+(/root/reference/Algorithms/BayesianOptimization/PCA_BO.py:48-720): constructor keywords,
+`__call__(problem, dim, bounds)`, result attributes, `TIME_PROFILES`, acquisition-name handling and
+error behaviour.  The four places where the reference hands arithmetic to sklearn / botorch /
+gpytorch / scipy are calls into libpcabo.so (HIP kernels for gfx950) here:
+
+    reference                                              this file -> C ABI (include/pcabo.h)
+    _calculate_weights + PCA().fit/transform (:316-408)    Context.wpca            pcabo_wpca
+    SingleTaskGP(...) + lazy Gram/Cholesky (:502-545)      Context.gp_condition    pcabo_gp_condition
+    optimize_acqf raw-sample scoring (:607)                Context.acq_eval        pcabo_acq_eval
+    optimize_acqf multi-start L-BFGS-B (:607-614)          Context.optimize_acqf   pcabo_optimize_acqf
+    pca.inverse_transform (:427)                           Context.inverse_map     pcabo_inverse_map
+
+What stays on the host is exactly what the reference does in Python: ranking with numpy's argsort
+(:330-333), the noise draw from numpy's global RNG (:376), Sobol / multinomial draws from torch's
+global CPU generator (botorch initialisers), the out-of-bounds rule (:248-263) and bookkeeping.
+There is no CPU fallback: importing this module needs libpcabo.so, running it needs a HIP device.
+"""
+from __future__ import annotations
+
+import os
+import warnings
+from time import perf_counter
+from typing import Callable, Optional, Union
+
+import numpy as np
+
+from pcabo import _native
+from pcabo import initializers as _init
+from .AbstractBayesianOptimizer import AbstractBayesianOptimizer
+
+ALLOWED_ACQUISITION_FUNCTION_STRINGS = (
+    "expected_improvement",
+    "probability_of_improvement",
+    "upper_confidence_bound",
+)
+ALLOWED_SHORTHAND_ACQUISITION_FUNCTION_STRINGS = {
+    "EI": "expected_improvement",
+    "PI": "probability_of_improvement",
+    "UCB": "upper_confidence_bound",
+}
+
+# Model constants of the never-trained SingleTaskGP(MaternKernel(2.5)).
+LENGTHSCALE = 0.6931471805599453     # softplus(0)
+NOISE = 0.006737946999085467         # exp(-5), mode of the LogNormal(-4, 1) noise prior
+OOB_PENALTY = 1000
+
+
+class AnalyticAcquisitionFunction:
+    """Descriptor of the acquisition the device kernels evaluate (stands in for botorch's class)."""
+    acq_code = _native.ACQ_LOG_EI
+
+    def __init__(self, model=None, best_f: float = 0.0, maximize: bool = True):
+        self.model, self.best_f, self.maximize = model, best_f, maximize
+
+
+class LogExpectedImprovement(AnalyticAcquisitionFunction):
+    acq_code = _native.ACQ_LOG_EI
+
+
+class ProbabilityOfImprovement(AnalyticAcquisitionFunction):
+    acq_code = _native.ACQ_PI
+
+
+class UpperConfidenceBound(AnalyticAcquisitionFunction):
+    """The reference constructs its acquisition with `best_f=` (PCA_BO.py:199-203), which botorch's
+    UpperConfidenceBound(model, beta, ...) does not accept: the first BO iteration raises TypeError.
+    That behaviour is kept."""
+
+    def __init__(self, model=None, beta=None, maximize: bool = True, **kwargs):
+        if kwargs or beta is None:
+            raise TypeError("UpperConfidenceBound.__init__() got an unexpected keyword argument 'best_f'")
+        super().__init__(model, 0.0, maximize)
+
+
+class _FittedPCA:
+    """Read-only view of the device wPCA result with sklearn's attribute names (reference: `self.pca`)."""
+
+    def __init__(self, components, mean, evr, k):
+        self.components_ = components[:k]
+        self.mean_ = mean
+        self.explained_variance_ratio_ = evr
+        self.n_components_ = components.shape[0]
+
+    def transform(self, X):
+        X = np.asarray(X, dtype=float)
+        return X @ self.components_.T - self.mean_.reshape(1, -1) @ self.components_.T
+
+    def inverse_transform(self, Z):
+        return np.asarray(Z, dtype=float) @ self.components_ + self.mean_
+
+
+class PCA_BO(AbstractBayesianOptimizer):
+    TIME_PROFILES = ["SingleTaskGP", "optimize_acqf", "pca"]
+
+    def __init__(self, budget: int, n_DoE: int = 0, n_components: int = 0, var_threshold: float = 0.95,
+                 acquisition_function: str = "expected_improvement", random_seed: int = 43,
+                 visualize: bool = False, **kwargs):
+        self.__device = int(kwargs.pop("device", 0))
+        super().__init__(budget, n_DoE, **kwargs)
+        self.random_seed = random_seed
+        smoke_test = os.environ.get("SMOKE_TEST")
+        self.__torch_config = {
+            "device": f"hip:{self.__device}",
+            "dtype": np.float64,
+            "SMOKE_TEST": smoke_test,
+            "BATCH_SIZE": 3 if not smoke_test else 2,
+            "NUM_RESTARTS": 10 if not smoke_test else 2,
+            "RAW_SAMPLES": 512 if not smoke_test else 32,
+        }
+        self.__acq_func_class = None
+        self.__acq_func = None
+        self.acquisition_function_name = acquisition_function
+        self.n_components = n_components
+        self.var_threshold = var_threshold
+        self.data_mean = None
+        self.pca = None
+        self.component_matrix = None
+        self.explained_variance_ratio = None
+        self.reduced_space_dim_num = None
+        self.visualize = visualize
+        if visualize:
+            warnings.warn("visualize=True: the GIF visualiser of the reference is not part of the MI355X path; ignored.")
+        self.__z_evals = []
+        self.__ctx: Optional[_native.Context] = None
+        self.lbfgsb_info = []          # per iteration: (iterations, evaluations, warnflag, task) per restart group
+
+    def __str__(self):
+        return "This is an instance of a PCA-assisted BO Optimizer"
+
+    # ---------------------------------------------------------------------------------------------
+    def __call__(self, problem: Union[Callable, object], dim: Optional[int] = -1,
+                 bounds: Optional[np.ndarray] = None, **kwargs) -> None:
+        self.impose_random_seed()
+        super().__call__(problem, dim, bounds, **kwargs)
+        if self._pbar is not None:
+            self._pbar.update(self.n_DoE)
+        self.__ctx = _native.Context(max_n=self.budget, max_d=self.dimension,
+                                     max_q=max(self.__torch_config["RAW_SAMPLES"], 16), device=self.__device)
+        try:
+            for _ in range(self.budget - self.n_DoE):
+                if self.number_of_function_evaluations >= self.budget:
+                    break
+                self._transform_points_to_reduced_space()
+                self._initialize_model(**kwargs)
+                self.acquisition_function = self.acquisition_function_class(
+                    model=self.__ctx, best_f=self.current_best, maximize=self.maximization)
+                new_z = self.optimize_acqf_and_get_observation()
+                for new_z_arr in new_z:
+                    if self.number_of_function_evaluations >= self.budget:
+                        break
+                    new_x = self._transform_point_to_original_space(np.asarray(new_z_arr).ravel())
+                    outside = not np.all(new_x >= self.bounds[:, 0]) or not np.all(new_x <= self.bounds[:, 1])
+                    if outside and self.verbose:
+                        print(f"Warning: PCA transformed point {new_x} was out of bounds, clipping to boundary")
+                    self.x_evals.append(new_x)
+                    self.__z_evals.append(np.asarray(new_z_arr).ravel())
+                    # out-of-box candidates are not evaluated; they cost budget and a fixed penalty
+                    new_f = (-OOB_PENALTY if self.maximization else OOB_PENALTY) if outside else problem(new_x)
+                    if self._pbar is not None:
+                        self._pbar.update(1)
+                    self.f_evals.append(new_f)
+                    self.number_of_function_evaluations += 1
+                    if self.verbose and ((self.maximization and new_f > self.current_best) or
+                                         (not self.maximization and new_f < self.current_best)):
+                        print(f"Found better solution: {new_f}")
+                        print(f"At point: {new_x}")
+                self.assign_new_best()
+                if self.verbose:
+                    print(f"Evaluations: {self.number_of_function_evaluations}/{self.budget}",
+                          f"Best: x:{self.x_evals[self.current_best_index]} y:{self.current_best}", flush=True)
+        finally:
+            self.__ctx.close()
+            self.__ctx = None
+        if self.verbose:
+            print("Optimization Process finalized!")
+        self.restore_random_states()
+
+    def assign_new_best(self):
+        super().assign_new_best()
+
+    # ---- row A (host part): ranks exactly as numpy gives them ------------------------------------
+    def _calculate_ranks(self) -> np.ndarray:
+        f = np.array(self.f_evals)
+        return np.argsort(np.argsort(-f if self.maximization else f)) + 1
+
+    def _calculate_weights(self) -> np.ndarray:
+        pre = np.log(len(self.f_evals)) - np.log(self._calculate_ranks())
+        return pre / pre.sum()
+
+    # ---- rows A-C ---------------------------------------------------------------------------------
+    def _transform_points_to_reduced_space(self) -> None:
+        if len(self.x_evals) < 2:
+            if len(self.x_evals) == 1:
+                self.__z_evals = [np.zeros(1)]
+            return
+        X = np.vstack(self.x_evals)
+        ranks = self._calculate_ranks()
+        noise = np.random.normal(0, 1e-8, size=X.shape)        # same draw, same global RNG as the reference
+        start = perf_counter()
+        res = self.__ctx.wpca(X, ranks=ranks, maximize=self.maximization, var_threshold=self.var_threshold,
+                              n_components=self.n_components, noise=noise, want_Z=False, want_full=True)
+        self.timing_logs["pca"].append(perf_counter() - start)
+        self.data_mean = res["data_mean"]
+        self.component_matrix = res["components"]
+        self.explained_variance_ratio = res["evr"]
+        self.reduced_space_dim_num = res["k"]
+        self.pca = _FittedPCA(res["components"], res["pca_mean"], res["evr"], res["k"])
+        if self.verbose:
+            k = res["k"]
+            print(f"Using {k} principal components with {np.sum(res['evr'][:k]) * 100:.2f}% explained variance")
+        # the reduced coordinates stay on the device (the reference keeps them in `__z_evals` only to
+        # rebuild bounds and the GP input, both of which happen on the device here)
+        self.__z_evals = [res["k"]] * X.shape[0]
+
+    # ---- rows D-H ---------------------------------------------------------------------------------
+    def _initialize_model(self, **kwargs):
+        if not self.__z_evals:
+            return
+        start = perf_counter()
+        self.__ctx.gp_condition(np.array(self.f_evals, dtype=np.float64), lengthscale=LENGTHSCALE, noise=NOISE,
+                                kernel=_native.KERNEL_MATERN52)
+        self.timing_logs["SingleTaskGP"].append(perf_counter() - start)
+
+    # ---- rows J-N ---------------------------------------------------------------------------------
+    def optimize_acqf_and_get_observation(self) -> np.ndarray:
+        ctx, cfg = self.__ctx, self.__torch_config
+        acq = self.acquisition_function
+        bounds = ctx.acq_bounds()
+        num_restarts, raw_samples, batch_limit = cfg["NUM_RESTARTS"], cfg["RAW_SAMPLES"], 5
+        start = perf_counter()
+
+        def initial_conditions():
+            raw = _init.draw_sobol(bounds, raw_samples)
+            vals = ctx.acq_eval(raw, acq.best_f, acq.maximize, acq.acq_code, grad=False)
+            if acq.acq_code == _native.ACQ_PI:
+                idx = _init.initialize_q_batch_nonneg(vals, num_restarts)
+            else:
+                idx = _init.initialize_q_batch(vals, num_restarts)
+            return raw[idx]
+
+        ics = initial_conditions()
+        cand, vals, info, failed = ctx.optimize_acqf(ics, bounds, acq.best_f, acq.maximize, acq.acq_code,
+                                                     batch_limit=batch_limit, maxiter=200)
+        if failed:   # botorch: OptimizationWarning -> one retry with freshly drawn initial conditions
+            warnings.warn("Optimization failed in `gen_candidates_scipy`; trying again with a new set of "
+                          "initial conditions.", RuntimeWarning)
+            ics = initial_conditions()
+            cand, vals, info, failed = ctx.optimize_acqf(ics, bounds, acq.best_f, acq.maximize, acq.acq_code,
+                                                         batch_limit=batch_limit, maxiter=200)
+        self.timing_logs["optimize_acqf"].append(perf_counter() - start)
+        self.lbfgsb_info.append(info)
+        best = int(np.argmax(vals))
+        return cand[best].reshape(1, -1)
+
+    # ---- row O ------------------------------------------------------------------------------------
+    def _transform_point_to_original_space(self, z: np.ndarray) -> np.ndarray:
+        if self.pca is None:
+            return np.random.uniform(self.bounds[:, 0], self.bounds[:, 1])
+        return self.__ctx.inverse_map(z)
+
+    def __repr__(self):
+        return super().__repr__()
+
+    def reset(self):
+        super().reset()
+        self.__z_evals = []
+        self.pca = None
+        self.explained_variance_ratio = None
+
+    # ---- acquisition-name plumbing (reference :643-720) -------------------------------------------
+    @property
+    def torch_config(self) -> dict:
+        return self.__torch_config
+
+    @property
+    def acquisition_function_name(self) -> str:
+        return self.__acquisition_function_name
+
+    @acquisition_function_name.setter
+    def acquisition_function_name(self, new_name: str) -> None:
+        new_name = new_name.strip()
+        if new_name in ALLOWED_SHORTHAND_ACQUISITION_FUNCTION_STRINGS:
+            self.__acquisition_function_name = ALLOWED_SHORTHAND_ACQUISITION_FUNCTION_STRINGS[new_name]
+        elif new_name.lower() in ALLOWED_ACQUISITION_FUNCTION_STRINGS:
+            self.__acquisition_function_name = new_name
+        else:
+            raise ValueError("Oddly defined name")
+        self.set_acquisition_function_subclass()
+
+    def set_acquisition_function_subclass(self) -> None:
+        name = self.__acquisition_function_name
+        if name == ALLOWED_ACQUISITION_FUNCTION_STRINGS[0]:
+            self.__acq_func_class = LogExpectedImprovement
+        elif name == ALLOWED_ACQUISITION_FUNCTION_STRINGS[1]:
+            self.__acq_func_class = ProbabilityOfImprovement
+        elif name == ALLOWED_ACQUISITION_FUNCTION_STRINGS[2]:
+            self.__acq_func_class = UpperConfidenceBound
+
+    @property
+    def acquisition_function_class(self) -> Callable:
+        return self.__acq_func_class
+
+    @property
+    def acquisition_function(self) -> AnalyticAcquisitionFunction:
+        return self.__acq_func
+
+    @acquisition_function.setter
+    def acquisition_function(self, new_acquisition_function: AnalyticAcquisitionFunction) -> None:
+        if issubclass(type(new_acquisition_function), AnalyticAcquisitionFunction):
+            self.__acq_func = new_acquisition_function
+        else:
+            raise AttributeError("Acquisition function does not inherit from 'AnalyticAcquisitionFunction'",
+                                 name="acquisition_function", obj=self.__acq_func)

@@ -1,0 +1,291 @@
+// Exact-GP conditioning on gfx950.
+//
+// Replaces what gpytorch/linear_operator do lazily on the first posterior call inside
+// botorch.optimize_acqf (/root/reference/Algorithms/BayesianOptimization/PCA_BO.py:535-545, 607):
+//   K = k(Zn,Zn) + s2 I  ->  L = chol(K)  ->  R = L^-1 (root-inverse cache)  ->  alpha = K^-1 y_s.
+//
+// Storage: K/L and R are NP x NP row-major with leading dimension ld, NP = n rounded up to 64.
+// The padding block is the identity, so every kernel works on whole 64 x 64 tiles and the
+// padded rows/columns never influence the leading n x n part.
+#include "pcabo_internal.h"
+
+#define BS PCABO_BS
+#define TLD PCABO_TLD
+
+// ---------------------------------------------------------------------------------------------
+// Gram matrix.  One 64x64 tile per work-group (lower triangle of tiles only), wave w owns 16 rows.
+// The cross term a_i.a_j runs on v_mfma_f64_16x16x4_f64 (gpytorch computes the squared distance
+// as one GEMM of [-2a, |a|^2, 1] x [b, 1, |b|^2]^T; the norms are added in the epilogue here),
+// followed by the fused Matern-5/2 (or RBF) map and the noise on the diagonal.
+// Operands are read straight from AT (KP x ld, point index contiguous): each MFMA operand load is
+// four 128-byte rows, fully coalesced; the whole AT (<= 36 x 512 doubles) is L2 resident.
+__global__ __launch_bounds__(256) void k_gram(const double* __restrict__ AT, const double* __restrict__ nrm, int n,
+                                              int KP, int ld, double noise, int kernel, double* __restrict__ K) {
+  const int ti = blockIdx.x, tj = blockIdx.y;
+  if (tj > ti) return;
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int i0 = ti * BS + 16 * w, j0 = tj * BS;
+  double4_t acc[4];
+  for (int t = 0; t < 4; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  for (int kk = 0; kk < KP; kk += 4) {
+    const double* row = AT + (size_t)(kk + (l >> 4)) * ld;
+    double a = row[i0 + (l & 15)];
+    for (int t = 0; t < 4; ++t) {
+      double b = row[j0 + 16 * t + (l & 15)];
+      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+    }
+  }
+  const double s5 = 2.23606797749979;   // sqrt(5)
+  for (int t = 0; t < 4; ++t) {
+    const int j = j0 + 16 * t + (l & 15);
+    const double nj = nrm[j];
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + (l >> 4) + 4 * r;
+      double v;
+      if (i >= n || j >= n) {
+        v = (i == j) ? 1.0 : 0.0;
+      } else {
+        double sq = (i == j) ? 0.0 : (nrm[i] + nj) - 2.0 * acc[t][r];
+        sq = fmax(sq, 0.0);
+        if (kernel == 1) {
+          v = exp(-0.5 * sq);
+        } else {
+          double dist = sqrt(fmax(sq, 1e-30));
+          v = ((s5 * dist + 1.0) + (5.0 / 3.0) * (dist * dist)) * exp(-s5 * dist);
+        }
+        if (i == j) v += noise;
+      }
+      K[(size_t)i * ld + j] = v;
+    }
+  }
+}
+
+__global__ void k_add_jitter(double* __restrict__ K, int n, int ld, double jitter) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) K[(size_t)i * ld + i] += jitter;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Blocked right-looking Cholesky, panel width 64.
+// k_chol_panel, block b of the grid: every work-group factors the 64x64 diagonal block in LDS
+// (redundantly - cheaper than a second launch), block 0 stores it, block b > 0 solves its 64x64
+// off-diagonal block X L_dd^T = A_bd.
+__device__ inline void load_tile(const double* __restrict__ src, int ld, double* s_t) {
+  for (int idx = threadIdx.x; idx < BS * BS; idx += 256) {
+    int r = idx >> 6, c = idx & 63;
+    s_t[r * TLD + c] = src[(size_t)r * ld + c];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ A, int p, int ld, int* __restrict__ info) {
+  __shared__ __attribute__((aligned(16))) double s_d[BS * TLD];
+  __shared__ __attribute__((aligned(16))) double s_b[BS * TLD];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x;
+  double* Add = A + (size_t)(p * BS) * ld + p * BS;
+  load_tile(Add, ld, s_d);
+  if (b > 0) load_tile(A + (size_t)((p + b) * BS) * ld + p * BS, ld, s_b);
+  __syncthreads();
+  // unblocked right-looking factorisation of the diagonal block (lower triangle)
+  const int ri = tid >> 2, part = tid & 3;       // four threads per row for the rank-1 update
+  for (int j = 0; j < BS; ++j) {
+    double piv = s_d[j * TLD + j];
+    if (!(piv > 0.0)) {
+      if (b == 0 && tid == 0) atomicCAS(info, 0, p * BS + j + 1);
+      piv = 1.0;
+    }
+    const double dj = sqrt(piv);
+    __syncthreads();
+    if (tid == j) s_d[j * TLD + j] = dj;
+    if (tid < BS && tid > j) s_d[tid * TLD + j] /= dj;
+    __syncthreads();
+    if (ri > j) {
+      const double lij = s_d[ri * TLD + j];
+      for (int c = j + 1 + part; c <= ri; c += 4) s_d[ri * TLD + c] -= lij * s_d[c * TLD + j];
+    }
+    __syncthreads();
+  }
+  if (b == 0) {
+    for (int idx = tid; idx < BS * BS; idx += 256) {
+      int r = idx >> 6, c = idx & 63;
+      Add[(size_t)r * ld + c] = (c <= r) ? s_d[r * TLD + c] : 0.0;
+    }
+    return;
+  }
+  // X L^T = B  =>  x_c = (b_c - sum_{m<c} x_m L[c][m]) / L[c][c]; four threads share a row
+  for (int c = 0; c < BS; ++c) {
+    double s = 0.0;
+    for (int m = part; m < c; m += 4) s += s_b[ri * TLD + m] * s_d[c * TLD + m];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (part == 0) s_b[ri * TLD + c] = (s_b[ri * TLD + c] - s) / s_d[c * TLD + c];
+    __syncthreads();
+  }
+  double* dst = A + (size_t)((p + b) * BS) * ld + p * BS;
+  for (int idx = tid; idx < BS * BS; idx += 256) {
+    int r = idx >> 6, c = idx & 63;
+    dst[(size_t)r * ld + c] = s_b[r * TLD + c];
+  }
+}
+
+// Trailing update A[I][J] -= L[I][p] L[J][p]^T for p < J <= I on f64 MFMA.
+// Both 64x64 operand tiles are staged in LDS with coalesced loads; fragments are read with a
+// leading dimension of 66 doubles (conflict-free for ds_read_b64).
+__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int p, int nblk, int ld) {
+  __shared__ __attribute__((aligned(16))) double s_a[BS * TLD];
+  __shared__ __attribute__((aligned(16))) double s_b[BS * TLD];
+  // linear block id -> (I, J) in the lower triangle of the trailing (nblk-p-1)^2 tiles
+  const int m = nblk - p - 1;
+  int t = blockIdx.x, I = 0;
+  while (t >= I + 1) { t -= I + 1; ++I; }
+  const int J = t;
+  if (I >= m) return;
+  const int gi = p + 1 + I, gj = p + 1 + J;
+  load_tile(A + (size_t)(gi * BS) * ld + p * BS, ld, s_a);
+  load_tile(A + (size_t)(gj * BS) * ld + p * BS, ld, s_b);
+  __syncthreads();
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  double4_t acc[4];
+  for (int q = 0; q < 4; ++q) acc[q] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  for (int kk = 0; kk < BS; kk += 4) {
+    double a = s_a[(16 * w + (l & 15)) * TLD + kk + (l >> 4)];
+    for (int q = 0; q < 4; ++q) {
+      double bb = s_b[(16 * q + (l & 15)) * TLD + kk + (l >> 4)];     // B[k][j] = L[J-row j][k]
+      acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[q], 0, 0, 0);
+    }
+  }
+  double* dst = A + (size_t)(gi * BS) * ld + gj * BS;
+  for (int q = 0; q < 4; ++q)
+    for (int r = 0; r < 4; ++r) {
+      size_t off = (size_t)(16 * w + (l >> 4) + 4 * r) * ld + 16 * q + (l & 15);
+      dst[off] -= acc[q][r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Root inverse R = L^-1 (what gpytorch caches as `covar_cache`, stored here un-transposed).
+// Step 1: invert every 64x64 diagonal block by forward substitution (one thread per column).
+__global__ __launch_bounds__(64) void k_trinv_diag(const double* __restrict__ L, int ld, double* __restrict__ R) {
+  __shared__ __attribute__((aligned(16))) double s_l[BS * TLD];
+  __shared__ __attribute__((aligned(16))) double s_x[BS * TLD];
+  const int b = blockIdx.x, c = threadIdx.x;
+  const double* src = L + (size_t)(b * BS) * ld + b * BS;
+  for (int idx = threadIdx.x; idx < BS * BS; idx += 64) {
+    int r = idx >> 6, cc = idx & 63;
+    s_l[r * TLD + cc] = src[(size_t)r * ld + cc];
+  }
+  __syncthreads();
+  for (int r = 0; r < BS; ++r) {
+    double v = 0.0;
+    if (r >= c) {
+      double s = (r == c) ? 1.0 : 0.0;
+      for (int m = c; m < r; ++m) s -= s_l[r * TLD + m] * s_x[m * TLD + c];
+      v = s / s_l[r * TLD + r];
+    }
+    s_x[r * TLD + c] = v;
+  }
+  __syncthreads();
+  double* dst = R + (size_t)(b * BS) * ld + b * BS;
+  for (int idx = threadIdx.x; idx < BS * BS; idx += 64) {
+    int r = idx >> 6, cc = idx & 63;
+    dst[(size_t)r * ld + cc] = s_x[r * TLD + cc];
+  }
+}
+
+// Step 2: one work-group per chunk of 16 columns of R.  Going down the block rows I = J+1..nblk-1
+// (J = block holding the chunk; its diagonal block is already done):
+//   S   = - sum_{K=J}^{I-1} L[I][K] X_K          (64x16 accumulators, f64 MFMA)
+//   X_I = Rdiag_I S
+// Column chunks are independent: NP/16 work-groups, no inter-group synchronisation.  X_K tiles
+// written earlier by this same work-group are re-read from global memory after a barrier.
+__global__ __launch_bounds__(256) void k_trinv_cols(const double* __restrict__ L, int nblk, int ld,
+                                                    double* R) {
+  __shared__ __attribute__((aligned(16))) double s_t[BS * TLD];   // 64x64 operand tile
+  __shared__ __attribute__((aligned(16))) double s_xk[BS * 16];   // 64x16 block of X (or S)
+  const int c0 = blockIdx.x * 16;
+  const int J = c0 / BS;
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  for (int I = J + 1; I < nblk; ++I) {
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+    for (int Kb = J; Kb < I; ++Kb) {
+      __syncthreads();
+      load_tile(L + (size_t)(I * BS) * ld + Kb * BS, ld, s_t);
+      for (int idx = threadIdx.x; idx < BS * 16; idx += 256)
+        s_xk[idx] = R[(size_t)(Kb * BS + (idx >> 4)) * ld + c0 + (idx & 15)];
+      __syncthreads();
+      for (int kk = 0; kk < BS; kk += 4) {
+        double a = s_t[(16 * w + (l & 15)) * TLD + kk + (l >> 4)];
+        double b = s_xk[(kk + (l >> 4)) * 16 + (l & 15)];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    for (int r = 0; r < 4; ++r) s_xk[(16 * w + (l >> 4) + 4 * r) * 16 + (l & 15)] = -acc[r];
+    load_tile(R + (size_t)(I * BS) * ld + I * BS, ld, s_t);     // Rdiag_I from step 1
+    __syncthreads();
+    double4_t x = {0.0, 0.0, 0.0, 0.0};
+    for (int kk = 0; kk < BS; kk += 4) {
+      double a = s_t[(16 * w + (l & 15)) * TLD + kk + (l >> 4)];
+      double b = s_xk[(kk + (l >> 4)) * 16 + (l & 15)];
+      x = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, x, 0, 0, 0);
+    }
+    for (int r = 0; r < 4; ++r)
+      R[(size_t)(I * BS + 16 * w + (l >> 4) + 4 * r) * ld + c0 + (l & 15)] = x[r];
+    __threadfence_block();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// alpha = K^-1 y_s = R^T (R y_s): two matrix-vector products with the root inverse.
+__global__ __launch_bounds__(256) void k_rmatvec(const double* __restrict__ R, const double* __restrict__ y, int n,
+                                                 int ld, double* __restrict__ t) {
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  for (int rr = 0; rr < 4; ++rr) {
+    const int i = blockIdx.x * 16 + w * 4 + rr;
+    double s = 0.0;
+    if (i < n)
+      for (int j = l; j <= i; j += 64) s += R[(size_t)i * ld + j] * y[j];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (l == 0) t[i] = (i < n) ? s : 0.0;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_rtmatvec(const double* __restrict__ R, const double* __restrict__ t, int n,
+                                                  int ld, double* __restrict__ out) {
+  __shared__ double s_p[4][64];
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int j = blockIdx.x * 64 + l;
+  double s = 0.0;
+  for (int i = j + w; i < n; i += 4) s += R[(size_t)i * ld + j] * t[i];
+  s_p[w][l] = s;
+  __syncthreads();
+  if (w == 0) out[j] = (j < n) ? ((s_p[0][l] + s_p[1][l]) + s_p[2][l]) + s_p[3][l] : 0.0;
+}
+
+// ---- launchers --------------------------------------------------------------------------------
+void launch_gram(hipStream_t s, const double* AT, const double* nrm, int n, int NP, int KP, int ld, double noise,
+                 int kernel, double* K) {
+  int nb = NP / BS;
+  hipLaunchKernelGGL(k_gram, dim3(nb, nb), dim3(256), 0, s, AT, nrm, n, KP, ld, noise, kernel, K);
+}
+void launch_add_jitter(hipStream_t s, double* K, int n, int ld, double jitter) {
+  hipLaunchKernelGGL(k_add_jitter, dim3((n + 255) / 256), dim3(256), 0, s, K, n, ld, jitter);
+}
+void launch_cholesky(hipStream_t s, double* L, int NP, int ld, int* info) {
+  const int nblk = NP / BS;
+  for (int p = 0; p < nblk; ++p) {
+    hipLaunchKernelGGL(k_chol_panel, dim3(nblk - p), dim3(256), 0, s, L, p, ld, info);
+    int m = nblk - p - 1;
+    if (m > 0) hipLaunchKernelGGL(k_chol_update, dim3(m * (m + 1) / 2), dim3(256), 0, s, L, p, nblk, ld);
+  }
+}
+void launch_trinv(hipStream_t s, const double* L, int NP, int ld, double* R) {
+  const int nblk = NP / BS;
+  hipMemsetAsync(R, 0, (size_t)NP * ld * sizeof(double), s);
+  hipLaunchKernelGGL(k_trinv_diag, dim3(nblk), dim3(64), 0, s, L, ld, R);
+  hipLaunchKernelGGL(k_trinv_cols, dim3(NP / 16), dim3(256), 0, s, L, nblk, ld, R);
+}
+void launch_alpha(hipStream_t s, const double* R, const double* ys, int n, int NP, int ld, double* tmp, double* alpha) {
+  hipLaunchKernelGGL(k_rmatvec, dim3(NP / 16), dim3(256), 0, s, R, ys, n, ld, tmp);
+  hipLaunchKernelGGL(k_rtmatvec, dim3(NP / 64), dim3(256), 0, s, R, tmp, n, ld, alpha);
+}

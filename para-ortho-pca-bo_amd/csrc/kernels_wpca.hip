@@ -1,0 +1,433 @@
+// Rank-weighted PCA on gfx950.
+//
+// Replaces numpy + sklearn.decomposition.PCA as used by
+// /root/reference/Algorithms/BayesianOptimization/PCA_BO.py:316-434.
+// All matrices here are small (d <= 128, n <= ~1k): the work is latency-bound, so the design is
+// "few launches, one work-group where a phase is sequential, MFMA for the one GEMM-like
+// contraction (the d x d covariance W^T W)".
+#include "pcabo_internal.h"
+
+#define WP_THREADS 1024
+
+// ---- deterministic block-wide sum (tree in LDS), result broadcast to every thread -----------
+__device__ inline double block_sum_1024(double v, double* s_red) {
+  int tid = threadIdx.x;
+  s_red[tid] = v;
+  __syncthreads();
+  for (int off = WP_THREADS / 2; off > 0; off >>= 1) {
+    if (tid < off) s_red[tid] += s_red[tid + off];
+    __syncthreads();
+  }
+  double r = s_red[0];
+  __syncthreads();
+  return r;
+}
+
+// Row A (device variant): 1-based rank of each f, best first, ties broken by index.
+__global__ void k_rank(const double* __restrict__ f, int n, int maximize, long long* __restrict__ ranks) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double fi = maximize ? -f[i] : f[i];
+  int r = 1;
+  for (int j = 0; j < n; ++j) {
+    double fj = maximize ? -f[j] : f[j];
+    r += (fj < fi) || (fj == fi && j < i);
+  }
+  ranks[i] = r;
+}
+
+// Rows A+B: weights, data mean, weighted+noised matrix W, its column mean, centred Wc (n4 x DP,
+// zero padded so the MFMA covariance kernel can run whole 16x4 fragments).
+// One work-group; thread (c = tid % CP, g = tid / CP) owns column c of the rows i = g (mod G), so
+// every pass touches only the thread's own elements (no inter-thread global dependencies).
+__global__ __launch_bounds__(WP_THREADS) void k_wpca_prep(
+    const double* __restrict__ X, const long long* __restrict__ ranks, const double* __restrict__ noise,
+    int n, int d, int DP, double* __restrict__ weights, double* __restrict__ data_mean,
+    double* __restrict__ pca_mean, double* __restrict__ Wc) {
+  __shared__ double s_red[WP_THREADS];
+  __shared__ double s_col[PCABO_MAXD];
+  const int tid = threadIdx.x;
+  const int CP = DP <= 64 ? 64 : 128;
+  const int G = WP_THREADS / CP;
+  const int c = tid % CP, g = tid / CP;
+  const int n4 = (n + 3) & ~3;
+
+  // pre-weights ln n - ln r_i and their sum (PCA_BO.py:336-339)
+  double loc = 0.0;
+  const double logn = log((double)n);
+  for (int i = tid; i < n; i += WP_THREADS) {
+    double pw = logn - log((double)ranks[i]);
+    weights[i] = pw;
+    loc += pw;
+  }
+  const double tot = block_sum_1024(loc, s_red);
+  for (int i = tid; i < n; i += WP_THREADS) weights[i] = weights[i] / tot;
+  __syncthreads();   // weights[] written by other threads are read below
+
+  // column means of X (PCA_BO.py:364)
+  double acc = 0.0;
+  if (c < d)
+    for (int i = g; i < n; i += G) acc += X[(size_t)i * d + c];
+  s_red[tid] = acc;
+  __syncthreads();
+  if (tid < CP) {
+    double s = 0.0;
+    for (int gg = 0; gg < G; ++gg) s += s_red[gg * CP + tid];
+    s_col[tid] = s / (double)n;
+    if (tid < d) data_mean[tid] = s_col[tid];
+  }
+  __syncthreads();
+  const double mu = (c < d) ? s_col[c] : 0.0;
+  __syncthreads();
+
+  // W = (X - mu) * sqrt(w_i) + noise (PCA_BO.py:365-377), column sums of W
+  acc = 0.0;
+  if (c < DP) {
+    for (int i = g; i < n4; i += G) {
+      double w = 0.0;
+      if (c < d && i < n) {
+        w = (X[(size_t)i * d + c] - mu) * sqrt(weights[i]);
+        if (noise) w += noise[(size_t)i * d + c];
+      }
+      Wc[(size_t)i * DP + c] = w;
+      acc += w;
+    }
+  }
+  s_red[tid] = acc;
+  __syncthreads();
+  if (tid < CP) {
+    double s = 0.0;
+    for (int gg = 0; gg < G; ++gg) s += s_red[gg * CP + tid];
+    s_col[tid] = s / (double)n;                       // sklearn: mean_ = mean(W, axis=0)
+    if (tid < d) pca_mean[tid] = s_col[tid];
+  }
+  __syncthreads();
+  const double mw = (c < d) ? s_col[c] : 0.0;
+  if (c < d)
+    for (int i = g; i < n; i += G) Wc[(size_t)i * DP + c] -= mw;
+}
+
+// Row C (covariance): C = Wc^T Wc / (n-1), DP x DP, one 16x16 tile per work-group; the four waves
+// split the n-long contraction and are summed in a fixed order (deterministic).
+// v_mfma_f64_16x16x4_f64: lane l supplies A[i=l&15][k=l>>4] and B[k=l>>4][j=l&15]; D holds
+// rows (l>>4)+4r, column l&15.
+__global__ __launch_bounds__(256) void k_cov(const double* __restrict__ Wc, int n4, int DP, double inv_nm1,
+                                             double* __restrict__ C) {
+  __shared__ double s_acc[4][4][64];
+  const int ti = blockIdx.x, tj = blockIdx.y;
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  double4_t acc = {0.0, 0.0, 0.0, 0.0};
+  const int steps = n4 >> 2;
+  for (int s = w; s < steps; s += 4) {
+    const size_t row = (size_t)(4 * s + (l >> 4)) * DP;
+    double a = Wc[row + ti * 16 + (l & 15)];
+    double b = Wc[row + tj * 16 + (l & 15)];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+  for (int r = 0; r < 4; ++r) s_acc[w][r][l] = acc[r];
+  __syncthreads();
+  if (w == 0) {
+    for (int r = 0; r < 4; ++r) {
+      double s = ((s_acc[0][r][l] + s_acc[1][r][l]) + s_acc[2][r][l]) + s_acc[3][r][l];
+      C[(size_t)(ti * 16 + (l >> 4) + 4 * r) * DP + tj * 16 + (l & 15)] = s * inv_nm1;
+    }
+  }
+}
+
+// Row C (eigen-decomposition): one-sided (Hestenes) Jacobi on G = C (symmetric PSD, d x d) in LDS.
+// Plane rotations are applied to column pairs until all columns are mutually orthogonal; then
+// G = C V = V diag(lambda): column norms are the eigenvalues and the normalised columns the
+// eigenvectors.  Round-robin ordering gives d/2 independent pairs per round, each handled by a
+// group of LP lanes (shuffle reductions, no LDS traffic for the dot products).
+#define JAC_THREADS 1024
+__global__ __launch_bounds__(JAC_THREADS) void k_jacobi(const double* __restrict__ C, int d, int DP,
+                                                        double* __restrict__ Gout, double* __restrict__ lam,
+                                                        int* __restrict__ sweeps_out) {
+  extern __shared__ __attribute__((aligned(16))) double s_g[];   // d columns of length d, column-major, stride LD
+  const int tid = threadIdx.x;
+  const int LD = d | 1;                    // odd stride: column p and q of a pair never share banks systematically
+  volatile int& s_rot = *reinterpret_cast<volatile int*>(s_g + (size_t)d * LD);   // flag lives after the matrix
+  for (int idx = tid; idx < d * d; idx += JAC_THREADS) {
+    int col = idx / d, row = idx % d;
+    s_g[col * LD + row] = C[(size_t)row * DP + col];
+  }
+  if (tid == 0) s_rot = 0;
+  __syncthreads();
+
+  const int de = (d + 1) & ~1;             // even number of players (a virtual empty column if d is odd)
+  const int npairs = de / 2;
+  int LP = 64;
+  while (LP * npairs > JAC_THREADS) LP >>= 1;
+  const int grp = tid / LP, lane = tid % LP;
+  const double tol = 1e-15;
+  int sweep = 0;
+  for (; sweep < 40; ++sweep) {
+    for (int round = 0; round < de - 1; ++round) {
+      if (grp < npairs) {
+        int p, q;
+        if (grp == 0) { p = round; q = de - 1; }
+        else { p = (round + grp) % (de - 1); q = (round - grp + (de - 1)) % (de - 1); }
+        if (p > q) { int t = p; p = q; q = t; }
+        if (q < d) {
+          double* gp = s_g + p * LD;
+          double* gq = s_g + q * LD;
+          double a = 0.0, b = 0.0, g = 0.0;
+          for (int r = lane; r < d; r += LP) {
+            double x = gp[r], y = gq[r];
+            a += x * x; b += y * y; g += x * y;
+          }
+          for (int off = LP >> 1; off > 0; off >>= 1) {
+            a += __shfl_xor(a, off, 64);
+            b += __shfl_xor(b, off, 64);
+            g += __shfl_xor(g, off, 64);
+          }
+          const double lim = tol * sqrt(a * b);
+          if (fabs(g) > lim && fabs(g) > 1e-300) {
+            double zeta = (b - a) / (2.0 * g);
+            double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            double cs = 1.0 / sqrt(1.0 + t * t);
+            double sn = cs * t;
+            for (int r = lane; r < d; r += LP) {
+              double x = gp[r], y = gq[r];
+              gp[r] = cs * x - sn * y;
+              gq[r] = sn * x + cs * y;
+            }
+            if (lane == 0) s_rot = 1;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    int rot = s_rot;
+    __syncthreads();
+    if (tid == 0) s_rot = 0;
+    __syncthreads();
+    if (!rot) { ++sweep; break; }
+  }
+  // eigenvalues = column norms; write normalised columns (eigenvectors), column-major d x d
+  for (int col = tid / 64; col < d; col += JAC_THREADS / 64) {
+    int l = tid & 63;
+    double a = 0.0;
+    for (int r = l; r < d; r += 64) { double x = s_g[col * LD + r]; a += x * x; }
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+    double nrm = sqrt(a);
+    double inv = nrm > 0.0 ? 1.0 / nrm : 0.0;
+    for (int r = l; r < d; r += 64) Gout[(size_t)col * d + r] = s_g[col * LD + r] * inv;
+    if (l == 0) lam[col] = nrm;
+  }
+  if (tid == 0) *sweeps_out = sweep;
+}
+
+// Row C (selection): sort eigenpairs by decreasing variance, explained-variance ratios, k from the
+// variance threshold (PCA_BO.py:389-394), sign rule svd_flip(u_based_decision=False).
+__global__ __launch_bounds__(128) void k_pca_finalize(const double* __restrict__ G, const double* __restrict__ lam,
+                                                       int n, int d, double var_threshold, int n_components,
+                                                       double* __restrict__ comps, double* __restrict__ evr,
+                                                       int* __restrict__ k_dev, HostMirror* hm) {
+  __shared__ int s_order[PCABO_MAXD];
+  __shared__ double s_lam[PCABO_MAXD];
+  __shared__ double s_tot;
+  const int tid = threadIdx.x;
+  if (tid < d) s_lam[tid] = lam[tid];
+  __syncthreads();
+  if (tid < d) {
+    double me = s_lam[tid];
+    int r = 0;
+    for (int j = 0; j < d; ++j) r += (s_lam[j] > me) || (s_lam[j] == me && j < tid);
+    s_order[r] = tid;
+  }
+  __syncthreads();
+  const int rcount = n < d ? n : d;           // sklearn keeps min(n, d) components
+  if (tid == 0) {
+    double tot = 0.0;
+    for (int r = 0; r < rcount; ++r) tot += s_lam[s_order[r]];
+    s_tot = tot;
+    int k;
+    double cum = 0.0;
+    int cnt = 0;
+    for (int r = 0; r < rcount; ++r) {
+      double e = s_lam[s_order[r]] / tot;
+      evr[r] = e;
+      cum += e;
+      cnt += (cum <= var_threshold);
+    }
+    if (n_components > 0) k = n_components < rcount ? n_components : rcount;
+    else {
+      k = cnt + 1;
+      if (k > rcount) k = rcount;
+      if (k < 1) k = 1;
+    }
+    *k_dev = k;
+    hm->k = k;
+  }
+  if (tid < rcount) {
+    const double* v = G + (size_t)s_order[tid] * d;
+    double best = -1.0, sgn = 1.0;
+    for (int j = 0; j < d; ++j) {
+      double a = fabs(v[j]);
+      if (a > best) { best = a; sgn = v[j] < 0.0 ? -1.0 : 1.0; }
+    }
+    for (int j = 0; j < d; ++j) comps[(size_t)tid * d + j] = sgn * v[j];
+  }
+}
+
+// Row C (projection): Z = (X - mu_x) Ck^T - m_w Ck^T  (PCA_BO.py:407; sklearn _base.py _transform).
+// Eight points per work-group; Z is n x k row-major, k read from device memory.
+__global__ __launch_bounds__(256) void k_project(const double* __restrict__ X, const double* __restrict__ data_mean,
+                                                 const double* __restrict__ pca_mean, const double* __restrict__ comps,
+                                                 const int* __restrict__ k_dev, int n, int d, double* __restrict__ Z) {
+  __shared__ double s_x[8][PCABO_MAXD];
+  __shared__ double s_m[PCABO_MAXD];
+  const int k = *k_dev;
+  const int i0 = blockIdx.x * 8;
+  for (int idx = threadIdx.x; idx < 8 * d; idx += 256) {
+    int r = idx / d, j = idx % d;
+    s_x[r][j] = (i0 + r < n) ? X[(size_t)(i0 + r) * d + j] - data_mean[j] : 0.0;
+  }
+  if (threadIdx.x < d) s_m[threadIdx.x] = pca_mean[threadIdx.x];
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 8 * k; idx += 256) {
+    int r = idx / k, c = idx % k;
+    if (i0 + r >= n) continue;
+    const double* ck = comps + (size_t)c * d;
+    double s = 0.0, sm = 0.0;
+    for (int j = 0; j < d; ++j) { s += s_x[r][j] * ck[j]; sm += s_m[j] * ck[j]; }
+    Z[(size_t)(i0 + r) * k + c] = s - sm;
+  }
+}
+
+// Rows D, F, J: per-component min/max of Z -> Normalize bounds (PCA_BO.py:514-518) and optimiser
+// box (PCA_BO.py:558-573); mean of the normalised inputs (gpytorch centres before the distance);
+// Standardize statistics of y and y_s.
+__global__ __launch_bounds__(WP_THREADS) void k_zstats(const double* __restrict__ Z, const double* __restrict__ y,
+                                                       int n, int k, const double* __restrict__ user_nb,
+                                                       double* __restrict__ bounds4, double* __restrict__ zn_mean,
+                                                       double* __restrict__ ystats, double* __restrict__ ys,
+                                                       HostMirror* hm) {
+  __shared__ double s_red[WP_THREADS];
+  __shared__ double s_min[WP_THREADS];
+  __shared__ double s_max[WP_THREADS];
+  const int tid = threadIdx.x;
+  const int CP = k <= 64 ? 64 : 128;
+  const int G = WP_THREADS / CP;
+  const int c = tid % CP, g = tid / CP;
+  double mn = INFINITY, mx = -INFINITY, sm = 0.0;
+  if (c < k)
+    for (int i = g; i < n; i += G) {
+      double z = Z[(size_t)i * k + c];
+      mn = fmin(mn, z); mx = fmax(mx, z); sm += z;
+    }
+  s_min[tid] = mn; s_max[tid] = mx; s_red[tid] = sm;
+  __syncthreads();
+  if (tid < k) {
+    double a = INFINITY, b = -INFINITY, s = 0.0;
+    for (int gg = 0; gg < G; ++gg) {
+      a = fmin(a, s_min[gg * CP + tid]); b = fmax(b, s_max[gg * CP + tid]); s += s_red[gg * CP + tid];
+    }
+    double rng = b - a;
+    double nlo = a - 0.1 * rng, nhi = b + 0.1 * rng;
+    if (user_nb) { nlo = user_nb[tid]; nhi = user_nb[k + tid]; }
+    double alo = a - 0.5 * rng, ahi = b + 0.5 * rng;
+    if (ahi - alo < 0.1) { double mid = (ahi + alo) / 2; alo = mid - 0.1 / 2; ahi = mid + 0.1 / 2; }
+    bounds4[tid] = nlo; bounds4[PCABO_MAXD + tid] = nhi;
+    bounds4[2 * PCABO_MAXD + tid] = alo; bounds4[3 * PCABO_MAXD + tid] = ahi;
+    hm->norm_lo[tid] = nlo; hm->norm_hi[tid] = nhi; hm->acq_lo[tid] = alo; hm->acq_hi[tid] = ahi;
+    zn_mean[tid] = (s / (double)n - nlo) / (nhi - nlo);
+  }
+  __syncthreads();
+  // Standardize(m=1): mean, unbiased std (>= 1e-8 else 1)
+  double loc = 0.0;
+  for (int i = tid; i < n; i += WP_THREADS) loc += y[i];
+  const double ym = block_sum_1024(loc, s_red) / (double)n;
+  loc = 0.0;
+  for (int i = tid; i < n; i += WP_THREADS) { double t = y[i] - ym; loc += t * t; }
+  double var = block_sum_1024(loc, s_red) / (double)(n > 1 ? n - 1 : 1);
+  double sd = sqrt(var);
+  if (!(sd >= 1e-8)) sd = 1.0;
+  for (int i = tid; i < n; i += WP_THREADS) ys[i] = (y[i] - ym) / sd;
+  if (tid == 0) { ystats[0] = ym; ystats[1] = sd; hm->y_mean = ym; hm->y_std = sd; }
+}
+
+// Row E: Normalize the training inputs and lay them out for the Gram / acquisition kernels:
+//   ZnT[c][i] = (Z[i][c]-lo_c)/(hi_c-lo_c)          (KP x ld, point index contiguous)
+//   AT[c][i]  = (ZnT[c][i] - mean_c)/lengthscale    (what gpytorch feeds its distance GEMM)
+//   nrm[i]    = sum_c AT[c][i]^2
+// Points i >= n and components c >= k are zero so whole tiles can be processed.
+__global__ __launch_bounds__(256) void k_znorm(const double* __restrict__ Z, int n, int k, int NP, int KP, int ld,
+                                               const double* __restrict__ bounds4, const double* __restrict__ zn_mean,
+                                               double inv_ls, double* __restrict__ ZnT, double* __restrict__ AT,
+                                               double* __restrict__ nrm) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= NP) return;
+  double s = 0.0;
+  for (int c = 0; c < KP; ++c) {
+    double zn = 0.0, a = 0.0;
+    if (i < n && c < k) {
+      double lo = bounds4[c], hi = bounds4[PCABO_MAXD + c];
+      zn = (Z[(size_t)i * k + c] - lo) / (hi - lo);
+      a = (zn - zn_mean[c]) * inv_ls;
+    }
+    ZnT[(size_t)c * ld + i] = zn;
+    AT[(size_t)c * ld + i] = a;
+    s += a * a;
+  }
+  nrm[i] = s;
+}
+
+// Row O: x = z Ck + m_w + mu_x (PCA_BO.py:427).
+__global__ __launch_bounds__(128) void k_inverse_map(const double* __restrict__ z, const double* __restrict__ comps,
+                                                     const double* __restrict__ data_mean,
+                                                     const double* __restrict__ pca_mean, int k, int d,
+                                                     double* __restrict__ x) {
+  const int j = threadIdx.x;
+  if (j >= d) return;
+  double s = 0.0;
+  for (int c = 0; c < k; ++c) s += z[c] * comps[(size_t)c * d + j];
+  x[j] = (s + pca_mean[j]) + data_mean[j];
+}
+
+// ---- launchers --------------------------------------------------------------------------------
+void launch_rank(hipStream_t s, const double* f, int n, int maximize, long long* ranks) {
+  hipLaunchKernelGGL(k_rank, dim3((n + 255) / 256), dim3(256), 0, s, f, n, maximize, ranks);
+}
+void launch_wpca_prep(hipStream_t s, const double* X, const long long* ranks, const double* noise, int n, int d,
+                      int DP, double* weights, double* data_mean, double* pca_mean, double* Wc) {
+  hipLaunchKernelGGL(k_wpca_prep, dim3(1), dim3(WP_THREADS), 0, s, X, ranks, noise, n, d, DP, weights, data_mean,
+                     pca_mean, Wc);
+}
+void launch_cov(hipStream_t s, const double* Wc, int n, int DP, double* C) {
+  int n4 = (n + 3) & ~3;
+  hipLaunchKernelGGL(k_cov, dim3(DP / 16, DP / 16), dim3(256), 0, s, Wc, n4, DP, 1.0 / (double)(n - 1), C);
+}
+void launch_jacobi(hipStream_t s, const double* C, int d, int DP, double* G, double* lam, int* sweeps) {
+  size_t lds = ((size_t)d * (d | 1) + 2) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)k_jacobi, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_jacobi, dim3(1), dim3(JAC_THREADS), lds, s, C, d, DP, G, lam, sweeps);
+}
+void launch_pca_finalize(hipStream_t s, const double* G, const double* lam, int n, int d, double var_threshold,
+                         int n_components, double* comps, double* evr, int* k_dev, HostMirror* hm) {
+  hipLaunchKernelGGL(k_pca_finalize, dim3(1), dim3(128), 0, s, G, lam, n, d, var_threshold, n_components, comps, evr,
+                     k_dev, hm);
+}
+void launch_project(hipStream_t s, const double* X, const double* data_mean, const double* pca_mean,
+                    const double* comps, const int* k_dev, int n, int d, double* Z) {
+  hipLaunchKernelGGL(k_project, dim3((n + 7) / 8), dim3(256), 0, s, X, data_mean, pca_mean, comps, k_dev, n, d, Z);
+}
+void launch_zstats(hipStream_t s, const double* Z, const double* y, int n, int k, const double* user_norm_bounds,
+                   double* bounds4, double* zn_mean, double* ystats, double* ys, HostMirror* hm) {
+  hipLaunchKernelGGL(k_zstats, dim3(1), dim3(WP_THREADS), 0, s, Z, y, n, k, user_norm_bounds, bounds4, zn_mean,
+                     ystats, ys, hm);
+}
+void launch_znorm(hipStream_t s, const double* Z, int n, int k, int NP, int KP, int ld, const double* bounds4,
+                  const double* zn_mean, double inv_ls, double* ZnT, double* AT, double* nrm) {
+  hipLaunchKernelGGL(k_znorm, dim3((NP + 255) / 256), dim3(256), 0, s, Z, n, k, NP, KP, ld, bounds4, zn_mean, inv_ls,
+                     ZnT, AT, nrm);
+}
+void launch_inverse_map(hipStream_t s, const double* z, const double* comps, const double* data_mean,
+                        const double* pca_mean, int k, int d, double* x) {
+  hipLaunchKernelGGL(k_inverse_map, dim3(1), dim3(128), 0, s, z, comps, data_mean, pca_mean, k, d, x);
+}

@@ -1,0 +1,891 @@
+// L-BFGS-B 3.0 restated as a reverse-communication C++ class.  See lbfgsb.h.
+// Array layouts follow the published Fortran description (column-major, circular column storage
+// for S and Y) so that every inner product is accumulated in the same order.
+#include "lbfgsb.h"
+
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+#define WS(i, p) ws_[(size_t)(p) * n_ + (i)]
+#define WY(i, p) wy_[(size_t)(p) * n_ + (i)]
+#define SY(i, j) sy_[(size_t)(j) * m_ + (i)]
+#define SS(i, j) ss_[(size_t)(j) * m_ + (i)]
+#define WT(i, j) wt_[(size_t)(j) * m_ + (i)]
+#define WN(i, j) wn_[(size_t)(j) * 2 * m_ + (i)]
+#define WN1(i, j) snd_[(size_t)(j) * 2 * m_ + (i)]
+
+namespace {
+
+inline double ddot(int n, const double* x, const double* y) {
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += x[i] * y[i];
+  return s;
+}
+
+// LINPACK dpofa: upper Cholesky factor of the leading nn x nn block (leading dimension lda).
+int dpofa(double* a, int lda, int nn) {
+  for (int j = 0; j < nn; ++j) {
+    double s = 0.0;
+    for (int k = 0; k < j; ++k) {
+      double t = a[(size_t)j * lda + k] - ddot(k, a + (size_t)k * lda, a + (size_t)j * lda);
+      t = t / a[(size_t)k * lda + k];
+      a[(size_t)j * lda + k] = t;
+      s += t * t;
+    }
+    s = a[(size_t)j * lda + j] - s;
+    if (s <= 0.0) return j + 1;
+    a[(size_t)j * lda + j] = std::sqrt(s);
+  }
+  return 0;
+}
+
+// LINPACK dtrsl for an upper-triangular t: job 1 -> t x = b, job 11 -> t' x = b.
+int dtrsl(const double* t, int ldt, int nn, double* b, int job) {
+  for (int i = 0; i < nn; ++i)
+    if (t[(size_t)i * ldt + i] == 0.0) return i + 1;
+  if (job == 1) {
+    b[nn - 1] = b[nn - 1] / t[(size_t)(nn - 1) * ldt + nn - 1];
+    for (int j = nn - 2; j >= 0; --j) {
+      double temp = -b[j + 1];
+      const double* col = t + (size_t)(j + 1) * ldt;
+      for (int i = 0; i <= j; ++i) b[i] += temp * col[i];
+      b[j] = b[j] / t[(size_t)j * ldt + j];
+    }
+  } else {
+    b[0] = b[0] / t[0];
+    for (int j = 1; j < nn; ++j) {
+      b[j] = b[j] - ddot(j, t + (size_t)j * ldt, b);
+      b[j] = b[j] / t[(size_t)j * ldt + j];
+    }
+  }
+  return 0;
+}
+
+}  // namespace
+
+void Lbfgsb::init(int n, int m, const double* lower, const double* upper, double factr, double pgtol, int maxls) {
+  n_ = n; m_ = m; factr_ = factr; pgtol_ = pgtol; maxls_ = maxls;
+  l_.assign(n, 0.0); u_.assign(n, 0.0); nbd_.assign(n, 0);
+  for (int i = 0; i < n; ++i) {
+    double lo = lower ? lower[i] : -INFINITY, hi = upper ? upper[i] : INFINITY;
+    bool hl = std::isfinite(lo), hu = std::isfinite(hi);
+    l_[i] = hl ? lo : 0.0; u_[i] = hu ? hi : 0.0;
+    nbd_[i] = hl ? (hu ? 2 : 1) : (hu ? 3 : 0);
+  }
+  ws_.assign((size_t)n * m, 0.0); wy_.assign((size_t)n * m, 0.0);
+  sy_.assign((size_t)m * m, 0.0); ss_.assign((size_t)m * m, 0.0); wt_.assign((size_t)m * m, 0.0);
+  wn_.assign((size_t)4 * m * m, 0.0); snd_.assign((size_t)4 * m * m, 0.0);
+  z_.assign(n, 0.0); r_.assign(n, 0.0); d_.assign(n, 0.0); t_.assign(n, 0.0); xp_.assign(n, 0.0);
+  wa_.assign((size_t)8 * m, 0.0);
+  index_.assign(n, 0); iwhere_.assign(n, 0); indx2_.assign(n, 0);
+  task_ = LBFGSB_START; phase_ = 0;
+}
+
+void Lbfgsb::reset_memory() {
+  info_ = 0; col_ = 0; head_ = 0; theta_ = 1.0; iupdat_ = 0; updatd_ = false;
+}
+
+void Lbfgsb::projgr(const double* x, const double* g) {
+  sbgnrm_ = 0.0;
+  for (int i = 0; i < n_; ++i) {
+    double gi = g[i];
+    if (nbd_[i] != 0) {
+      if (gi < 0.0) { if (nbd_[i] >= 2) gi = std::fmax(x[i] - u_[i], gi); }
+      else { if (nbd_[i] <= 2) gi = std::fmin(x[i] - l_[i], gi); }
+    }
+    sbgnrm_ = std::fmax(sbgnrm_, std::fabs(gi));
+  }
+}
+
+bool Lbfgsb::active_init(double* x) {
+  prjctd_ = false; cnstnd_ = false; boxed_ = true;
+  for (int i = 0; i < n_; ++i) {
+    if (nbd_[i] > 0) {
+      if (nbd_[i] <= 2 && x[i] <= l_[i]) { if (x[i] < l_[i]) { prjctd_ = true; x[i] = l_[i]; } }
+      else if (nbd_[i] >= 2 && x[i] >= u_[i]) { if (x[i] > u_[i]) { prjctd_ = true; x[i] = u_[i]; } }
+    }
+  }
+  for (int i = 0; i < n_; ++i) {
+    if (nbd_[i] != 2) boxed_ = false;
+    if (nbd_[i] == 0) iwhere_[i] = -1;
+    else {
+      cnstnd_ = true;
+      iwhere_[i] = (nbd_[i] == 2 && u_[i] - l_[i] <= 0.0) ? 3 : 0;
+    }
+  }
+  return true;
+}
+
+void Lbfgsb::hpsolb(int n, double* t, int* iorder, int iheap) {
+  // 1-based heap arithmetic on 0-based storage
+  if (iheap == 0) {
+    for (int k = 2; k <= n; ++k) {
+      double ddum = t[k - 1];
+      int indxin = iorder[k - 1];
+      int i = k;
+      while (i > 1) {
+        int j = i / 2;
+        if (ddum < t[j - 1]) { t[i - 1] = t[j - 1]; iorder[i - 1] = iorder[j - 1]; i = j; }
+        else break;
+      }
+      t[i - 1] = ddum; iorder[i - 1] = indxin;
+    }
+  }
+  if (n > 1) {
+    int i = 1;
+    double out = t[0];
+    int indxou = iorder[0];
+    double ddum = t[n - 1];
+    int indxin = iorder[n - 1];
+    while (true) {
+      int j = i + i;
+      if (j <= n - 1) {
+        if (t[j] < t[j - 1]) j = j + 1;
+        if (t[j - 1] < ddum) { t[i - 1] = t[j - 1]; iorder[i - 1] = iorder[j - 1]; i = j; }
+        else break;
+      } else break;
+    }
+    t[i - 1] = ddum; iorder[i - 1] = indxin;
+    t[n - 1] = out; iorder[n - 1] = indxou;
+  }
+}
+
+// p = M v with the 2col x 2col middle matrix of the compact representation
+void Lbfgsb::bmv(const double* v, double* p) {
+  const int col = col_;
+  if (col == 0) return;
+  p[col] = v[col];
+  for (int i = 1; i < col; ++i) {
+    double sum = 0.0;
+    for (int k = 0; k < i; ++k) sum += SY(i, k) * v[k] / SY(k, k);
+    p[col + i] = v[col + i] + sum;
+  }
+  info_ = dtrsl(wt_.data(), m_, col, p + col, 11);
+  if (info_ != 0) return;
+  for (int i = 0; i < col; ++i) p[i] = v[i] / std::sqrt(SY(i, i));
+  info_ = dtrsl(wt_.data(), m_, col, p + col, 1);
+  if (info_ != 0) return;
+  for (int i = 0; i < col; ++i) p[i] = -p[i] / std::sqrt(SY(i, i));
+  for (int i = 0; i < col; ++i) {
+    double sum = 0.0;
+    for (int k = i + 1; k < col; ++k) sum += SY(k, i) * p[col + k] / SY(i, i);
+    p[i] += sum;
+  }
+}
+
+// Generalised Cauchy point along the projected steepest-descent path
+void Lbfgsb::cauchy(const double* x, const double* g) {
+  const int n = n_, m = m_, col = col_;
+  double* p = wa_.data();
+  double* c = wa_.data() + 2 * m;
+  double* wbp = wa_.data() + 4 * m;
+  double* v = wa_.data() + 6 * m;
+  double* t = t_.data();
+  double* d = d_.data();
+  double* xcp = z_.data();
+  int* iorder = indx2_.data();
+  if (sbgnrm_ <= 0.0) { std::memcpy(xcp, x, sizeof(double) * n); return; }
+  bool bnded = true;
+  int nfree = n, nbreak = 0, ibkmin = 0;
+  double bkmin = 0.0;
+  const int col2 = 2 * col;
+  double f1 = 0.0;
+  for (int i = 0; i < col2; ++i) p[i] = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const double neggi = -g[i];
+    double tl = 0.0, tu = 0.0;
+    if (iwhere_[i] != 3 && iwhere_[i] != -1) {
+      if (nbd_[i] <= 2) tl = x[i] - l_[i];
+      if (nbd_[i] >= 2) tu = u_[i] - x[i];
+      const bool xlower = nbd_[i] <= 2 && tl <= 0.0;
+      const bool xupper = nbd_[i] >= 2 && tu <= 0.0;
+      iwhere_[i] = 0;
+      if (xlower) { if (neggi <= 0.0) iwhere_[i] = 1; }
+      else if (xupper) { if (neggi >= 0.0) iwhere_[i] = 2; }
+      else { if (std::fabs(neggi) <= 0.0) iwhere_[i] = -3; }
+    }
+    int pointr = head_;
+    if (iwhere_[i] != 0 && iwhere_[i] != -1) {
+      d[i] = 0.0;
+    } else {
+      d[i] = neggi;
+      f1 -= neggi * neggi;
+      for (int j = 0; j < col; ++j) {
+        p[j] += WY(i, pointr) * neggi;
+        p[col + j] += WS(i, pointr) * neggi;
+        pointr = (pointr + 1) % m;
+      }
+      if (nbd_[i] <= 2 && nbd_[i] != 0 && neggi < 0.0) {
+        iorder[nbreak] = i;
+        t[nbreak] = tl / (-neggi);
+        if (nbreak == 0 || t[nbreak] < bkmin) { bkmin = t[nbreak]; ibkmin = nbreak; }
+        ++nbreak;
+      } else if (nbd_[i] >= 2 && neggi > 0.0) {
+        iorder[nbreak] = i;
+        t[nbreak] = tu / neggi;
+        if (nbreak == 0 || t[nbreak] < bkmin) { bkmin = t[nbreak]; ibkmin = nbreak; }
+        ++nbreak;
+      } else {
+        --nfree;
+        iorder[nfree] = i;
+        if (std::fabs(neggi) > 0.0) bnded = false;
+      }
+    }
+  }
+  if (theta_ != 1.0)
+    for (int j = 0; j < col; ++j) p[col + j] *= theta_;
+  std::memcpy(xcp, x, sizeof(double) * n);
+  if (nbreak == 0 && nfree == n) return;
+  for (int j = 0; j < col2; ++j) c[j] = 0.0;
+  double f2 = -theta_ * f1;
+  const double f2_org = f2;
+  if (col > 0) {
+    bmv(p, v);
+    if (info_ != 0) return;
+    f2 -= ddot(col2, v, p);
+  }
+  double dtm = -f1 / f2;
+  double tsum = 0.0;
+  nseg_ = 1;
+  bool skip_to_999 = false;
+  if (nbreak > 0) {
+    int nleft = nbreak, iter = 1;
+    double tj = 0.0;
+    while (true) {
+      const double tj0 = tj;
+      int ibp;
+      if (iter == 1) {
+        tj = bkmin;
+        ibp = iorder[ibkmin];
+      } else {
+        if (iter == 2) {
+          if (ibkmin != nbreak - 1) { t[ibkmin] = t[nbreak - 1]; iorder[ibkmin] = iorder[nbreak - 1]; }
+        }
+        hpsolb(nleft, t, iorder, iter - 2);
+        tj = t[nleft - 1];
+        ibp = iorder[nleft - 1];
+      }
+      const double dt = tj - tj0;
+      if (dtm < dt) break;                     // minimiser inside this segment
+      tsum += dt;
+      --nleft;
+      ++iter;
+      const double dibp = d[ibp];
+      d[ibp] = 0.0;
+      double zibp;
+      if (dibp > 0.0) { zibp = u_[ibp] - x[ibp]; xcp[ibp] = u_[ibp]; iwhere_[ibp] = 2; }
+      else { zibp = l_[ibp] - x[ibp]; xcp[ibp] = l_[ibp]; iwhere_[ibp] = 1; }
+      if (nleft == 0 && nbreak == n) { dtm = dt; skip_to_999 = true; break; }
+      ++nseg_;
+      const double dibp2 = dibp * dibp;
+      f1 = f1 + dt * f2 + dibp2 - theta_ * dibp * zibp;
+      f2 = f2 - theta_ * dibp2;
+      if (col > 0) {
+        for (int j = 0; j < col2; ++j) c[j] += dt * p[j];
+        int pointr = head_;
+        for (int j = 0; j < col; ++j) {
+          wbp[j] = WY(ibp, pointr);
+          wbp[col + j] = theta_ * WS(ibp, pointr);
+          pointr = (pointr + 1) % m;
+        }
+        bmv(wbp, v);
+        if (info_ != 0) return;
+        const double wmc = ddot(col2, c, v);
+        const double wmp = ddot(col2, p, v);
+        const double wmw = ddot(col2, wbp, v);
+        for (int j = 0; j < col2; ++j) p[j] -= dibp * wbp[j];
+        f1 += dibp * wmc;
+        f2 = f2 + 2.0 * dibp * wmp - dibp2 * wmw;
+      }
+      f2 = std::fmax(epsmch_ * f2_org, f2);
+      if (nleft > 0) {
+        dtm = -f1 / f2;
+        continue;
+      } else if (bnded) {
+        f1 = 0.0; f2 = 0.0; dtm = 0.0;
+      } else {
+        dtm = -f1 / f2;
+      }
+      break;
+    }
+  }
+  if (!skip_to_999) {
+    if (dtm <= 0.0) dtm = 0.0;
+    tsum += dtm;
+    for (int i = 0; i < n; ++i) xcp[i] += tsum * d[i];
+  }
+  if (col > 0)
+    for (int j = 0; j < col2; ++j) c[j] += dtm * p[j];
+}
+
+void Lbfgsb::freev() {
+  const int n = n_;
+  nenter_ = 0;
+  ileave_ = n;
+  if (iter_ > 0 && cnstnd_) {
+    for (int i = 0; i < nfree_; ++i) {
+      int k = index_[i];
+      if (iwhere_[k] > 0) { --ileave_; indx2_[ileave_] = k; }
+    }
+    for (int i = nfree_; i < n; ++i) {
+      int k = index_[i];
+      if (iwhere_[k] <= 0) { indx2_[nenter_] = k; ++nenter_; }
+    }
+  }
+  wrk_ = (ileave_ < n) || (nenter_ > 0) || updatd_;
+  nfree_ = 0;
+  int iact = n;
+  for (int i = 0; i < n; ++i) {
+    if (iwhere_[i] <= 0) { index_[nfree_] = i; ++nfree_; }
+    else { --iact; index_[iact] = i; }
+  }
+}
+
+// LEL^T factorisation of the indefinite subspace matrix
+void Lbfgsb::formk() {
+  const int n = n_, m = m_, col = col_, head = head_, nsub = nfree_;
+  const int* ind = index_.data();
+  const int* indx2 = indx2_.data();
+  int upcl;
+  if (updatd_) {
+    if (iupdat_ > m) {
+      for (int jy = 0; jy < m - 1; ++jy) {
+        const int js = m + jy;
+        for (int t = 0; t < m - 1 - jy; ++t) {
+          WN1(jy + t, jy) = WN1(jy + 1 + t, jy + 1);
+          WN1(js + t, js) = WN1(js + 1 + t, js + 1);
+        }
+        for (int t = 0; t < m - 1; ++t) WN1(m + t, jy) = WN1(m + 1 + t, jy + 1);
+      }
+    }
+    int ipntr = (head + col - 1) % m;
+    const int iy = col - 1, is = m + col - 1;
+    int jpntr = head;
+    for (int jy = 0; jy < col; ++jy) {
+      const int js = m + jy;
+      double temp1 = 0.0, temp2 = 0.0, temp3 = 0.0;
+      for (int k = 0; k < nsub; ++k) { int k1 = ind[k]; temp1 += WY(k1, ipntr) * WY(k1, jpntr); }
+      for (int k = nsub; k < n; ++k) {
+        int k1 = ind[k];
+        temp2 += WS(k1, ipntr) * WS(k1, jpntr);
+        temp3 += WS(k1, ipntr) * WY(k1, jpntr);
+      }
+      WN1(iy, jy) = temp1; WN1(is, js) = temp2; WN1(is, jy) = temp3;
+      jpntr = (jpntr + 1) % m;
+    }
+    const int jyc = col - 1;
+    jpntr = (head + col - 1) % m;
+    ipntr = head;
+    for (int i = 0; i < col; ++i) {
+      const int is2 = m + i;
+      double temp3 = 0.0;
+      for (int k = 0; k < nsub; ++k) { int k1 = ind[k]; temp3 += WS(k1, ipntr) * WY(k1, jpntr); }
+      ipntr = (ipntr + 1) % m;
+      WN1(is2, jyc) = temp3;
+    }
+    upcl = col - 1;
+  } else {
+    upcl = col;
+  }
+  int ipntr = head;
+  for (int iy = 0; iy < upcl; ++iy) {
+    const int is = m + iy;
+    int jpntr = head;
+    for (int jy = 0; jy <= iy; ++jy) {
+      const int js = m + jy;
+      double temp1 = 0.0, temp2 = 0.0, temp3 = 0.0, temp4 = 0.0;
+      for (int k = 0; k < nenter_; ++k) {
+        int k1 = indx2[k];
+        temp1 += WY(k1, ipntr) * WY(k1, jpntr);
+        temp2 += WS(k1, ipntr) * WS(k1, jpntr);
+      }
+      for (int k = ileave_; k < n; ++k) {
+        int k1 = indx2[k];
+        temp3 += WY(k1, ipntr) * WY(k1, jpntr);
+        temp4 += WS(k1, ipntr) * WS(k1, jpntr);
+      }
+      WN1(iy, jy) = WN1(iy, jy) + temp1 - temp3;
+      WN1(is, js) = WN1(is, js) - temp2 + temp4;
+      jpntr = (jpntr + 1) % m;
+    }
+    ipntr = (ipntr + 1) % m;
+  }
+  ipntr = head;
+  for (int is = m; is < m + upcl; ++is) {
+    int jpntr = head;
+    for (int jy = 0; jy < upcl; ++jy) {
+      double temp1 = 0.0, temp3 = 0.0;
+      for (int k = 0; k < nenter_; ++k) { int k1 = indx2[k]; temp1 += WS(k1, ipntr) * WY(k1, jpntr); }
+      for (int k = ileave_; k < n; ++k) { int k1 = indx2[k]; temp3 += WS(k1, ipntr) * WY(k1, jpntr); }
+      if (is <= jy + m) WN1(is, jy) = WN1(is, jy) + temp1 - temp3;
+      else WN1(is, jy) = WN1(is, jy) - temp1 + temp3;
+      jpntr = (jpntr + 1) % m;
+    }
+    ipntr = (ipntr + 1) % m;
+  }
+  const int m2 = 2 * m;
+  for (int iy = 0; iy < col; ++iy) {
+    const int is = col + iy, is1 = m + iy;
+    for (int jy = 0; jy <= iy; ++jy) {
+      const int js = col + jy, js1 = m + jy;
+      WN(jy, iy) = WN1(iy, jy) / theta_;
+      WN(js, is) = WN1(is1, js1) * theta_;
+    }
+    for (int jy = 0; jy < iy; ++jy) WN(jy, is) = -WN1(is1, jy);
+    for (int jy = iy; jy < col; ++jy) WN(jy, is) = WN1(is1, jy);
+    WN(iy, iy) += SY(iy, iy);
+  }
+  int info = dpofa(wn_.data(), m2, col);
+  if (info != 0) { info_ = -1; return; }
+  const int col2 = 2 * col;
+  for (int js = col; js < col2; ++js) dtrsl(wn_.data(), m2, col, &WN(0, js), 11);
+  for (int is = col; is < col2; ++is)
+    for (int js = is; js < col2; ++js) WN(is, js) += ddot(col, &WN(0, is), &WN(0, js));
+  info = dpofa(&WN(col, col), m2, col);
+  if (info != 0) info_ = -2;
+}
+
+void Lbfgsb::cmprlb(const double* x, const double* g) {
+  const int n = n_, m = m_, col = col_;
+  if (!cnstnd_ && col > 0) {
+    for (int i = 0; i < n; ++i) r_[i] = -g[i];
+    return;
+  }
+  for (int i = 0; i < nfree_; ++i) { int k = index_[i]; r_[i] = -theta_ * (z_[k] - x[k]) - g[k]; }
+  bmv(wa_.data() + 2 * m, wa_.data());
+  if (info_ != 0) { info_ = -8; return; }
+  int pointr = head_;
+  for (int j = 0; j < col; ++j) {
+    const double a1 = wa_[j], a2 = theta_ * wa_[col + j];
+    for (int i = 0; i < nfree_; ++i) { int k = index_[i]; r_[i] += WY(k, pointr) * a1 + WS(k, pointr) * a2; }
+    pointr = (pointr + 1) % m;
+  }
+}
+
+void Lbfgsb::subsm(const double* xx, const double* gg) {
+  const int n = n_, m = m_, col = col_, nsub = nfree_;
+  const int* ind = index_.data();
+  double* x = z_.data();      // on entry the Cauchy point, on exit the subspace minimiser
+  double* d = r_.data();      // reduced gradient -> Newton direction
+  double* wv = wa_.data();
+  if (nsub <= 0) return;
+  int pointr = head_;
+  for (int i = 0; i < col; ++i) {
+    double temp1 = 0.0, temp2 = 0.0;
+    for (int j = 0; j < nsub; ++j) { int k = ind[j]; temp1 += WY(k, pointr) * d[j]; temp2 += WS(k, pointr) * d[j]; }
+    wv[i] = temp1;
+    wv[col + i] = theta_ * temp2;
+    pointr = (pointr + 1) % m;
+  }
+  const int m2 = 2 * m, col2 = 2 * col;
+  info_ = dtrsl(wn_.data(), m2, col2, wv, 11);
+  if (info_ != 0) return;
+  for (int i = 0; i < col; ++i) wv[i] = -wv[i];
+  info_ = dtrsl(wn_.data(), m2, col2, wv, 1);
+  if (info_ != 0) return;
+  pointr = head_;
+  for (int jy = 0; jy < col; ++jy) {
+    const int js = col + jy;
+    for (int i = 0; i < nsub; ++i) {
+      int k = ind[i];
+      d[i] = d[i] + WY(k, pointr) * wv[jy] / theta_ + WS(k, pointr) * wv[js];
+    }
+    pointr = (pointr + 1) % m;
+  }
+  const double inv_theta = 1.0 / theta_;
+  for (int i = 0; i < nsub; ++i) d[i] *= inv_theta;
+  // projected Newton step (3.0), falling back to a truncated step when it is not a descent direction
+  iword_ = 0;
+  std::memcpy(xp_.data(), x, sizeof(double) * n);
+  for (int i = 0; i < nsub; ++i) {
+    const int k = ind[i];
+    const double dk = d[i];
+    double xk = x[k];
+    if (nbd_[k] != 0) {
+      if (nbd_[k] == 1) {
+        x[k] = std::fmax(l_[k], xk + dk);
+        if (x[k] == l_[k]) iword_ = 1;
+      } else if (nbd_[k] == 2) {
+        xk = std::fmax(l_[k], xk + dk);
+        x[k] = std::fmin(u_[k], xk);
+        if (x[k] == l_[k] || x[k] == u_[k]) iword_ = 1;
+      } else if (nbd_[k] == 3) {
+        x[k] = std::fmin(u_[k], xk + dk);
+        if (x[k] == u_[k]) iword_ = 1;
+      }
+    } else {
+      x[k] = xk + dk;
+    }
+  }
+  if (iword_ == 0) return;
+  double dd_p = 0.0;
+  for (int i = 0; i < n; ++i) dd_p += (x[i] - xx[i]) * gg[i];
+  if (dd_p > 0.0) {
+    std::memcpy(x, xp_.data(), sizeof(double) * n);
+    double alpha = 1.0, temp1 = alpha;
+    int ibd = 0;
+    for (int i = 0; i < nsub; ++i) {
+      const int k = ind[i];
+      const double dk = d[i];
+      if (nbd_[k] != 0) {
+        if (dk < 0.0 && nbd_[k] <= 2) {
+          double temp2 = l_[k] - x[k];
+          if (temp2 >= 0.0) temp1 = 0.0;
+          else if (dk * alpha < temp2) temp1 = temp2 / dk;
+        } else if (dk > 0.0 && nbd_[k] >= 2) {
+          double temp2 = u_[k] - x[k];
+          if (temp2 <= 0.0) temp1 = 0.0;
+          else if (dk * alpha > temp2) temp1 = temp2 / dk;
+        }
+        if (temp1 < alpha) { alpha = temp1; ibd = i; }
+      }
+    }
+    if (alpha < 1.0) {
+      const double dk = d[ibd];
+      const int k = ind[ibd];
+      if (dk > 0.0) { x[k] = u_[k]; d[ibd] = 0.0; }
+      else if (dk < 0.0) { x[k] = l_[k]; d[ibd] = 0.0; }
+    }
+    for (int i = 0; i < nsub; ++i) { int k = ind[i]; x[k] += alpha * d[i]; }
+  }
+}
+
+void Lbfgsb::dcstep(double* stx, double* fx, double* dx, double* sty, double* fy, double* dy, double* stp, double fp,
+                    double dp, bool* brackt, double stpmin, double stpmax) {
+  const double sgnd = dp * (*dx / std::fabs(*dx));
+  double stpf, stpc, stpq, theta, s, gamma, p, q, r;
+  if (fp > *fx) {
+    theta = 3.0 * (*fx - fp) / (*stp - *stx) + *dx + dp;
+    s = std::fmax(std::fabs(theta), std::fmax(std::fabs(*dx), std::fabs(dp)));
+    gamma = s * std::sqrt((theta / s) * (theta / s) - (*dx / s) * (dp / s));
+    if (*stp < *stx) gamma = -gamma;
+    p = (gamma - *dx) + theta;
+    q = ((gamma - *dx) + gamma) + dp;
+    r = p / q;
+    stpc = *stx + r * (*stp - *stx);
+    stpq = *stx + ((*dx / ((*fx - fp) / (*stp - *stx) + *dx)) / 2.0) * (*stp - *stx);
+    if (std::fabs(stpc - *stx) < std::fabs(stpq - *stx)) stpf = stpc;
+    else stpf = stpc + (stpq - stpc) / 2.0;
+    *brackt = true;
+  } else if (sgnd < 0.0) {
+    theta = 3.0 * (*fx - fp) / (*stp - *stx) + *dx + dp;
+    s = std::fmax(std::fabs(theta), std::fmax(std::fabs(*dx), std::fabs(dp)));
+    gamma = s * std::sqrt((theta / s) * (theta / s) - (*dx / s) * (dp / s));
+    if (*stp > *stx) gamma = -gamma;
+    p = (gamma - dp) + theta;
+    q = ((gamma - dp) + gamma) + *dx;
+    r = p / q;
+    stpc = *stp + r * (*stx - *stp);
+    stpq = *stp + (dp / (dp - *dx)) * (*stx - *stp);
+    if (std::fabs(stpc - *stp) > std::fabs(stpq - *stp)) stpf = stpc;
+    else stpf = stpq;
+    *brackt = true;
+  } else if (std::fabs(dp) < std::fabs(*dx)) {
+    theta = 3.0 * (*fx - fp) / (*stp - *stx) + *dx + dp;
+    s = std::fmax(std::fabs(theta), std::fmax(std::fabs(*dx), std::fabs(dp)));
+    gamma = s * std::sqrt(std::fmax(0.0, (theta / s) * (theta / s) - (*dx / s) * (dp / s)));
+    if (*stp > *stx) gamma = -gamma;
+    p = (gamma - dp) + theta;
+    q = (gamma + (*dx - dp)) + gamma;
+    r = p / q;
+    if (r < 0.0 && gamma != 0.0) stpc = *stp + r * (*stx - *stp);
+    else if (*stp > *stx) stpc = stpmax;
+    else stpc = stpmin;
+    stpq = *stp + (dp / (dp - *dx)) * (*stx - *stp);
+    if (*brackt) {
+      if (std::fabs(stpc - *stp) < std::fabs(stpq - *stp)) stpf = stpc;
+      else stpf = stpq;
+      if (*stp > *stx) stpf = std::fmin(*stp + 0.66 * (*sty - *stp), stpf);
+      else stpf = std::fmax(*stp + 0.66 * (*sty - *stp), stpf);
+    } else {
+      if (std::fabs(stpc - *stp) > std::fabs(stpq - *stp)) stpf = stpc;
+      else stpf = stpq;
+      stpf = std::fmin(stpmax, stpf);
+      stpf = std::fmax(stpmin, stpf);
+    }
+  } else {
+    if (*brackt) {
+      theta = 3.0 * (fp - *fy) / (*sty - *stp) + *dy + dp;
+      s = std::fmax(std::fabs(theta), std::fmax(std::fabs(*dy), std::fabs(dp)));
+      gamma = s * std::sqrt((theta / s) * (theta / s) - (*dy / s) * (dp / s));
+      if (*stp > *sty) gamma = -gamma;
+      p = (gamma - dp) + theta;
+      q = ((gamma - dp) + gamma) + *dy;
+      r = p / q;
+      stpc = *stp + r * (*sty - *stp);
+      stpf = stpc;
+    } else if (*stp > *stx) stpf = stpmax;
+    else stpf = stpmin;
+  }
+  if (fp > *fx) { *sty = *stp; *fy = fp; *dy = dp; }
+  else {
+    if (sgnd < 0.0) { *sty = *stx; *fy = *fx; *dy = *dx; }
+    *stx = *stp; *fx = fp; *dx = dp;
+  }
+  *stp = stpf;
+}
+
+void Lbfgsb::dcsrch(double f, double g, double* stp, double ftol, double gtol, double xtol, double stpmin,
+                    double stpmax, Dcsrch& s) {
+  const double xtrapl = 1.1, xtrapu = 4.0, p5 = 0.5, p66 = 0.66;
+  if (s.task == 0) {
+    if (*stp < stpmin || *stp > stpmax || g >= 0.0) { s.task = 4; return; }
+    s.brackt = false; s.stage = 1; s.finit = f; s.ginit = g; s.gtest = ftol * s.ginit;
+    s.width = stpmax - stpmin; s.width1 = s.width / p5;
+    s.stx = 0.0; s.fx = s.finit; s.gx = s.ginit; s.sty = 0.0; s.fy = s.finit; s.gy = s.ginit;
+    s.stmin = 0.0; s.stmax = *stp + xtrapu * *stp;
+    s.task = 1;
+    return;
+  }
+  const double ftest = s.finit + *stp * s.gtest;
+  if (s.stage == 1 && f <= ftest && g >= 0.0) s.stage = 2;
+  int task = 1;
+  if (s.brackt && (*stp <= s.stmin || *stp >= s.stmax)) task = 3;
+  if (s.brackt && s.stmax - s.stmin <= xtol * s.stmax) task = 3;
+  if (*stp == stpmax && f <= ftest && g <= s.gtest) task = 3;
+  if (*stp == stpmin && (f > ftest || g >= s.gtest)) task = 3;
+  if (f <= ftest && std::fabs(g) <= gtol * (-s.ginit)) task = 2;
+  if (task == 2 || task == 3) { s.task = task; return; }
+  if (s.stage == 1 && f <= s.fx && f > ftest) {
+    double fm = f - *stp * s.gtest, fxm = s.fx - s.stx * s.gtest, fym = s.fy - s.sty * s.gtest;
+    double gm = g - s.gtest, gxm = s.gx - s.gtest, gym = s.gy - s.gtest;
+    dcstep(&s.stx, &fxm, &gxm, &s.sty, &fym, &gym, stp, fm, gm, &s.brackt, s.stmin, s.stmax);
+    s.fx = fxm + s.stx * s.gtest; s.fy = fym + s.sty * s.gtest; s.gx = gxm + s.gtest; s.gy = gym + s.gtest;
+  } else {
+    dcstep(&s.stx, &s.fx, &s.gx, &s.sty, &s.fy, &s.gy, stp, f, g, &s.brackt, s.stmin, s.stmax);
+  }
+  if (s.brackt) {
+    if (std::fabs(s.sty - s.stx) >= p66 * s.width1) *stp = s.stx + p5 * (s.sty - s.stx);
+    s.width1 = s.width;
+    s.width = std::fabs(s.sty - s.stx);
+  }
+  if (s.brackt) { s.stmin = std::fmin(s.stx, s.sty); s.stmax = std::fmax(s.stx, s.sty); }
+  else { s.stmin = *stp + xtrapl * (*stp - s.stx); s.stmax = *stp + xtrapu * (*stp - s.stx); }
+  *stp = std::fmax(*stp, stpmin);
+  *stp = std::fmin(*stp, stpmax);
+  if ((s.brackt && (*stp <= s.stmin || *stp >= s.stmax)) || (s.brackt && s.stmax - s.stmin <= xtol * s.stmax))
+    *stp = s.stx;
+  s.task = 1;
+}
+
+// One call of the line-search driver.  Sets task_ to LBFGSB_FG (x holds the trial point) or
+// LBFGSB_NEW_X (line search finished); info_ != 0 on failure.
+void Lbfgsb::lnsrlb(double* x, double f, const double* g) {
+  const int n = n_;
+  const double big = 1e10, ftol = 1e-3, gtol = 0.9, xtol = 0.1;
+  if (phase_ != 2) {
+    dtd_ = ddot(n, d_.data(), d_.data());
+    dnorm_ = std::sqrt(dtd_);
+    stpmx_ = big;
+    if (cnstnd_) {
+      if (iter_ == 0) stpmx_ = 1.0;
+      else {
+        for (int i = 0; i < n; ++i) {
+          const double a1 = d_[i];
+          if (nbd_[i] != 0) {
+            if (a1 < 0.0 && nbd_[i] <= 2) {
+              double a2 = l_[i] - x[i];
+              if (a2 >= 0.0) stpmx_ = 0.0;
+              else if (a1 * stpmx_ < a2) stpmx_ = a2 / a1;
+            } else if (a1 > 0.0 && nbd_[i] >= 2) {
+              double a2 = u_[i] - x[i];
+              if (a2 <= 0.0) stpmx_ = 0.0;
+              else if (a1 * stpmx_ > a2) stpmx_ = a2 / a1;
+            }
+          }
+        }
+      }
+    }
+    if (iter_ == 0 && !boxed_) stp_ = std::fmin(1.0 / dnorm_, stpmx_);
+    else stp_ = 1.0;
+    std::memcpy(t_.data(), x, sizeof(double) * n);
+    std::memcpy(r_.data(), g, sizeof(double) * n);
+    fold_ = f;
+    ifun_ = 0;
+    iback_ = 0;
+    ls_ = Dcsrch();
+  }
+  gd_ = ddot(n, g, d_.data());
+  if (ifun_ == 0) {
+    gdold_ = gd_;
+    if (gd_ >= 0.0) { info_ = -4; return; }     // ascent direction: line search impossible
+  }
+  dcsrch(f, gd_, &stp_, ftol, gtol, xtol, 0.0, stpmx_, ls_);
+  xstep_ = stp_ * dnorm_;
+  if (ls_.task != 2 && ls_.task != 3) {
+    task_ = LBFGSB_FG;
+    ++ifun_;
+    ++nfgv_;
+    iback_ = ifun_ - 1;
+    if (stp_ == 1.0) std::memcpy(x, z_.data(), sizeof(double) * n);
+    else
+      for (int i = 0; i < n; ++i) x[i] = stp_ * d_[i] + t_[i];
+  } else {
+    task_ = LBFGSB_NEW_X;
+  }
+}
+
+void Lbfgsb::matupd(double rr, double dr) {
+  const int n = n_, m = m_;
+  if (iupdat_ <= m) {
+    col_ = iupdat_;
+    itail_ = (head_ + iupdat_ - 1) % m;
+  } else {
+    itail_ = (itail_ + 1) % m;
+    head_ = (head_ + 1) % m;
+  }
+  std::memcpy(&WS(0, itail_), d_.data(), sizeof(double) * n);
+  std::memcpy(&WY(0, itail_), r_.data(), sizeof(double) * n);
+  theta_ = rr / dr;
+  const int col = col_;
+  if (iupdat_ > m) {
+    for (int j = 0; j < col - 1; ++j) {
+      for (int t = 0; t <= j; ++t) SS(t, j) = SS(t + 1, j + 1);
+      for (int t = 0; t < col - 1 - j; ++t) SY(j + t, j) = SY(j + 1 + t, j + 1);
+    }
+  }
+  int pointr = head_;
+  for (int j = 0; j < col - 1; ++j) {
+    SY(col - 1, j) = ddot(n, d_.data(), &WY(0, pointr));
+    SS(j, col - 1) = ddot(n, &WS(0, pointr), d_.data());
+    pointr = (pointr + 1) % m;
+  }
+  if (stp_ == 1.0) SS(col - 1, col - 1) = dtd_;
+  else SS(col - 1, col - 1) = stp_ * stp_ * dtd_;
+  SY(col - 1, col - 1) = dr;
+}
+
+void Lbfgsb::formt() {
+  const int col = col_;
+  for (int j = 0; j < col; ++j) WT(0, j) = theta_ * SS(0, j);
+  for (int i = 1; i < col; ++i) {
+    for (int j = i; j < col; ++j) {
+      const int k1 = (i < j ? i : j);
+      double ddum = 0.0;
+      for (int k = 0; k < k1; ++k) ddum += SY(i, k) * SY(j, k) / SY(k, k);
+      WT(i, j) = ddum + theta_ * SS(i, j);
+    }
+  }
+  int info = dpofa(wt_.data(), m_, col);
+  if (info != 0) info_ = -3;
+}
+
+int Lbfgsb::step(double* x, double* fp, double* g) {
+  const int n = n_;
+  double f = *fp;
+  if (task_ >= LBFGSB_CONV_PG) return task_;         // finished (or stopped by the caller)
+
+  bool need_iteration_start = false;   // jump target 222
+  bool resume_linesearch = false;      // jump target 666 with task FG_LN
+
+  if (phase_ == 0) {
+    epsmch_ = DBL_EPSILON;
+    col_ = 0; head_ = 0; theta_ = 1.0; iupdat_ = 0; updatd_ = false;
+    iback_ = 0; itail_ = 0; iword_ = 0; nact_ = 0; ileave_ = 0; nenter_ = 0;
+    fold_ = 0; dnorm_ = 0; gd_ = 0; stpmx_ = 0; sbgnrm_ = 0; stp_ = 0; gdold_ = 0; dtd_ = 0;
+    iter_ = 0; nfgv_ = 0; nseg_ = 0; nintol_ = 0; nskip_ = 0; nfree_ = n; ifun_ = 0;
+    tol_ = factr_ * epsmch_;
+    info_ = 0;
+    for (int i = 0; i < n; ++i)
+      if (nbd_[i] == 2 && l_[i] > u_[i]) { task_ = LBFGSB_ERROR; return task_; }
+    if (n <= 0 || m_ <= 0 || factr_ < 0.0) { task_ = LBFGSB_ERROR; return task_; }
+    active_init(x);
+    phase_ = 1;
+    task_ = LBFGSB_FG;
+    return task_;
+  }
+  if (phase_ == 1) {
+    nfgv_ = 1;
+    projgr(x, g);
+    if (sbgnrm_ <= pgtol_) { task_ = LBFGSB_CONV_PG; return task_; }
+    need_iteration_start = true;
+  } else if (phase_ == 2) {
+    resume_linesearch = true;
+  } else {  // phase_ == 3: back from NEW_X
+    if (sbgnrm_ <= pgtol_) { task_ = LBFGSB_CONV_PG; return task_; }
+    const double ddum = std::fmax(std::fmax(std::fabs(fold_), std::fabs(f)), 1.0);
+    if ((fold_ - f) <= tol_ * ddum) {
+      task_ = LBFGSB_CONV_F;
+      if (iback_ >= 10) info_ = -5;
+      return task_;
+    }
+    for (int i = 0; i < n; ++i) r_[i] = g[i] - r_[i];
+    const double rr = ddot(n, r_.data(), r_.data());
+    double dr, ddum2;
+    if (stp_ == 1.0) { dr = gd_ - gdold_; ddum2 = -gdold_; }
+    else {
+      dr = (gd_ - gdold_) * stp_;
+      for (int i = 0; i < n; ++i) d_[i] *= stp_;
+      ddum2 = -gdold_ * stp_;
+    }
+    if (dr <= epsmch_ * ddum2) {
+      ++nskip_;
+      updatd_ = false;
+    } else {
+      updatd_ = true;
+      ++iupdat_;
+      matupd(rr, dr);
+      formt();
+      if (info_ != 0) reset_memory();
+    }
+    need_iteration_start = true;
+  }
+
+  while (true) {
+    if (need_iteration_start) {
+      need_iteration_start = false;
+      // ----- 222: start of an iteration -----
+      iword_ = -1;
+      bool skip_cauchy = (!cnstnd_ && col_ > 0);
+      if (skip_cauchy) {
+        std::memcpy(z_.data(), x, sizeof(double) * n);
+        wrk_ = updatd_;
+        nseg_ = 0;
+      } else {
+        cauchy(x, g);
+        if (info_ != 0) { reset_memory(); need_iteration_start = true; continue; }
+        nintol_ += nseg_;
+        freev();
+        nact_ = n - nfree_;
+      }
+      // ----- 333: subspace minimisation -----
+      if (nfree_ != 0 && col_ != 0) {
+        if (wrk_) formk();
+        if (info_ != 0) { reset_memory(); need_iteration_start = true; continue; }
+        cmprlb(x, g);
+        if (info_ == 0) subsm(x, g);
+        if (info_ != 0) { reset_memory(); need_iteration_start = true; continue; }
+      }
+      // ----- 555: line search direction -----
+      for (int i = 0; i < n; ++i) d_[i] = z_[i] - x[i];
+      phase_ = 0;   // lnsrlb: fresh line search (anything != 2)
+    }
+    // ----- 666 -----
+    if (resume_linesearch) { resume_linesearch = false; phase_ = 2; }
+    lnsrlb(x, f, g);
+    if (info_ != 0 || iback_ >= maxls_) {
+      std::memcpy(x, t_.data(), sizeof(double) * n);
+      std::memcpy(g, r_.data(), sizeof(double) * n);
+      f = fold_;
+      *fp = f;
+      if (col_ == 0) {
+        if (info_ == 0) { info_ = -9; --nfgv_; --ifun_; --iback_; }
+        task_ = LBFGSB_ABNORMAL;
+        ++iter_;
+        return task_;
+      }
+      if (info_ == 0) --nfgv_;
+      reset_memory();
+      need_iteration_start = true;
+      continue;
+    }
+    if (task_ == LBFGSB_FG) { phase_ = 2; return task_; }
+    // NEW_X
+    ++iter_;
+    projgr(x, g);
+    phase_ = 3;
+    task_ = LBFGSB_NEW_X;
+    return task_;
+  }
+}

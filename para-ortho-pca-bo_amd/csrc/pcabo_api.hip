@@ -1,0 +1,583 @@
+// C-ABI of libpcabo.so (declared in include/pcabo.h): context management, host<->device staging and
+// the launch sequences of the wPCA / GP-conditioning / acquisition phases.
+#include "../../include/pcabo.h"
+#include "pcabo_internal.h"
+#include "lbfgsb.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#define PCABO_ABI_VERSION 1
+#define PROF_GROUPS 6
+#define PROF_POOL 4096
+
+struct ProfPair { hipEvent_t a, b; int group; };
+
+struct pcabo_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int max_n = 0, max_d = 0, max_q = 0;
+  int NPcap = 0, ld = 0, DPcap = 0, KPcap = 0, Scap = 0;
+  int ptr_mode = PCABO_PTR_HOST;
+  // problem state
+  int n = 0, d = 0, k = 0, NP = 0, KP = 0;
+  bool have_wpca = false, have_gp = false;
+  double lengthscale = 0.0, noise = 0.0;
+  int kernel = 0;
+  // device buffers
+  double *dX = nullptr, *dNoise = nullptr, *dF = nullptr, *dWeights = nullptr, *dWc = nullptr;
+  long long* dRanks = nullptr;
+  double *dDataMean = nullptr, *dPcaMean = nullptr, *dC = nullptr, *dG = nullptr, *dLam = nullptr;
+  double *dComps = nullptr, *dEvr = nullptr, *dZ = nullptr;
+  int *dK = nullptr, *dSweeps = nullptr, *dInfo = nullptr;
+  double *dY = nullptr, *dYs = nullptr, *dYstats = nullptr, *dBounds4 = nullptr, *dZnMean = nullptr, *dUserNB = nullptr;
+  double *dZnT = nullptr, *dAT = nullptr, *dNrm = nullptr, *dGram = nullptr, *dL = nullptr, *dR = nullptr;
+  double *dTmp = nullptr, *dAlpha = nullptr;
+  double *dXq = nullptr, *dPartial = nullptr, *dVal = nullptr, *dGrad = nullptr, *dZq = nullptr, *dXout = nullptr;
+  // pinned host
+  HostMirror* hm = nullptr;
+  double *hXq = nullptr, *hVal = nullptr, *hGrad = nullptr, *hSmall = nullptr;
+  unsigned long long seq = 0;
+  char err[512] = {0};
+  // profiling
+  bool prof = false;
+  std::vector<ProfPair> pairs;
+  size_t pairs_used = 0;
+  double prof_ms[PROF_GROUPS] = {0};
+  int64_t prof_launches[PROF_GROUPS] = {0};
+};
+
+static int set_err(pcabo_ctx* c, int code, const char* fmt, const char* a = "", int v = 0) {
+  if (c) snprintf(c->err, sizeof(c->err), fmt, a, v);
+  return code;
+}
+#define HIPCHK(call)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess) return set_err(ctx, PCABO_ERR_HIP, "HIP error: %s (line %d)", hipGetErrorString(e_), __LINE__); \
+  } while (0)
+
+// ---- profiling helpers ------------------------------------------------------------------------
+static void prof_resolve(pcabo_ctx* c) {
+  if (c->pairs_used == 0) return;
+  hipStreamSynchronize(c->stream);
+  for (size_t i = 0; i < c->pairs_used; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->pairs[i].a, c->pairs[i].b) == hipSuccess) {
+      c->prof_ms[c->pairs[i].group] += ms;
+      c->prof_launches[c->pairs[i].group] += 1;
+    }
+  }
+  c->pairs_used = 0;
+}
+struct ProfScope {
+  pcabo_ctx* c; ProfPair* p = nullptr;
+  ProfScope(pcabo_ctx* ctx, int group) : c(ctx) {
+    if (!c->prof) return;
+    if (c->pairs_used == c->pairs.size()) prof_resolve(c);
+    p = &c->pairs[c->pairs_used++];
+    p->group = group;
+    hipEventRecord(p->a, c->stream);
+  }
+  ~ProfScope() { if (p) hipEventRecord(p->b, c->stream); }
+};
+
+template <typename T>
+static hipError_t dalloc(T** p, size_t count) { return hipMalloc((void**)p, count * sizeof(T)); }
+
+extern "C" {
+
+int pcabo_abi_version(void) { return PCABO_ABI_VERSION; }
+
+int pcabo_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int pcabo_ctx_create(int device, int max_n, int max_d, int max_q, pcabo_ctx** out) {
+  if (!out) return PCABO_ERR_ARG;
+  *out = nullptr;
+  if (max_n < 2 || max_d < 1 || max_d > PCABO_MAXD || max_q < 1) return PCABO_ERR_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return PCABO_ERR_HIP;
+  pcabo_ctx* ctx = new (std::nothrow) pcabo_ctx();
+  if (!ctx) return PCABO_ERR_HIP;
+  *out = ctx;                       // handed back even on failure so the caller can read the message
+  ctx->device = device;
+  ctx->max_n = max_n; ctx->max_d = max_d; ctx->max_q = max_q;
+  ctx->NPcap = round_up(max_n, PCABO_BS);
+  ctx->ld = ctx->NPcap;
+  ctx->DPcap = round_up(max_d, 16);
+  ctx->KPcap = round_up(max_d, 4);
+  ctx->Scap = ctx->NPcap / PCABO_SLAB;
+  HIPCHK(hipSetDevice(device));
+  HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  const size_t N = ctx->NPcap, D = ctx->DPcap, n = max_n, d = max_d, Q = max_q;
+  HIPCHK(dalloc(&ctx->dX, n * d));       HIPCHK(dalloc(&ctx->dNoise, n * d));
+  HIPCHK(dalloc(&ctx->dF, n));           HIPCHK(dalloc(&ctx->dWeights, n));
+  HIPCHK(dalloc(&ctx->dWc, (n + 4) * D)); HIPCHK(dalloc(&ctx->dRanks, n));
+  HIPCHK(dalloc(&ctx->dDataMean, d));    HIPCHK(dalloc(&ctx->dPcaMean, d));
+  HIPCHK(dalloc(&ctx->dC, D * D));       HIPCHK(dalloc(&ctx->dG, d * d));
+  HIPCHK(dalloc(&ctx->dLam, d));         HIPCHK(dalloc(&ctx->dComps, d * d));
+  HIPCHK(dalloc(&ctx->dEvr, d));         HIPCHK(dalloc(&ctx->dZ, n * d));
+  HIPCHK(dalloc(&ctx->dK, 1));           HIPCHK(dalloc(&ctx->dSweeps, 1));   HIPCHK(dalloc(&ctx->dInfo, 1));
+  HIPCHK(dalloc(&ctx->dY, n));           HIPCHK(dalloc(&ctx->dYs, N));
+  HIPCHK(dalloc(&ctx->dYstats, 2));      HIPCHK(dalloc(&ctx->dBounds4, 4 * PCABO_MAXD));
+  HIPCHK(dalloc(&ctx->dZnMean, PCABO_MAXD)); HIPCHK(dalloc(&ctx->dUserNB, 2 * PCABO_MAXD));
+  HIPCHK(dalloc(&ctx->dZnT, (size_t)ctx->KPcap * N)); HIPCHK(dalloc(&ctx->dAT, (size_t)ctx->KPcap * N));
+  HIPCHK(dalloc(&ctx->dNrm, N));
+  HIPCHK(dalloc(&ctx->dGram, N * N));    HIPCHK(dalloc(&ctx->dL, N * N));    HIPCHK(dalloc(&ctx->dR, N * N));
+  HIPCHK(dalloc(&ctx->dTmp, N));         HIPCHK(dalloc(&ctx->dAlpha, N));
+  HIPCHK(dalloc(&ctx->dXq, Q * d));
+  HIPCHK(dalloc(&ctx->dPartial, Q * (size_t)ctx->Scap * (2 + 2 * PCABO_MAXD)));
+  HIPCHK(dalloc(&ctx->dVal, Q));         HIPCHK(dalloc(&ctx->dGrad, Q * d));
+  HIPCHK(dalloc(&ctx->dZq, d));          HIPCHK(dalloc(&ctx->dXout, d));
+  HIPCHK(hipMemsetAsync(ctx->dYs, 0, N * sizeof(double), ctx->stream));
+  HIPCHK(hipHostMalloc((void**)&ctx->hm, sizeof(HostMirror), hipHostMallocDefault));
+  memset((void*)ctx->hm, 0, sizeof(HostMirror));
+  HIPCHK(hipHostMalloc((void**)&ctx->hXq, Q * d * sizeof(double), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&ctx->hVal, Q * sizeof(double), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&ctx->hGrad, Q * d * sizeof(double), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&ctx->hSmall, (d * d + 8 * d + 64) * sizeof(double), hipHostMallocDefault));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return PCABO_OK;
+}
+
+int pcabo_ctx_destroy(pcabo_ctx* ctx) {
+  if (!ctx) return PCABO_ERR_ARG;
+  hipSetDevice(ctx->device);
+  if (ctx->stream) hipStreamSynchronize(ctx->stream);
+  for (auto& p : ctx->pairs) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+  void* dev[] = {ctx->dX, ctx->dNoise, ctx->dF, ctx->dWeights, ctx->dWc, ctx->dRanks, ctx->dDataMean, ctx->dPcaMean,
+                 ctx->dC, ctx->dG, ctx->dLam, ctx->dComps, ctx->dEvr, ctx->dZ, ctx->dK, ctx->dSweeps, ctx->dInfo,
+                 ctx->dY, ctx->dYs, ctx->dYstats, ctx->dBounds4, ctx->dZnMean, ctx->dUserNB, ctx->dZnT, ctx->dAT,
+                 ctx->dNrm, ctx->dGram, ctx->dL, ctx->dR, ctx->dTmp, ctx->dAlpha, ctx->dXq, ctx->dPartial, ctx->dVal,
+                 ctx->dGrad, ctx->dZq, ctx->dXout};
+  for (void* p : dev) if (p) hipFree(p);
+  void* host[] = {(void*)ctx->hm, ctx->hXq, ctx->hVal, ctx->hGrad, ctx->hSmall};
+  for (void* p : host) if (p) hipHostFree(p);
+  if (ctx->stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return PCABO_OK;
+}
+
+int pcabo_set_pointer_mode(pcabo_ctx* ctx, int mode) {
+  if (!ctx || (mode != PCABO_PTR_HOST && mode != PCABO_PTR_DEVICE)) return PCABO_ERR_ARG;
+  ctx->ptr_mode = mode;
+  return PCABO_OK;
+}
+
+int pcabo_last_error(pcabo_ctx* ctx, char* buf, int buflen) {
+  if (!ctx || !buf || buflen <= 0) return PCABO_ERR_ARG;
+  snprintf(buf, buflen, "%s", ctx->err);
+  return PCABO_OK;
+}
+
+// bulk input: copy host data to the staging buffer, or use the caller's device pointer as is
+#define STAGE_IN(dst, src, count, T)                                                                        \
+  do {                                                                                                      \
+    if (ctx->ptr_mode == PCABO_PTR_HOST) {                                                                  \
+      HIPCHK(hipMemcpyAsync((void*)(dst), (const void*)(src), (size_t)(count) * sizeof(T), hipMemcpyHostToDevice, ctx->stream)); \
+    } else {                                                                                                \
+      HIPCHK(hipMemcpyAsync((void*)(dst), (const void*)(src), (size_t)(count) * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream)); \
+    }                                                                                                       \
+  } while (0)
+#define STAGE_OUT(dst, src, count, T)                                                                       \
+  do {                                                                                                      \
+    HIPCHK(hipMemcpyAsync((void*)(dst), (const void*)(src), (size_t)(count) * sizeof(T),                    \
+                          ctx->ptr_mode == PCABO_PTR_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, ctx->stream)); \
+  } while (0)
+#define HOST_OUT(dst, src, count, T) \
+  HIPCHK(hipMemcpyAsync((void*)(dst), (const void*)(src), (size_t)(count) * sizeof(T), hipMemcpyDeviceToHost, ctx->stream))
+
+int pcabo_wpca(pcabo_ctx* ctx, const double* X, const double* f, const int64_t* ranks, int n, int d, int maximize,
+               double var_threshold, int n_components, const double* noise, double* data_mean, double* pca_mean,
+               double* comps, double* evr, int* k, double* Z) {
+  if (!ctx) return PCABO_ERR_ARG;
+  if (!X || (!f && !ranks) || n < 2 || n > ctx->max_n || d < 1 || d > ctx->max_d)
+    return set_err(ctx, PCABO_ERR_ARG, "pcabo_wpca: bad argument or size beyond context capacity%s", "");
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const int DP = round_up(d, 16);
+  STAGE_IN(ctx->dX, X, (size_t)n * d, double);
+  if (ranks) {
+    STAGE_IN(ctx->dRanks, ranks, n, long long);
+  } else {
+    STAGE_IN(ctx->dF, f, n, double);
+    launch_rank(s, ctx->dF, n, maximize, ctx->dRanks);
+  }
+  if (noise) STAGE_IN(ctx->dNoise, noise, (size_t)n * d, double);
+  {
+    ProfScope ps(ctx, 0);
+    launch_wpca_prep(s, ctx->dX, ctx->dRanks, noise ? ctx->dNoise : nullptr, n, d, DP, ctx->dWeights, ctx->dDataMean,
+                     ctx->dPcaMean, ctx->dWc);
+    launch_cov(s, ctx->dWc, n, DP, ctx->dC);
+    launch_jacobi(s, ctx->dC, d, DP, ctx->dG, ctx->dLam, ctx->dSweeps);
+    launch_pca_finalize(s, ctx->dG, ctx->dLam, n, d, var_threshold, n_components, ctx->dComps, ctx->dEvr, ctx->dK,
+                        ctx->hm);
+    launch_project(s, ctx->dX, ctx->dDataMean, ctx->dPcaMean, ctx->dComps, ctx->dK, n, d, ctx->dZ);
+  }
+  const int rcount = n < d ? n : d;
+  if (data_mean) HOST_OUT(data_mean, ctx->dDataMean, d, double);
+  if (pca_mean) HOST_OUT(pca_mean, ctx->dPcaMean, d, double);
+  if (comps) HOST_OUT(comps, ctx->dComps, (size_t)rcount * d, double);
+  if (evr) HOST_OUT(evr, ctx->dEvr, rcount, double);
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipGetLastError());
+  ctx->n = n; ctx->d = d; ctx->k = ctx->hm->k;
+  ctx->have_wpca = true; ctx->have_gp = false;
+  if (k) *k = ctx->k;
+  if (Z) {
+    STAGE_OUT(Z, ctx->dZ, (size_t)n * ctx->k, double);
+    HIPCHK(hipStreamSynchronize(s));
+  }
+  return PCABO_OK;
+}
+
+static int run_factorisation(pcabo_ctx* ctx, double jitter) {
+  hipStream_t s = ctx->stream;
+  const size_t bytes = (size_t)ctx->NP * ctx->ld * sizeof(double);
+  HIPCHK(hipMemcpyAsync(ctx->dL, ctx->dGram, bytes, hipMemcpyDeviceToDevice, s));
+  if (jitter > 0.0) launch_add_jitter(s, ctx->dL, ctx->n, ctx->ld, jitter);
+  HIPCHK(hipMemsetAsync(ctx->dInfo, 0, sizeof(int), s));
+  { ProfScope ps(ctx, 2); launch_cholesky(s, ctx->dL, ctx->NP, ctx->ld, ctx->dInfo); }
+  {
+    ProfScope ps(ctx, 3);
+    launch_trinv(s, ctx->dL, ctx->NP, ctx->ld, ctx->dR);
+    launch_alpha(s, ctx->dR, ctx->dYs, ctx->n, ctx->NP, ctx->ld, ctx->dTmp, ctx->dAlpha);
+  }
+  HIPCHK(hipMemcpyAsync((void*)&ctx->hm->chol_info, ctx->dInfo, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipGetLastError());
+  return PCABO_OK;
+}
+
+int pcabo_gp_condition(pcabo_ctx* ctx, const double* Z, const double* y, int n, int k, const double* norm_bounds,
+                       double lengthscale, double noise, int kernel) {
+  if (!ctx) return PCABO_ERR_ARG;
+  if (!y || n < 2 || n > ctx->max_n || k < 1 || k > ctx->max_d || !(lengthscale > 0.0) || !(noise >= 0.0) ||
+      (kernel != PCABO_KERNEL_MATERN52 && kernel != PCABO_KERNEL_RBF))
+    return set_err(ctx, PCABO_ERR_ARG, "pcabo_gp_condition: bad argument or size beyond context capacity%s", "");
+  if (!Z && (!ctx->have_wpca || ctx->n != n || ctx->k != k))
+    return set_err(ctx, PCABO_ERR_ARG, "pcabo_gp_condition: Z == NULL needs a matching pcabo_wpca call first%s", "");
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  if (Z) STAGE_IN(ctx->dZ, Z, (size_t)n * k, double);
+  STAGE_IN(ctx->dY, y, n, double);
+  const double* unb = nullptr;
+  if (norm_bounds) {
+    HIPCHK(hipMemcpyAsync(ctx->dUserNB, norm_bounds, (size_t)2 * k * sizeof(double), hipMemcpyHostToDevice, s));
+    unb = ctx->dUserNB;
+  }
+  ctx->n = n; ctx->k = k;
+  ctx->NP = round_up(n, PCABO_BS);
+  ctx->KP = round_up(k, 4);
+  ctx->lengthscale = lengthscale; ctx->noise = noise; ctx->kernel = kernel;
+  ctx->have_gp = false;
+  {
+    ProfScope ps(ctx, 1);
+    launch_zstats(s, ctx->dZ, ctx->dY, n, k, unb, ctx->dBounds4, ctx->dZnMean, ctx->dYstats, ctx->dYs, ctx->hm);
+    launch_znorm(s, ctx->dZ, n, k, ctx->NP, ctx->KP, ctx->ld, ctx->dBounds4, ctx->dZnMean, 1.0 / lengthscale, ctx->dZnT,
+                 ctx->dAT, ctx->dNrm);
+    launch_gram(s, ctx->dAT, ctx->dNrm, n, ctx->NP, ctx->KP, ctx->ld, noise, kernel, ctx->dGram);
+  }
+  double jitter = 0.0;
+  for (int attempt = 0; attempt < 4; ++attempt) {       // psd_safe_cholesky: 0, 1e-8, 1e-7, 1e-6
+    int rc = run_factorisation(ctx, jitter);
+    if (rc != PCABO_OK) return rc;
+    if (ctx->hm->chol_info == 0) { ctx->have_gp = true; return PCABO_OK; }
+    jitter = (attempt == 0) ? 1e-8 : jitter * 10.0;
+  }
+  return set_err(ctx, PCABO_ERR_NOT_PD, "K + s2 I not positive definite after jitter retries (pivot %s%d)", "",
+                 ctx->hm->chol_info);
+}
+
+int pcabo_acq_bounds(pcabo_ctx* ctx, double* bounds) {
+  if (!ctx || !bounds) return PCABO_ERR_ARG;
+  if (!ctx->have_gp) return set_err(ctx, PCABO_ERR_ARG, "pcabo_acq_bounds: call pcabo_gp_condition first%s", "");
+  for (int c = 0; c < ctx->k; ++c) { bounds[c] = ctx->hm->acq_lo[c]; bounds[ctx->k + c] = ctx->hm->acq_hi[c]; }
+  return PCABO_OK;
+}
+
+static AcqParams make_params(pcabo_ctx* ctx, double best_f, int maximize, int acq, int want_grad) {
+  AcqParams p;
+  p.best_f = (double)(float)best_f;     // torch.as_tensor(python float) keeps float32 (see oracle)
+  p.y_mean = 0.0; p.y_std = 1.0;
+  p.inv_ls = 1.0 / ctx->lengthscale;
+  p.maximize = maximize ? 1 : 0;
+  p.acq = acq;
+  p.kernel = ctx->kernel;
+  p.want_grad = want_grad;
+  return p;
+}
+
+int pcabo_acq_eval(pcabo_ctx* ctx, const double* Xq, int q, double best_f, int maximize, int acq, double* val,
+                   double* grad) {
+  if (!ctx) return PCABO_ERR_ARG;
+  if (!Xq || !val || q < 1 || q > ctx->max_q || (acq != PCABO_ACQ_LOG_EI && acq != PCABO_ACQ_PI))
+    return set_err(ctx, PCABO_ERR_ARG, "pcabo_acq_eval: bad argument or q beyond context capacity%s", "");
+  if (!ctx->have_gp) return set_err(ctx, PCABO_ERR_ARG, "pcabo_acq_eval: call pcabo_gp_condition first%s", "");
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const int k = ctx->k;
+  STAGE_IN(ctx->dXq, Xq, (size_t)q * k, double);
+  AcqParams p = make_params(ctx, best_f, maximize, acq, grad ? 1 : 0);
+  {
+    ProfScope ps(ctx, 4);
+    launch_acq_partial(s, ctx->dXq, q, ctx->n, k, ctx->NP, ctx->ld, ctx->dZnT, ctx->dR, ctx->dAlpha, ctx->dBounds4, p,
+                       ctx->dPartial);
+  }
+  {
+    ProfScope ps(ctx, 5);
+    launch_acq_combine(s, q, k, ctx->NP, ctx->dBounds4, ctx->dYstats, p, ctx->dPartial, ctx->dVal, ctx->dGrad, nullptr,
+                       nullptr, nullptr, 0ull);
+  }
+  STAGE_OUT(val, ctx->dVal, q, double);
+  if (grad) STAGE_OUT(grad, ctx->dGrad, (size_t)q * k, double);
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipGetLastError());
+  return PCABO_OK;
+}
+
+int pcabo_logei(pcabo_ctx* ctx, const double* Xq, int q, double best_f, int maximize, double* val, double* grad) {
+  return pcabo_acq_eval(ctx, Xq, q, best_f, maximize, PCABO_ACQ_LOG_EI, val, grad);
+}
+
+// ---- multi-start L-BFGS-B over the device acquisition ------------------------------------------
+// All restart groups advance in lock-step: per round every still-active group asks for one joint
+// value+gradient evaluation; the points of all groups go to the device in ONE launch pair whose
+// results land in pinned host memory, and the host spins on the sequence flag.
+static int eval_groups(pcabo_ctx* ctx, int q, AcqParams& p) {
+  hipStream_t s = ctx->stream;
+  const unsigned long long seq = ++ctx->seq;
+  {
+    ProfScope ps(ctx, 4);
+    launch_acq_partial(s, ctx->hXq, q, ctx->n, ctx->k, ctx->NP, ctx->ld, ctx->dZnT, ctx->dR, ctx->dAlpha, ctx->dBounds4,
+                       p, ctx->dPartial);
+  }
+  {
+    ProfScope ps(ctx, 5);
+    launch_acq_combine(s, q, ctx->k, ctx->NP, ctx->dBounds4, ctx->dYstats, p, ctx->dPartial, ctx->dVal, ctx->dGrad,
+                       ctx->hVal, ctx->hGrad, ctx->hm, seq);
+  }
+  if (q > 16) {                               // multi-block combine: no flag, plain synchronisation
+    HIPCHK(hipStreamSynchronize(s));
+    return PCABO_OK;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned long spins = 0;
+  while (__atomic_load_n(&ctx->hm->flag, __ATOMIC_ACQUIRE) != seq) {
+    if ((++spins & 0xFFFF) == 0) {
+      if (hipStreamQuery(s) == hipSuccess) {              // kernels done: the flag must be there
+        if (__atomic_load_n(&ctx->hm->flag, __ATOMIC_ACQUIRE) == seq) break;
+        HIPCHK(hipGetLastError());
+      }
+      double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (el > 20.0) return set_err(ctx, PCABO_ERR_TIMEOUT, "device did not publish acquisition results%s", "");
+    }
+  }
+  return PCABO_OK;
+}
+
+int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int batch_limit, const double* bounds,
+                        int maxiter, double best_f, int maximize, int acq, double* cand, double* vals, int* info,
+                        int* failed) {
+  if (!ctx) return PCABO_ERR_ARG;
+  if (!ics || !bounds || !cand || !vals || num_restarts < 1 || batch_limit < 1 || num_restarts > ctx->max_q ||
+      (acq != PCABO_ACQ_LOG_EI && acq != PCABO_ACQ_PI))
+    return set_err(ctx, PCABO_ERR_ARG, "pcabo_optimize_acqf: bad argument%s", "");
+  if (!ctx->have_gp) return set_err(ctx, PCABO_ERR_ARG, "pcabo_optimize_acqf: call pcabo_gp_condition first%s", "");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int k = ctx->k;
+  const int ngroups = (num_restarts + batch_limit - 1) / batch_limit;
+  std::vector<Lbfgsb> opt(ngroups);
+  std::vector<int> gstart(ngroups), gsize(ngroups), niter(ngroups, 0), nfev(ngroups, 0);
+  std::vector<bool> active(ngroups, true), want_fg(ngroups, false);
+  std::vector<std::vector<double>> x(ngroups), g(ngroups), lo(ngroups), hi(ngroups);
+  std::vector<double> fval(ngroups, 0.0);
+  for (int gi = 0; gi < ngroups; ++gi) {
+    gstart[gi] = gi * batch_limit;
+    gsize[gi] = std::min(batch_limit, num_restarts - gstart[gi]);
+    const int nv = gsize[gi] * k;
+    x[gi].resize(nv); g[gi].assign(nv, 0.0); lo[gi].resize(nv); hi[gi].resize(nv);
+    for (int j = 0; j < gsize[gi]; ++j)
+      for (int c = 0; c < k; ++c) {
+        double l = bounds[c], h = bounds[k + c];
+        double v = ics[(size_t)(gstart[gi] + j) * k + c];
+        lo[gi][j * k + c] = l; hi[gi][j * k + c] = h;
+        x[gi][j * k + c] = v < l ? l : (v > h ? h : v);          // columnwise_clamp / np.clip
+      }
+    opt[gi].init(nv, 10, lo[gi].data(), hi[gi].data(), 1e7, 1e-5, 20);
+  }
+  AcqParams p = make_params(ctx, best_f, maximize, acq, 1);
+  const int maxfun = 15000;
+  int any_failed = 0;
+  while (true) {
+    // advance every active state machine until it needs f,g (or stops)
+    int nq = 0;
+    std::vector<int> qoff(ngroups, -1);
+    for (int gi = 0; gi < ngroups; ++gi) {
+      if (!active[gi]) continue;
+      while (true) {
+        int task = opt[gi].step(x[gi].data(), &fval[gi], g[gi].data());
+        if (task == LBFGSB_FG) { want_fg[gi] = true; break; }
+        if (task == LBFGSB_NEW_X) {
+          niter[gi] += 1;
+          if (niter[gi] >= maxiter) opt[gi].stop(LBFGSB_STOP_ITER);
+          else if (nfev[gi] > maxfun) opt[gi].stop(LBFGSB_STOP_FUN);
+          continue;
+        }
+        active[gi] = false; want_fg[gi] = false;
+        break;
+      }
+      if (active[gi]) {
+        qoff[gi] = nq;
+        memcpy(ctx->hXq + (size_t)nq * k, x[gi].data(), (size_t)gsize[gi] * k * sizeof(double));
+        nq += gsize[gi];
+      }
+    }
+    if (nq == 0) break;
+    int rc = eval_groups(ctx, nq, p);
+    if (rc != PCABO_OK) return rc;
+    for (int gi = 0; gi < ngroups; ++gi) {
+      if (qoff[gi] < 0) continue;
+      double fs = 0.0;
+      bool nan = false;
+      for (int j = 0; j < gsize[gi]; ++j) fs += ctx->hVal[qoff[gi] + j];
+      for (int t = 0; t < gsize[gi] * k; ++t) {
+        double gv = -ctx->hGrad[(size_t)qoff[gi] * k + t];
+        if (gv != gv) nan = true;
+        g[gi][t] = gv;
+      }
+      if (nan) return set_err(ctx, PCABO_ERR_NAN, "NaN in acquisition gradient%s", "");
+      fval[gi] = -fs;
+      nfev[gi] += 1;
+    }
+  }
+  // final clamp and acquisition values at the candidates (no gradient)
+  for (int gi = 0; gi < ngroups; ++gi) {
+    for (int t = 0; t < gsize[gi] * k; ++t) {
+      double v = x[gi][t];
+      v = v < lo[gi][t] ? lo[gi][t] : (v > hi[gi][t] ? hi[gi][t] : v);
+      cand[(size_t)gstart[gi] * k + t] = v;
+      ctx->hXq[(size_t)gstart[gi] * k + t] = v;
+    }
+    int wf = opt[gi].warnflag();
+    if (info) { info[4 * gi] = niter[gi]; info[4 * gi + 1] = nfev[gi]; info[4 * gi + 2] = wf; info[4 * gi + 3] = opt[gi].task(); }
+    if (wf == 2) any_failed = 1;
+  }
+  AcqParams pv = make_params(ctx, best_f, maximize, acq, 0);
+  int rc = eval_groups(ctx, num_restarts, pv);
+  if (rc != PCABO_OK) return rc;
+  for (int j = 0; j < num_restarts; ++j) vals[j] = ctx->hVal[j];
+  if (failed) *failed = any_failed;
+  return PCABO_OK;
+}
+
+int pcabo_inverse_map(pcabo_ctx* ctx, const double* z, double* x) {
+  if (!ctx || !z || !x) return PCABO_ERR_ARG;
+  if (!ctx->have_wpca) return set_err(ctx, PCABO_ERR_ARG, "pcabo_inverse_map: call pcabo_wpca first%s", "");
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  HIPCHK(hipMemcpyAsync(ctx->dZq, z, (size_t)ctx->k * sizeof(double), hipMemcpyHostToDevice, s));
+  launch_inverse_map(s, ctx->dZq, ctx->dComps, ctx->dDataMean, ctx->dPcaMean, ctx->k, ctx->d, ctx->dXout);
+  HIPCHK(hipMemcpyAsync(x, ctx->dXout, (size_t)ctx->d * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return PCABO_OK;
+}
+
+int pcabo_get_gp_state(pcabo_ctx* ctx, double* K_chol, double* Rinv, double* alpha, double* y_mean_std,
+                       double* norm_bounds) {
+  if (!ctx) return PCABO_ERR_ARG;
+  if (!ctx->have_gp) return set_err(ctx, PCABO_ERR_ARG, "pcabo_get_gp_state: call pcabo_gp_condition first%s", "");
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const size_t n = ctx->n, w = n * sizeof(double), pitch = (size_t)ctx->ld * sizeof(double);
+  if (K_chol) HIPCHK(hipMemcpy2DAsync(K_chol, w, ctx->dL, pitch, w, n, hipMemcpyDeviceToHost, s));
+  if (Rinv) HIPCHK(hipMemcpy2DAsync(Rinv, w, ctx->dR, pitch, w, n, hipMemcpyDeviceToHost, s));
+  if (alpha) HOST_OUT(alpha, ctx->dAlpha, n, double);
+  HIPCHK(hipStreamSynchronize(s));
+  if (y_mean_std) { y_mean_std[0] = ctx->hm->y_mean; y_mean_std[1] = ctx->hm->y_std; }
+  if (norm_bounds)
+    for (int c = 0; c < ctx->k; ++c) { norm_bounds[c] = ctx->hm->norm_lo[c]; norm_bounds[ctx->k + c] = ctx->hm->norm_hi[c]; }
+  return PCABO_OK;
+}
+
+int pcabo_get_gram(pcabo_ctx* ctx, double* K) {
+  if (!ctx || !K) return PCABO_ERR_ARG;
+  if (!ctx->have_gp) return set_err(ctx, PCABO_ERR_ARG, "pcabo_get_gram: call pcabo_gp_condition first%s", "");
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t n = ctx->n, w = n * sizeof(double), pitch = (size_t)ctx->ld * sizeof(double);
+  HIPCHK(hipMemcpy2DAsync(K, w, ctx->dGram, pitch, w, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i < n; ++i)                  // only the lower tiles are built on the device
+    for (size_t j = i + 1; j < n; ++j) K[i * n + j] = K[j * n + i];
+  return PCABO_OK;
+}
+
+static double cb_shim(const double*, double*, void*) { return 0.0; }
+
+int pcabo_lbfgsb_minimize(int nvar, double* x, const double* lower, const double* upper, pcabo_fg_callback fg,
+                          void* user, int m, double factr, double pgtol, int maxiter, int maxfun, int maxls,
+                          double* f_out, int* nit, int* nfev, int* task_out) {
+  (void)cb_shim;
+  if (nvar < 1 || !x || !fg || m < 1) return PCABO_ERR_ARG;
+  Lbfgsb opt;
+  opt.init(nvar, m, lower, upper, factr, pgtol, maxls);
+  if (lower && upper)
+    for (int i = 0; i < nvar; ++i) x[i] = x[i] < lower[i] ? lower[i] : (x[i] > upper[i] ? upper[i] : x[i]);
+  std::vector<double> g(nvar, 0.0);
+  double f = 0.0;
+  int iters = 0, evals = 0;
+  while (true) {
+    int task = opt.step(x, &f, g.data());
+    if (task == LBFGSB_FG) { f = fg(x, g.data(), user); ++evals; continue; }
+    if (task == LBFGSB_NEW_X) {
+      ++iters;
+      if (iters >= maxiter) opt.stop(LBFGSB_STOP_ITER);
+      else if (evals > maxfun) opt.stop(LBFGSB_STOP_FUN);
+      continue;
+    }
+    break;
+  }
+  if (f_out) *f_out = f;
+  if (nit) *nit = iters;
+  if (nfev) *nfev = evals;
+  if (task_out) *task_out = opt.task();
+  return opt.warnflag();
+}
+
+int pcabo_set_profiling(pcabo_ctx* ctx, int enabled) {
+  if (!ctx) return PCABO_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (enabled && ctx->pairs.empty()) {
+    ctx->pairs.resize(PROF_POOL);
+    for (auto& p : ctx->pairs) { HIPCHK(hipEventCreate(&p.a)); HIPCHK(hipEventCreate(&p.b)); p.group = 0; }
+  }
+  if (!enabled) prof_resolve(ctx);
+  ctx->prof = enabled != 0;
+  return PCABO_OK;
+}
+
+int pcabo_get_profile(pcabo_ctx* ctx, int which, double* ms, int64_t* launches) {
+  if (!ctx || which < 0 || which >= PROF_GROUPS) return PCABO_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  prof_resolve(ctx);
+  if (ms) *ms = ctx->prof_ms[which];
+  if (launches) *launches = ctx->prof_launches[which];
+  return PCABO_OK;
+}
+
+int pcabo_reset_profile(pcabo_ctx* ctx) {
+  if (!ctx) return PCABO_ERR_ARG;
+  prof_resolve(ctx);
+  for (int i = 0; i < PROF_GROUPS; ++i) { ctx->prof_ms[i] = 0.0; ctx->prof_launches[i] = 0; }
+  return PCABO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+// Internal declarations shared by the HIP translation units of libpcabo.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PCABO_BS 64          // tile edge of the Gram / Cholesky / root-inverse kernels
+#define PCABO_SLAB 16        // rows of R handled by one acquisition work-group
+#define PCABO_MAXD 128       // largest ambient / reduced dimension supported
+#define PCABO_TLD 66         // LDS leading dimension (doubles) of a 64x64 tile: conflict-free ds_read_b64
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// Model / problem constants handed to the acquisition kernels by value.
+struct AcqParams {
+  double best_f;        // already rounded like torch.as_tensor(float) does
+  double y_mean, y_std; // filled on device from the standardisation kernel (host copy unused)
+  double inv_ls;        // 1 / lengthscale
+  int maximize;
+  int acq;              // PCABO_ACQ_*
+  int kernel;           // PCABO_KERNEL_*
+  int want_grad;
+};
+
+// Small results the host needs after a device phase; lives in pinned host memory.
+struct HostMirror {
+  int k;                 // reduced dimension chosen by the wPCA
+  int chol_info;         // 0 or 1 + index of the failing pivot
+  int pad0, pad1;
+  double y_mean, y_std;
+  double norm_lo[PCABO_MAXD], norm_hi[PCABO_MAXD];
+  double acq_lo[PCABO_MAXD], acq_hi[PCABO_MAXD];
+  volatile unsigned long long flag;   // sequence number written last by the combine kernel
+  unsigned long long pad2;
+};
+
+// ---- launchers (defined in kernels_*.hip); all asynchronous on `s` -------------------
+void launch_rank(hipStream_t s, const double* f, int n, int maximize, long long* ranks);
+void launch_wpca_prep(hipStream_t s, const double* X, const long long* ranks, const double* noise, int n, int d,
+                      int DP, double* weights, double* data_mean, double* pca_mean, double* Wc);
+void launch_cov(hipStream_t s, const double* Wc, int n, int DP, double* C);
+void launch_jacobi(hipStream_t s, const double* C, int d, int DP, double* G, double* lam, int* sweeps);
+void launch_pca_finalize(hipStream_t s, const double* G, const double* lam, int n, int d, double var_threshold,
+                         int n_components, double* comps, double* evr, int* k_dev, HostMirror* hm);
+void launch_project(hipStream_t s, const double* X, const double* data_mean, const double* pca_mean,
+                    const double* comps, const int* k_dev, int n, int d, double* Z);
+void launch_zstats(hipStream_t s, const double* Z, const double* y, int n, int k, const double* user_norm_bounds,
+                   double* bounds4 /*norm_lo,norm_hi,acq_lo,acq_hi each MAXD*/, double* zn_mean, double* ystats,
+                   double* ys, HostMirror* hm);
+void launch_znorm(hipStream_t s, const double* Z, int n, int k, int NP, int KP, int ld, const double* bounds4,
+                  const double* zn_mean, double inv_ls, double* ZnT, double* AT, double* nrm);
+void launch_gram(hipStream_t s, const double* AT, const double* nrm, int n, int NP, int KP, int ld, double noise,
+                 int kernel, double* K);
+void launch_add_jitter(hipStream_t s, double* K, int n, int ld, double jitter);
+void launch_cholesky(hipStream_t s, double* L, int NP, int ld, int* info);
+void launch_trinv(hipStream_t s, const double* L, int NP, int ld, double* R);
+void launch_alpha(hipStream_t s, const double* R, const double* ys, int n, int NP, int ld, double* tmp, double* alpha);
+void launch_acq_partial(hipStream_t s, const double* Xq, int q, int n, int k, int NP, int ld, const double* ZnT,
+                        const double* R, const double* alpha, const double* bounds4, AcqParams p, double* partial);
+void launch_acq_combine(hipStream_t s, int q, int k, int NP, const double* bounds4, const double* ystats, AcqParams p,
+                        const double* partial, double* val, double* grad, double* host_val, double* host_grad,
+                        HostMirror* hm, unsigned long long seq);
+void launch_inverse_map(hipStream_t s, const double* z, const double* comps, const double* data_mean,
+                        const double* pca_mean, int k, int d, double* x);

@@ -1,0 +1,252 @@
+"""ctypes binding of libpcabo.so (C ABI declared in include/pcabo.h).
+
+Thin by design: numpy arrays (or torch tensors' device pointers) go in as plain pointers + sizes,
+every status code is turned into a Python exception, and nothing here computes.  If the shared
+library is missing the import of this module fails loudly - there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+ABI_VERSION = 1
+KERNEL_MATERN52, KERNEL_RBF = 0, 1
+ACQ_LOG_EI, ACQ_PI = 0, 1
+PTR_HOST, PTR_DEVICE = 0, 1
+PROFILE_GROUPS = ("wpca", "gram", "cholesky", "root_inverse_alpha", "acq_partial", "acq_combine")
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "lib", "libpcabo.so")
+
+EXPORTS = [
+    "pcabo_abi_version", "pcabo_device_count", "pcabo_ctx_create", "pcabo_ctx_destroy",
+    "pcabo_set_pointer_mode", "pcabo_last_error", "pcabo_wpca", "pcabo_gp_condition", "pcabo_acq_bounds",
+    "pcabo_acq_eval", "pcabo_logei", "pcabo_optimize_acqf", "pcabo_inverse_map", "pcabo_get_gp_state",
+    "pcabo_get_gram", "pcabo_lbfgsb_minimize", "pcabo_set_profiling", "pcabo_get_profile", "pcabo_reset_profile",
+]
+
+
+class PcaboError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libpcabo error {code}: {msg}")
+        self.code = code
+
+
+def lib_path() -> str:
+    return os.path.normpath(_LIB_PATH)
+
+
+def _load() -> C.CDLL:
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C para-ortho-pca-bo_amd/csrc`).  There is no CPU fallback for the HIP path.")
+    lib = C.CDLL(path)
+    lib.pcabo_abi_version.restype = C.c_int
+    if lib.pcabo_abi_version() != ABI_VERSION:
+        raise ImportError(f"{path}: ABI version mismatch")
+    dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
+    lib.pcabo_device_count.restype = C.c_int
+    lib.pcabo_ctx_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.pcabo_ctx_destroy.argtypes = [vp]
+    lib.pcabo_set_pointer_mode.argtypes = [vp, C.c_int]
+    lib.pcabo_last_error.argtypes = [vp, C.c_char_p, C.c_int]
+    lib.pcabo_wpca.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp,
+                               vp, vp, vp, vp, ip, vp]
+    lib.pcabo_gp_condition.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_double, C.c_double, C.c_int]
+    lib.pcabo_acq_bounds.argtypes = [vp, vp]
+    lib.pcabo_acq_eval.argtypes = [vp, vp, C.c_int, C.c_double, C.c_int, C.c_int, vp, vp]
+    lib.pcabo_logei.argtypes = [vp, vp, C.c_int, C.c_double, C.c_int, vp, vp]
+    lib.pcabo_optimize_acqf.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_double, C.c_int, C.c_int,
+                                        vp, vp, vp, ip]
+    lib.pcabo_inverse_map.argtypes = [vp, vp, vp]
+    lib.pcabo_get_gp_state.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.pcabo_get_gram.argtypes = [vp, vp]
+    lib.pcabo_set_profiling.argtypes = [vp, C.c_int]
+    lib.pcabo_get_profile.argtypes = [vp, C.c_int, dp, C.POINTER(C.c_int64)]
+    lib.pcabo_reset_profile.argtypes = [vp]
+    for name in EXPORTS:
+        getattr(lib, name).restype = C.c_int
+    return lib
+
+
+LIB = _load()
+FG_CALLBACK = C.CFUNCTYPE(C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
+LIB.pcabo_lbfgsb_minimize.argtypes = [
+    C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, FG_CALLBACK, C.c_void_p, C.c_int, C.c_double, C.c_double,
+    C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+
+
+def device_count() -> int:
+    return int(LIB.pcabo_device_count())
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a, shape=None) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+class Context:
+    """One per-run device context (a HIP stream + workspaces).  Not thread-safe; use one per thread."""
+
+    def __init__(self, max_n: int, max_d: int, max_q: int = 512, device: int = 0):
+        self._h = C.c_void_p()
+        rc = LIB.pcabo_ctx_create(int(device), int(max_n), int(max_d), int(max_q), C.byref(self._h))
+        if rc != 0:
+            msg = self._err() if self._h else "no usable HIP device (the HIP path has no CPU fallback)"
+            if self._h:
+                LIB.pcabo_ctx_destroy(self._h)
+                self._h = C.c_void_p()
+            raise PcaboError(rc, msg)
+        self.max_n, self.max_d, self.max_q, self.device = max_n, max_d, max_q, device
+        self.n = self.d = self.k = 0
+
+    def _err(self) -> str:
+        buf = C.create_string_buffer(512)
+        LIB.pcabo_last_error(self._h, buf, 512)
+        return buf.value.decode(errors="replace")
+
+    def _chk(self, rc: int) -> None:
+        if rc != 0:
+            raise PcaboError(rc, self._err())
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            LIB.pcabo_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- rows A-C -----------------------------------------------------------------------------
+    def wpca(self, X, f=None, ranks=None, maximize=False, var_threshold=0.95, n_components=0, noise=None,
+             want_Z=True, want_full=True):
+        X = _f64(X)
+        n, d = X.shape
+        f_a = None if f is None else _f64(f, (n,))
+        r_a = None if ranks is None else np.ascontiguousarray(ranks, dtype=np.int64).reshape(n)
+        nz = None if noise is None else _f64(noise, (n, d))
+        rc_ = min(n, d)
+        data_mean, pca_mean = np.empty(d), np.empty(d)
+        comps = np.empty((rc_, d)) if want_full else None
+        evr = np.empty(rc_) if want_full else None
+        k = C.c_int(0)
+        Z = np.empty((n, d)) if want_Z else None
+        self._chk(LIB.pcabo_wpca(self._h, _ptr(X), _ptr(f_a), _ptr(r_a), n, d, int(bool(maximize)),
+                                 float(var_threshold), int(n_components), _ptr(nz), _ptr(data_mean), _ptr(pca_mean),
+                                 _ptr(comps), _ptr(evr), C.byref(k), _ptr(Z)))
+        self.n, self.d, self.k = n, d, k.value
+        if want_Z:
+            Z = Z.reshape(-1)[: n * k.value].reshape(n, k.value).copy()
+        return {"data_mean": data_mean, "pca_mean": pca_mean, "components": comps, "evr": evr, "k": k.value, "Z": Z}
+
+    # ---- rows D-H -----------------------------------------------------------------------------
+    def gp_condition(self, y, Z=None, norm_bounds=None, lengthscale=0.6931471805599453,
+                     noise=0.006737946999085467, kernel=KERNEL_MATERN52):
+        y = _f64(y).reshape(-1)
+        n = y.shape[0]
+        if Z is not None:
+            Z = _f64(Z)
+            k = Z.shape[1]
+        else:
+            k = self.k
+        nb = None if norm_bounds is None else _f64(norm_bounds, (2, k))
+        self._chk(LIB.pcabo_gp_condition(self._h, _ptr(Z), _ptr(y), n, k, _ptr(nb), float(lengthscale), float(noise),
+                                         int(kernel)))
+        self.n, self.k = n, k
+
+    def acq_bounds(self) -> np.ndarray:
+        b = np.empty((2, self.k))
+        self._chk(LIB.pcabo_acq_bounds(self._h, _ptr(b)))
+        return b
+
+    # ---- row I --------------------------------------------------------------------------------
+    def acq_eval(self, Xq, best_f, maximize=False, acq=ACQ_LOG_EI, grad=True):
+        Xq = _f64(Xq).reshape(-1, self.k)
+        q = Xq.shape[0]
+        val = np.empty(q)
+        g = np.empty((q, self.k)) if grad else None
+        self._chk(LIB.pcabo_acq_eval(self._h, _ptr(Xq), q, float(best_f), int(bool(maximize)), int(acq), _ptr(val),
+                                     _ptr(g)))
+        return (val, g) if grad else val
+
+    # ---- rows M-N -----------------------------------------------------------------------------
+    def optimize_acqf(self, ics, bounds, best_f, maximize=False, acq=ACQ_LOG_EI, batch_limit=5, maxiter=200):
+        ics = _f64(ics).reshape(-1, self.k)
+        nr = ics.shape[0]
+        bounds = _f64(bounds, (2, self.k))
+        cand = np.empty((nr, self.k))
+        vals = np.empty(nr)
+        ng = (nr + batch_limit - 1) // batch_limit
+        info = np.zeros((ng, 4), dtype=np.int32)
+        failed = C.c_int(0)
+        self._chk(LIB.pcabo_optimize_acqf(self._h, _ptr(ics), nr, int(batch_limit), _ptr(bounds), int(maxiter),
+                                          float(best_f), int(bool(maximize)), int(acq), _ptr(cand), _ptr(vals),
+                                          _ptr(info), C.byref(failed)))
+        return cand, vals, info, bool(failed.value)
+
+    # ---- row O --------------------------------------------------------------------------------
+    def inverse_map(self, z) -> np.ndarray:
+        z = _f64(z).reshape(-1)
+        x = np.empty(self.d)
+        self._chk(LIB.pcabo_inverse_map(self._h, _ptr(z), _ptr(x)))
+        return x
+
+    # ---- introspection / profiling ------------------------------------------------------------
+    def gp_state(self):
+        n, k = self.n, self.k
+        L, R, alpha, ys, nb = np.empty((n, n)), np.empty((n, n)), np.empty(n), np.empty(2), np.empty((2, k))
+        self._chk(LIB.pcabo_get_gp_state(self._h, _ptr(L), _ptr(R), _ptr(alpha), _ptr(ys), _ptr(nb)))
+        return {"L": np.tril(L), "R": np.tril(R), "alpha": alpha, "y_mean": ys[0], "y_std": ys[1], "norm_bounds": nb}
+
+    def gram(self) -> np.ndarray:
+        K = np.empty((self.n, self.n))
+        self._chk(LIB.pcabo_get_gram(self._h, _ptr(K)))
+        return K
+
+    def set_profiling(self, on: bool) -> None:
+        self._chk(LIB.pcabo_set_profiling(self._h, int(bool(on))))
+
+    def reset_profile(self) -> None:
+        self._chk(LIB.pcabo_reset_profile(self._h))
+
+    def profile(self) -> dict:
+        out = {}
+        for i, name in enumerate(PROFILE_GROUPS):
+            ms, cnt = C.c_double(0), C.c_int64(0)
+            self._chk(LIB.pcabo_get_profile(self._h, i, C.byref(ms), C.byref(cnt)))
+            out[name] = {"ms": ms.value, "launches": cnt.value}
+        return out
+
+
+def lbfgsb_minimize(fun, x0, bounds, m=10, factr=1e7, pgtol=1e-5, maxiter=15000, maxfun=15000, maxls=20):
+    """Host-only entry: this library's L-BFGS-B on a Python objective `fun(x) -> (f, g)` (for tests)."""
+    x = _f64(x0).reshape(-1).copy()
+    nvar = x.shape[0]
+    lo = _f64([b[0] if b[0] is not None else -np.inf for b in bounds])
+    hi = _f64([b[1] if b[1] is not None else np.inf for b in bounds])
+
+    def cb(xp, gp, _user):
+        xv = np.ctypeslib.as_array(xp, shape=(nvar,))
+        f, g = fun(xv.copy())
+        np.ctypeslib.as_array(gp, shape=(nvar,))[:] = g
+        return float(f)
+
+    cfun = FG_CALLBACK(cb)
+    f_out, nit, nfev, task = C.c_double(0), C.c_int(0), C.c_int(0), C.c_int(0)
+    warn = LIB.pcabo_lbfgsb_minimize(nvar, _ptr(x), _ptr(lo), _ptr(hi), cfun, None, int(m), float(factr), float(pgtol),
+                                     int(maxiter), int(maxfun), int(maxls), C.byref(f_out), C.byref(nit),
+                                     C.byref(nfev), C.byref(task))
+    return {"x": x, "fun": f_out.value, "nit": nit.value, "nfev": nfev.value, "warnflag": warn, "task": task.value}

@@ -1,0 +1,81 @@
+"""Host-side initial-condition logic of the acquisition optimiser (rows K, L of SURVEY.md 8a).
+
+This is control flow + RNG consumption, not arithmetic: it must draw from the *global torch CPU
+generator* in exactly the order botorch does, so that runs are reproducible against the reference
+on the same seed (reference call site: Algorithms/BayesianOptimization/PCA_BO.py:607-614 ->
+botorch.optim.initializers.gen_batch_initial_conditions).  torch is used here as the reference's
+dependency uses it: `SobolEngine(scramble=True, seed=None)` and `torch.multinomial`.
+"""
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+import torch
+
+INIT_ETA = 1.0   # botorch initialize_q_batch(eta=1.0)
+
+
+def draw_sobol(bounds: np.ndarray, n: int) -> np.ndarray:
+    """botorch `draw_sobol_samples(bounds, n, q=1, seed=None)` -> n x k points inside `bounds` (2 x k)."""
+    k = bounds.shape[1]
+    engine = torch.quasirandom.SobolEngine(k, scramble=True, seed=None)
+    u = engine.draw(n, dtype=torch.float64)
+    lo = torch.from_numpy(np.ascontiguousarray(bounds[0]))
+    rng = torch.from_numpy(np.ascontiguousarray(bounds[1] - bounds[0]))
+    return (lo + rng * u).numpy()
+
+
+def initialize_q_batch(acq_vals: np.ndarray, n: int, eta: float = INIT_ETA) -> np.ndarray:
+    """Boltzmann sampling of n restart indices (without replacement) + forced arg-max."""
+    v = torch.from_numpy(np.ascontiguousarray(acq_vals, dtype=np.float64))
+    n_samples = v.shape[0]
+    if n > n_samples:
+        raise RuntimeError(f"n ({n}) cannot be larger than the number of provided samples ({n_samples})")
+    if n == n_samples:
+        return np.arange(n)
+    std = v.std(dim=0)
+    if bool(torch.any(std == 0)):
+        warnings.warn("All acquisition values for raw samples points are the same. "
+                      "Choosing initial conditions at random.", RuntimeWarning)
+        return torch.randperm(n=n_samples)[:n].numpy()
+    max_idx = torch.max(v, dim=0)[1]
+    eta_z = eta * ((v - v.mean(dim=0)) / std)
+    weights = torch.exp(eta_z)
+    while bool(torch.isinf(weights).any()):
+        eta_z = eta_z * 0.5
+        weights = torch.exp(eta_z)
+    idcs = torch.multinomial(weights, n)
+    if max_idx not in idcs:
+        idcs[-1] = max_idx
+    return idcs.numpy()
+
+
+def initialize_q_batch_nonneg(acq_vals: np.ndarray, n: int, eta: float = 1.0, alpha: float = 1e-4) -> np.ndarray:
+    """Variant botorch uses for non-negative acquisitions (probability of improvement)."""
+    v = torch.from_numpy(np.ascontiguousarray(acq_vals, dtype=np.float64))
+    n_samples = v.shape[0]
+    if n == n_samples:
+        return np.arange(n)
+    max_val, max_idx = torch.max(v, dim=0)
+    if bool(max_val <= 0):
+        warnings.warn("All acquisition values for raw sampled points are nonpositive, so initial conditions "
+                      "are being selected randomly.", RuntimeWarning)
+        return torch.randperm(n=n_samples)[:n].numpy()
+    pos = v > 0
+    num_pos = int(pos.sum())
+    if num_pos < n:
+        remaining = (~pos).nonzero(as_tuple=False).view(-1)
+        rand = torch.randperm(remaining.shape[0])
+        pos[remaining[rand[: n - num_pos]]] = 1
+        return pos.nonzero(as_tuple=False).view(-1).numpy()
+    alpha_pos = v >= alpha * max_val
+    while int(alpha_pos.sum()) < n:
+        alpha = 0.1 * alpha
+        alpha_pos = v >= alpha * max_val
+    alpha_pos_idcs = torch.arange(len(v))[alpha_pos]
+    weights = torch.exp(eta * (v[alpha_pos] / max_val - 1))
+    idcs = alpha_pos_idcs[torch.multinomial(weights, n)]
+    if max_idx not in idcs:
+        idcs[-1] = max_idx
+    return idcs.numpy()

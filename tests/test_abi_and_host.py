@@ -1,0 +1,96 @@
+"""CPU-side checks of the boundary: the shared library loads and exports every symbol declared in
+include/pcabo.h, fails loudly without a device, and the host mirror keeps the reference's surface."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(native):
+    header = open(os.path.join(ROOT, "include", "pcabo.h")).read()
+    declared = set(re.findall(r"\b(pcabo_[a-z_0-9]+)\s*\(", header)) - {"pcabo_fg_callback"}
+    assert declared == set(native.EXPORTS)
+    lib = ctypes.CDLL(native.lib_path())
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.pcabo_abi_version() == native.ABI_VERSION
+
+
+def test_no_cpu_fallback_without_device(native):
+    if native.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(native.PcaboError) as e:
+        native.Context(max_n=32, max_d=4)
+    assert e.value.code == -3
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "para-ortho-pca-bo_amd")
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(base, f)).read()
+                assert "pcabo_oracle" not in src and "import oracle" not in src, f
+
+
+def test_class_surface_matches_reference(native):
+    from Algorithms import PCA_BO, AbstractBayesianOptimizer
+    assert PCA_BO.TIME_PROFILES == ["SingleTaskGP", "optimize_acqf", "pca"]
+    o = PCA_BO(budget=20, n_DoE=5, var_threshold=0.9, acquisition_function="EI", random_seed=7,
+               maximization=False, verbose=False, DoE_parameters={"criterion": "center", "iterations": 1000})
+    assert isinstance(o, AbstractBayesianOptimizer)
+    assert o.acquisition_function_name == "expected_improvement"
+    assert (o.budget, o.n_DoE, o.random_seed, o.var_threshold, o.n_components) == (20, 5, 7, 0.9, 0)
+    assert o.torch_config["NUM_RESTARTS"] == 10 and o.torch_config["RAW_SAMPLES"] == 512
+    assert set(o.timing_logs) == {"SingleTaskGP", "optimize_acqf", "pca"} and o.total_times["pca"] == 0
+    assert o.current_best == np.inf and o.number_of_function_evaluations == 0
+    with pytest.raises(ValueError, match="Oddly defined name"):
+        PCA_BO(budget=10, acquisition_function="thompson")
+    with pytest.raises(AssertionError):
+        PCA_BO(budget=0)
+    with pytest.raises(ValueError):
+        o.current_best_index = -1
+    o.maximization = True
+    assert o.current_best == -np.inf
+    with pytest.raises(AttributeError):
+        o.acquisition_function = object()
+    with pytest.raises(AttributeError):
+        o(lambda x: 0.0, 3, None)            # callable problem without bounds
+    with pytest.raises(AttributeError):
+        o(42, 3, np.array([-1.0, 1.0]))      # neither ioh-like nor callable
+
+
+def test_bounds_setter_forms():
+    from Algorithms import PCA_BO
+    from types import SimpleNamespace
+    o = PCA_BO(budget=10)
+    o.dimension = 3
+    o.bounds = np.array([-5.0, 5.0])
+    assert o.bounds.shape == (3, 2) and o.bounds[2, 1] == 5.0
+    o.bounds = [[-1, 1], [-2, 2], [-3, 3]]
+    assert o.bounds[1].tolist() == [-2.0, 2.0]
+    o.bounds = SimpleNamespace(lb=np.array([-4.0]), ub=np.array([4.0]))
+    assert o.bounds.tolist() == [[-4.0, 4.0]] * 3
+    assert o.compute_space_volume() == pytest.approx(512.0)
+    with pytest.raises(AttributeError):
+        o.bounds = [1.0, 2.0, 3.0]
+
+
+def test_host_initializers_consume_torch_rng_like_the_oracle():
+    import torch
+    import pcabo_oracle as O
+    from pcabo import initializers as I
+    b = np.vstack([-np.arange(1, 7, dtype=float), np.arange(1, 7, dtype=float)])
+    torch.manual_seed(11)
+    a = I.draw_sobol(b, 64)
+    va = np.sin(a).sum(1)
+    ia = I.initialize_q_batch(va, 10)
+    torch.manual_seed(11)
+    c = O.draw_sobol(b, 64)
+    ic = O.initialize_q_batch(c, torch.from_numpy(np.sin(c.numpy()).sum(1)), 10)
+    assert np.array_equal(a, c.numpy()) and np.array_equal(ia, ic.numpy())
+    assert int(np.argmax(va)) in ia

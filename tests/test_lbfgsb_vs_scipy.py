@@ -1,0 +1,69 @@
+"""This library's host L-BFGS-B (csrc/lbfgsb.cpp) pinned against scipy's own implementation - the
+third-party code the reference reaches through botorch (PCA_BO.py:607-614).  Host-only: no GPU."""
+import numpy as np
+import pytest
+import torch
+from scipy.optimize import minimize
+
+import pcabo_oracle as O
+from pcabo.bbob import BBOBProblem
+
+
+def rosen(x):
+    f = np.sum(100 * (x[1:] - x[:-1] ** 2) ** 2 + (1 - x[:-1]) ** 2)
+    g = np.zeros_like(x)
+    g[:-1] = -400 * x[:-1] * (x[1:] - x[:-1] ** 2) - 2 * (1 - x[:-1])
+    g[1:] += 200 * (x[1:] - x[:-1] ** 2)
+    return f, g
+
+
+def _both(native, fun, x0, bounds, maxiter):
+    ref = minimize(fun, x0, jac=True, method="L-BFGS-B", bounds=bounds, options={"maxiter": maxiter})
+    mine = native.lbfgsb_minimize(fun, x0, bounds, maxiter=maxiter)
+    return ref, mine
+
+
+def test_bounded_rosenbrock_same_path_as_scipy(native):
+    rng = np.random.default_rng(1)
+    for _ in range(25):
+        n = int(rng.integers(2, 30))
+        x0 = rng.uniform(-2, 2, n)
+        lo = rng.uniform(-3, 0.5, n)
+        hi = lo + rng.uniform(0.5, 4, n)
+        ref, mine = _both(native, rosen, x0, list(zip(lo, hi)), int(rng.integers(5, 300)))
+        assert (ref.nit, ref.nfev) == (mine["nit"], mine["nfev"])
+        assert np.abs(ref.x - mine["x"]).max() < 1e-8
+        assert (0 if ref.success else (1 if ref.status == 1 else 2)) == mine["warnflag"]
+
+
+def test_unbounded_and_half_bounded_variables(native):
+    rng = np.random.default_rng(5)
+    for _ in range(10):
+        n = 8
+        x0 = rng.uniform(-2, 2, n)
+        bounds = [(None, None), (0.0, None), (None, 1.5), (-1.0, 1.0)] * 2
+        ref, mine = _both(native, rosen, x0, bounds, 200)
+        assert (ref.nit, ref.nfev) == (mine["nit"], mine["nfev"])
+        assert np.abs(ref.x - mine["x"]).max() < 1e-8
+
+
+def test_joint_five_restart_acquisition_problem_same_path_as_scipy(native):
+    torch.set_num_threads(1)
+    p = BBOBProblem(15, 0, 10)
+    o = O.OraclePCABO(budget=150, n_DoE=30, random_seed=15100, record=True)
+    o(p, 10, np.array([-5.0, 5.0]), max_iters=2)
+    for rec in o.records:
+        gp = O.ExactGP(rec.wpca.Z, rec.f, rec.norm_bounds)
+        acq = O.Acquisition(gp, rec.best_f, False)
+        b, k = 5, rec.wpca.k
+        lo, hi = np.tile(rec.acq_bounds[0], b), np.tile(rec.acq_bounds[1], b)
+
+        def fun(x):
+            v, g = acq.value_and_grad(x.reshape(b, k))
+            return -float(v.sum()), -g.reshape(-1)
+
+        for s in (0, 5):
+            x0 = np.clip(rec.trace.ics[s:s + 5].reshape(-1), lo, hi)
+            ref, mine = _both(native, fun, x0, list(zip(lo, hi)), 200)
+            assert (ref.nit, ref.nfev) == (mine["nit"], mine["nfev"])
+            assert np.abs(ref.x - mine["x"]).max() < 1e-9

@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""Benchmark of the PCA_BO inner loop on MI355X:  BO iterations / second on BBOB f15, d = 40.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one BO iteration (rank-weighted PCA -> GP re-conditioning -> 512 raw samples + 10-restart
+L-BFGS-B over log-EI -> inverse map -> objective) of the configuration BASELINE.json quotes the metric
+on: configs[1] = PCA_BO on BBOB f15, d=40, budget 450, n_DoE 120 (330 BO iterations, n grows 120 -> 449).
+Each rank (one process per GPU) advances its OWN run (instance = rank, seed per ExperimentRunner.py:146):
+runs are independent, there is no data-path collective (weak scaling); best-so-far values are gathered
+over RCCL after the timed region.  Data: synthetic (in-repo BBOB f15 restatement, pinned by the
+reference's own known answers).
+
+Output: ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, "para-ortho-pca-bo_amd"), ROOT):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from pcabo import distributed as D  # noqa: E402
+from pcabo.bbob import BBOBProblem  # noqa: E402
+
+FID, DIM, BUDGET, NDOE = 15, 40, 450, 120
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+FP64_PEAK_TFLOPS = 78.6        # MI355X FP64 vector = matrix peak (spec)
+
+
+class RunChain:
+    """Consecutive BO iterations; when a run reaches its budget the next instance starts (DoE included)."""
+
+    def __init__(self, device: int, first_instance: int, stride: int):
+        from Algorithms import PCA_BO
+        self._cls, self.device = PCA_BO, device
+        self.instance, self.stride = first_instance, stride
+        self.opt = None
+        self.problem = None
+        self.best = []
+        self.iterations = 0
+
+    def _open(self):
+        self.problem = BBOBProblem(FID, self.instance, DIM)
+        seed = 1000 * FID + 10 * DIM + self.instance
+        self.opt = self._cls(budget=BUDGET, n_DoE=NDOE, var_threshold=0.95, acquisition_function="expected_improvement",
+                             random_seed=seed, maximization=False, verbose=False, device=self.device,
+                             DoE_parameters={"criterion": "center", "iterations": 1000})
+        self.opt._start(self.problem)
+
+    def _close(self):
+        if self.opt is not None:
+            self.best.append(float(self.opt.current_best))
+            self.opt._finish()
+            self.opt = None
+
+    def step(self):
+        if self.opt is None:
+            self._open()
+        self.opt._bo_iteration(self.problem)
+        self.iterations += 1
+        if self.opt.number_of_function_evaluations >= self.opt.budget:
+            self._close()
+            self.instance += self.stride
+
+    def finish(self):
+        self._close()
+
+
+def cpu_baseline(states, threads: int):
+    """Time the CPU oracle (restated reference path) on a bounded sample: one BO iteration from each of the
+    sampled states of the SAME run (teacher-forced), spread over n = 120..449."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pcabo_oracle as O
+    torch.set_num_threads(threads)
+    times, ns = [], []
+    for X, f in states:
+        prob = BBOBProblem(FID, 0, DIM)
+        orc = O.OraclePCABO(budget=BUDGET, n_DoE=NDOE, random_seed=15400)
+        orc.x_evals = [row.copy() for row in X]
+        orc.f_evals = [float(v) for v in f]
+        orc._assign_new_best()
+        np.random.seed(7)
+        torch.manual_seed(7)
+        t0 = time.perf_counter()
+        orc.step(prob, np.full(DIM, -5.0), np.full(DIM, 5.0))
+        times.append(time.perf_counter() - t0)
+        ns.append(len(f))
+    mean_t = float(np.mean(times))
+    return {"value": 1.0 / mean_t, "unit": "BO iterations/s", "cores": threads, "kind": "port",
+            "sample": f"{len(times)} teacher-forced BO iterations of the d=40 run at n={ns} (mean {mean_t:.3f} s/iteration); "
+                      "oracle = numpy/sklearn/torch-fp64-autograd/scipy L-BFGS-B restatement of the reference path "
+                      f"with BoTorch's call granularity; botorch importable: {_has('botorch')}"}
+
+
+def _has(mod: str) -> bool:
+    import importlib.util
+    return importlib.util.find_spec(mod) is not None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=BUDGET - NDOE)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank, local_rank, size = D.init()
+    if size != args.gpus and size > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={size}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    device = local_rank if size > 1 else 0
+    torch.cuda.set_device(device)
+    torch.set_num_threads(4)
+
+    # ---- warmup: W iterations of a throw-away run (different instance) -------------------------------
+    if args.warmup > 0:
+        w = RunChain(device, first_instance=29, stride=0)
+        for _ in range(args.warmup):
+            w.step()
+        w.finish()
+
+    # ---- timed region: exactly K BO iterations per rank -----------------------------------------------
+    chain = RunChain(device, first_instance=rank, stride=size)
+    chain._open()                                   # DoE of the first run (120 objective calls) is set-up
+    states = []
+    sample_at = {int(v) for v in np.linspace(0, max(0, min(args.steps, BUDGET - NDOE) - 1), 6)}
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        if rank == 0 and not args.no_cpu_baseline and i in sample_at and chain.opt is not None and chain.instance == 0:
+            states.append((np.vstack(chain.opt.x_evals), np.array(chain.opt.f_evals)))   # cheap host copies
+        chain.step()
+    torch.cuda.synchronize()
+    D.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = D.max_over_ranks(elapsed)
+    timing = dict(chain.opt.total_times) if chain.opt is not None else {}
+    last_best = chain.opt.current_best if chain.opt is not None else (chain.best[-1] if chain.best else float("nan"))
+    chain.finish()
+    total_steps = D.sum_over_ranks(args.steps)
+    gathered = D.gather_best([float(last_best)])    # the one collective of the design (RCCL when size > 1)
+
+    # ---- roofline: second, profiled pass (HIP events on the context's stream), same workload ------------
+    roof, extra = None, {}
+    if rank == 0 and not args.no_roofline:
+        prof_steps = min(args.steps, 40)
+        pc = RunChain(device, first_instance=0, stride=0)
+        pc._open()
+        ctx = pc.opt.device_context
+        ctx.set_profiling(True)
+        ctx.reset_profile()
+        for _ in range(prof_steps):
+            pc.step()
+            if pc.opt is None:
+                break
+        prof = ctx.profile() if pc.opt is not None else {}
+        pc.finish()
+        if prof:
+            a = prof["acq_partial"]
+            dur = a["ms"] * 1e-3 / max(1, a["launches"])
+            byt = a["bytes"] / max(1, a["launches"])
+            roof = {"kernel": "k_acq_partial", "bound": "hbm", "achieved": byt / dur / 1e9, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": byt / dur / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                    "avg_launch_us": dur * 1e6, "launches": a["launches"], "algorithmic_bytes_per_launch": byt,
+                    "achieved_tflops": a["flops"] / (a["ms"] * 1e-3) / 1e12,
+                    "note": f"profiled pass over the first {prof_steps} BO iterations (n=120..{120 + prof_steps - 1}); "
+                            "latency-bound kernel, R stays L2-resident"}
+            for name in ("wpca", "gram", "cholesky", "root_inverse_alpha", "acq_combine"):
+                g = prof[name]
+                if g["launches"]:
+                    extra[name] = {"avg_us": g["ms"] * 1e3 / g["launches"], "calls": g["launches"],
+                                   "GBs": g["bytes"] / (g["ms"] * 1e-3) / 1e9 if g["ms"] else None,
+                                   "TFLOPs": g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] else None}
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline and states:
+        cpu = cpu_baseline(states, threads=min(16, os.cpu_count() or 1))
+
+    if rank == 0:
+        value = total_steps / elapsed
+        line = {
+            "metric": "BO iterations/sec (incl. GP refit + EI opt), BBOB f15 d=40",
+            "value": value, "unit": "BO iterations/s", "n_gpus": size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[1]: PCA_BO on BBOB f15 d=40, budget=450, n_DoE=120, EI, var_threshold=0.95, "
+                                   "one run per GPU (instance = rank), steps = consecutive BO iterations",
+                       "num_restarts": 10, "raw_samples": 512, "batch_limit": 5, "maxiter": 200,
+                       "parallelism": f"run-parallel x{size}"},
+            "roofline": roof, "cpu_baseline": cpu,
+            "kernels": extra, "host_phase_seconds": timing, "best_f": gathered,
+            "speedup_vs_cpu_baseline": (value / size / cpu["value"]) if cpu else None,
+        }
+        print(json.dumps(line), flush=True)
+    D.finalize()
+
+
+if __name__ == "__main__":
+    main()

@@ -133,50 +133,67 @@ class PCA_BO(AbstractBayesianOptimizer):
     # ---------------------------------------------------------------------------------------------
     def __call__(self, problem: Union[Callable, object], dim: Optional[int] = -1,
                  bounds: Optional[np.ndarray] = None, **kwargs) -> None:
-        self.impose_random_seed()
-        super().__call__(problem, dim, bounds, **kwargs)
-        if self._pbar is not None:
-            self._pbar.update(self.n_DoE)
-        self.__ctx = _native.Context(max_n=self.budget, max_d=self.dimension,
-                                     max_q=max(self.__torch_config["RAW_SAMPLES"], 16), device=self.__device)
+        self._start(problem, dim, bounds, **kwargs)
         try:
             for _ in range(self.budget - self.n_DoE):
                 if self.number_of_function_evaluations >= self.budget:
                     break
-                self._transform_points_to_reduced_space()
-                self._initialize_model(**kwargs)
-                self.acquisition_function = self.acquisition_function_class(
-                    model=self.__ctx, best_f=self.current_best, maximize=self.maximization)
-                new_z = self.optimize_acqf_and_get_observation()
-                for new_z_arr in new_z:
-                    if self.number_of_function_evaluations >= self.budget:
-                        break
-                    new_x = self._transform_point_to_original_space(np.asarray(new_z_arr).ravel())
-                    outside = not np.all(new_x >= self.bounds[:, 0]) or not np.all(new_x <= self.bounds[:, 1])
-                    if outside and self.verbose:
-                        print(f"Warning: PCA transformed point {new_x} was out of bounds, clipping to boundary")
-                    self.x_evals.append(new_x)
-                    self.__z_evals.append(np.asarray(new_z_arr).ravel())
-                    # out-of-box candidates are not evaluated; they cost budget and a fixed penalty
-                    new_f = (-OOB_PENALTY if self.maximization else OOB_PENALTY) if outside else problem(new_x)
-                    if self._pbar is not None:
-                        self._pbar.update(1)
-                    self.f_evals.append(new_f)
-                    self.number_of_function_evaluations += 1
-                    if self.verbose and ((self.maximization and new_f > self.current_best) or
-                                         (not self.maximization and new_f < self.current_best)):
-                        print(f"Found better solution: {new_f}")
-                        print(f"At point: {new_x}")
-                self.assign_new_best()
-                if self.verbose:
-                    print(f"Evaluations: {self.number_of_function_evaluations}/{self.budget}",
-                          f"Best: x:{self.x_evals[self.current_best_index]} y:{self.current_best}", flush=True)
+                self._bo_iteration(problem, **kwargs)
         finally:
+            self._finish()
+
+    # The three pieces of `__call__`, exposed so that a driver (bench.py, the sharded runner) can time or
+    # interleave single BO iterations; together they are exactly the reference's loop (PCA_BO.py:140-310).
+    def _start(self, problem, dim=-1, bounds=None, **kwargs) -> None:
+        self.impose_random_seed()
+        AbstractBayesianOptimizer.__call__(self, problem, dim, bounds, **kwargs)
+        if self._pbar is not None:
+            self._pbar.update(self.n_DoE)
+        self.__ctx = _native.Context(max_n=self.budget, max_d=self.dimension,
+                                     max_q=max(self.__torch_config["RAW_SAMPLES"], 16), device=self.__device)
+
+    def _bo_iteration(self, problem, **kwargs) -> None:
+        self._transform_points_to_reduced_space()
+        self._initialize_model(**kwargs)
+        self.acquisition_function = self.acquisition_function_class(
+            model=self.__ctx, best_f=self.current_best, maximize=self.maximization)
+        new_z = self.optimize_acqf_and_get_observation()
+        for new_z_arr in new_z:
+            if self.number_of_function_evaluations >= self.budget:
+                break
+            new_x = self._transform_point_to_original_space(np.asarray(new_z_arr).ravel())
+            outside = not np.all(new_x >= self.bounds[:, 0]) or not np.all(new_x <= self.bounds[:, 1])
+            if outside and self.verbose:
+                print(f"Warning: PCA transformed point {new_x} was out of bounds, clipping to boundary")
+            self.x_evals.append(new_x)
+            self.__z_evals.append(np.asarray(new_z_arr).ravel())
+            # out-of-box candidates are not evaluated; they cost budget and a fixed penalty (PCA_BO.py:260-263)
+            new_f = (-OOB_PENALTY if self.maximization else OOB_PENALTY) if outside else problem(new_x)
+            if self._pbar is not None:
+                self._pbar.update(1)
+            self.f_evals.append(new_f)
+            self.number_of_function_evaluations += 1
+            if self.verbose and ((self.maximization and new_f > self.current_best) or
+                                 (not self.maximization and new_f < self.current_best)):
+                print(f"Found better solution: {new_f}")
+                print(f"At point: {new_x}")
+        self.assign_new_best()
+        if self.verbose:
+            print(f"Evaluations: {self.number_of_function_evaluations}/{self.budget}",
+                  f"Best: x:{self.x_evals[self.current_best_index]} y:{self.current_best}", flush=True)
+
+    def _finish(self) -> None:
+        if self.__ctx is not None:
             self.__ctx.close()
             self.__ctx = None
         if self.verbose:
             print("Optimization Process finalized!")
         self.restore_random_states()
+
+    @property
+    def device_context(self):
+        """The live libpcabo context of a run in progress (profiling hooks); None outside a run."""
+        return self.__ctx
 
     def assign_new_best(self):
         super().assign_new_best()

@@ -15,7 +15,7 @@
 #define PROF_GROUPS 6
 #define PROF_POOL 4096
 
-struct ProfPair { hipEvent_t a, b; int group; };
+struct ProfPair { hipEvent_t a, b; int group; double bytes, flops; };
 
 struct pcabo_ctx {
   int device = 0;
@@ -49,6 +49,7 @@ struct pcabo_ctx {
   size_t pairs_used = 0;
   double prof_ms[PROF_GROUPS] = {0};
   int64_t prof_launches[PROF_GROUPS] = {0};
+  double prof_bytes[PROF_GROUPS] = {0}, prof_flops[PROF_GROUPS] = {0};
 };
 
 static int set_err(pcabo_ctx* c, int code, const char* fmt, const char* a = "", int v = 0) {
@@ -70,21 +71,34 @@ static void prof_resolve(pcabo_ctx* c) {
     if (hipEventElapsedTime(&ms, c->pairs[i].a, c->pairs[i].b) == hipSuccess) {
       c->prof_ms[c->pairs[i].group] += ms;
       c->prof_launches[c->pairs[i].group] += 1;
+      c->prof_bytes[c->pairs[i].group] += c->pairs[i].bytes;
+      c->prof_flops[c->pairs[i].group] += c->pairs[i].flops;
     }
   }
   c->pairs_used = 0;
 }
 struct ProfScope {
   pcabo_ctx* c; ProfPair* p = nullptr;
-  ProfScope(pcabo_ctx* ctx, int group) : c(ctx) {
+  // bytes / flops: ALGORITHMIC work of the bracketed launches (formulas in DESIGN.md section 4)
+  ProfScope(pcabo_ctx* ctx, int group, double bytes = 0.0, double flops = 0.0) : c(ctx) {
     if (!c->prof) return;
     if (c->pairs_used == c->pairs.size()) prof_resolve(c);
     p = &c->pairs[c->pairs_used++];
-    p->group = group;
+    p->group = group; p->bytes = bytes; p->flops = flops;
     hipEventRecord(p->a, c->stream);
   }
   ~ProfScope() { if (p) hipEventRecord(p->b, c->stream); }
 };
+
+// ---- algorithmic work models (per launch), see DESIGN.md section 4 ----------------------------
+static double acq_bytes(int n, int k, int q, int grad) {
+  return 4.0 * n * (n + 1.0) + 8.0 * n * k + 8.0 * n + 8.0 * q * k + 8.0 * q * (grad ? 1 + k : 1);
+}
+static double acq_flops(int n, int k, int q, int grad) {
+  double v = 3.0 * n * k + 20.0 * n + (double)n * n;          // ks, mu, v = R ks (triangular)
+  if (grad) v += (double)n * n + 4.0 * n * k;                   // w = R^T v, contraction with dks/dx
+  return q * v;
+}
 
 template <typename T>
 static hipError_t dalloc(T** p, size_t count) { return hipMalloc((void**)p, count * sizeof(T)); }
@@ -213,7 +227,7 @@ int pcabo_wpca(pcabo_ctx* ctx, const double* X, const double* f, const int64_t* 
   }
   if (noise) STAGE_IN(ctx->dNoise, noise, (size_t)n * d, double);
   {
-    ProfScope ps(ctx, 0);
+    ProfScope ps(ctx, 0, 8.0 * n * d * 2 + 8.0 * n * d, 2.0 * n * d * d + 9.0 * d * d * d + 2.0 * n * d * d);
     launch_wpca_prep(s, ctx->dX, ctx->dRanks, noise ? ctx->dNoise : nullptr, n, d, DP, ctx->dWeights, ctx->dDataMean,
                      ctx->dPcaMean, ctx->dWc);
     launch_cov(s, ctx->dWc, n, DP, ctx->dC);
@@ -245,9 +259,9 @@ static int run_factorisation(pcabo_ctx* ctx, double jitter) {
   HIPCHK(hipMemcpyAsync(ctx->dL, ctx->dGram, bytes, hipMemcpyDeviceToDevice, s));
   if (jitter > 0.0) launch_add_jitter(s, ctx->dL, ctx->n, ctx->ld, jitter);
   HIPCHK(hipMemsetAsync(ctx->dInfo, 0, sizeof(int), s));
-  { ProfScope ps(ctx, 2); launch_cholesky(s, ctx->dL, ctx->NP, ctx->ld, ctx->dInfo); }
+  { ProfScope ps(ctx, 2, 16.0 * ctx->n * ctx->n, (double)ctx->n * ctx->n * ctx->n / 3.0); launch_cholesky(s, ctx->dL, ctx->NP, ctx->ld, ctx->dInfo); }
   {
-    ProfScope ps(ctx, 3);
+    ProfScope ps(ctx, 3, 16.0 * ctx->n * ctx->n, (double)ctx->n * ctx->n * ctx->n / 3.0 + 2.0 * ctx->n * ctx->n);
     launch_trinv(s, ctx->dL, ctx->NP, ctx->ld, ctx->dR);
     launch_alpha(s, ctx->dR, ctx->dYs, ctx->n, ctx->NP, ctx->ld, ctx->dTmp, ctx->dAlpha);
   }
@@ -280,7 +294,7 @@ int pcabo_gp_condition(pcabo_ctx* ctx, const double* Z, const double* y, int n, 
   ctx->lengthscale = lengthscale; ctx->noise = noise; ctx->kernel = kernel;
   ctx->have_gp = false;
   {
-    ProfScope ps(ctx, 1);
+    ProfScope ps(ctx, 1, 8.0 * n * k + 4.0 * n * (n + 1.0), 2.0 * n * n * k + 12.0 * n * n);
     launch_zstats(s, ctx->dZ, ctx->dY, n, k, unb, ctx->dBounds4, ctx->dZnMean, ctx->dYstats, ctx->dYs, ctx->hm);
     launch_znorm(s, ctx->dZ, n, k, ctx->NP, ctx->KP, ctx->ld, ctx->dBounds4, ctx->dZnMean, 1.0 / lengthscale, ctx->dZnT,
                  ctx->dAT, ctx->dNrm);
@@ -328,7 +342,7 @@ int pcabo_acq_eval(pcabo_ctx* ctx, const double* Xq, int q, double best_f, int m
   STAGE_IN(ctx->dXq, Xq, (size_t)q * k, double);
   AcqParams p = make_params(ctx, best_f, maximize, acq, grad ? 1 : 0);
   {
-    ProfScope ps(ctx, 4);
+    ProfScope ps(ctx, 4, acq_bytes(ctx->n, k, q, p.want_grad), acq_flops(ctx->n, k, q, p.want_grad));
     launch_acq_partial(s, ctx->dXq, q, ctx->n, k, ctx->NP, ctx->ld, ctx->dZnT, ctx->dR, ctx->dAlpha, ctx->dBounds4, p,
                        ctx->dPartial);
   }
@@ -356,7 +370,7 @@ static int eval_groups(pcabo_ctx* ctx, int q, AcqParams& p) {
   hipStream_t s = ctx->stream;
   const unsigned long long seq = ++ctx->seq;
   {
-    ProfScope ps(ctx, 4);
+    ProfScope ps(ctx, 4, acq_bytes(ctx->n, ctx->k, q, p.want_grad), acq_flops(ctx->n, ctx->k, q, p.want_grad));
     launch_acq_partial(s, ctx->hXq, q, ctx->n, ctx->k, ctx->NP, ctx->ld, ctx->dZnT, ctx->dR, ctx->dAlpha, ctx->dBounds4,
                        p, ctx->dPartial);
   }
@@ -564,19 +578,21 @@ int pcabo_set_profiling(pcabo_ctx* ctx, int enabled) {
   return PCABO_OK;
 }
 
-int pcabo_get_profile(pcabo_ctx* ctx, int which, double* ms, int64_t* launches) {
+int pcabo_get_profile(pcabo_ctx* ctx, int which, double* ms, int64_t* launches, double* bytes, double* flops) {
   if (!ctx || which < 0 || which >= PROF_GROUPS) return PCABO_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
   prof_resolve(ctx);
   if (ms) *ms = ctx->prof_ms[which];
   if (launches) *launches = ctx->prof_launches[which];
+  if (bytes) *bytes = ctx->prof_bytes[which];
+  if (flops) *flops = ctx->prof_flops[which];
   return PCABO_OK;
 }
 
 int pcabo_reset_profile(pcabo_ctx* ctx) {
   if (!ctx) return PCABO_ERR_ARG;
   prof_resolve(ctx);
-  for (int i = 0; i < PROF_GROUPS; ++i) { ctx->prof_ms[i] = 0.0; ctx->prof_launches[i] = 0; }
+  for (int i = 0; i < PROF_GROUPS; ++i) { ctx->prof_ms[i] = 0.0; ctx->prof_launches[i] = 0; ctx->prof_bytes[i] = 0.0; ctx->prof_flops[i] = 0.0; }
   return PCABO_OK;
 }
 

@@ -66,7 +66,7 @@ def _load() -> C.CDLL:
     lib.pcabo_get_gp_state.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.pcabo_get_gram.argtypes = [vp, vp]
     lib.pcabo_set_profiling.argtypes = [vp, C.c_int]
-    lib.pcabo_get_profile.argtypes = [vp, C.c_int, dp, C.POINTER(C.c_int64)]
+    lib.pcabo_get_profile.argtypes = [vp, C.c_int, dp, C.POINTER(C.c_int64), dp, dp]
     lib.pcabo_reset_profile.argtypes = [vp]
     for name in EXPORTS:
         getattr(lib, name).restype = C.c_int
@@ -225,9 +225,9 @@ class Context:
     def profile(self) -> dict:
         out = {}
         for i, name in enumerate(PROFILE_GROUPS):
-            ms, cnt = C.c_double(0), C.c_int64(0)
-            self._chk(LIB.pcabo_get_profile(self._h, i, C.byref(ms), C.byref(cnt)))
-            out[name] = {"ms": ms.value, "launches": cnt.value}
+            ms, cnt, by, fl = C.c_double(0), C.c_int64(0), C.c_double(0), C.c_double(0)
+            self._chk(LIB.pcabo_get_profile(self._h, i, C.byref(ms), C.byref(cnt), C.byref(by), C.byref(fl)))
+            out[name] = {"ms": ms.value, "launches": cnt.value, "bytes": by.value, "flops": fl.value}
         return out
 
 

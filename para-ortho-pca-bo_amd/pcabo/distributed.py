@@ -1,0 +1,69 @@
+"""One-process-per-GPU plumbing over torch.distributed (backend "nccl" = RCCL over xGMI on ROCm,
+"gloo" for the CPU tests).  The hot path has NO collective: ranks run independent BO runs; the only
+exchange is the final gather of best-so-far values (a few hundred bytes - pure latency)."""
+from __future__ import annotations
+
+import os
+from typing import List, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def world() -> tuple:
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init(backend: str = None) -> tuple:
+    rank, local_rank, size = world()
+    if size > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=size)
+    return rank, local_rank, size
+
+
+def _dev():
+    if dist.is_initialized() and dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def barrier() -> None:
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value: float) -> float:
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=_dev())
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value: float) -> float:
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=_dev())
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def gather_best(local_best: Sequence[float]) -> List[List[float]]:
+    """All-gather of each rank's best-so-far values (equal counts per rank padded with NaN by the caller)."""
+    if not dist.is_initialized():
+        return [list(map(float, local_best))]
+    t = torch.tensor(list(local_best), dtype=torch.float64, device=_dev())
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [o.cpu().tolist() for o in out]
+
+
+def finalize() -> None:
+    if dist.is_initialized():
+        dist.destroy_process_group()

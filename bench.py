@@ -49,6 +49,7 @@ class RunChain:
         self.problem = None
         self.best = []
         self.iterations = 0
+        self.phase_seconds = {}
 
     def _open(self):
         self.problem = BBOBProblem(FID, self.instance, DIM)
@@ -61,6 +62,8 @@ class RunChain:
     def _close(self):
         if self.opt is not None:
             self.best.append(float(self.opt.current_best))
+            for key, val in self.opt.total_times.items():
+                self.phase_seconds[key] = self.phase_seconds.get(key, 0.0) + val
             self.opt._finish()
             self.opt = None
 
@@ -149,9 +152,9 @@ def main():
     D.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = D.max_over_ranks(elapsed)
-    timing = dict(chain.opt.total_times) if chain.opt is not None else {}
-    last_best = chain.opt.current_best if chain.opt is not None else (chain.best[-1] if chain.best else float("nan"))
     chain.finish()
+    timing = dict(chain.phase_seconds)
+    last_best = chain.best[-1] if chain.best else float("nan")
     total_steps = D.sum_over_ranks(args.steps)
     gathered = D.gather_best([float(last_best)])    # the one collective of the design (RCCL when size > 1)
 

@@ -136,7 +136,7 @@ int pcabo_lbfgsb_minimize(int nvar, double* x, const double* lower, const double
 /* Device-time accounting: accumulated HIP-event time (ms, events recorded on the context's own
  * stream), launch count and ALGORITHMIC bytes / flops of the kernel groups since the last reset.
  * which: 0 wpca (5 kernels), 1 normalise+Gram (3 kernels), 2 Cholesky (2 kernels per 64-wide panel),
- * 3 root inverse + alpha (5 launches), 4 acquisition partial kernel, 5 acquisition combine kernel.
+ * 3 root inverse + alpha (5 launches), 4 fused acquisition kernel (value+gradient+combine), 5 unused.
  * Enabled by pcabo_set_profiling(ctx, 1) (adds an event pair per bracketed group of launches). */
 int pcabo_set_profiling(pcabo_ctx* ctx, int enabled);
 int pcabo_get_profile(pcabo_ctx* ctx, int which, double* ms, int64_t* launches, double* bytes, double* flops);

@@ -99,6 +99,7 @@ class PCA_BO(AbstractBayesianOptimizer):
                  acquisition_function: str = "expected_improvement", random_seed: int = 43,
                  visualize: bool = False, **kwargs):
         self.__device = int(kwargs.pop("device", 0))
+        self.__record_trace = bool(kwargs.pop("record_trace", False))
         super().__init__(budget, n_DoE, **kwargs)
         self.random_seed = random_seed
         smoke_test = os.environ.get("SMOKE_TEST")
@@ -126,6 +127,7 @@ class PCA_BO(AbstractBayesianOptimizer):
         self.__z_evals = []
         self.__ctx: Optional[_native.Context] = None
         self.lbfgsb_info = []          # per iteration: (iterations, evaluations, warnflag, task) per restart group
+        self.trace = []                # record_trace=True: per iteration RNG states, restart candidates/values
 
     def __str__(self):
         return "This is an instance of a PCA-assisted BO Optimizer"
@@ -153,6 +155,10 @@ class PCA_BO(AbstractBayesianOptimizer):
                                      max_q=max(self.__torch_config["RAW_SAMPLES"], 16), device=self.__device)
 
     def _bo_iteration(self, problem, **kwargs) -> None:
+        if self.__record_trace:
+            import torch
+            self.trace.append({"n": len(self.f_evals), "numpy_state": np.random.get_state(),
+                               "torch_state": torch.get_rng_state(), "best_f": self.current_best})
         self._transform_points_to_reduced_space()
         self._initialize_model(**kwargs)
         self.acquisition_function = self.acquisition_function_class(
@@ -270,6 +276,9 @@ class PCA_BO(AbstractBayesianOptimizer):
         self.timing_logs["optimize_acqf"].append(perf_counter() - start)
         self.lbfgsb_info.append(info)
         best = int(np.argmax(vals))
+        if self.__record_trace:
+            self.trace[-1].update(ics=ics.copy(), cands=cand.copy(), vals=vals.copy(), chosen=best, info=info.copy(),
+                                  k=int(cand.shape[1]))
         return cand[best].reshape(1, -1)
 
     # ---- row O ------------------------------------------------------------------------------------

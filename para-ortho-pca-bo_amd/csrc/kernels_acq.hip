@@ -12,26 +12,43 @@
 // and the reverse-mode gradient  w = R^T v,  grad = sum_j (c_mu alpha_j + c_s w_j) dks_j/dx.
 //
 // Work decomposition (latency-bound: ~1 MFLOP per query at n = 450):
-//   k_acq_partial  grid (S, q): work-group (s, q) owns 16 rows of R (8 from the top, 8 mirrored from
+//   k_acq_fused    grid (S, q): work-group (s, q) owns 16 rows of R (8 from the top, 8 mirrored from
 //                  the bottom -> balanced triangular work) for query q.  It recomputes ks (n*k
 //                  flops, cheaper than a launch boundary), forms its 16 entries of v by
 //                  wave-per-row shuffle reductions, its contribution R_slab^T v_slab to w, and
 //                  contracts that with dks/dx.  Because the gradient is linear in w, partial
-//                  gradients of different slabs simply add.  No inter-group communication.
-//   k_acq_combine  one wave per query: fixed-order sum over the S partials (deterministic), then the
-//                  scalar log-EI chain rule; results go to device buffers and, for the L-BFGS-B loop,
-//                  straight into pinned host memory followed by a sequence flag.
+//                  gradients of different slabs simply add.
+//                  The S partial records of a query are then combined INSIDE the launch by the
+//                  last work-group to arrive at a per-query ticket counter (split-K style hand-off:
+//                  plain stores -> vmcnt(0) -> barrier -> agent-scope release -> relaxed ticket;
+//                  the last arriver does one agent-scope acquire, then plain loads).  It sums the
+//                  partials in a fixed order (deterministic), applies the scalar log-EI chain rule
+//                  and writes value/gradient to device memory and to pinned host memory; the group
+//                  finishing the last query of the launch publishes a sequence number the host
+//                  polls.  One launch per L-BFGS-B evaluation, no second kernel, no memcpy.
+//                  Query points arrive as kernel arguments when they fit (<= 3 KB) so that no
+//                  work-group has to read host memory over PCIe.
 #include "pcabo_internal.h"
+#include <cstdlib>
 
 #define SLAB PCABO_SLAB
 #define PSTRIDE (2 + 2 * PCABO_MAXD)   // doubles per (query, slab) partial record
 
 __device__ inline int slab_row(int s, int m, int NP) { return m < 8 ? 8 * s + m : NP - 8 * (s + 1) + (m - 8); }
 
-__global__ __launch_bounds__(256) void k_acq_partial(
-    const double* __restrict__ Xq, int n, int k, int NP, int ld, const double* __restrict__ ZnT,
-    const double* __restrict__ R, const double* __restrict__ alpha, const double* __restrict__ bounds4,
-    double inv_ls, int kernel, int want_grad, double* __restrict__ partial) {
+// forward declaration: scalar part, defined below
+__device__ void acq_finish_query(const double* base, int S, int k, int q, const double* bounds4, const double* ystats,
+                                 const AcqParams& p, double* val, double* grad, double* host_val, double* host_grad,
+                                 int lane);
+
+__global__ __launch_bounds__(256) void k_acq_fused(
+    QueryArgs qa, const double* __restrict__ Xq, int q_total, int n, int k, int NP, int ld,
+    const double* __restrict__ ZnT, const double* __restrict__ R, const double* __restrict__ alpha,
+    const double* __restrict__ bounds4, const double* __restrict__ ystats, AcqParams prm, double* partial,
+    unsigned int* counters, unsigned int done_target, double* __restrict__ val, double* __restrict__ grad,
+    double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq, int variant) {
+  const double inv_ls = prm.inv_ls;
+  const int kernel = prm.kernel, want_grad = prm.want_grad;
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
   double* s_ks = s_dyn;              // NP
   double* s_cf = s_dyn + NP;         // NP  coef_j (dks_j/dxn = coef_j (xn - zn_j))
@@ -44,7 +61,8 @@ __global__ __launch_bounds__(256) void k_acq_partial(
 
   if (tid < k) {
     double lo = bounds4[tid], hi = bounds4[PCABO_MAXD + tid];
-    s_xn[tid] = (Xq[(size_t)q * k + tid] - lo) / (hi - lo);
+    double xv = Xq ? Xq[(size_t)q * k + tid] : qa.x[q * k + tid];
+    s_xn[tid] = (xv - lo) / (hi - lo);
   }
   __syncthreads();
   // kernel vector and the radial derivative factor
@@ -69,54 +87,122 @@ __global__ __launch_bounds__(256) void k_acq_partial(
     s_cf[j] = cf;
   }
   __syncthreads();
-  // v_i = R[i][0..i] . ks for the slab's 16 rows: one wave per row, 64-lane shuffle reduction
-  for (int m = w; m < SLAB; m += 4) {
-    const int i = slab_row(s, m, NP);
-    const double* Ri = R + (size_t)i * ld;
-    double acc = 0.0;
-    for (int j = l; j <= i; j += 64) acc += Ri[j] * s_ks[j];
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if (l == 0) s_v[m] = acc;
+  // v_i = R[i][0..i] . ks for the slab's 16 rows: each wave owns 4 rows and streams them together (4
+  // independent load streams in flight), then 64-lane shuffle reductions
+  {
+    int ri[4];
+    const double* Rr[4];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { ri[u] = slab_row(s, w + 4 * u, NP); Rr[u] = R + (size_t)ri[u] * ld; }
+    const int imax = max(max(ri[0], ri[1]), max(ri[2], ri[3]));
+    for (int j = l; j <= imax; j += 64) {
+      const double kj = s_ks[j];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] += Rr[u][j] * kj;      // R is exactly zero above its diagonal
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] += __shfl_xor(acc[u], off, 64);
+    }
+    if (l == 0) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s_v[w + 4 * u] = acc[u];
+    }
   }
   __syncthreads();
-  if (tid == 0) {
+  // slab contributions to |v|^2 and to mu_s = alpha . ks: 16 lanes, one round trip
+  if (w == 0) {
     double vv = 0.0, mu = 0.0;
-    for (int m = 0; m < SLAB; ++m) {
-      vv += s_v[m] * s_v[m];
-      int i = slab_row(s, m, NP);
-      if (i < n) mu += alpha[i] * s_ks[i];
+    if (l < SLAB) {
+      const int i = slab_row(s, l, NP);
+      const double vi = s_v[l];
+      vv = vi * vi;
+      if (i < n) mu = alpha[i] * s_ks[i];
     }
-    out[0] = vv;
-    out[1] = mu;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) { vv += __shfl_xor(vv, off, 64); mu += __shfl_xor(mu, off, 64); }
+    if (l == 0) { out[0] = vv; out[1] = mu; }
   }
-  if (!want_grad) return;
+  if (want_grad) {
   __syncthreads();   // thread 0 has finished reading s_ks before it is reused below
-  // w_j (slab part) = sum_{i in slab, i >= j} R[i][j] v_i ; fold in coef_j.  Rows are re-read
-  // column-wise here (coalesced over j).
+  // w_j (slab part) = sum_{i in slab} R[i][j] v_i (R[i][j] = 0 for j > i); fold in coef_j.  The 16 row
+  // segments are read column-wise (coalesced over j), all loads independent.
   for (int j = tid; j < NP; j += 256) {
     double wj = 0.0;
-    for (int m = 0; m < SLAB; ++m) {
-      const int i = slab_row(s, m, NP);
-      if (i >= j) wj += R[(size_t)i * ld + j] * s_v[m];
-    }
+#pragma unroll
+    for (int m = 0; m < SLAB; ++m) wj += R[(size_t)slab_row(s, m, NP) * ld + j] * s_v[m];
     const bool mine = ((j >> 3) == s) || (((NP - 1 - j) >> 3) == s);
     const double cf = s_cf[j];
     s_tm[j] = (mine && j < n) ? alpha[j] * cf : 0.0;
     s_ks[j] = wj * cf;                    // ks no longer needed: reuse as t_sigma
   }
   __syncthreads();
-  // contraction with (xn_c - zn_jc): wave w handles components c = w, w+4, ...
-  for (int c = w; c < k; c += 4) {
-    const double xc = s_xn[c];
-    const double* zrow = ZnT + (size_t)c * ld;
-    double gs = 0.0, gm = 0.0;
-    for (int j = l; j < n; j += 64) {
-      double dlt = xc - zrow[j];
-      gs += s_ks[j] * dlt;
-      gm += s_tm[j] * dlt;
+  // contraction with (xn_c - zn_jc): a wave keeps 8 components in flight (c = c0 + w + 4u)
+  for (int c0 = 0; c0 < k; c0 += 32) {
+    double gs[8], gm[8], xc[8];
+    const double* zrow[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = c0 + w + 4 * u;
+      const int cc = c < k ? c : 0;
+      gs[u] = 0.0; gm[u] = 0.0; xc[u] = s_xn[cc]; zrow[u] = ZnT + (size_t)cc * ld;
     }
-    for (int off = 32; off > 0; off >>= 1) { gs += __shfl_xor(gs, off, 64); gm += __shfl_xor(gm, off, 64); }
-    if (l == 0) { out[2 + c] = gs; out[2 + PCABO_MAXD + c] = gm; }
+    for (int j = l; j < n; j += 64) {
+      const double ts = s_ks[j], tm = s_tm[j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const double dlt = xc[u] - zrow[u][j];
+        gs[u] += ts * dlt;
+        gm[u] += tm * dlt;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { gs[u] += __shfl_xor(gs[u], off, 64); gm[u] += __shfl_xor(gm[u], off, 64); }
+    }
+    if (l == 0) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = c0 + w + 4 * u;
+        if (c < k) { out[2 + c] = gs[u]; out[2 + PCABO_MAXD + c] = gm[u]; }
+      }
+    }
+  }
+  }  // want_grad
+
+  // ---- in-launch combine: the last slab group of this query to arrive finishes it -----------------
+  int* s_flag = reinterpret_cast<int*>(s_v + SLAB);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    if (!(variant & 1)) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    unsigned int t = __hip_atomic_fetch_add(&counters[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int last = ((t % (unsigned int)S) == (unsigned int)(S - 1));
+    if (last && !(variant & 1)) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    *s_flag = last;
+  }
+  __syncthreads();
+  if (!*s_flag) return;
+  if (w == 0) {
+    acq_finish_query(partial + (size_t)q * S * PSTRIDE, S, k, q, bounds4, ystats, prm, val, grad,
+                     (variant & 2) ? nullptr : host_val, (variant & 2) ? nullptr : host_grad, l);
+    if (hm && !(variant & 2)) {
+      __threadfence_system();                 // this query's host writes are visible before it is counted
+      if (l == 0) {
+        unsigned int t2 = __hip_atomic_fetch_add(&counters[PCABO_CNT_DONE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t2 + 1u == done_target)
+          __hip_atomic_store(const_cast<unsigned long long*>(&hm->flag), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
   }
 }
 
@@ -147,82 +233,81 @@ __device__ inline void log_ei_helper(double u, double* h, double* dh) {
   }
 }
 
-// One wave per query; lanes over reduced components (c, c + 64).
-__global__ __launch_bounds__(1024) void k_acq_combine(
-    const double* __restrict__ partial, int q_total, int S, int k, const double* __restrict__ bounds4,
-    const double* __restrict__ ystats, AcqParams p, double* __restrict__ val, double* __restrict__ grad,
-    double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq) {
-  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-  const int q = blockIdx.x * (blockDim.x >> 6) + w;
-  if (q < q_total) {
-    const double* base = partial + (size_t)q * S * PSTRIDE;
-    double vv = 0.0, mus = 0.0;
-    for (int s = 0; s < S; ++s) { vv += base[(size_t)s * PSTRIDE]; mus += base[(size_t)s * PSTRIDE + 1]; }
-    const double ym = ystats[0], ysd = ystats[1];
-    const double mu = ym + ysd * mus;
-    double var = (1.0 - vv) * (ysd * ysd);
-    bool clamped = false;
-    if (!(var >= 1e-10)) { var = 1e-10; clamped = true; }     // gpytorch min_variance (double)
-    if (var < 1e-12) { var = 1e-12; clamped = true; }          // botorch _mean_and_sigma(min_var)
-    const double sigma = sqrt(var);
-    double u = (mu - p.best_f) / sigma;
-    const double sgn = p.maximize ? 1.0 : -1.0;
-    u *= sgn;
-    double value, dv_du, dv_dsig_over;   // d value/du and explicit d value/d sigma * 1 (log sigma term)
-    if (p.acq == 0) {
-      double h, dh;
-      log_ei_helper(u, &h, &dh);
-      value = h + log(sigma);
-      dv_du = dh;
-      dv_dsig_over = 1.0 / sigma;
-    } else {
-      value = 0.5 * erfc(-0.7071067811865476 * u);
-      dv_du = 0.3989422804014327 * exp(-0.5 * u * u);
-      dv_dsig_over = 0.0;
-    }
-    if (l == 0) { val[q] = value; if (host_val) host_val[q] = value; }
-    if (p.want_grad) {
-      // du = sgn dmu/sigma - u dsigma/sigma ; dsigma = -s_y^2 g_sigma / sigma (0 if clamped)
-      const double c_mu = dv_du * sgn * ysd / sigma;
-      const double c_sg = clamped ? 0.0 : (dv_dsig_over - dv_du * u / sigma) * (-(ysd * ysd) / sigma);
-      for (int c = l; c < k; c += 64) {
-        double gs = 0.0, gm = 0.0;
-        for (int s = 0; s < S; ++s) {
-          gs += base[(size_t)s * PSTRIDE + 2 + c];
-          gm += base[(size_t)s * PSTRIDE + 2 + PCABO_MAXD + c];
-        }
-        double g = (c_mu * gm + c_sg * gs) / (bounds4[PCABO_MAXD + c] - bounds4[c]);
-        grad[(size_t)q * k + c] = g;
-        if (host_grad) host_grad[(size_t)q * k + c] = g;
-      }
-    }
-  }
-  if (hm && seq) {           // single-block launches only: publish the sequence number last
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      __hip_atomic_store(const_cast<unsigned long long*>(&hm->flag), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
-}
-
-void launch_acq_partial(hipStream_t st, const double* Xq, int q, int n, int k, int NP, int ld, const double* ZnT,
-                        const double* R, const double* alpha, const double* bounds4, AcqParams p, double* partial) {
-  const int S = NP / SLAB;
-  size_t lds = (size_t)(3 * NP + PCABO_MAXD + SLAB) * sizeof(double);
-  hipLaunchKernelGGL(k_acq_partial, dim3(S, q), dim3(256), lds, st, Xq, n, k, NP, ld, ZnT, R, alpha, bounds4,
-                     p.inv_ls, p.kernel, p.want_grad, partial);
-}
-
-void launch_acq_combine(hipStream_t st, int q, int k, int NP, const double* bounds4, const double* ystats, AcqParams p,
-                        const double* partial, double* val, double* grad, double* host_val, double* host_grad,
-                        HostMirror* hm, unsigned long long seq) {
-  const int S = NP / SLAB;
-  if (q <= 16) {
-    hipLaunchKernelGGL(k_acq_combine, dim3(1), dim3(64 * q), 0, st, partial, q, S, k, bounds4, ystats, p, val, grad,
-                       host_val, host_grad, hm, seq);
+// Scalar tail for one query, executed by one wave (lanes over reduced components c, c + 64).
+__device__ void acq_finish_query(const double* base, int S, int k, int q, const double* bounds4, const double* ystats,
+                                 const AcqParams& p, double* val, double* grad, double* host_val, double* host_grad,
+                                 int l) {
+  // lanes over slabs (S <= 128): two loads per lane, fixed shuffle tree -> deterministic
+  double vv = 0.0, mus = 0.0;
+  for (int s = l; s < S; s += 64) { vv += base[(size_t)s * PSTRIDE]; mus += base[(size_t)s * PSTRIDE + 1]; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { vv += __shfl_xor(vv, off, 64); mus += __shfl_xor(mus, off, 64); }
+  const double ym = ystats[0], ysd = ystats[1];
+  const double mu = ym + ysd * mus;
+  double var = (1.0 - vv) * (ysd * ysd);
+  bool clamped = false;
+  if (!(var >= 1e-10)) { var = 1e-10; clamped = true; }     // gpytorch min_variance (double)
+  if (var < 1e-12) { var = 1e-12; clamped = true; }          // botorch _mean_and_sigma(min_var)
+  const double sigma = sqrt(var);
+  double u = (mu - p.best_f) / sigma;
+  const double sgn = p.maximize ? 1.0 : -1.0;
+  u *= sgn;
+  double value, dv_du, dv_dsig;
+  if (p.acq == 0) {
+    double h, dh;
+    log_ei_helper(u, &h, &dh);
+    value = h + log(sigma);
+    dv_du = dh;
+    dv_dsig = 1.0 / sigma;
   } else {
-    hipLaunchKernelGGL(k_acq_combine, dim3((q + 3) / 4), dim3(256), 0, st, partial, q, S, k, bounds4, ystats, p, val,
-                       grad, host_val, host_grad, (HostMirror*)nullptr, 0ull);
+    value = 0.5 * erfc(-0.7071067811865476 * u);
+    dv_du = 0.3989422804014327 * exp(-0.5 * u * u);
+    dv_dsig = 0.0;
   }
+  if (l == 0) { val[q] = value; if (host_val) host_val[q] = value; }
+  if (p.want_grad) {
+    // du = sgn dmu/sigma - u dsigma/sigma ; dsigma = -s_y^2 g_sigma / sigma (0 where the variance was clamped)
+    const double c_mu = dv_du * sgn * ysd / sigma;
+    const double c_sg = clamped ? 0.0 : (dv_dsig - dv_du * u / sigma) * (-(ysd * ysd) / sigma);
+    for (int c = l; c < k; c += 64) {
+      double gs = 0.0, gm = 0.0;
+      int s = 0;
+      for (; s + 8 <= S; s += 8) {                     // 16 independent loads in flight, summed in order
+        double a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          a[u] = base[(size_t)(s + u) * PSTRIDE + 2 + c];
+          b[u] = base[(size_t)(s + u) * PSTRIDE + 2 + PCABO_MAXD + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { gs += a[u]; gm += b[u]; }
+      }
+      for (; s < S; ++s) {
+        gs += base[(size_t)s * PSTRIDE + 2 + c];
+        gm += base[(size_t)s * PSTRIDE + 2 + PCABO_MAXD + c];
+      }
+      double g = (c_mu * gm + c_sg * gs) / (bounds4[PCABO_MAXD + c] - bounds4[c]);
+      grad[(size_t)q * k + c] = g;
+      if (host_grad) host_grad[(size_t)q * k + c] = g;
+    }
+  }
+}
+
+int acq_variant() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("PCABO_ACQ_VARIANT"); v = e ? atoi(e) : 0; }
+  return v;
+}
+
+void launch_acq(hipStream_t st, const QueryArgs* qa, const double* Xq, int q, int n, int k, int NP, int ld,
+                const double* ZnT, const double* R, const double* alpha, const double* bounds4, const double* ystats,
+                AcqParams p, double* partial, unsigned int* counters, unsigned int done_target, double* val,
+                double* grad, double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq) {
+  const int S = NP / SLAB;
+  size_t lds = (size_t)(3 * NP + PCABO_MAXD + SLAB + 2) * sizeof(double);
+  static const QueryArgs empty = {};
+  if (acq_variant() & 4) p.want_grad = 0;
+  hipLaunchKernelGGL(k_acq_fused, dim3(S, q), dim3(256), lds, st, qa ? *qa : empty, Xq, q, n, k, NP, ld, ZnT, R, alpha,
+                     bounds4, ystats, p, partial, counters, done_target, val, grad, host_val, host_grad, hm, seq,
+                     acq_variant());
 }

@@ -4,7 +4,9 @@
 #include "pcabo_internal.h"
 #include "lbfgsb.h"
 
+#include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -38,6 +40,8 @@ struct pcabo_ctx {
   double *dZnT = nullptr, *dAT = nullptr, *dNrm = nullptr, *dGram = nullptr, *dL = nullptr, *dR = nullptr;
   double *dTmp = nullptr, *dAlpha = nullptr;
   double *dXq = nullptr, *dPartial = nullptr, *dVal = nullptr, *dGrad = nullptr, *dZq = nullptr, *dXout = nullptr;
+  unsigned int* dCounters = nullptr;     // per-query tickets + [PCABO_CNT_DONE] finished-queries counter
+  unsigned int done_total = 0;           // host copy of the finished-queries counter's expected value
   // pinned host
   HostMirror* hm = nullptr;
   double *hXq = nullptr, *hVal = nullptr, *hGrad = nullptr, *hSmall = nullptr;
@@ -116,7 +120,7 @@ int pcabo_device_count(void) {
 int pcabo_ctx_create(int device, int max_n, int max_d, int max_q, pcabo_ctx** out) {
   if (!out) return PCABO_ERR_ARG;
   *out = nullptr;
-  if (max_n < 2 || max_d < 1 || max_d > PCABO_MAXD || max_q < 1) return PCABO_ERR_ARG;
+  if (max_n < 2 || max_d < 1 || max_d > PCABO_MAXD || max_q < 1 || max_q >= PCABO_CNT_DONE) return PCABO_ERR_ARG;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return PCABO_ERR_HIP;
   pcabo_ctx* ctx = new (std::nothrow) pcabo_ctx();
@@ -151,6 +155,8 @@ int pcabo_ctx_create(int device, int max_n, int max_d, int max_q, pcabo_ctx** ou
   HIPCHK(dalloc(&ctx->dPartial, Q * (size_t)ctx->Scap * (2 + 2 * PCABO_MAXD)));
   HIPCHK(dalloc(&ctx->dVal, Q));         HIPCHK(dalloc(&ctx->dGrad, Q * d));
   HIPCHK(dalloc(&ctx->dZq, d));          HIPCHK(dalloc(&ctx->dXout, d));
+  HIPCHK(dalloc(&ctx->dCounters, PCABO_CNT_DONE + 1));
+  HIPCHK(hipMemsetAsync(ctx->dCounters, 0, (PCABO_CNT_DONE + 1) * sizeof(unsigned int), ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->dYs, 0, N * sizeof(double), ctx->stream));
   HIPCHK(hipHostMalloc((void**)&ctx->hm, sizeof(HostMirror), hipHostMallocDefault));
   memset((void*)ctx->hm, 0, sizeof(HostMirror));
@@ -171,7 +177,7 @@ int pcabo_ctx_destroy(pcabo_ctx* ctx) {
                  ctx->dC, ctx->dG, ctx->dLam, ctx->dComps, ctx->dEvr, ctx->dZ, ctx->dK, ctx->dSweeps, ctx->dInfo,
                  ctx->dY, ctx->dYs, ctx->dYstats, ctx->dBounds4, ctx->dZnMean, ctx->dUserNB, ctx->dZnT, ctx->dAT,
                  ctx->dNrm, ctx->dGram, ctx->dL, ctx->dR, ctx->dTmp, ctx->dAlpha, ctx->dXq, ctx->dPartial, ctx->dVal,
-                 ctx->dGrad, ctx->dZq, ctx->dXout};
+                 ctx->dGrad, ctx->dZq, ctx->dXout, ctx->dCounters};
   for (void* p : dev) if (p) hipFree(p);
   void* host[] = {(void*)ctx->hm, ctx->hXq, ctx->hVal, ctx->hGrad, ctx->hSmall};
   for (void* p : host) if (p) hipHostFree(p);
@@ -293,6 +299,8 @@ int pcabo_gp_condition(pcabo_ctx* ctx, const double* Z, const double* y, int n, 
   ctx->KP = round_up(k, 4);
   ctx->lengthscale = lengthscale; ctx->noise = noise; ctx->kernel = kernel;
   ctx->have_gp = false;
+  HIPCHK(hipMemsetAsync(ctx->dCounters, 0, (PCABO_CNT_DONE + 1) * sizeof(unsigned int), s));
+  ctx->done_total = 0;
   {
     ProfScope ps(ctx, 1, 8.0 * n * k + 4.0 * n * (n + 1.0), 2.0 * n * n * k + 12.0 * n * n);
     launch_zstats(s, ctx->dZ, ctx->dY, n, k, unb, ctx->dBounds4, ctx->dZnMean, ctx->dYstats, ctx->dYs, ctx->hm);
@@ -330,6 +338,44 @@ static AcqParams make_params(pcabo_ctx* ctx, double best_f, int maximize, int ac
   return p;
 }
 
+// One evaluation of the acquisition at the nq points staged in ctx->hXq (pinned): a single fused launch
+// whose results land in ctx->hVal / ctx->hGrad; the host spins on the sequence flag.
+static int eval_staged(pcabo_ctx* ctx, int nq, AcqParams& p) {
+  hipStream_t s = ctx->stream;
+  const int k = ctx->k;
+  const unsigned long long seq = ++ctx->seq;
+  ctx->done_total += (unsigned int)nq;
+  const QueryArgs* qa = nullptr;
+  const double* xdev = nullptr;
+  if ((size_t)nq * k <= PCABO_QA_MAX) {
+    qa = reinterpret_cast<const QueryArgs*>(ctx->hXq);        // copied by value into the kernel arguments
+  } else {
+    HIPCHK(hipMemcpyAsync(ctx->dXq, ctx->hXq, (size_t)nq * k * sizeof(double), hipMemcpyHostToDevice, s));
+    xdev = ctx->dXq;
+  }
+  {
+    ProfScope ps(ctx, 4, acq_bytes(ctx->n, k, nq, p.want_grad), acq_flops(ctx->n, k, nq, p.want_grad));
+    launch_acq(s, qa, xdev, nq, ctx->n, k, ctx->NP, ctx->ld, ctx->dZnT, ctx->dR, ctx->dAlpha, ctx->dBounds4, ctx->dYstats,
+               p, ctx->dPartial, ctx->dCounters, ctx->done_total, ctx->dVal, ctx->dGrad, ctx->hVal, ctx->hGrad, ctx->hm,
+               seq);
+  }
+  if (acq_variant() & 2) { HIPCHK(hipStreamSynchronize(s)); return PCABO_OK; }
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned long spins = 0;
+  while (__atomic_load_n(&ctx->hm->flag, __ATOMIC_ACQUIRE) != seq) {
+    if ((++spins & 0xFFFF) == 0) {
+      if (hipStreamQuery(s) == hipSuccess) {              // kernel done: the flag must be there
+        if (__atomic_load_n(&ctx->hm->flag, __ATOMIC_ACQUIRE) == seq) break;
+        HIPCHK(hipGetLastError());
+        return set_err(ctx, PCABO_ERR_TIMEOUT, "acquisition kernel finished without publishing its results%s", "");
+      }
+      double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (el > 20.0) return set_err(ctx, PCABO_ERR_TIMEOUT, "device did not publish acquisition results%s", "");
+    }
+  }
+  return PCABO_OK;
+}
+
 int pcabo_acq_eval(pcabo_ctx* ctx, const double* Xq, int q, double best_f, int maximize, int acq, double* val,
                    double* grad) {
   if (!ctx) return PCABO_ERR_ARG;
@@ -339,22 +385,23 @@ int pcabo_acq_eval(pcabo_ctx* ctx, const double* Xq, int q, double best_f, int m
   HIPCHK(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   const int k = ctx->k;
-  STAGE_IN(ctx->dXq, Xq, (size_t)q * k, double);
+  const size_t nx = (size_t)q * k;
+  if (ctx->ptr_mode == PCABO_PTR_HOST) memcpy(ctx->hXq, Xq, nx * sizeof(double));
+  else {
+    HIPCHK(hipMemcpyAsync(ctx->hXq, Xq, nx * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+  }
   AcqParams p = make_params(ctx, best_f, maximize, acq, grad ? 1 : 0);
-  {
-    ProfScope ps(ctx, 4, acq_bytes(ctx->n, k, q, p.want_grad), acq_flops(ctx->n, k, q, p.want_grad));
-    launch_acq_partial(s, ctx->dXq, q, ctx->n, k, ctx->NP, ctx->ld, ctx->dZnT, ctx->dR, ctx->dAlpha, ctx->dBounds4, p,
-                       ctx->dPartial);
+  int rc = eval_staged(ctx, q, p);
+  if (rc != PCABO_OK) return rc;
+  if (ctx->ptr_mode == PCABO_PTR_HOST) {
+    memcpy(val, ctx->hVal, (size_t)q * sizeof(double));
+    if (grad) memcpy(grad, ctx->hGrad, nx * sizeof(double));
+  } else {
+    HIPCHK(hipMemcpyAsync(val, ctx->dVal, (size_t)q * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (grad) HIPCHK(hipMemcpyAsync(grad, ctx->dGrad, nx * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
   }
-  {
-    ProfScope ps(ctx, 5);
-    launch_acq_combine(s, q, k, ctx->NP, ctx->dBounds4, ctx->dYstats, p, ctx->dPartial, ctx->dVal, ctx->dGrad, nullptr,
-                       nullptr, nullptr, 0ull);
-  }
-  STAGE_OUT(val, ctx->dVal, q, double);
-  if (grad) STAGE_OUT(grad, ctx->dGrad, (size_t)q * k, double);
-  HIPCHK(hipStreamSynchronize(s));
-  HIPCHK(hipGetLastError());
   return PCABO_OK;
 }
 
@@ -364,40 +411,8 @@ int pcabo_logei(pcabo_ctx* ctx, const double* Xq, int q, double best_f, int maxi
 
 // ---- multi-start L-BFGS-B over the device acquisition ------------------------------------------
 // All restart groups advance in lock-step: per round every still-active group asks for one joint
-// value+gradient evaluation; the points of all groups go to the device in ONE launch pair whose
-// results land in pinned host memory, and the host spins on the sequence flag.
-static int eval_groups(pcabo_ctx* ctx, int q, AcqParams& p) {
-  hipStream_t s = ctx->stream;
-  const unsigned long long seq = ++ctx->seq;
-  {
-    ProfScope ps(ctx, 4, acq_bytes(ctx->n, ctx->k, q, p.want_grad), acq_flops(ctx->n, ctx->k, q, p.want_grad));
-    launch_acq_partial(s, ctx->hXq, q, ctx->n, ctx->k, ctx->NP, ctx->ld, ctx->dZnT, ctx->dR, ctx->dAlpha, ctx->dBounds4,
-                       p, ctx->dPartial);
-  }
-  {
-    ProfScope ps(ctx, 5);
-    launch_acq_combine(s, q, ctx->k, ctx->NP, ctx->dBounds4, ctx->dYstats, p, ctx->dPartial, ctx->dVal, ctx->dGrad,
-                       ctx->hVal, ctx->hGrad, ctx->hm, seq);
-  }
-  if (q > 16) {                               // multi-block combine: no flag, plain synchronisation
-    HIPCHK(hipStreamSynchronize(s));
-    return PCABO_OK;
-  }
-  const auto t0 = std::chrono::steady_clock::now();
-  unsigned long spins = 0;
-  while (__atomic_load_n(&ctx->hm->flag, __ATOMIC_ACQUIRE) != seq) {
-    if ((++spins & 0xFFFF) == 0) {
-      if (hipStreamQuery(s) == hipSuccess) {              // kernels done: the flag must be there
-        if (__atomic_load_n(&ctx->hm->flag, __ATOMIC_ACQUIRE) == seq) break;
-        HIPCHK(hipGetLastError());
-      }
-      double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      if (el > 20.0) return set_err(ctx, PCABO_ERR_TIMEOUT, "device did not publish acquisition results%s", "");
-    }
-  }
-  return PCABO_OK;
-}
-
+// value+gradient evaluation; the points of all groups go to the device in ONE launch whose results
+// land in pinned host memory (eval_staged above).
 int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int batch_limit, const double* bounds,
                         int maxiter, double best_f, int maximize, int acq, double* cand, double* vals, int* info,
                         int* failed) {
@@ -430,9 +445,13 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
   }
   AcqParams p = make_params(ctx, best_f, maximize, acq, 1);
   const int maxfun = 15000;
+  static const bool trace = getenv("PCABO_TRACE_OPT") != nullptr;
+  double t_step = 0.0, t_eval = 0.0; int rounds = 0;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   int any_failed = 0;
   while (true) {
     // advance every active state machine until it needs f,g (or stops)
+    const double ta = trace ? now() : 0.0;
     int nq = 0;
     std::vector<int> qoff(ngroups, -1);
     for (int gi = 0; gi < ngroups; ++gi) {
@@ -456,8 +475,10 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
       }
     }
     if (nq == 0) break;
-    int rc = eval_groups(ctx, nq, p);
+    const double tb = trace ? now() : 0.0;
+    int rc = eval_staged(ctx, nq, p);
     if (rc != PCABO_OK) return rc;
+    if (trace) { const double tc = now(); t_step += tb - ta; t_eval += tc - tb; ++rounds; }
     for (int gi = 0; gi < ngroups; ++gi) {
       if (qoff[gi] < 0) continue;
       double fs = 0.0;
@@ -473,6 +494,7 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
       nfev[gi] += 1;
     }
   }
+  if (trace) fprintf(stderr, "[pcabo] optimize: rounds %d, host L-BFGS-B %.1f us/round, eval %.1f us/round (n=%d k=%d)\n", rounds, 1e6 * t_step / std::max(1, rounds), 1e6 * t_eval / std::max(1, rounds), ctx->n, ctx->k);
   // final clamp and acquisition values at the candidates (no gradient)
   for (int gi = 0; gi < ngroups; ++gi) {
     for (int t = 0; t < gsize[gi] * k; ++t) {
@@ -486,7 +508,7 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
     if (wf == 2) any_failed = 1;
   }
   AcqParams pv = make_params(ctx, best_f, maximize, acq, 0);
-  int rc = eval_groups(ctx, num_restarts, pv);
+  int rc = eval_staged(ctx, num_restarts, pv);
   if (rc != PCABO_OK) return rc;
   for (int j = 0; j < num_restarts; ++j) vals[j] = ctx->hVal[j];
   if (failed) *failed = any_failed;

@@ -8,7 +8,11 @@
 #define PCABO_MAXD 128       // largest ambient / reduced dimension supported
 #define PCABO_TLD 66         // LDS leading dimension (doubles) of a 64x64 tile: conflict-free ds_read_b64
 
+#define PCABO_QA_MAX 384      // query coordinates that travel as kernel arguments (3 KB)
+#define PCABO_CNT_DONE 0x3fff // index of the "queries finished" counter behind the per-query tickets
+
 typedef double double4_t __attribute__((ext_vector_type(4)));
+struct QueryArgs { double x[PCABO_QA_MAX]; };
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -56,10 +60,10 @@ void launch_add_jitter(hipStream_t s, double* K, int n, int ld, double jitter);
 void launch_cholesky(hipStream_t s, double* L, int NP, int ld, int* info);
 void launch_trinv(hipStream_t s, const double* L, int NP, int ld, double* R);
 void launch_alpha(hipStream_t s, const double* R, const double* ys, int n, int NP, int ld, double* tmp, double* alpha);
-void launch_acq_partial(hipStream_t s, const double* Xq, int q, int n, int k, int NP, int ld, const double* ZnT,
-                        const double* R, const double* alpha, const double* bounds4, AcqParams p, double* partial);
-void launch_acq_combine(hipStream_t s, int q, int k, int NP, const double* bounds4, const double* ystats, AcqParams p,
-                        const double* partial, double* val, double* grad, double* host_val, double* host_grad,
-                        HostMirror* hm, unsigned long long seq);
+int acq_variant();
+void launch_acq(hipStream_t s, const QueryArgs* qa, const double* Xq, int q, int n, int k, int NP, int ld,
+                const double* ZnT, const double* R, const double* alpha, const double* bounds4, const double* ystats,
+                AcqParams p, double* partial, unsigned int* counters, unsigned int done_target, double* val,
+                double* grad, double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq);
 void launch_inverse_map(hipStream_t s, const double* z, const double* comps, const double* data_mean,
                         const double* pca_mean, int k, int d, double* x);

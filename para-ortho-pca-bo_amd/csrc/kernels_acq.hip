@@ -29,7 +29,6 @@
 //                  Query points arrive as kernel arguments when they fit (<= 3 KB) so that no
 //                  work-group has to read host memory over PCIe.
 #include "pcabo_internal.h"
-#include <cstdlib>
 
 #define SLAB PCABO_SLAB
 #define PSTRIDE (2 + 2 * PCABO_MAXD)   // doubles per (query, slab) partial record
@@ -46,7 +45,7 @@ __global__ __launch_bounds__(256) void k_acq_fused(
     const double* __restrict__ ZnT, const double* __restrict__ R, const double* __restrict__ alpha,
     const double* __restrict__ bounds4, const double* __restrict__ ystats, AcqParams prm, double* partial,
     unsigned int* counters, unsigned int done_target, double* __restrict__ val, double* __restrict__ grad,
-    double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq, int variant) {
+    double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq, int combine) {
   const double inv_ls = prm.inv_ls;
   const int kernel = prm.kernel, want_grad = prm.want_grad;
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
@@ -174,17 +173,16 @@ __global__ __launch_bounds__(256) void k_acq_fused(
   }  // want_grad
 
   // ---- in-launch combine: the last slab group of this query to arrive finishes it -----------------
+  if (!combine) return;          // large batches: a follow-up k_acq_combine launch reads the partials instead
   int* s_flag = reinterpret_cast<int*>(s_v + SLAB);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    if (!(variant & 1)) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     unsigned int t = __hip_atomic_fetch_add(&counters[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int last = ((t % (unsigned int)S) == (unsigned int)(S - 1));
-    if (last && !(variant & 1)) {
+    if (last) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -193,9 +191,8 @@ __global__ __launch_bounds__(256) void k_acq_fused(
   __syncthreads();
   if (!*s_flag) return;
   if (w == 0) {
-    acq_finish_query(partial + (size_t)q * S * PSTRIDE, S, k, q, bounds4, ystats, prm, val, grad,
-                     (variant & 2) ? nullptr : host_val, (variant & 2) ? nullptr : host_grad, l);
-    if (hm && !(variant & 2)) {
+    acq_finish_query(partial + (size_t)q * S * PSTRIDE, S, k, q, bounds4, ystats, prm, val, grad, host_val, host_grad, l);
+    if (hm) {
       __threadfence_system();                 // this query's host writes are visible before it is counted
       if (l == 0) {
         unsigned int t2 = __hip_atomic_fetch_add(&counters[PCABO_CNT_DONE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -293,10 +290,15 @@ __device__ void acq_finish_query(const double* base, int S, int k, int q, const 
   }
 }
 
-int acq_variant() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("PCABO_ACQ_VARIANT"); v = e ? atoi(e) : 0; }
-  return v;
+// Combine pass for large batches (the launch boundary makes the partial records visible): one wave per query.
+__global__ __launch_bounds__(256) void k_acq_combine(const double* __restrict__ partial, int q_total, int S, int k,
+                                                     const double* __restrict__ bounds4,
+                                                     const double* __restrict__ ystats, AcqParams p,
+                                                     double* __restrict__ val, double* __restrict__ grad) {
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q < q_total)
+    acq_finish_query(partial + (size_t)q * S * PSTRIDE, S, k, q, bounds4, ystats, p, val, grad, nullptr, nullptr,
+                     threadIdx.x & 63);
 }
 
 void launch_acq(hipStream_t st, const QueryArgs* qa, const double* Xq, int q, int n, int k, int NP, int ld,
@@ -306,8 +308,11 @@ void launch_acq(hipStream_t st, const QueryArgs* qa, const double* Xq, int q, in
   const int S = NP / SLAB;
   size_t lds = (size_t)(3 * NP + PCABO_MAXD + SLAB + 2) * sizeof(double);
   static const QueryArgs empty = {};
-  if (acq_variant() & 4) p.want_grad = 0;
+  const int combine = hm != nullptr;      // small batches: finish inside the launch and publish to the host
   hipLaunchKernelGGL(k_acq_fused, dim3(S, q), dim3(256), lds, st, qa ? *qa : empty, Xq, q, n, k, NP, ld, ZnT, R, alpha,
                      bounds4, ystats, p, partial, counters, done_target, val, grad, host_val, host_grad, hm, seq,
-                     acq_variant());
+                     combine);
+  if (!combine)
+    hipLaunchKernelGGL(k_acq_combine, dim3((q + 3) / 4), dim3(256), 0, st, partial, q, S, k, bounds4, ystats, p, val,
+                       grad);
 }

@@ -86,41 +86,69 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ A, int 
   load_tile(Add, ld, s_d);
   if (b > 0) load_tile(A + (size_t)((p + b) * BS) * ld + p * BS, ld, s_b);
   __syncthreads();
-  // unblocked right-looking factorisation of the diagonal block (lower triangle)
-  const int ri = tid >> 2, part = tid & 3;       // four threads per row for the rank-1 update
-  for (int j = 0; j < BS; ++j) {
+  // Right-looking factorisation of the diagonal block with DELAYED scaling: at step j column j is final
+  // (a_ij^(j)), the trailing update uses a_ij a_cj / a_jj, and L = a^(j) / sqrt(a_jj) is applied once at the
+  // end - one barrier per step instead of three.  Four threads share a row.
+  const int ri = tid >> 2, part = tid & 3;
+  for (int j = 0; j < BS - 1; ++j) {
     double piv = s_d[j * TLD + j];
     if (!(piv > 0.0)) {
       if (b == 0 && tid == 0) atomicCAS(info, 0, p * BS + j + 1);
       piv = 1.0;
     }
-    const double dj = sqrt(piv);
-    __syncthreads();
-    if (tid == j) s_d[j * TLD + j] = dj;
-    if (tid < BS && tid > j) s_d[tid * TLD + j] /= dj;
-    __syncthreads();
     if (ri > j) {
-      const double lij = s_d[ri * TLD + j];
-      for (int c = j + 1 + part; c <= ri; c += 4) s_d[ri * TLD + c] -= lij * s_d[c * TLD + j];
+      const double f = s_d[ri * TLD + j] / piv;
+      for (int c = j + 1 + part; c <= ri; c += 4) s_d[ri * TLD + c] -= f * s_d[c * TLD + j];
+    }
+    __syncthreads();
+  }
+  {
+    double piv = s_d[(BS - 1) * TLD + BS - 1];
+    if (!(piv > 0.0) && b == 0 && tid == 0) atomicCAS(info, 0, p * BS + BS);
+  }
+  __syncthreads();
+  // scale: L[i][j] = a_ij / sqrt(a_jj) for j < i, L[i][i] = sqrt(a_ii), zero above the diagonal.
+  // Pivots are read into registers first; the diagonal itself is rewritten in a separate phase.
+  {
+    double dinv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const double pv = s_d[(part + 4 * u) * TLD + part + 4 * u];
+      dinv[u] = 1.0 / sqrt(pv > 0.0 ? pv : 1.0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int c = part + 4 * u;
+      if (c < ri) s_d[ri * TLD + c] *= dinv[u];
+      else if (c > ri) s_d[ri * TLD + c] = 0.0;
+    }
+    if (part == (ri & 3)) {
+      const double pv = s_d[ri * TLD + ri];
+      s_d[ri * TLD + ri] = sqrt(pv > 0.0 ? pv : 1.0);
     }
     __syncthreads();
   }
   if (b == 0) {
     for (int idx = tid; idx < BS * BS; idx += 256) {
       int r = idx >> 6, c = idx & 63;
-      Add[(size_t)r * ld + c] = (c <= r) ? s_d[r * TLD + c] : 0.0;
+      Add[(size_t)r * ld + c] = s_d[r * TLD + c];
     }
     return;
   }
-  // X L^T = B  =>  x_c = (b_c - sum_{m<c} x_m L[c][m]) / L[c][c]; four threads share a row
+  // X L^T = B  =>  x_c = (b_c - sum_{m<c} x_m L[c][m]) / L[c][c].  The four threads of a row sit in one wave,
+  // whose LDS operations complete in issue order, so no block barrier is needed between the steps.
   for (int c = 0; c < BS; ++c) {
     double s = 0.0;
     for (int m = part; m < c; m += 4) s += s_b[ri * TLD + m] * s_d[c * TLD + m];
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
     if (part == 0) s_b[ri * TLD + c] = (s_b[ri * TLD + c] - s) / s_d[c * TLD + c];
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
+  __syncthreads();
   double* dst = A + (size_t)((p + b) * BS) * ld + p * BS;
   for (int idx = tid; idx < BS * BS; idx += 256) {
     int r = idx >> 6, c = idx & 63;
@@ -165,30 +193,29 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int
 // ---------------------------------------------------------------------------------------------
 // Root inverse R = L^-1 (what gpytorch caches as `covar_cache`, stored here un-transposed).
 // Step 1: invert every 64x64 diagonal block by forward substitution (one thread per column).
-__global__ __launch_bounds__(64) void k_trinv_diag(const double* __restrict__ L, int ld, double* __restrict__ R) {
+__global__ __launch_bounds__(256) void k_trinv_diag(const double* __restrict__ L, int ld, double* __restrict__ R) {
   __shared__ __attribute__((aligned(16))) double s_l[BS * TLD];
-  __shared__ __attribute__((aligned(16))) double s_x[BS * TLD];
-  const int b = blockIdx.x, c = threadIdx.x;
-  const double* src = L + (size_t)(b * BS) * ld + b * BS;
-  for (int idx = threadIdx.x; idx < BS * BS; idx += 64) {
-    int r = idx >> 6, cc = idx & 63;
-    s_l[r * TLD + cc] = src[(size_t)r * ld + cc];
-  }
+  __shared__ __attribute__((aligned(16))) double s_x[BS * TLD];   // s_x[c][r]: column c of the inverse, contiguous in r
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int c = tid >> 2, part = tid & 3;                         // four lanes (same wave) per column
+  load_tile(L + (size_t)(b * BS) * ld + b * BS, ld, s_l);
   __syncthreads();
   for (int r = 0; r < BS; ++r) {
-    double v = 0.0;
-    if (r >= c) {
-      double s = (r == c) ? 1.0 : 0.0;
-      for (int m = c; m < r; ++m) s -= s_l[r * TLD + m] * s_x[m * TLD + c];
-      v = s / s_l[r * TLD + r];
-    }
-    s_x[r * TLD + c] = v;
+    double s = 0.0;
+    if (r > c)
+      for (int m = c + part; m < r; m += 4) s += s_l[r * TLD + m] * s_x[c * TLD + m];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (part == 0) s_x[c * TLD + r] = (r < c) ? 0.0 : (((r == c) ? 1.0 : 0.0) - s) / s_l[r * TLD + r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   __syncthreads();
   double* dst = R + (size_t)(b * BS) * ld + b * BS;
-  for (int idx = threadIdx.x; idx < BS * BS; idx += 64) {
+  for (int idx = tid; idx < BS * BS; idx += 256) {
     int r = idx >> 6, cc = idx & 63;
-    dst[(size_t)r * ld + cc] = s_x[r * TLD + cc];
+    dst[(size_t)r * ld + cc] = s_x[cc * TLD + r];
   }
 }
 
@@ -282,7 +309,7 @@ void launch_cholesky(hipStream_t s, double* L, int NP, int ld, int* info) {
 void launch_trinv(hipStream_t s, const double* L, int NP, int ld, double* R) {
   const int nblk = NP / BS;
   hipMemsetAsync(R, 0, (size_t)NP * ld * sizeof(double), s);
-  hipLaunchKernelGGL(k_trinv_diag, dim3(nblk), dim3(64), 0, s, L, ld, R);
+  hipLaunchKernelGGL(k_trinv_diag, dim3(nblk), dim3(256), 0, s, L, ld, R);
   hipLaunchKernelGGL(k_trinv_cols, dim3(NP / 16), dim3(256), 0, s, L, nblk, ld, R);
 }
 void launch_alpha(hipStream_t s, const double* R, const double* ys, int n, int NP, int ld, double* tmp, double* alpha) {

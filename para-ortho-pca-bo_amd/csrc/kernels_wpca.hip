@@ -140,16 +140,40 @@ __global__ __launch_bounds__(256) void k_cov(const double* __restrict__ Wc, int 
 // eigenvectors.  Round-robin ordering gives d/2 independent pairs per round, each handled by a
 // group of LP lanes (shuffle reductions, no LDS traffic for the dot products).
 #define JAC_THREADS 1024
+// Warm start: if the eigenvectors V0 of the previous BO iteration are given (and orthonormal), iterate on
+// G0 = C V0 instead of C: still G = C V with V orthogonal, but the columns start almost orthogonal, so two or
+// three sweeps suffice instead of ~8.  The result does not depend on the start beyond rounding.
 __global__ __launch_bounds__(JAC_THREADS) void k_jacobi(const double* __restrict__ C, int d, int DP,
-                                                        double* __restrict__ Gout, double* __restrict__ lam,
-                                                        int* __restrict__ sweeps_out) {
+                                                        const double* __restrict__ V0, double* __restrict__ Gout,
+                                                        double* __restrict__ lam, int* __restrict__ sweeps_out) {
   extern __shared__ __attribute__((aligned(16))) double s_g[];   // d columns of length d, column-major, stride LD
   const int tid = threadIdx.x;
   const int LD = d | 1;                    // odd stride: column p and q of a pair never share banks systematically
   volatile int& s_rot = *reinterpret_cast<volatile int*>(s_g + (size_t)d * LD);   // flag lives after the matrix
+  if (tid == 0) s_rot = 0;
+  __syncthreads();
+  if (V0) {                                  // usable only if every column has unit norm (none collapsed to zero)
+    for (int col = tid; col < d; col += JAC_THREADS) {
+      double a = 0.0;
+      for (int r = 0; r < d; ++r) { double v = V0[(size_t)col * d + r]; a += v * v; }
+      if (!(fabs(a - 1.0) < 1e-8)) s_rot = 1;
+    }
+  }
+  __syncthreads();
+  const bool warm = V0 && !s_rot;
+  __syncthreads();
   for (int idx = tid; idx < d * d; idx += JAC_THREADS) {
     int col = idx / d, row = idx % d;
-    s_g[col * LD + row] = C[(size_t)row * DP + col];
+    double v;
+    if (warm) {
+      v = 0.0;
+      const double* crow = C + (size_t)row * DP;
+      const double* vcol = V0 + (size_t)col * d;
+      for (int j = 0; j < d; ++j) v += crow[j] * vcol[j];
+    } else {
+      v = C[(size_t)row * DP + col];
+    }
+    s_g[col * LD + row] = v;
   }
   if (tid == 0) s_rot = 0;
   __syncthreads();
@@ -192,7 +216,7 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi(const double* __restrict
               gp[r] = cs * x - sn * y;
               gq[r] = sn * x + cs * y;
             }
-            if (lane == 0) s_rot = 1;
+            if (lane == 0 && fabs(g) > 1e-8 * sqrt(a * b)) s_rot = 1;   // a further sweep is needed
           }
         }
       }
@@ -399,14 +423,14 @@ void launch_cov(hipStream_t s, const double* Wc, int n, int DP, double* C) {
   int n4 = (n + 3) & ~3;
   hipLaunchKernelGGL(k_cov, dim3(DP / 16, DP / 16), dim3(256), 0, s, Wc, n4, DP, 1.0 / (double)(n - 1), C);
 }
-void launch_jacobi(hipStream_t s, const double* C, int d, int DP, double* G, double* lam, int* sweeps) {
+void launch_jacobi(hipStream_t s, const double* C, int d, int DP, const double* V0, double* G, double* lam, int* sweeps) {
   size_t lds = ((size_t)d * (d | 1) + 2) * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)k_jacobi, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_jacobi, dim3(1), dim3(JAC_THREADS), lds, s, C, d, DP, G, lam, sweeps);
+  hipLaunchKernelGGL(k_jacobi, dim3(1), dim3(JAC_THREADS), lds, s, C, d, DP, V0, G, lam, sweeps);
 }
 void launch_pca_finalize(hipStream_t s, const double* G, const double* lam, int n, int d, double var_threshold,
                          int n_components, double* comps, double* evr, int* k_dev, HostMirror* hm) {

@@ -16,6 +16,7 @@
 #define PCABO_ABI_VERSION 1
 #define PROF_GROUPS 6
 #define PROF_POOL 4096
+#define PCABO_INLAUNCH_MAXQ 32
 
 struct ProfPair { hipEvent_t a, b; int group; double bytes, flops; };
 
@@ -34,6 +35,8 @@ struct pcabo_ctx {
   double *dX = nullptr, *dNoise = nullptr, *dF = nullptr, *dWeights = nullptr, *dWc = nullptr;
   long long* dRanks = nullptr;
   double *dDataMean = nullptr, *dPcaMean = nullptr, *dC = nullptr, *dG = nullptr, *dLam = nullptr;
+  double* dGbuf[2] = {nullptr, nullptr};   // eigenvector ping-pong: the previous result warm-starts the next Jacobi
+  int gcur = 0, vprev_d = 0;
   double *dComps = nullptr, *dEvr = nullptr, *dZ = nullptr;
   int *dK = nullptr, *dSweeps = nullptr, *dInfo = nullptr;
   double *dY = nullptr, *dYs = nullptr, *dYstats = nullptr, *dBounds4 = nullptr, *dZnMean = nullptr, *dUserNB = nullptr;
@@ -140,7 +143,8 @@ int pcabo_ctx_create(int device, int max_n, int max_d, int max_q, pcabo_ctx** ou
   HIPCHK(dalloc(&ctx->dF, n));           HIPCHK(dalloc(&ctx->dWeights, n));
   HIPCHK(dalloc(&ctx->dWc, (n + 4) * D)); HIPCHK(dalloc(&ctx->dRanks, n));
   HIPCHK(dalloc(&ctx->dDataMean, d));    HIPCHK(dalloc(&ctx->dPcaMean, d));
-  HIPCHK(dalloc(&ctx->dC, D * D));       HIPCHK(dalloc(&ctx->dG, d * d));
+  HIPCHK(dalloc(&ctx->dC, D * D));       HIPCHK(dalloc(&ctx->dGbuf[0], d * d));  HIPCHK(dalloc(&ctx->dGbuf[1], d * d));
+  ctx->dG = ctx->dGbuf[0];
   HIPCHK(dalloc(&ctx->dLam, d));         HIPCHK(dalloc(&ctx->dComps, d * d));
   HIPCHK(dalloc(&ctx->dEvr, d));         HIPCHK(dalloc(&ctx->dZ, n * d));
   HIPCHK(dalloc(&ctx->dK, 1));           HIPCHK(dalloc(&ctx->dSweeps, 1));   HIPCHK(dalloc(&ctx->dInfo, 1));
@@ -174,7 +178,7 @@ int pcabo_ctx_destroy(pcabo_ctx* ctx) {
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   for (auto& p : ctx->pairs) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   void* dev[] = {ctx->dX, ctx->dNoise, ctx->dF, ctx->dWeights, ctx->dWc, ctx->dRanks, ctx->dDataMean, ctx->dPcaMean,
-                 ctx->dC, ctx->dG, ctx->dLam, ctx->dComps, ctx->dEvr, ctx->dZ, ctx->dK, ctx->dSweeps, ctx->dInfo,
+                 ctx->dC, ctx->dGbuf[0], ctx->dGbuf[1], ctx->dLam, ctx->dComps, ctx->dEvr, ctx->dZ, ctx->dK, ctx->dSweeps, ctx->dInfo,
                  ctx->dY, ctx->dYs, ctx->dYstats, ctx->dBounds4, ctx->dZnMean, ctx->dUserNB, ctx->dZnT, ctx->dAT,
                  ctx->dNrm, ctx->dGram, ctx->dL, ctx->dR, ctx->dTmp, ctx->dAlpha, ctx->dXq, ctx->dPartial, ctx->dVal,
                  ctx->dGrad, ctx->dZq, ctx->dXout, ctx->dCounters};
@@ -237,7 +241,11 @@ int pcabo_wpca(pcabo_ctx* ctx, const double* X, const double* f, const int64_t* 
     launch_wpca_prep(s, ctx->dX, ctx->dRanks, noise ? ctx->dNoise : nullptr, n, d, DP, ctx->dWeights, ctx->dDataMean,
                      ctx->dPcaMean, ctx->dWc);
     launch_cov(s, ctx->dWc, n, DP, ctx->dC);
-    launch_jacobi(s, ctx->dC, d, DP, ctx->dG, ctx->dLam, ctx->dSweeps);
+    const double* v0 = (ctx->vprev_d == d) ? ctx->dGbuf[ctx->gcur] : nullptr;
+    ctx->gcur ^= 1;
+    ctx->dG = ctx->dGbuf[ctx->gcur];
+    launch_jacobi(s, ctx->dC, d, DP, v0, ctx->dG, ctx->dLam, ctx->dSweeps);
+    ctx->vprev_d = d;
     launch_pca_finalize(s, ctx->dG, ctx->dLam, n, d, var_threshold, n_components, ctx->dComps, ctx->dEvr, ctx->dK,
                         ctx->hm);
     launch_project(s, ctx->dX, ctx->dDataMean, ctx->dPcaMean, ctx->dComps, ctx->dK, n, d, ctx->dZ);
@@ -353,13 +361,21 @@ static int eval_staged(pcabo_ctx* ctx, int nq, AcqParams& p) {
     HIPCHK(hipMemcpyAsync(ctx->dXq, ctx->hXq, (size_t)nq * k * sizeof(double), hipMemcpyHostToDevice, s));
     xdev = ctx->dXq;
   }
+  const bool small = nq <= PCABO_INLAUNCH_MAXQ;   // in-launch combine + host flag; larger batches: two launches + copy
+  if (!small) ctx->done_total -= (unsigned int)nq;
   {
     ProfScope ps(ctx, 4, acq_bytes(ctx->n, k, nq, p.want_grad), acq_flops(ctx->n, k, nq, p.want_grad));
     launch_acq(s, qa, xdev, nq, ctx->n, k, ctx->NP, ctx->ld, ctx->dZnT, ctx->dR, ctx->dAlpha, ctx->dBounds4, ctx->dYstats,
-               p, ctx->dPartial, ctx->dCounters, ctx->done_total, ctx->dVal, ctx->dGrad, ctx->hVal, ctx->hGrad, ctx->hm,
-               seq);
+               p, ctx->dPartial, ctx->dCounters, ctx->done_total, ctx->dVal, ctx->dGrad, small ? ctx->hVal : nullptr,
+               small ? ctx->hGrad : nullptr, small ? ctx->hm : nullptr, seq);
   }
-  if (acq_variant() & 2) { HIPCHK(hipStreamSynchronize(s)); return PCABO_OK; }
+  if (!small) {
+    HIPCHK(hipMemcpyAsync(ctx->hVal, ctx->dVal, (size_t)nq * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (p.want_grad) HIPCHK(hipMemcpyAsync(ctx->hGrad, ctx->dGrad, (size_t)nq * k * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    return PCABO_OK;
+  }
   const auto t0 = std::chrono::steady_clock::now();
   unsigned long spins = 0;
   while (__atomic_load_n(&ctx->hm->flag, __ATOMIC_ACQUIRE) != seq) {

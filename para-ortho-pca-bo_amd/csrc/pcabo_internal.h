@@ -44,7 +44,7 @@ void launch_rank(hipStream_t s, const double* f, int n, int maximize, long long*
 void launch_wpca_prep(hipStream_t s, const double* X, const long long* ranks, const double* noise, int n, int d,
                       int DP, double* weights, double* data_mean, double* pca_mean, double* Wc);
 void launch_cov(hipStream_t s, const double* Wc, int n, int DP, double* C);
-void launch_jacobi(hipStream_t s, const double* C, int d, int DP, double* G, double* lam, int* sweeps);
+void launch_jacobi(hipStream_t s, const double* C, int d, int DP, const double* V0, double* G, double* lam, int* sweeps);
 void launch_pca_finalize(hipStream_t s, const double* G, const double* lam, int n, int d, double var_threshold,
                          int n_components, double* comps, double* evr, int* k_dev, HostMirror* hm);
 void launch_project(hipStream_t s, const double* X, const double* data_mean, const double* pca_mean,
@@ -60,7 +60,6 @@ void launch_add_jitter(hipStream_t s, double* K, int n, int ld, double jitter);
 void launch_cholesky(hipStream_t s, double* L, int NP, int ld, int* info);
 void launch_trinv(hipStream_t s, const double* L, int NP, int ld, double* R);
 void launch_alpha(hipStream_t s, const double* R, const double* ys, int n, int NP, int ld, double* tmp, double* alpha);
-int acq_variant();
 void launch_acq(hipStream_t s, const QueryArgs* qa, const double* Xq, int q, int n, int k, int NP, int ld,
                 const double* ZnT, const double* R, const double* alpha, const double* bounds4, const double* ystats,
                 AcqParams p, double* partial, unsigned int* counters, unsigned int done_target, double* val,

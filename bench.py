@@ -62,8 +62,9 @@ class RunChain:
     def _close(self):
         if self.opt is not None:
             self.best.append(float(self.opt.current_best))
-            for key, val in self.opt.total_times.items():
+            for key, val in list(self.opt.total_times.items()) + [("optimize_acqf/" + k, v) for k, v in self.opt.phase_breakdown.items()]:
                 self.phase_seconds[key] = self.phase_seconds.get(key, 0.0) + val
+            self.phase_seconds["lbfgsb_rounds"] = self.phase_seconds.get("lbfgsb_rounds", 0) + int(sum(int(i[:, 1].max()) for i in self.opt.lbfgsb_info))
             self.opt._finish()
             self.opt = None
 

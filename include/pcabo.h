@@ -133,6 +133,12 @@ int pcabo_lbfgsb_minimize(int nvar, double* x, const double* lower, const double
                           int maxiter, int maxfun, int maxls, double* f_out, int* nit, int* nfev,
                           int* task_out);
 
+/* Host-only helper for the initial-condition draw (botorch -> torch.quasirandom.SobolEngine, row K):
+ * the matrix scramble of torch's `_sobol_engine_scramble_` on state[k*30] (in/out) with the k lower-
+ * triangular 30x30 0/1 matrices ltm[k*30*30] (as drawn by torch.randint(...).tril()); bit-identical to torch,
+ * ~50x faster than torch's accessor loop.  The random bits themselves still come from torch's generator. */
+int pcabo_sobol_scramble(int64_t* state, const int64_t* ltm, int k);
+
 /* Device-time accounting: accumulated HIP-event time (ms, events recorded on the context's own
  * stream), launch count and ALGORITHMIC bytes / flops of the kernel groups since the last reset.
  * which: 0 wpca (5 kernels), 1 normalise+Gram (3 kernels), 2 Cholesky (2 kernels per 64-wide panel),

@@ -128,6 +128,7 @@ class PCA_BO(AbstractBayesianOptimizer):
         self.__ctx: Optional[_native.Context] = None
         self.lbfgsb_info = []          # per iteration: (iterations, evaluations, warnflag, task) per restart group
         self.trace = []                # record_trace=True: per iteration RNG states, restart candidates/values
+        self.phase_breakdown = {"sobol": 0.0, "raw_eval": 0.0, "init_pick": 0.0, "lbfgsb": 0.0}   # inside optimize_acqf
 
     def __str__(self):
         return "This is an instance of a PCA-assisted BO Optimizer"
@@ -255,18 +256,29 @@ class PCA_BO(AbstractBayesianOptimizer):
         num_restarts, raw_samples, batch_limit = cfg["NUM_RESTARTS"], cfg["RAW_SAMPLES"], 5
         start = perf_counter()
 
+        pb = self.phase_breakdown
+
         def initial_conditions():
+            t0 = perf_counter()
             raw = _init.draw_sobol(bounds, raw_samples)
+            t1 = perf_counter()
             vals = ctx.acq_eval(raw, acq.best_f, acq.maximize, acq.acq_code, grad=False)
+            t2 = perf_counter()
             if acq.acq_code == _native.ACQ_PI:
                 idx = _init.initialize_q_batch_nonneg(vals, num_restarts)
             else:
                 idx = _init.initialize_q_batch(vals, num_restarts)
+            t3 = perf_counter()
+            pb["sobol"] += t1 - t0
+            pb["raw_eval"] += t2 - t1
+            pb["init_pick"] += t3 - t2
             return raw[idx]
 
         ics = initial_conditions()
+        t_opt = perf_counter()
         cand, vals, info, failed = ctx.optimize_acqf(ics, bounds, acq.best_f, acq.maximize, acq.acq_code,
                                                      batch_limit=batch_limit, maxiter=200)
+        pb["lbfgsb"] += perf_counter() - t_opt
         if failed:   # botorch: OptimizationWarning -> one retry with freshly drawn initial conditions
             warnings.warn("Optimization failed in `gen_candidates_scipy`; trying again with a new set of "
                           "initial conditions.", RuntimeWarning)

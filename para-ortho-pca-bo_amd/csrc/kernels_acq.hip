@@ -20,7 +20,7 @@
 //                  gradients of different slabs simply add.
 //                  The S partial records of a query are then combined INSIDE the launch by the
 //                  last work-group to arrive at a per-query ticket counter (split-K style hand-off:
-//                  plain stores -> vmcnt(0) -> barrier -> agent-scope release -> relaxed ticket;
+//                  write-through (sc1) stores -> vmcnt(0) -> barrier -> relaxed ticket;
 //                  the last arriver does one agent-scope acquire, then plain loads).  It sums the
 //                  partials in a fixed order (deterministic), applies the scalar log-EI chain rule
 //                  and writes value/gradient to device memory and to pinned host memory; the group
@@ -32,6 +32,13 @@
 
 #define SLAB PCABO_SLAB
 #define PSTRIDE (2 + 2 * PCABO_MAXD)   // doubles per (query, slab) partial record
+
+// Write-through store (global_store ... sc1): the partial records are handed to another work-group inside
+// the launch; written this way they never sit dirty in this XCD's L2, so the hand-off needs no L2 write-back
+// (agent-scope release) on the producer side - only the drain + ticket, and the consumer's acquire.
+__device__ inline void st_wt(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 __device__ inline int slab_row(int s, int m, int NP) { return m < 8 ? 8 * s + m : NP - 8 * (s + 1) + (m - 8); }
 
@@ -122,7 +129,7 @@ __global__ __launch_bounds__(256) void k_acq_fused(
     }
 #pragma unroll
     for (int off = 8; off > 0; off >>= 1) { vv += __shfl_xor(vv, off, 64); mu += __shfl_xor(mu, off, 64); }
-    if (l == 0) { out[0] = vv; out[1] = mu; }
+    if (l == 0) { st_wt(out + 0, vv); st_wt(out + 1, mu); }
   }
   if (want_grad) {
   __syncthreads();   // thread 0 has finished reading s_ks before it is reused below
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(256) void k_acq_fused(
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int c = c0 + w + 4 * u;
-        if (c < k) { out[2 + c] = gs[u]; out[2 + PCABO_MAXD + c] = gm[u]; }
+        if (c < k) { st_wt(out + 2 + c, gs[u]); st_wt(out + 2 + PCABO_MAXD + c, gm[u]); }
       }
     }
   }
@@ -178,8 +185,6 @@ __global__ __launch_bounds__(256) void k_acq_fused(
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     unsigned int t = __hip_atomic_fetch_add(&counters[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int last = ((t % (unsigned int)S) == (unsigned int)(S - 1));
     if (last) {

@@ -17,6 +17,9 @@
 
 namespace {
 
+// circular column index of the limited-memory matrices (avoids an integer division per use)
+inline int nxt(int p, int m) { return p + 1 == m ? 0 : p + 1; }
+
 inline double ddot(int n, const double* x, const double* y) {
   double s = 0.0;
   for (int i = 0; i < n; ++i) s += x[i] * y[i];
@@ -65,6 +68,7 @@ int dtrsl(const double* t, int ldt, int nn, double* b, int job) {
 }  // namespace
 
 void Lbfgsb::init(int n, int m, const double* lower, const double* upper, double factr, double pgtol, int maxls) {
+  if (m > LBFGSB_MAXM) m = LBFGSB_MAXM;
   n_ = n; m_ = m; factr_ = factr; pgtol_ = pgtol; maxls_ = maxls;
   l_.assign(n, 0.0); u_.assign(n, 0.0); nbd_.assign(n, 0);
   for (int i = 0; i < n; ++i) {
@@ -214,7 +218,7 @@ void Lbfgsb::cauchy(const double* x, const double* g) {
       for (int j = 0; j < col; ++j) {
         p[j] += WY(i, pointr) * neggi;
         p[col + j] += WS(i, pointr) * neggi;
-        pointr = (pointr + 1) % m;
+        pointr = nxt(pointr, m);
       }
       if (nbd_[i] <= 2 && nbd_[i] != 0 && neggi < 0.0) {
         iorder[nbreak] = i;
@@ -287,7 +291,7 @@ void Lbfgsb::cauchy(const double* x, const double* g) {
         for (int j = 0; j < col; ++j) {
           wbp[j] = WY(ibp, pointr);
           wbp[col + j] = theta_ * WS(ibp, pointr);
-          pointr = (pointr + 1) % m;
+          pointr = nxt(pointr, m);
         }
         bmv(wbp, v);
         if (info_ != 0) return;
@@ -361,28 +365,35 @@ void Lbfgsb::formk() {
     }
     int ipntr = (head + col - 1) % m;
     const int iy = col - 1, is = m + col - 1;
-    int jpntr = head;
-    for (int jy = 0; jy < col; ++jy) {
-      const int js = m + jy;
-      double temp1 = 0.0, temp2 = 0.0, temp3 = 0.0;
-      for (int k = 0; k < nsub; ++k) { int k1 = ind[k]; temp1 += WY(k1, ipntr) * WY(k1, jpntr); }
-      for (int k = nsub; k < n; ++k) {
-        int k1 = ind[k];
-        temp2 += WS(k1, ipntr) * WS(k1, jpntr);
-        temp3 += WS(k1, ipntr) * WY(k1, jpntr);
+    // Elements jy = 0..col-1 of the new rows: col independent dot products per block, accumulated side by
+    // side (k outer) - every accumulator still sums k in increasing order, exactly like one-at-a-time ddots.
+    {
+      double t1[LBFGSB_MAXM], t2[LBFGSB_MAXM], t3[LBFGSB_MAXM], t4[LBFGSB_MAXM];
+      int ptr[LBFGSB_MAXM];
+      int jp = head;
+      for (int jy = 0; jy < col; ++jy) { t1[jy] = t2[jy] = t3[jy] = t4[jy] = 0.0; ptr[jy] = jp; jp = nxt(jp, m); }
+      const int jlast = (head + col - 1) % m;
+      for (int k = 0; k < nsub; ++k) {
+        const int k1 = ind[k];
+        const double wyi = WY(k1, ipntr), wyl = WY(k1, jlast);
+        for (int jy = 0; jy < col; ++jy) {
+          t1[jy] += wyi * WY(k1, ptr[jy]);               // row col of Y'ZZ'Y
+          t4[jy] += WS(k1, ptr[jy]) * wyl;               // column col of R_z
+        }
       }
-      WN1(iy, jy) = temp1; WN1(is, js) = temp2; WN1(is, jy) = temp3;
-      jpntr = (jpntr + 1) % m;
-    }
-    const int jyc = col - 1;
-    jpntr = (head + col - 1) % m;
-    ipntr = head;
-    for (int i = 0; i < col; ++i) {
-      const int is2 = m + i;
-      double temp3 = 0.0;
-      for (int k = 0; k < nsub; ++k) { int k1 = ind[k]; temp3 += WS(k1, ipntr) * WY(k1, jpntr); }
-      ipntr = (ipntr + 1) % m;
-      WN1(is2, jyc) = temp3;
+      for (int k = nsub; k < n; ++k) {
+        const int k1 = ind[k];
+        const double wsi = WS(k1, ipntr);
+        for (int jy = 0; jy < col; ++jy) {
+          t2[jy] += wsi * WS(k1, ptr[jy]);               // row col of S'AA'S
+          t3[jy] += wsi * WY(k1, ptr[jy]);               // row col of L_a
+        }
+      }
+      for (int jy = 0; jy < col; ++jy) {
+        WN1(iy, jy) = t1[jy]; WN1(is, m + jy) = t2[jy]; WN1(is, jy) = t3[jy];
+      }
+      const int jyc = col - 1;
+      for (int i = 0; i < col; ++i) WN1(m + i, jyc) = t4[i];
     }
     upcl = col - 1;
   } else {
@@ -407,9 +418,9 @@ void Lbfgsb::formk() {
       }
       WN1(iy, jy) = WN1(iy, jy) + temp1 - temp3;
       WN1(is, js) = WN1(is, js) - temp2 + temp4;
-      jpntr = (jpntr + 1) % m;
+      jpntr = nxt(jpntr, m);
     }
-    ipntr = (ipntr + 1) % m;
+    ipntr = nxt(ipntr, m);
   }
   ipntr = head;
   for (int is = m; is < m + upcl; ++is) {
@@ -420,9 +431,9 @@ void Lbfgsb::formk() {
       for (int k = ileave_; k < n; ++k) { int k1 = indx2[k]; temp3 += WS(k1, ipntr) * WY(k1, jpntr); }
       if (is <= jy + m) WN1(is, jy) = WN1(is, jy) + temp1 - temp3;
       else WN1(is, jy) = WN1(is, jy) - temp1 + temp3;
-      jpntr = (jpntr + 1) % m;
+      jpntr = nxt(jpntr, m);
     }
-    ipntr = (ipntr + 1) % m;
+    ipntr = nxt(ipntr, m);
   }
   const int m2 = 2 * m;
   for (int iy = 0; iy < col; ++iy) {
@@ -459,7 +470,7 @@ void Lbfgsb::cmprlb(const double* x, const double* g) {
   for (int j = 0; j < col; ++j) {
     const double a1 = wa_[j], a2 = theta_ * wa_[col + j];
     for (int i = 0; i < nfree_; ++i) { int k = index_[i]; r_[i] += WY(k, pointr) * a1 + WS(k, pointr) * a2; }
-    pointr = (pointr + 1) % m;
+    pointr = nxt(pointr, m);
   }
 }
 
@@ -471,12 +482,16 @@ void Lbfgsb::subsm(const double* xx, const double* gg) {
   double* wv = wa_.data();
   if (nsub <= 0) return;
   int pointr = head_;
-  for (int i = 0; i < col; ++i) {
-    double temp1 = 0.0, temp2 = 0.0;
-    for (int j = 0; j < nsub; ++j) { int k = ind[j]; temp1 += WY(k, pointr) * d[j]; temp2 += WS(k, pointr) * d[j]; }
-    wv[i] = temp1;
-    wv[col + i] = theta_ * temp2;
-    pointr = (pointr + 1) % m;
+  {
+    double t1[LBFGSB_MAXM], t2[LBFGSB_MAXM];
+    int ptr[LBFGSB_MAXM];
+    for (int i = 0; i < col; ++i) { t1[i] = t2[i] = 0.0; ptr[i] = pointr; pointr = nxt(pointr, m); }
+    for (int j = 0; j < nsub; ++j) {
+      const int k = ind[j];
+      const double dj = d[j];
+      for (int i = 0; i < col; ++i) { t1[i] += WY(k, ptr[i]) * dj; t2[i] += WS(k, ptr[i]) * dj; }
+    }
+    for (int i = 0; i < col; ++i) { wv[i] = t1[i]; wv[col + i] = theta_ * t2[i]; }
   }
   const int m2 = 2 * m, col2 = 2 * col;
   info_ = dtrsl(wn_.data(), m2, col2, wv, 11);
@@ -491,7 +506,7 @@ void Lbfgsb::subsm(const double* xx, const double* gg) {
       int k = ind[i];
       d[i] = d[i] + WY(k, pointr) * wv[jy] / theta_ + WS(k, pointr) * wv[js];
     }
-    pointr = (pointr + 1) % m;
+    pointr = nxt(pointr, m);
   }
   const double inv_theta = 1.0 / theta_;
   for (int i = 0; i < nsub; ++i) d[i] *= inv_theta;
@@ -732,8 +747,8 @@ void Lbfgsb::matupd(double rr, double dr) {
     col_ = iupdat_;
     itail_ = (head_ + iupdat_ - 1) % m;
   } else {
-    itail_ = (itail_ + 1) % m;
-    head_ = (head_ + 1) % m;
+    itail_ = nxt(itail_, m);
+    head_ = nxt(head_, m);
   }
   std::memcpy(&WS(0, itail_), d_.data(), sizeof(double) * n);
   std::memcpy(&WY(0, itail_), r_.data(), sizeof(double) * n);
@@ -745,11 +760,16 @@ void Lbfgsb::matupd(double rr, double dr) {
       for (int t = 0; t < col - 1 - j; ++t) SY(j + t, j) = SY(j + 1 + t, j + 1);
     }
   }
-  int pointr = head_;
-  for (int j = 0; j < col - 1; ++j) {
-    SY(col - 1, j) = ddot(n, d_.data(), &WY(0, pointr));
-    SS(j, col - 1) = ddot(n, &WS(0, pointr), d_.data());
-    pointr = (pointr + 1) % m;
+  {
+    double t1[LBFGSB_MAXM], t2[LBFGSB_MAXM];
+    int ptr[LBFGSB_MAXM];
+    int pointr = head_;
+    for (int j = 0; j < col - 1; ++j) { t1[j] = t2[j] = 0.0; ptr[j] = pointr; pointr = nxt(pointr, m); }
+    for (int k = 0; k < n; ++k) {
+      const double dk = d_[k];
+      for (int j = 0; j < col - 1; ++j) { t1[j] += dk * WY(k, ptr[j]); t2[j] += WS(k, ptr[j]) * dk; }
+    }
+    for (int j = 0; j < col - 1; ++j) { SY(col - 1, j) = t1[j]; SS(j, col - 1) = t2[j]; }
   }
   if (stp_ == 1.0) SS(col - 1, col - 1) = dtd_;
   else SS(col - 1, col - 1) = stp_ * stp_ * dtd_;

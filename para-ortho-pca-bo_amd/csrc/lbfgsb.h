@@ -10,6 +10,8 @@
 #pragma once
 #include <vector>
 
+#define LBFGSB_MAXM 32   // largest history length supported (scipy's default is 10)
+
 enum {
   LBFGSB_START = 0,
   LBFGSB_NEW_X = 1,        // an iteration finished; caller may stop() or call step() again

@@ -5,7 +5,9 @@
 #include "lbfgsb.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <thread>
 #include <cstdlib>
 #include <cmath>
 #include <cstdio>
@@ -442,7 +444,7 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
   const int ngroups = (num_restarts + batch_limit - 1) / batch_limit;
   std::vector<Lbfgsb> opt(ngroups);
   std::vector<int> gstart(ngroups), gsize(ngroups), niter(ngroups, 0), nfev(ngroups, 0);
-  std::vector<bool> active(ngroups, true), want_fg(ngroups, false);
+  std::vector<char> active(ngroups, 1);     // char, not vector<bool>: groups are touched from two threads
   std::vector<std::vector<double>> x(ngroups), g(ngroups), lo(ngroups), hi(ngroups);
   std::vector<double> fval(ngroups, 0.0);
   for (int gi = 0; gi < ngroups; ++gi) {
@@ -465,30 +467,59 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
   double t_step = 0.0, t_eval = 0.0; int rounds = 0;
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   int any_failed = 0;
-  while (true) {
-    // advance every active state machine until it needs f,g (or stops)
-    const double ta = trace ? now() : 0.0;
-    int nq = 0;
-    std::vector<int> qoff(ngroups, -1);
-    for (int gi = 0; gi < ngroups; ++gi) {
-      if (!active[gi]) continue;
+  // advance one group's state machine until it needs f,g at x[gi] (or stops)
+  auto advance = [&](int gi) {
+    if (!active[gi]) return;
+    while (true) {
+      int task = opt[gi].step(x[gi].data(), &fval[gi], g[gi].data());
+      if (task == LBFGSB_FG) return;
+      if (task == LBFGSB_NEW_X) {
+        niter[gi] += 1;
+        if (niter[gi] >= maxiter) opt[gi].stop(LBFGSB_STOP_ITER);
+        else if (nfev[gi] > maxfun) opt[gi].stop(LBFGSB_STOP_FUN);
+        continue;
+      }
+      active[gi] = false;
+      return;
+    }
+  };
+  // The groups are independent between evaluations: odd-numbered groups advance on a helper thread while the
+  // calling thread advances the even ones (hand-off through two sequence counters, spin-waiting).
+  std::atomic<unsigned> go{0}, done{0};
+  std::atomic<bool> quit{false};
+  std::thread helper;
+  if (ngroups > 1) {
+    helper = std::thread([&] {
+      unsigned seen = 0;
       while (true) {
-        int task = opt[gi].step(x[gi].data(), &fval[gi], g[gi].data());
-        if (task == LBFGSB_FG) { want_fg[gi] = true; break; }
-        if (task == LBFGSB_NEW_X) {
-          niter[gi] += 1;
-          if (niter[gi] >= maxiter) opt[gi].stop(LBFGSB_STOP_ITER);
-          else if (nfev[gi] > maxfun) opt[gi].stop(LBFGSB_STOP_FUN);
-          continue;
+        unsigned cur;
+        while ((cur = go.load(std::memory_order_acquire)) == seen) {
+          if (quit.load(std::memory_order_acquire)) return;
+          __builtin_ia32_pause();
         }
-        active[gi] = false; want_fg[gi] = false;
-        break;
+        seen = cur;
+        for (int gi = 1; gi < ngroups; gi += 2) advance(gi);
+        done.store(cur, std::memory_order_release);
       }
-      if (active[gi]) {
-        qoff[gi] = nq;
-        memcpy(ctx->hXq + (size_t)nq * k, x[gi].data(), (size_t)gsize[gi] * k * sizeof(double));
-        nq += gsize[gi];
-      }
+    });
+  }
+  struct Joiner { std::thread& t; std::atomic<bool>& q; ~Joiner() { q.store(true, std::memory_order_release); if (t.joinable()) t.join(); } } joiner{helper, quit};
+  unsigned round_no = 0;
+  std::vector<int> qoff(ngroups, -1);
+  while (true) {
+    const double ta = trace ? now() : 0.0;
+    ++round_no;
+    if (ngroups > 1) go.store(round_no, std::memory_order_release);
+    for (int gi = 0; gi < ngroups; gi += 2) advance(gi);
+    if (ngroups > 1)
+      while (done.load(std::memory_order_acquire) != round_no) __builtin_ia32_pause();
+    int nq = 0;
+    for (int gi = 0; gi < ngroups; ++gi) {
+      qoff[gi] = -1;
+      if (!active[gi]) continue;
+      qoff[gi] = nq;
+      memcpy(ctx->hXq + (size_t)nq * k, x[gi].data(), (size_t)gsize[gi] * k * sizeof(double));
+      nq += gsize[gi];
     }
     if (nq == 0) break;
     const double tb = trace ? now() : 0.0;
@@ -602,6 +633,33 @@ int pcabo_lbfgsb_minimize(int nvar, double* x, const double* lower, const double
   if (nfev) *nfev = evals;
   if (task_out) *task_out = opt.task();
   return opt.warnflag();
+}
+
+int pcabo_sobol_scramble(int64_t* state, const int64_t* ltm, int k) {
+  if (!state || !ltm || k < 1) return PCABO_ERR_ARG;
+  const int MAXBIT = 30;
+  for (int d = 0; d < k; ++d) {
+    int64_t lsm[30];
+    for (int p = 0; p < MAXBIT; ++p) {                  // row p of matrix d (diagonal forced to 1) as a bit vector
+      int64_t v = 0;
+      const int64_t* row = ltm + ((size_t)d * MAXBIT + p) * MAXBIT;
+      for (int c = 0; c < MAXBIT; ++c) {
+        int64_t bit = (c == p) ? 1 : (row[c] & 1);
+        v += bit << (MAXBIT - 1 - c);
+      }
+      lsm[p] = v;
+    }
+    for (int j = 0; j < MAXBIT; ++j) {
+      const int64_t vdj = state[(size_t)d * MAXBIT + j];
+      int64_t t2 = 0;
+      for (int p = MAXBIT - 1; p >= 0; --p) {
+        int64_t t1 = __builtin_popcountll((unsigned long long)(lsm[p] & vdj)) & 1;
+        t2 += t1 << (MAXBIT - 1 - p);
+      }
+      state[(size_t)d * MAXBIT + j] = t2;
+    }
+  }
+  return PCABO_OK;
 }
 
 int pcabo_set_profiling(pcabo_ctx* ctx, int enabled) {

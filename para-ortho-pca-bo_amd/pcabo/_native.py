@@ -24,7 +24,7 @@ EXPORTS = [
     "pcabo_abi_version", "pcabo_device_count", "pcabo_ctx_create", "pcabo_ctx_destroy",
     "pcabo_set_pointer_mode", "pcabo_last_error", "pcabo_wpca", "pcabo_gp_condition", "pcabo_acq_bounds",
     "pcabo_acq_eval", "pcabo_logei", "pcabo_optimize_acqf", "pcabo_inverse_map", "pcabo_get_gp_state",
-    "pcabo_get_gram", "pcabo_lbfgsb_minimize", "pcabo_set_profiling", "pcabo_get_profile", "pcabo_reset_profile",
+    "pcabo_get_gram", "pcabo_lbfgsb_minimize", "pcabo_sobol_scramble", "pcabo_set_profiling", "pcabo_get_profile", "pcabo_reset_profile",
 ]
 
 
@@ -65,6 +65,7 @@ def _load() -> C.CDLL:
     lib.pcabo_inverse_map.argtypes = [vp, vp, vp]
     lib.pcabo_get_gp_state.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.pcabo_get_gram.argtypes = [vp, vp]
+    lib.pcabo_sobol_scramble.argtypes = [vp, vp, C.c_int]
     lib.pcabo_set_profiling.argtypes = [vp, C.c_int]
     lib.pcabo_get_profile.argtypes = [vp, C.c_int, dp, C.POINTER(C.c_int64), dp, dp]
     lib.pcabo_reset_profile.argtypes = [vp]
@@ -229,6 +230,14 @@ class Context:
             self._chk(LIB.pcabo_get_profile(self._h, i, C.byref(ms), C.byref(cnt), C.byref(by), C.byref(fl)))
             out[name] = {"ms": ms.value, "launches": cnt.value, "bytes": by.value, "flops": fl.value}
         return out
+
+
+def sobol_scramble(state: np.ndarray, ltm: np.ndarray) -> None:
+    """In-place scramble of a (k, 30) int64 Sobol state with (k, 30, 30) int64 lower-triangular bit matrices."""
+    assert state.dtype == np.int64 and ltm.dtype == np.int64 and state.flags.c_contiguous and ltm.flags.c_contiguous
+    rc = LIB.pcabo_sobol_scramble(_ptr(state), _ptr(ltm), int(state.shape[0]))
+    if rc != 0:
+        raise PcaboError(rc, "pcabo_sobol_scramble: bad argument")
 
 
 def lbfgsb_minimize(fun, x0, bounds, m=10, factr=1e7, pgtol=1e-5, maxiter=15000, maxfun=15000, maxls=20):

@@ -127,6 +127,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     device = local_rank if size > 1 else 0
+    if os.environ.get("PCABO_BENCH_DEVICE") is not None:      # rehearsal override: all ranks on one device (gloo)
+        device = int(os.environ["PCABO_BENCH_DEVICE"])
     torch.cuda.set_device(device)
     torch.set_num_threads(4)
 
@@ -178,13 +180,21 @@ def main():
             a = prof["acq_partial"]
             dur = a["ms"] * 1e-3 / max(1, a["launches"])
             byt = a["bytes"] / max(1, a["launches"])
-            roof = {"kernel": "k_acq_partial", "bound": "hbm", "achieved": byt / dur / 1e9, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": byt / dur / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            traffic = None
+            try:    # PMC pass of profiles/r01 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 correction applied)
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
+                traffic = pmc["n250_k33_q10"]["traffic_bytes"]
+            except Exception:   # noqa: BLE001
+                pass
+            roof = {"kernel": "k_acq_fused", "bound": "hbm", "achieved": byt / dur / 1e9, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": byt / dur / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                    "traffic_note": "fabric-side bytes per launch at n=250,k=33,q=10 from the PMC pass in profiles/r01 "
+                                    "(2*FETCH_SIZE+WRITE_SIZE); table for n=120/250/449 in profiles/r01/pmc_traffic.json",
                     "avg_launch_us": dur * 1e6, "launches": a["launches"], "algorithmic_bytes_per_launch": byt,
                     "achieved_tflops": a["flops"] / (a["ms"] * 1e-3) / 1e12,
                     "note": f"profiled pass over the first {prof_steps} BO iterations (n=120..{120 + prof_steps - 1}); "
                             "latency-bound kernel, R stays L2-resident"}
-            for name in ("wpca", "gram", "cholesky", "root_inverse_alpha", "acq_combine"):
+            for name in ("wpca", "gram", "cholesky", "root_inverse_alpha"):
                 g = prof[name]
                 if g["launches"]:
                     extra[name] = {"avg_us": g["ms"] * 1e3 / g["launches"], "calls": g["launches"],

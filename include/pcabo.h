@@ -88,6 +88,13 @@ int pcabo_wpca(pcabo_ctx* ctx, const double* X, const double* f, const int64_t* 
 int pcabo_gp_condition(pcabo_ctx* ctx, const double* Z, const double* y, int n, int k,
                        const double* norm_bounds, double lengthscale, double noise, int kernel);
 
+/* The same in two halves: _begin stages the inputs and enqueues every kernel without waiting, _end waits,
+ * checks the factorisation and performs the jitter retries.  Lets the host prepare the next phase (e.g. the
+ * Sobol engine of the initial-condition draw) while the device conditions the GP. */
+int pcabo_gp_condition_begin(pcabo_ctx* ctx, const double* Z, const double* y, int n, int k,
+                             const double* norm_bounds, double lengthscale, double noise, int kernel);
+int pcabo_gp_condition_end(pcabo_ctx* ctx);
+
 /* Row J: search box of the acquisition optimiser, PCA_BO.py:558-573. bounds[2*k] [host] (lo row, hi row). */
 int pcabo_acq_bounds(pcabo_ctx* ctx, double* bounds);
 

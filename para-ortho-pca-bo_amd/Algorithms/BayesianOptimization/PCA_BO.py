@@ -125,6 +125,7 @@ class PCA_BO(AbstractBayesianOptimizer):
         if visualize:
             warnings.warn("visualize=True: the GIF visualiser of the reference is not part of the MI355X path; ignored.")
         self.__z_evals = []
+        self.__gp_pending = False
         self.__ctx: Optional[_native.Context] = None
         self.lbfgsb_info = []          # per iteration: (iterations, evaluations, warnflag, task) per restart group
         self.trace = []                # record_trace=True: per iteration RNG states, restart candidates/values
@@ -244,23 +245,32 @@ class PCA_BO(AbstractBayesianOptimizer):
         if not self.__z_evals:
             return
         start = perf_counter()
+        # enqueue only: the device conditions the GP while the host prepares the Sobol engine (gp_wait below)
         self.__ctx.gp_condition(np.array(self.f_evals, dtype=np.float64), lengthscale=LENGTHSCALE, noise=NOISE,
-                                kernel=_native.KERNEL_MATERN52)
+                                kernel=_native.KERNEL_MATERN52, wait=False)
+        self.__gp_pending = True
         self.timing_logs["SingleTaskGP"].append(perf_counter() - start)
 
     # ---- rows J-N ---------------------------------------------------------------------------------
     def optimize_acqf_and_get_observation(self) -> np.ndarray:
         ctx, cfg = self.__ctx, self.__torch_config
         acq = self.acquisition_function
-        bounds = ctx.acq_bounds()
         num_restarts, raw_samples, batch_limit = cfg["NUM_RESTARTS"], cfg["RAW_SAMPLES"], 5
         start = perf_counter()
+        # Like the reference, where gpytorch's Gram/Cholesky happen lazily inside optimize_acqf, the wait for the
+        # conditioning is accounted here; the scrambled Sobol engine (needs only k) is built meanwhile.
+        engine = _init.scrambled_sobol_engine(ctx.k)
+        if self.__gp_pending:
+            ctx.gp_wait()
+            self.__gp_pending = False
+        bounds = ctx.acq_bounds()
 
         pb = self.phase_breakdown
+        engines = [engine]        # the retry path draws a fresh engine itself
 
         def initial_conditions():
             t0 = perf_counter()
-            raw = _init.draw_sobol(bounds, raw_samples)
+            raw = _init.draw_sobol(bounds, raw_samples, engines.pop() if engines else None)
             t1 = perf_counter()
             vals = ctx.acq_eval(raw, acq.best_f, acq.maximize, acq.acq_code, grad=False)
             t2 = perf_counter()

@@ -77,58 +77,89 @@ __device__ inline void load_tile(const double* __restrict__ src, int ld, double*
   }
 }
 
+// Factor the 64x64 SPD block held in s_d (lower triangle used) in place into its Cholesky factor (upper part
+// zeroed).  256 threads; thread (ri = tid>>2, part = tid&3) owns the row elements c = part + 4u in registers.
+// Right-looking with DELAYED scaling: at step j column j is final, its owner lanes capture it (fin) and publish
+// it through a double-buffered LDS column (one barrier per step); every row then subtracts (a_ij / a_jj) a_cj
+// from its not-yet-final columns.  Updates are unconditional (columns <= j are never read again; rows <= j use
+// a zero factor), columns final for every lane are pruned at compile time, and L = fin / sqrt(a_jj) is applied
+// once at the end.  Returns through *bad_pivot the 1-based index of the first non-positive pivot (0 = none).
+__device__ inline void chol64_inplace(double* s_d, double (*s_col)[BS], int* bad_pivot) {
+  const int tid = threadIdx.x;
+  const int ri = tid >> 2, part = tid & 3;
+  double a[16], fin[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) { a[u] = s_d[ri * TLD + part + 4 * u]; fin[u] = a[u]; }
+  int bad = 0;
+#pragma unroll
+  for (int j = 0; j < BS; ++j) {
+    if (part == (j & 3)) { fin[j >> 2] = a[j >> 2]; s_col[j & 1][ri] = a[j >> 2]; }
+    __syncthreads();
+    double piv = s_col[j & 1][j];
+    if (!(piv > 0.0)) { if (bad == 0) bad = j + 1; piv = 1.0; }
+    const double f = (ri > j) ? s_col[j & 1][ri] * fast_rcp(piv) : 0.0;
+#pragma unroll
+    for (int u = j >> 2; u < 16; ++u) {
+      a[u] -= f * s_col[j & 1][part + 4 * u];
+      asm volatile("" : "+v"(a[u]));         // evaluate now: hipcc otherwise defers these FMAs and spills their inputs
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 16; ++u)
+    if (part + 4 * u == ri) s_col[0][ri] = fin[u];     // pivots (static register index: a runtime one would spill)
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int c = part + 4 * u;
+    const double pv = s_col[0][c];
+    const double rs = fast_rsq(pv > 0.0 ? pv : 1.0);
+    double v;
+    if (c < ri) v = fin[u] * rs;
+    else if (c == ri) v = (pv > 0.0 ? pv : 1.0) * rs;     // sqrt(pv)
+    else v = 0.0;
+    s_d[ri * TLD + c] = v;
+  }
+  *bad_pivot = bad;
+  __syncthreads();
+}
+
+// Solve X L^T = B for a 64x64 block B (global, leading dimension ld) with the factor L in s_d; rows in
+// registers, column by column: x_c = b_c / L[c][c] is broadcast inside the 4-lane row group by a shuffle, then
+// b_m -= x_c L[m][c] (unconditional for columns certainly beyond c; the boundary group is predicated).
+__device__ inline void trsm64_right_lt(const double* s_d, const double* s_rdiag, double* Bt, int ld) {
+  const int tid = threadIdx.x;
+  const int ri = tid >> 2, part = tid & 3, lane = tid & 63;
+  double bb[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) bb[u] = Bt[(size_t)ri * ld + part + 4 * u];
+#pragma unroll
+  for (int c = 0; c < BS; ++c) {
+    const double own = bb[c >> 2] * s_rdiag[c];
+    const double xc = __shfl(own, (lane & ~3) | (c & 3), 64);
+    if (part == (c & 3)) bb[c >> 2] = xc;
+    if (part > (c & 3)) bb[c >> 2] -= xc * s_d[(part + 4 * (c >> 2)) * TLD + c];
+#pragma unroll
+    for (int u = (c >> 2) + 1; u < 16; ++u) {
+      bb[u] -= xc * s_d[(part + 4 * u) * TLD + c];
+      asm volatile("" : "+v"(bb[u]));
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 16; ++u) Bt[(size_t)ri * ld + part + 4 * u] = bb[u];
+}
+
 __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ A, int p, int ld, int* __restrict__ info) {
   __shared__ __attribute__((aligned(16))) double s_d[BS * TLD];
-  __shared__ __attribute__((aligned(16))) double s_b[BS * TLD];
+  __shared__ __attribute__((aligned(16))) double s_col[2][BS];
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
   double* Add = A + (size_t)(p * BS) * ld + p * BS;
   load_tile(Add, ld, s_d);
-  if (b > 0) load_tile(A + (size_t)((p + b) * BS) * ld + p * BS, ld, s_b);
   __syncthreads();
-  // Right-looking factorisation of the diagonal block with DELAYED scaling: at step j column j is final
-  // (a_ij^(j)), the trailing update uses a_ij a_cj / a_jj, and L = a^(j) / sqrt(a_jj) is applied once at the
-  // end - one barrier per step instead of three.  Four threads share a row.
-  const int ri = tid >> 2, part = tid & 3;
-  for (int j = 0; j < BS - 1; ++j) {
-    double piv = s_d[j * TLD + j];
-    if (!(piv > 0.0)) {
-      if (b == 0 && tid == 0) atomicCAS(info, 0, p * BS + j + 1);
-      piv = 1.0;
-    }
-    if (ri > j) {
-      const double f = s_d[ri * TLD + j] / piv;
-      for (int c = j + 1 + part; c <= ri; c += 4) s_d[ri * TLD + c] -= f * s_d[c * TLD + j];
-    }
-    __syncthreads();
-  }
-  {
-    double piv = s_d[(BS - 1) * TLD + BS - 1];
-    if (!(piv > 0.0) && b == 0 && tid == 0) atomicCAS(info, 0, p * BS + BS);
-  }
-  __syncthreads();
-  // scale: L[i][j] = a_ij / sqrt(a_jj) for j < i, L[i][i] = sqrt(a_ii), zero above the diagonal.
-  // Pivots are read into registers first; the diagonal itself is rewritten in a separate phase.
-  {
-    double dinv[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const double pv = s_d[(part + 4 * u) * TLD + part + 4 * u];
-      dinv[u] = 1.0 / sqrt(pv > 0.0 ? pv : 1.0);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int c = part + 4 * u;
-      if (c < ri) s_d[ri * TLD + c] *= dinv[u];
-      else if (c > ri) s_d[ri * TLD + c] = 0.0;
-    }
-    if (part == (ri & 3)) {
-      const double pv = s_d[ri * TLD + ri];
-      s_d[ri * TLD + ri] = sqrt(pv > 0.0 ? pv : 1.0);
-    }
-    __syncthreads();
-  }
+  int bad = 0;
+  chol64_inplace(s_d, s_col, &bad);
+  if (bad && b == 0 && tid == 0) atomicCAS(info, 0, p * BS + bad);
   if (b == 0) {
     for (int idx = tid; idx < BS * BS; idx += 256) {
       int r = idx >> 6, c = idx & 63;
@@ -136,24 +167,9 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ A, int 
     }
     return;
   }
-  // X L^T = B  =>  x_c = (b_c - sum_{m<c} x_m L[c][m]) / L[c][c].  The four threads of a row sit in one wave,
-  // whose LDS operations complete in issue order, so no block barrier is needed between the steps.
-  for (int c = 0; c < BS; ++c) {
-    double s = 0.0;
-    for (int m = part; m < c; m += 4) s += s_b[ri * TLD + m] * s_d[c * TLD + m];
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    if (part == 0) s_b[ri * TLD + c] = (s_b[ri * TLD + c] - s) / s_d[c * TLD + c];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  }
+  if (tid < BS) s_col[1][tid] = fast_rcp(s_d[tid * TLD + tid]);
   __syncthreads();
-  double* dst = A + (size_t)((p + b) * BS) * ld + p * BS;
-  for (int idx = tid; idx < BS * BS; idx += 256) {
-    int r = idx >> 6, c = idx & 63;
-    dst[(size_t)r * ld + c] = s_b[r * TLD + c];
-  }
+  trsm64_right_lt(s_d, s_col[1], A + (size_t)((p + b) * BS) * ld + p * BS, ld);
 }
 
 // Trailing update A[I][J] -= L[I][p] L[J][p]^T for p < J <= I on f64 MFMA.

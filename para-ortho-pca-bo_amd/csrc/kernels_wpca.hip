@@ -153,7 +153,7 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi(const double* __restrict
   if (tid == 0) s_rot = 0;
   __syncthreads();
   if (V0) {                                  // usable only if every column has unit norm (none collapsed to zero)
-    for (int col = tid; col < d; col += JAC_THREADS) {
+    for (int col = tid; col < d; col += (int)blockDim.x) {
       double a = 0.0;
       for (int r = 0; r < d; ++r) { double v = V0[(size_t)col * d + r]; a += v * v; }
       if (!(fabs(a - 1.0) < 1e-8)) s_rot = 1;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi(const double* __restrict
   __syncthreads();
   const bool warm = V0 && !s_rot;
   __syncthreads();
-  for (int idx = tid; idx < d * d; idx += JAC_THREADS) {
+  for (int idx = tid; idx < d * d; idx += (int)blockDim.x) {
     int col = idx / d, row = idx % d;
     double v;
     if (warm) {
@@ -180,8 +180,7 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi(const double* __restrict
 
   const int de = (d + 1) & ~1;             // even number of players (a virtual empty column if d is odd)
   const int npairs = de / 2;
-  int LP = 64;
-  while (LP * npairs > JAC_THREADS) LP >>= 1;
+  const int LP = (int)blockDim.x >= npairs * 16 ? 16 : 8;      // lanes per column pair (launcher sizes the block)
   const int grp = tid / LP, lane = tid % LP;
   const double tol = 1e-15;
   int sweep = 0;
@@ -205,18 +204,20 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi(const double* __restrict
             b += __shfl_xor(b, off, 64);
             g += __shfl_xor(g, off, 64);
           }
-          const double lim = tol * sqrt(a * b);
-          if (fabs(g) > lim && fabs(g) > 1e-300) {
-            double zeta = (b - a) / (2.0 * g);
-            double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-            double cs = 1.0 / sqrt(1.0 + t * t);
-            double sn = cs * t;
+          const double ab = a * b;
+          if (g * g > tol * tol * ab && fabs(g) > 1e-300) {
+            // rotation from hardware rcp/rsq estimates + Newton steps (c^2 + s^2 = 1 to ~1 ulp is what matters)
+            const double zeta = (b - a) * 0.5 * fast_rcp(g);
+            const double hyp = 1.0 + zeta * zeta;
+            const double t = (zeta >= 0.0 ? 1.0 : -1.0) * fast_rcp(fabs(zeta) + hyp * fast_rsq(hyp));
+            const double cs = fast_rsq(1.0 + t * t);
+            const double sn = cs * t;
             for (int r = lane; r < d; r += LP) {
               double x = gp[r], y = gq[r];
               gp[r] = cs * x - sn * y;
               gq[r] = sn * x + cs * y;
             }
-            if (lane == 0 && fabs(g) > 1e-8 * sqrt(a * b)) s_rot = 1;   // a further sweep is needed
+            if (lane == 0 && g * g > 1e-16 * ab) s_rot = 1;   // a further sweep is needed
           }
         }
       }
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi(const double* __restrict
     if (!rot) { ++sweep; break; }
   }
   // eigenvalues = column norms; write normalised columns (eigenvectors), column-major d x d
-  for (int col = tid / 64; col < d; col += JAC_THREADS / 64) {
+  for (int col = tid / 64; col < d; col += (int)blockDim.x / 64) {
     int l = tid & 63;
     double a = 0.0;
     for (int r = l; r < d; r += 64) { double x = s_g[col * LD + r]; a += x * x; }
@@ -430,7 +431,10 @@ void launch_jacobi(hipStream_t s, const double* C, int d, int DP, const double* 
     hipFuncSetAttribute((const void*)k_jacobi, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_jacobi, dim3(1), dim3(JAC_THREADS), lds, s, C, d, DP, V0, G, lam, sweeps);
+  const int npairs = ((d + 1) & ~1) / 2;
+  int threads = npairs * 16 <= JAC_THREADS ? npairs * 16 : npairs * 8;
+  threads = (threads + 63) & ~63;
+  hipLaunchKernelGGL(k_jacobi, dim3(1), dim3(threads), lds, s, C, d, DP, V0, G, lam, sweeps);
 }
 void launch_pca_finalize(hipStream_t s, const double* G, const double* lam, int n, int d, double var_threshold,
                          int n_components, double* comps, double* evr, int* k_dev, HostMirror* hm) {

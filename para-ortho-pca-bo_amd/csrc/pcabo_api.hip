@@ -30,7 +30,7 @@ struct pcabo_ctx {
   int ptr_mode = PCABO_PTR_HOST;
   // problem state
   int n = 0, d = 0, k = 0, NP = 0, KP = 0;
-  bool have_wpca = false, have_gp = false;
+  bool have_wpca = false, have_gp = false, gp_pending = false;
   double lengthscale = 0.0, noise = 0.0;
   int kernel = 0;
   // device buffers
@@ -269,7 +269,7 @@ int pcabo_wpca(pcabo_ctx* ctx, const double* X, const double* f, const int64_t* 
   return PCABO_OK;
 }
 
-static int run_factorisation(pcabo_ctx* ctx, double jitter) {
+static int launch_factorisation(pcabo_ctx* ctx, double jitter) {
   hipStream_t s = ctx->stream;
   const size_t bytes = (size_t)ctx->NP * ctx->ld * sizeof(double);
   HIPCHK(hipMemcpyAsync(ctx->dL, ctx->dGram, bytes, hipMemcpyDeviceToDevice, s));
@@ -282,13 +282,11 @@ static int run_factorisation(pcabo_ctx* ctx, double jitter) {
     launch_alpha(s, ctx->dR, ctx->dYs, ctx->n, ctx->NP, ctx->ld, ctx->dTmp, ctx->dAlpha);
   }
   HIPCHK(hipMemcpyAsync((void*)&ctx->hm->chol_info, ctx->dInfo, sizeof(int), hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
-  HIPCHK(hipGetLastError());
   return PCABO_OK;
 }
 
-int pcabo_gp_condition(pcabo_ctx* ctx, const double* Z, const double* y, int n, int k, const double* norm_bounds,
-                       double lengthscale, double noise, int kernel) {
+int pcabo_gp_condition_begin(pcabo_ctx* ctx, const double* Z, const double* y, int n, int k, const double* norm_bounds,
+                             double lengthscale, double noise, int kernel) {
   if (!ctx) return PCABO_ERR_ARG;
   if (!y || n < 2 || n > ctx->max_n || k < 1 || k > ctx->max_d || !(lengthscale > 0.0) || !(noise >= 0.0) ||
       (kernel != PCABO_KERNEL_MATERN52 && kernel != PCABO_KERNEL_RBF))
@@ -309,6 +307,7 @@ int pcabo_gp_condition(pcabo_ctx* ctx, const double* Z, const double* y, int n, 
   ctx->KP = round_up(k, 4);
   ctx->lengthscale = lengthscale; ctx->noise = noise; ctx->kernel = kernel;
   ctx->have_gp = false;
+  ctx->gp_pending = true;
   HIPCHK(hipMemsetAsync(ctx->dCounters, 0, (PCABO_CNT_DONE + 1) * sizeof(unsigned int), s));
   ctx->done_total = 0;
   {
@@ -318,15 +317,33 @@ int pcabo_gp_condition(pcabo_ctx* ctx, const double* Z, const double* y, int n, 
                  ctx->dAT, ctx->dNrm);
     launch_gram(s, ctx->dAT, ctx->dNrm, n, ctx->NP, ctx->KP, ctx->ld, noise, kernel, ctx->dGram);
   }
+  return launch_factorisation(ctx, 0.0);       // asynchronous: pcabo_gp_condition_end() waits and checks
+}
+
+int pcabo_gp_condition_end(pcabo_ctx* ctx) {
+  if (!ctx) return PCABO_ERR_ARG;
+  if (!ctx->gp_pending) return set_err(ctx, PCABO_ERR_ARG, "pcabo_gp_condition_end: no conditioning in flight%s", "");
+  HIPCHK(hipSetDevice(ctx->device));
+  ctx->gp_pending = false;
   double jitter = 0.0;
   for (int attempt = 0; attempt < 4; ++attempt) {       // psd_safe_cholesky: 0, 1e-8, 1e-7, 1e-6
-    int rc = run_factorisation(ctx, jitter);
-    if (rc != PCABO_OK) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipGetLastError());
     if (ctx->hm->chol_info == 0) { ctx->have_gp = true; return PCABO_OK; }
+    if (attempt == 3) break;
     jitter = (attempt == 0) ? 1e-8 : jitter * 10.0;
+    int rc = launch_factorisation(ctx, jitter);
+    if (rc != PCABO_OK) return rc;
   }
   return set_err(ctx, PCABO_ERR_NOT_PD, "K + s2 I not positive definite after jitter retries (pivot %s%d)", "",
                  ctx->hm->chol_info);
+}
+
+int pcabo_gp_condition(pcabo_ctx* ctx, const double* Z, const double* y, int n, int k, const double* norm_bounds,
+                       double lengthscale, double noise, int kernel) {
+  int rc = pcabo_gp_condition_begin(ctx, Z, y, n, k, norm_bounds, lengthscale, noise, kernel);
+  if (rc != PCABO_OK) return rc;
+  return pcabo_gp_condition_end(ctx);
 }
 
 int pcabo_acq_bounds(pcabo_ctx* ctx, double* bounds) {

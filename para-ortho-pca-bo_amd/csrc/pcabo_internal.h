@@ -14,6 +14,24 @@
 typedef double double4_t __attribute__((ext_vector_type(4)));
 struct QueryArgs { double x[PCABO_QA_MAX]; };
 
+#ifdef __HIPCC__
+// fp64 reciprocal / reciprocal square root from the hardware estimate (v_rcp_f64 / v_rsq_f64) plus two
+// Newton steps: <= 2 ulp, ~6 instructions instead of the ~25-40 of an IEEE divide / sqrt sequence.  Used where
+// a sequential dependency chain makes instruction count the bottleneck (panel factorisation, Jacobi rotations).
+__device__ inline double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ inline double fast_rsq(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  return y;
+}
+#endif
+
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // Model / problem constants handed to the acquisition kernels by value.

@@ -22,7 +22,8 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "lib"
 
 EXPORTS = [
     "pcabo_abi_version", "pcabo_device_count", "pcabo_ctx_create", "pcabo_ctx_destroy",
-    "pcabo_set_pointer_mode", "pcabo_last_error", "pcabo_wpca", "pcabo_gp_condition", "pcabo_acq_bounds",
+    "pcabo_set_pointer_mode", "pcabo_last_error", "pcabo_wpca", "pcabo_gp_condition", "pcabo_gp_condition_begin",
+    "pcabo_gp_condition_end", "pcabo_acq_bounds",
     "pcabo_acq_eval", "pcabo_logei", "pcabo_optimize_acqf", "pcabo_inverse_map", "pcabo_get_gp_state",
     "pcabo_get_gram", "pcabo_lbfgsb_minimize", "pcabo_sobol_scramble", "pcabo_set_profiling", "pcabo_get_profile", "pcabo_reset_profile",
 ]
@@ -57,6 +58,8 @@ def _load() -> C.CDLL:
     lib.pcabo_wpca.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp,
                                vp, vp, vp, vp, ip, vp]
     lib.pcabo_gp_condition.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_double, C.c_double, C.c_int]
+    lib.pcabo_gp_condition_begin.argtypes = lib.pcabo_gp_condition.argtypes
+    lib.pcabo_gp_condition_end.argtypes = [vp]
     lib.pcabo_acq_bounds.argtypes = [vp, vp]
     lib.pcabo_acq_eval.argtypes = [vp, vp, C.c_int, C.c_double, C.c_int, C.c_int, vp, vp]
     lib.pcabo_logei.argtypes = [vp, vp, C.c_int, C.c_double, C.c_int, vp, vp]
@@ -155,7 +158,8 @@ class Context:
 
     # ---- rows D-H -----------------------------------------------------------------------------
     def gp_condition(self, y, Z=None, norm_bounds=None, lengthscale=0.6931471805599453,
-                     noise=0.006737946999085467, kernel=KERNEL_MATERN52):
+                     noise=0.006737946999085467, kernel=KERNEL_MATERN52, wait=True):
+        """wait=False enqueues the conditioning and returns; call gp_wait() before using the GP."""
         y = _f64(y).reshape(-1)
         n = y.shape[0]
         if Z is not None:
@@ -164,9 +168,14 @@ class Context:
         else:
             k = self.k
         nb = None if norm_bounds is None else _f64(norm_bounds, (2, k))
-        self._chk(LIB.pcabo_gp_condition(self._h, _ptr(Z), _ptr(y), n, k, _ptr(nb), float(lengthscale), float(noise),
-                                         int(kernel)))
+        self._keep = (y, Z, nb)      # host buffers must outlive the asynchronous copies
+        fn = LIB.pcabo_gp_condition if wait else LIB.pcabo_gp_condition_begin
+        self._chk(fn(self._h, _ptr(Z), _ptr(y), n, k, _ptr(nb), float(lengthscale), float(noise), int(kernel)))
         self.n, self.k = n, k
+
+    def gp_wait(self) -> None:
+        self._chk(LIB.pcabo_gp_condition_end(self._h))
+        self._keep = None
 
     def acq_bounds(self) -> np.ndarray:
         b = np.empty((2, self.k))

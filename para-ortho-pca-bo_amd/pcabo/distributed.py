@@ -20,7 +20,8 @@ def init(backend: str = None) -> tuple:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # PCABO_DIST_BACKEND=gloo: rehearsal on a box with fewer GPUs than ranks (ranks then share a device)
+            backend = os.environ.get("PCABO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=size)

@@ -40,10 +40,12 @@ def scrambled_sobol_engine(k: int) -> torch.quasirandom.SobolEngine:
     return eng
 
 
-def draw_sobol(bounds: np.ndarray, n: int) -> np.ndarray:
-    """botorch `draw_sobol_samples(bounds, n, q=1, seed=None)` -> n x k points inside `bounds` (2 x k)."""
+def draw_sobol(bounds: np.ndarray, n: int, engine=None) -> np.ndarray:
+    """botorch `draw_sobol_samples(bounds, n, q=1, seed=None)` -> n x k points inside `bounds` (2 x k).
+    `engine`: a fresh engine from `scrambled_sobol_engine(k)` built earlier (same RNG consumption, earlier in time)."""
     k = bounds.shape[1]
-    engine = scrambled_sobol_engine(k)
+    if engine is None:
+        engine = scrambled_sobol_engine(k)
     u = engine.draw(n, dtype=torch.float64)
     lo = torch.from_numpy(np.ascontiguousarray(bounds[0]))
     rng = torch.from_numpy(np.ascontiguousarray(bounds[1] - bounds[0]))

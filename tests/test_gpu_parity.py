@@ -415,3 +415,52 @@ def test_256_restarts_equal_independent_groups(native):
         assert np.array_equal(i1[0], info[g])
         assert np.array_equal(c1, cand[sl]) and np.array_equal(v1, vals[sl])
     c.close()
+
+
+# ---- remaining interface paths ---------------------------------------------------------------------------
+def test_probability_of_improvement_run_replayed_by_oracle(native):
+    """acquisition_function="PI": non-negative initial-condition heuristic + PI kernel branch, replayed."""
+    from Algorithms import PCA_BO
+    torch.set_num_threads(4)
+    opt = PCA_BO(budget=24, n_DoE=18, random_seed=77, acquisition_function="PI", maximization=False,
+                 record_trace=True)
+    opt(BBOBProblem(15, 2, 6))
+    assert opt.acquisition_function_name == "probability_of_improvement"
+    X_all, f_all = np.vstack(opt.x_evals), np.array(opt.f_evals)
+    for tr in opt.trace:
+        n = tr["n"]
+        orc = O.OraclePCABO(budget=n + 1, n_DoE=n, acquisition_function="PI", record=True)
+        orc.x_evals = [r.copy() for r in X_all[:n]]
+        orc.f_evals = [float(v) for v in f_all[:n]]
+        orc._assign_new_best()
+        np.random.set_state(tr["numpy_state"])
+        torch.set_rng_state(tr["torch_state"])
+        rec = orc.step(BBOBProblem(15, 2, 6), np.full(6, -5.0), np.full(6, 5.0))
+        assert np.abs(rec.trace.ics - tr["ics"]).max() < 1e-9
+        assert np.abs(rec.trace.vals - tr["vals"]).max() < 1e-6
+        assert np.abs(rec.trace.cands - tr["cands"]).max() < 2e-4 * max(1.0, np.abs(rec.trace.cands).max())
+
+
+def test_fixed_number_of_components(native, records):
+    rec = records["d10"][0]
+    c = native.Context(max_n=64, max_d=10, max_q=16)
+    for ncomp in (1, 3, 10, 25):
+        res = c.wpca(rec.X, ranks=rec.ranks, noise=rec.noise, n_components=ncomp)
+        want = O.weighted_pca(rec.X, rec.f, False, 0.95, ncomp, noise=rec.noise, ranks=rec.ranks)
+        k = min(ncomp, 10)
+        assert res["k"] == k and want.Z.shape[1] == k
+        assert np.abs(res["Z"] - want.Z).max() < 1e-9
+    c.close()
+
+
+def test_ucb_fails_like_the_reference_and_smoke_test_env(native, monkeypatch):
+    from Algorithms import PCA_BO
+    opt = PCA_BO(budget=12, n_DoE=8, acquisition_function="UCB", random_seed=1)
+    with pytest.raises(TypeError):                      # reference: UpperConfidenceBound(best_f=...) is invalid
+        opt(BBOBProblem(15, 0, 4))
+    assert opt.number_of_function_evaluations == 8      # the DoE ran, the first BO iteration raised
+    monkeypatch.setenv("SMOKE_TEST", "1")
+    quick = PCA_BO(budget=11, n_DoE=8, random_seed=1, record_trace=True)
+    assert quick.torch_config["NUM_RESTARTS"] == 2 and quick.torch_config["RAW_SAMPLES"] == 32
+    quick(BBOBProblem(15, 0, 4))
+    assert len(quick.f_evals) == 11 and quick.trace[0]["cands"].shape[0] == 2

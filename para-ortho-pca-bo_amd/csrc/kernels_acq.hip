@@ -29,8 +29,8 @@
 //                  Query points arrive as kernel arguments when they fit (<= 3 KB) so that no
 //                  work-group has to read host memory over PCIe.
 #include "pcabo_internal.h"
+#include <cstdlib>
 
-#define SLAB PCABO_SLAB
 #define PSTRIDE (2 + 2 * PCABO_MAXD)   // doubles per (query, slab) partial record
 
 // Write-through store (global_store ... sc1): the partial records are handed to another work-group inside
@@ -40,13 +40,18 @@ __device__ inline void st_wt(double* p, double v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ inline int slab_row(int s, int m, int NP) { return m < 8 ? 8 * s + m : NP - 8 * (s + 1) + (m - 8); }
+// rows of slab s: SLAB/2 from the top plus SLAB/2 mirrored from the bottom (balanced triangular work)
+template <int SLAB>
+__device__ inline int slab_row(int s, int m, int NP) {
+  return m < SLAB / 2 ? (SLAB / 2) * s + m : NP - (SLAB / 2) * (s + 1) + (m - SLAB / 2);
+}
 
 // forward declaration: scalar part, defined below
 __device__ void acq_finish_query(const double* base, int S, int k, int q, const double* bounds4, const double* ystats,
                                  const AcqParams& p, double* val, double* grad, double* host_val, double* host_grad,
                                  int lane);
 
+template <int SLAB>
 __global__ __launch_bounds__(256) void k_acq_fused(
     QueryArgs qa, const double* __restrict__ Xq, int q_total, int n, int k, int NP, int ld,
     const double* __restrict__ ZnT, const double* __restrict__ R, const double* __restrict__ alpha,
@@ -96,25 +101,28 @@ __global__ __launch_bounds__(256) void k_acq_fused(
   // v_i = R[i][0..i] . ks for the slab's 16 rows: each wave owns 4 rows and streams them together (4
   // independent load streams in flight), then 64-lane shuffle reductions
   {
-    int ri[4];
-    const double* Rr[4];
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    constexpr int RW = SLAB / 4;          // rows per wave
+    int ri[RW];
+    const double* Rr[RW];
+    double acc[RW];
+    int imax = 0;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { ri[u] = slab_row(s, w + 4 * u, NP); Rr[u] = R + (size_t)ri[u] * ld; }
-    const int imax = max(max(ri[0], ri[1]), max(ri[2], ri[3]));
+    for (int u = 0; u < RW; ++u) {
+      ri[u] = slab_row<SLAB>(s, w + 4 * u, NP); Rr[u] = R + (size_t)ri[u] * ld; acc[u] = 0.0; imax = max(imax, ri[u]);
+    }
     for (int j = l; j <= imax; j += 64) {
       const double kj = s_ks[j];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc[u] += Rr[u][j] * kj;      // R is exactly zero above its diagonal
+      for (int u = 0; u < RW; ++u) acc[u] += Rr[u][j] * kj;      // R is exactly zero above its diagonal
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc[u] += __shfl_xor(acc[u], off, 64);
+      for (int u = 0; u < RW; ++u) acc[u] += __shfl_xor(acc[u], off, 64);
     }
     if (l == 0) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) s_v[w + 4 * u] = acc[u];
+      for (int u = 0; u < RW; ++u) s_v[w + 4 * u] = acc[u];
     }
   }
   __syncthreads();
@@ -122,13 +130,13 @@ __global__ __launch_bounds__(256) void k_acq_fused(
   if (w == 0) {
     double vv = 0.0, mu = 0.0;
     if (l < SLAB) {
-      const int i = slab_row(s, l, NP);
+      const int i = slab_row<SLAB>(s, l, NP);
       const double vi = s_v[l];
       vv = vi * vi;
       if (i < n) mu = alpha[i] * s_ks[i];
     }
 #pragma unroll
-    for (int off = 8; off > 0; off >>= 1) { vv += __shfl_xor(vv, off, 64); mu += __shfl_xor(mu, off, 64); }
+    for (int off = SLAB / 2; off > 0; off >>= 1) { vv += __shfl_xor(vv, off, 64); mu += __shfl_xor(mu, off, 64); }
     if (l == 0) { st_wt(out + 0, vv); st_wt(out + 1, mu); }
   }
   if (want_grad) {
@@ -138,8 +146,8 @@ __global__ __launch_bounds__(256) void k_acq_fused(
   for (int j = tid; j < NP; j += 256) {
     double wj = 0.0;
 #pragma unroll
-    for (int m = 0; m < SLAB; ++m) wj += R[(size_t)slab_row(s, m, NP) * ld + j] * s_v[m];
-    const bool mine = ((j >> 3) == s) || (((NP - 1 - j) >> 3) == s);
+    for (int m = 0; m < SLAB; ++m) wj += R[(size_t)slab_row<SLAB>(s, m, NP) * ld + j] * s_v[m];
+    const bool mine = ((j / (SLAB / 2)) == s) || (((NP - 1 - j) / (SLAB / 2)) == s);
     const double cf = s_cf[j];
     s_tm[j] = (mine && j < n) ? alpha[j] * cf : 0.0;
     s_ks[j] = wj * cf;                    // ks no longer needed: reuse as t_sigma
@@ -310,13 +318,24 @@ void launch_acq(hipStream_t st, const QueryArgs* qa, const double* Xq, int q, in
                 const double* ZnT, const double* R, const double* alpha, const double* bounds4, const double* ystats,
                 AcqParams p, double* partial, unsigned int* counters, unsigned int done_target, double* val,
                 double* grad, double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq) {
-  const int S = NP / SLAB;
-  size_t lds = (size_t)(3 * NP + PCABO_MAXD + SLAB + 2) * sizeof(double);
+  // 16 rows per work-group while S*q groups fit the 256 CUs (NP <= 384 at q = 10), 32 rows beyond that: measured
+  // on MI355X (q=10, with gradient) 16 rows win at n=120/250 (22.2 vs 23.0, 26.9 vs 27.8 us), 32 rows at n=449 (34.4 vs
+  // 37.3 us).  PCABO_SLAB32_NP overrides the switch point (tuning only).
+  static int slab_thr = -1;
+  if (slab_thr < 0) { const char* e = getenv("PCABO_SLAB32_NP"); slab_thr = e ? atoi(e) : 448; }
+  const int slab = NP >= slab_thr ? 32 : 16;
+  const int S = NP / slab;
+  size_t lds = (size_t)(3 * NP + PCABO_MAXD + 32 + 2) * sizeof(double);
   static const QueryArgs empty = {};
   const int combine = hm != nullptr;      // small batches: finish inside the launch and publish to the host
-  hipLaunchKernelGGL(k_acq_fused, dim3(S, q), dim3(256), lds, st, qa ? *qa : empty, Xq, q, n, k, NP, ld, ZnT, R, alpha,
-                     bounds4, ystats, p, partial, counters, done_target, val, grad, host_val, host_grad, hm, seq,
-                     combine);
+  if (slab == 16)
+    hipLaunchKernelGGL(k_acq_fused<16>, dim3(S, q), dim3(256), lds, st, qa ? *qa : empty, Xq, q, n, k, NP, ld, ZnT, R,
+                       alpha, bounds4, ystats, p, partial, counters, done_target, val, grad, host_val, host_grad, hm,
+                       seq, combine);
+  else
+    hipLaunchKernelGGL(k_acq_fused<32>, dim3(S, q), dim3(256), lds, st, qa ? *qa : empty, Xq, q, n, k, NP, ld, ZnT, R,
+                       alpha, bounds4, ystats, p, partial, counters, done_target, val, grad, host_val, host_grad, hm,
+                       seq, combine);
   if (!combine)
     hipLaunchKernelGGL(k_acq_combine, dim3((q + 3) / 4), dim3(256), 0, st, partial, q, S, k, bounds4, ystats, p, val,
                        grad);

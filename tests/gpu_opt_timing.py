@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "para-ortho-pca-bo_amd"))
 from pcabo import _native as N
 rng = np.random.default_rng(0)
-for n, k in ((120, 31), (449, 36)):
+for n, k in ((120, 31), (250, 33), (449, 36)):
     Z = rng.uniform(-1, 1, size=(n, k)); y = rng.normal(size=n) * 300 + 2000
     c = N.Context(max_n=450, max_d=40, max_q=512)
     c.gp_condition(y, Z=Z)

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_acq_fused(
     QueryArgs qa, const double* __restrict__ Xq, int q_total, int n, int k, int NP, int ld,
     const double* __restrict__ ZnT, const double* __restrict__ R, const double* __restrict__ alpha,
     const double* __restrict__ bounds4, const double* __restrict__ ystats, AcqParams prm, double* partial,
-    unsigned int* counters, unsigned int done_target, double* __restrict__ val, double* __restrict__ grad,
+    unsigned int* counters, double* __restrict__ val, double* __restrict__ grad,
     double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq, int combine) {
   const double inv_ls = prm.inv_ls;
   const int kernel = prm.kernel, want_grad = prm.want_grad;
@@ -205,14 +205,10 @@ __global__ __launch_bounds__(256) void k_acq_fused(
   if (!*s_flag) return;
   if (w == 0) {
     acq_finish_query(partial + (size_t)q * S * PSTRIDE, S, k, q, bounds4, ystats, prm, val, grad, host_val, host_grad, l);
-    if (hm) {
-      __threadfence_system();                 // this query's host writes are visible before it is counted
-      if (l == 0) {
-        unsigned int t2 = __hip_atomic_fetch_add(&counters[PCABO_CNT_DONE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t2 + 1u == done_target)
-          __hip_atomic_store(const_cast<unsigned long long*>(&hm->flag), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-    }
+    // publish: this query's sequence word follows its results with a system-scope release (one wave, so the
+    // release store's drain covers every lane's host writes)
+    if (hm && l == 0)
+      __hip_atomic_store(const_cast<unsigned long long*>(&hm->qflag[q]), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -316,7 +312,7 @@ __global__ __launch_bounds__(256) void k_acq_combine(const double* __restrict__ 
 
 void launch_acq(hipStream_t st, const QueryArgs* qa, const double* Xq, int q, int n, int k, int NP, int ld,
                 const double* ZnT, const double* R, const double* alpha, const double* bounds4, const double* ystats,
-                AcqParams p, double* partial, unsigned int* counters, unsigned int done_target, double* val,
+                AcqParams p, double* partial, unsigned int* counters, double* val,
                 double* grad, double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq) {
   // 16 rows per work-group while S*q groups fit the 256 CUs (NP <= 384 at q = 10), 32 rows beyond that: measured
   // on MI355X (q=10, with gradient) 16 rows win at n=120/250 (22.2 vs 23.0, 26.9 vs 27.8 us), 32 rows at n=449 (34.4 vs
@@ -330,11 +326,11 @@ void launch_acq(hipStream_t st, const QueryArgs* qa, const double* Xq, int q, in
   const int combine = hm != nullptr;      // small batches: finish inside the launch and publish to the host
   if (slab == 16)
     hipLaunchKernelGGL(k_acq_fused<16>, dim3(S, q), dim3(256), lds, st, qa ? *qa : empty, Xq, q, n, k, NP, ld, ZnT, R,
-                       alpha, bounds4, ystats, p, partial, counters, done_target, val, grad, host_val, host_grad, hm,
+                       alpha, bounds4, ystats, p, partial, counters, val, grad, host_val, host_grad, hm,
                        seq, combine);
   else
     hipLaunchKernelGGL(k_acq_fused<32>, dim3(S, q), dim3(256), lds, st, qa ? *qa : empty, Xq, q, n, k, NP, ld, ZnT, R,
-                       alpha, bounds4, ystats, p, partial, counters, done_target, val, grad, host_val, host_grad, hm,
+                       alpha, bounds4, ystats, p, partial, counters, val, grad, host_val, host_grad, hm,
                        seq, combine);
   if (!combine)
     hipLaunchKernelGGL(k_acq_combine, dim3((q + 3) / 4), dim3(256), 0, st, partial, q, S, k, bounds4, ystats, p, val,

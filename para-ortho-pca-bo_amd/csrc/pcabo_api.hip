@@ -18,7 +18,6 @@
 #define PCABO_ABI_VERSION 1
 #define PROF_GROUPS 6
 #define PROF_POOL 4096
-#define PCABO_INLAUNCH_MAXQ 32
 
 struct ProfPair { hipEvent_t a, b; int group; double bytes, flops; };
 
@@ -45,8 +44,7 @@ struct pcabo_ctx {
   double *dZnT = nullptr, *dAT = nullptr, *dNrm = nullptr, *dGram = nullptr, *dL = nullptr, *dR = nullptr;
   double *dTmp = nullptr, *dAlpha = nullptr;
   double *dXq = nullptr, *dPartial = nullptr, *dVal = nullptr, *dGrad = nullptr, *dZq = nullptr, *dXout = nullptr;
-  unsigned int* dCounters = nullptr;     // per-query tickets + [PCABO_CNT_DONE] finished-queries counter
-  unsigned int done_total = 0;           // host copy of the finished-queries counter's expected value
+  unsigned int* dCounters = nullptr;     // per-query tickets of the in-launch combine
   // pinned host
   HostMirror* hm = nullptr;
   double *hXq = nullptr, *hVal = nullptr, *hGrad = nullptr, *hSmall = nullptr;
@@ -309,7 +307,6 @@ int pcabo_gp_condition_begin(pcabo_ctx* ctx, const double* Z, const double* y, i
   ctx->have_gp = false;
   ctx->gp_pending = true;
   HIPCHK(hipMemsetAsync(ctx->dCounters, 0, (PCABO_CNT_DONE + 1) * sizeof(unsigned int), s));
-  ctx->done_total = 0;
   {
     ProfScope ps(ctx, 1, 8.0 * n * k + 4.0 * n * (n + 1.0), 2.0 * n * n * k + 12.0 * n * n);
     launch_zstats(s, ctx->dZ, ctx->dY, n, k, unb, ctx->dBounds4, ctx->dZnMean, ctx->dYstats, ctx->dYs, ctx->hm);
@@ -371,7 +368,6 @@ static int eval_staged(pcabo_ctx* ctx, int nq, AcqParams& p) {
   hipStream_t s = ctx->stream;
   const int k = ctx->k;
   const unsigned long long seq = ++ctx->seq;
-  ctx->done_total += (unsigned int)nq;
   const QueryArgs* qa = nullptr;
   const double* xdev = nullptr;
   if ((size_t)nq * k <= PCABO_QA_MAX) {
@@ -381,11 +377,10 @@ static int eval_staged(pcabo_ctx* ctx, int nq, AcqParams& p) {
     xdev = ctx->dXq;
   }
   const bool small = nq <= PCABO_INLAUNCH_MAXQ;   // in-launch combine + host flag; larger batches: two launches + copy
-  if (!small) ctx->done_total -= (unsigned int)nq;
   {
     ProfScope ps(ctx, 4, acq_bytes(ctx->n, k, nq, p.want_grad), acq_flops(ctx->n, k, nq, p.want_grad));
     launch_acq(s, qa, xdev, nq, ctx->n, k, ctx->NP, ctx->ld, ctx->dZnT, ctx->dR, ctx->dAlpha, ctx->dBounds4, ctx->dYstats,
-               p, ctx->dPartial, ctx->dCounters, ctx->done_total, ctx->dVal, ctx->dGrad, small ? ctx->hVal : nullptr,
+               p, ctx->dPartial, ctx->dCounters, ctx->dVal, ctx->dGrad, small ? ctx->hVal : nullptr,
                small ? ctx->hGrad : nullptr, small ? ctx->hm : nullptr, seq);
   }
   if (!small) {
@@ -397,15 +392,17 @@ static int eval_staged(pcabo_ctx* ctx, int nq, AcqParams& p) {
   }
   const auto t0 = std::chrono::steady_clock::now();
   unsigned long spins = 0;
-  while (__atomic_load_n(&ctx->hm->flag, __ATOMIC_ACQUIRE) != seq) {
-    if ((++spins & 0xFFFF) == 0) {
-      if (hipStreamQuery(s) == hipSuccess) {              // kernel done: the flag must be there
-        if (__atomic_load_n(&ctx->hm->flag, __ATOMIC_ACQUIRE) == seq) break;
-        HIPCHK(hipGetLastError());
-        return set_err(ctx, PCABO_ERR_TIMEOUT, "acquisition kernel finished without publishing its results%s", "");
+  for (int qi = 0; qi < nq; ++qi) {
+    while (__atomic_load_n(&ctx->hm->qflag[qi], __ATOMIC_ACQUIRE) != seq) {
+      if ((++spins & 0xFFFF) == 0) {
+        if (hipStreamQuery(s) == hipSuccess) {              // kernel done: the flag must be there
+          if (__atomic_load_n(&ctx->hm->qflag[qi], __ATOMIC_ACQUIRE) == seq) break;
+          HIPCHK(hipGetLastError());
+          return set_err(ctx, PCABO_ERR_TIMEOUT, "acquisition kernel finished without publishing its results%s", "");
+        }
+        double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (el > 20.0) return set_err(ctx, PCABO_ERR_TIMEOUT, "device did not publish acquisition results%s", "");
       }
-      double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      if (el > 20.0) return set_err(ctx, PCABO_ERR_TIMEOUT, "device did not publish acquisition results%s", "");
     }
   }
   return PCABO_OK;

@@ -9,7 +9,8 @@
 #define PCABO_TLD 66         // LDS leading dimension (doubles) of a 64x64 tile: conflict-free ds_read_b64
 
 #define PCABO_QA_MAX 384      // query coordinates that travel as kernel arguments (3 KB)
-#define PCABO_CNT_DONE 0x3fff // index of the "queries finished" counter behind the per-query tickets
+#define PCABO_CNT_DONE 0x3fff // capacity of the per-query ticket array
+#define PCABO_INLAUNCH_MAXQ 32 // largest batch finished inside the launch (results + flags straight to the host)
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 struct QueryArgs { double x[PCABO_QA_MAX]; };
@@ -53,8 +54,7 @@ struct HostMirror {
   double y_mean, y_std;
   double norm_lo[PCABO_MAXD], norm_hi[PCABO_MAXD];
   double acq_lo[PCABO_MAXD], acq_hi[PCABO_MAXD];
-  volatile unsigned long long flag;   // sequence number written last by the combine kernel
-  unsigned long long pad2;
+  volatile unsigned long long qflag[PCABO_INLAUNCH_MAXQ];   // per query: sequence number written after its results
 };
 
 // ---- launchers (defined in kernels_*.hip); all asynchronous on `s` -------------------
@@ -80,7 +80,7 @@ void launch_trinv(hipStream_t s, const double* L, int NP, int ld, double* R);
 void launch_alpha(hipStream_t s, const double* R, const double* ys, int n, int NP, int ld, double* tmp, double* alpha);
 void launch_acq(hipStream_t s, const QueryArgs* qa, const double* Xq, int q, int n, int k, int NP, int ld,
                 const double* ZnT, const double* R, const double* alpha, const double* bounds4, const double* ystats,
-                AcqParams p, double* partial, unsigned int* counters, unsigned int done_target, double* val,
+                AcqParams p, double* partial, unsigned int* counters, double* val,
                 double* grad, double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq);
 void launch_inverse_map(hipStream_t s, const double* z, const double* comps, const double* data_mean,
                         const double* pca_mean, int k, int d, double* x);

@@ -164,7 +164,7 @@ def main():
     # ---- roofline: second, profiled pass (HIP events on the context's stream), same workload ------------
     roof, extra = None, {}
     if rank == 0 and not args.no_roofline:
-        prof_steps = min(args.steps, 40)
+        prof_steps = min(args.steps, BUDGET - NDOE)
         pc = RunChain(device, first_instance=0, stride=0)
         pc._open()
         ctx = pc.opt.device_context
@@ -192,8 +192,9 @@ def main():
                                     "(2*FETCH_SIZE+WRITE_SIZE); table for n=120/250/449 in profiles/r01/pmc_traffic.json",
                     "avg_launch_us": dur * 1e6, "launches": a["launches"], "algorithmic_bytes_per_launch": byt,
                     "achieved_tflops": a["flops"] / (a["ms"] * 1e-3) / 1e12,
-                    "note": f"profiled pass over the first {prof_steps} BO iterations (n=120..{120 + prof_steps - 1}); "
-                            "latency-bound kernel, R stays L2-resident"}
+                    "note": f"second, profiled pass over {prof_steps} BO iterations of the same run (n=120..{120 + prof_steps - 1}), "
+                            "HIP events on the context's stream around every launch; latency-bound kernel, "
+                            "R and ZnT stay L2 / Infinity-Cache resident"}
             for name in ("wpca", "gram", "cholesky", "root_inverse_alpha"):
                 g = prof[name]
                 if g["launches"]:

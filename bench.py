@@ -203,7 +203,7 @@ def main():
                                    "TFLOPs": g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] else None}
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline and states:
+    if rank == 0 and size == 1 and not args.no_cpu_baseline and states:      # N = 1 only (contract)
         cpu = cpu_baseline(states, threads=min(16, os.cpu_count() or 1))
 
     if rank == 0:
@@ -222,6 +222,7 @@ def main():
             "speedup_vs_cpu_baseline": (value / size / cpu["value"]) if cpu else None,
         }
         print(json.dumps(line), flush=True)
+    D.barrier()          # ranks leave together (rank 0 ran the profiled pass meanwhile)
     D.finalize()
 
 

@@ -104,7 +104,8 @@ def cpu_baseline(states, threads: int):
     return {"value": 1.0 / mean_t, "unit": "BO iterations/s", "cores": threads, "kind": "port",
             "sample": f"{len(times)} teacher-forced BO iterations of the d=40 run at n={ns} (mean {mean_t:.3f} s/iteration); "
                       "oracle = numpy/sklearn/torch-fp64-autograd/scipy L-BFGS-B restatement of the reference path "
-                      f"with BoTorch's call granularity; botorch importable: {_has('botorch')}"}
+                      f"with BoTorch's call granularity; torch threads = {threads} (fastest of 1..32 on this host); "
+                      f"botorch importable: {_has('botorch')}"}
 
 
 def _has(mod: str) -> bool:
@@ -204,7 +205,9 @@ def main():
 
     cpu = None
     if rank == 0 and size == 1 and not args.no_cpu_baseline and states:      # N = 1 only (contract)
-        cpu = cpu_baseline(states, threads=min(16, os.cpu_count() or 1))
+        # the oracle's tiny fp64 tensors run fastest single-threaded on this host (measured 0.246 s/iteration at 1
+        # thread vs 0.465 s at 16, tests/cpu_oracle_threads.py), so the baseline gets its best setting
+        cpu = cpu_baseline(states, threads=1)
 
     if rank == 0:
         value = total_steps / elapsed

@@ -296,6 +296,8 @@ class PCA_BO(AbstractBayesianOptimizer):
             pb["sobol"] += t1 - t0
             pb["raw_eval"] += t2 - t1
             pb["init_pick"] += t3 - t2
+            if self._PCA_BO__record_trace:
+                self.trace[-1].update(raw_vals=vals.copy(), ic_idx=np.asarray(idx).copy())
             return raw[idx]
 
         ics = initial_conditions()

@@ -460,7 +460,9 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
   std::vector<int> gstart(ngroups), gsize(ngroups), niter(ngroups, 0), nfev(ngroups, 0);
   std::vector<char> active(ngroups, 1);     // char, not vector<bool>: groups are touched from two threads
   std::vector<std::vector<double>> x(ngroups), g(ngroups), lo(ngroups), hi(ngroups);
-  std::vector<double> fval(ngroups, 0.0);
+  std::vector<double> fval(ngroups, 0.0), fc(ngroups, 0.0);
+  std::vector<std::vector<double>> xc(ngroups), gc(ngroups);
+  std::vector<char> have_cache(ngroups, 0);
   for (int gi = 0; gi < ngroups; ++gi) {
     gstart[gi] = gi * batch_limit;
     gsize[gi] = std::min(batch_limit, num_restarts - gstart[gi]);
@@ -482,11 +484,21 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   int any_failed = 0;
   // advance one group's state machine until it needs f,g at x[gi] (or stops)
+  // scipy wraps the objective in a ScalarFunction that memoises the last evaluated point: when a shrinking
+  // line-search step underflows and the trial point repeats, the function is neither called nor counted.
+  // Same here (xc/fc/gc = last evaluated point of the group and its value/gradient).
   auto advance = [&](int gi) {
     if (!active[gi]) return;
     while (true) {
       int task = opt[gi].step(x[gi].data(), &fval[gi], g[gi].data());
-      if (task == LBFGSB_FG) return;
+      if (task == LBFGSB_FG) {
+        if (have_cache[gi] && memcmp(x[gi].data(), xc[gi].data(), x[gi].size() * sizeof(double)) == 0) {
+          fval[gi] = fc[gi];
+          g[gi] = gc[gi];
+          continue;
+        }
+        return;
+      }
       if (task == LBFGSB_NEW_X) {
         niter[gi] += 1;
         if (niter[gi] >= maxiter) opt[gi].stop(LBFGSB_STOP_ITER);
@@ -553,6 +565,7 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
       if (nan) return set_err(ctx, PCABO_ERR_NAN, "NaN in acquisition gradient%s", "");
       fval[gi] = -fs;
       nfev[gi] += 1;
+      xc[gi] = x[gi]; gc[gi] = g[gi]; fc[gi] = fval[gi]; have_cache[gi] = 1;
     }
   }
   if (trace) fprintf(stderr, "[pcabo] optimize: rounds %d, host L-BFGS-B %.1f us/round, eval %.1f us/round (n=%d k=%d)\n", rounds, 1e6 * t_step / std::max(1, rounds), 1e6 * t_eval / std::max(1, rounds), ctx->n, ctx->k);
@@ -628,12 +641,17 @@ int pcabo_lbfgsb_minimize(int nvar, double* x, const double* lower, const double
   opt.init(nvar, m, lower, upper, factr, pgtol, maxls);
   if (lower && upper)
     for (int i = 0; i < nvar; ++i) x[i] = x[i] < lower[i] ? lower[i] : (x[i] > upper[i] ? upper[i] : x[i]);
-  std::vector<double> g(nvar, 0.0);
-  double f = 0.0;
+  std::vector<double> g(nvar, 0.0), xc, gc;
+  double f = 0.0, fc = 0.0;
   int iters = 0, evals = 0;
   while (true) {
     int task = opt.step(x, &f, g.data());
-    if (task == LBFGSB_FG) { f = fg(x, g.data(), user); ++evals; continue; }
+    if (task == LBFGSB_FG) {
+      if (!xc.empty() && memcmp(x, xc.data(), nvar * sizeof(double)) == 0) { f = fc; g = gc; continue; }   // scipy's memoisation
+      f = fg(x, g.data(), user); ++evals;
+      xc.assign(x, x + nvar); gc = g; fc = f;
+      continue;
+    }
     if (task == LBFGSB_NEW_X) {
       ++iters;
       if (iters >= maxiter) opt.stop(LBFGSB_STOP_ITER);

@@ -67,3 +67,24 @@ def test_joint_five_restart_acquisition_problem_same_path_as_scipy(native):
             ref, mine = _both(native, fun, x0, list(zip(lo, hi)), 200)
             assert (ref.nit, ref.nfev) == (mine["nit"], mine["nfev"])
             assert np.abs(ref.x - mine["x"]).max() < 1e-9
+
+
+def test_abnormal_line_search_and_memoised_repeats_like_scipy(native):
+    """Inconsistent objective (value rises along the descent direction): the line search shrinks until the trial
+    point repeats; scipy's ScalarFunction memoises such repeats (not called, not counted) and the run ends as
+    ABNORMAL (warnflag 2) - the case in which botorch redraws initial conditions."""
+    for n, bounds in ((1, [(-10, 10)]), (3, [(-10, 10)] * 3), (3, [(None, None)] * 3)):
+        calls = {"scipy": 0, "mine": 0}
+
+        def make(tag):
+            def fun(x):
+                calls[tag] += 1
+                return float(np.sum(x)), -np.ones_like(x)
+            return fun
+
+        ref = minimize(make("scipy"), np.full(n, 0.5), jac=True, method="L-BFGS-B", bounds=bounds, options={"maxiter": 50})
+        mine = native.lbfgsb_minimize(make("mine"), np.full(n, 0.5), bounds, maxiter=50)
+        assert ref.status == 2 and mine["warnflag"] == 2 and mine["task"] == 70
+        assert (ref.nit, ref.nfev) == (mine["nit"], mine["nfev"])
+        assert calls["scipy"] == calls["mine"]
+        assert np.array_equal(ref.x, mine["x"])

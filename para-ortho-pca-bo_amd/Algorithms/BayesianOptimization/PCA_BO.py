@@ -308,6 +308,8 @@ class PCA_BO(AbstractBayesianOptimizer):
         if failed:   # botorch: OptimizationWarning -> one retry with freshly drawn initial conditions
             warnings.warn("Optimization failed in `gen_candidates_scipy`; trying again with a new set of "
                           "initial conditions.", RuntimeWarning)
+            if self._PCA_BO__record_trace:
+                self.trace[-1]["retried"] = True
             ics = initial_conditions()
             cand, vals, info, failed = ctx.optimize_acqf(ics, bounds, acq.best_f, acq.maximize, acq.acq_code,
                                                          batch_limit=batch_limit, maxiter=200)

@@ -632,3 +632,38 @@ class OraclePCABO:
         for _ in range(iters):
             self.step(problem, lb, ub)
         self.timing["loop"] += perf_counter() - t0
+
+
+# --------------------------------------------------------------------------------------
+# Vanilla_BO: the same loop without PCA
+# (/root/reference/Algorithms/BayesianOptimization/Vanilla_BO.py:100-216)
+# --------------------------------------------------------------------------------------
+class OracleVanillaBO(OraclePCABO):
+    """GP on the raw d-dimensional points, Normalize switched off (Vanilla_BO.py:188-194), acquisition optimised
+    inside the problem's box (:206-213), every candidate evaluated (no out-of-bounds rule)."""
+
+    def step(self, problem: Callable, lb: np.ndarray, ub: np.ndarray) -> IterationRecord:
+        X = np.vstack(self.x_evals)
+        n, d = X.shape
+        f = np.array(self.f_evals, dtype=np.float64)
+        identity = np.vstack([np.zeros(d), np.ones(d)])
+        t0 = perf_counter()
+        gp = ExactGP(X, f, identity)
+        self.timing["SingleTaskGP"] += perf_counter() - t0
+        acq = Acquisition(gp, self.current_best, self.maximization, self.acq_kind)
+        box = np.vstack([lb, ub])
+        trace = AcqfTrace()
+        rng_before = torch.get_rng_state() if self.record else None
+        t0 = perf_counter()
+        x_new, _ = optimize_acqf(acq, box, self.num_restarts, self.raw_samples, self.batch_limit, self.maxiter, trace)
+        self.timing["optimize_acqf"] += perf_counter() - t0
+        f_new = problem(x_new)
+        best_before = self.current_best
+        self.x_evals.append(x_new)
+        self.f_evals.append(f_new)
+        self._assign_new_best()
+        rec = IterationRecord(n, d, X, f, np.zeros(n, dtype=np.int64), np.zeros((0, d)), best_before, None, identity, box,
+                              trace, x_new, x_new, False, float(f_new), rng_before)
+        if self.record:
+            self.records.append(rec)
+        return rec

@@ -29,6 +29,7 @@ import numpy as np
 
 from pcabo import _native
 from pcabo import initializers as _init
+from pcabo import acqopt as _acqopt
 from .AbstractBayesianOptimizer import AbstractBayesianOptimizer
 
 ALLOWED_ACQUISITION_FUNCTION_STRINGS = (
@@ -279,47 +280,12 @@ class PCA_BO(AbstractBayesianOptimizer):
             self.__gp_pending = False
         bounds = ctx.acq_bounds()
 
-        pb = self.phase_breakdown
-        engines = [engine]        # the retry path draws a fresh engine itself
-
-        def initial_conditions():
-            t0 = perf_counter()
-            raw = _init.draw_sobol(bounds, raw_samples, engines.pop() if engines else None)
-            t1 = perf_counter()
-            vals = ctx.acq_eval(raw, acq.best_f, acq.maximize, acq.acq_code, grad=False)
-            t2 = perf_counter()
-            if acq.acq_code == _native.ACQ_PI:
-                idx = _init.initialize_q_batch_nonneg(vals, num_restarts)
-            else:
-                idx = _init.initialize_q_batch(vals, num_restarts)
-            t3 = perf_counter()
-            pb["sobol"] += t1 - t0
-            pb["raw_eval"] += t2 - t1
-            pb["init_pick"] += t3 - t2
-            if self._PCA_BO__record_trace:
-                self.trace[-1].update(raw_vals=vals.copy(), ic_idx=np.asarray(idx).copy())
-            return raw[idx]
-
-        ics = initial_conditions()
-        t_opt = perf_counter()
-        cand, vals, info, failed = ctx.optimize_acqf(ics, bounds, acq.best_f, acq.maximize, acq.acq_code,
-                                                     batch_limit=batch_limit, maxiter=200)
-        pb["lbfgsb"] += perf_counter() - t_opt
-        if failed:   # botorch: OptimizationWarning -> one retry with freshly drawn initial conditions
-            warnings.warn("Optimization failed in `gen_candidates_scipy`; trying again with a new set of "
-                          "initial conditions.", RuntimeWarning)
-            if self._PCA_BO__record_trace:
-                self.trace[-1]["retried"] = True
-            ics = initial_conditions()
-            cand, vals, info, failed = ctx.optimize_acqf(ics, bounds, acq.best_f, acq.maximize, acq.acq_code,
-                                                         batch_limit=batch_limit, maxiter=200)
+        new_z, cand, vals, info = _acqopt.optimize_acqf(
+            ctx, bounds, acq.best_f, acq.maximize, acq.acq_code, num_restarts, raw_samples, batch_limit, 200,
+            engine=engine, breakdown=self.phase_breakdown, trace=self.trace[-1] if self.__record_trace else None)
         self.timing_logs["optimize_acqf"].append(perf_counter() - start)
         self.lbfgsb_info.append(info)
-        best = int(np.argmax(vals))
-        if self.__record_trace:
-            self.trace[-1].update(ics=ics.copy(), cands=cand.copy(), vals=vals.copy(), chosen=best, info=info.copy(),
-                                  k=int(cand.shape[1]))
-        return cand[best].reshape(1, -1)
+        return new_z
 
     # ---- row O ------------------------------------------------------------------------------------
     def _transform_point_to_original_space(self, z: np.ndarray) -> np.ndarray:

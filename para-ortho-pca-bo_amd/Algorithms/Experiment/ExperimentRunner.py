@@ -1,0 +1,195 @@
+"""Experiment runner: many independent BO runs over (algorithm, function, dimension, instance).
+
+Same constructor and `run_experiment()` as the reference's runner
+(/root/reference/Algorithms/Experiment/ExperimentRunner.py:23-200), so the reference's `main.py` works unchanged
+with this package first on PYTHONPATH.  Differences, all on the far side of the hot path:
+
+  * run-level data parallelism: under `torch.distributed.run` (RANK / WORLD_SIZE / LOCAL_RANK in the
+    environment) every rank takes a balanced share of the run list (`pcabo.sharding.assign_runs`, longest first) and
+    drives its own GPU (`device=LOCAL_RANK`); ranks write into `<experiment>-rank<r>` folders, no collective is
+    needed.  A single process does all runs on device 0, exactly like the reference.
+  * `ioh` is optional: when it imports, problems come from `ioh.iohcpp.suite.BBOB` and the real `Analyzer` logs
+    them; otherwise `pcabo.bbob` (f15 / f20, pinned by the reference's data) and `pcabo.iohlog.Analyzer`
+    (same on-disk layout) are used.
+"""
+from __future__ import annotations
+
+import os
+from time import time
+from typing import List, Optional
+
+from numpy.linalg import norm
+
+from Algorithms import Vanilla_BO
+from Algorithms import PCA_BO
+from pcabo import sharding as _sharding
+
+try:                                           # pragma: no cover - ioh is absent from the build image
+    from ioh.iohcpp.suite import BBOB as _IohBBOB
+    from ioh.iohcpp.logger import Analyzer as _IohAnalyzer
+    from ioh.iohcpp.logger.property import RAWYBEST
+    from ioh.iohcpp.logger.trigger import ALWAYS
+    HAVE_IOH = True
+except ImportError:
+    HAVE_IOH = False
+    RAWYBEST = "raw_y_best"
+    ALWAYS = "always"
+
+try:
+    from tqdm.auto import tqdm
+except ImportError:                            # pragma: no cover
+    tqdm = None
+
+
+class _NoBar:
+    def __init__(self, *a, **k): pass
+    def __enter__(self): return self
+    def __exit__(self, *a): return False
+    def update(self, n=1): pass
+    def set_description(self, s): pass
+    def write(self, s): print(s)
+    def close(self): pass
+
+
+class ExperimentRunner:
+    """Class to run and manage experiments comparing Vanilla BO and PCA-BO algorithms."""
+
+    def __init__(self, algorithms: List[str], dimensions: List[int], problem_ids: List[int], num_runs: int = 30,
+                 budget_factor: int = 10, doe_factor: float = 3.0, root_dir: str = os.getcwd(),
+                 experiment_name: str = "experiment", acquisition_function: str = "expected_improvement",
+                 pca_components: Optional[int] = None, var_threshold: float = 0.95, verbose: bool = False,
+                 progress: bool = True):
+        self.algorithms = algorithms
+        self.dimensions = dimensions
+        self.problem_ids = problem_ids
+        self.num_runs = num_runs
+        self.budget_factor = budget_factor
+        self.doe_factor = doe_factor
+        self.root_dir = root_dir
+        self.experiment_name = experiment_name
+        self.acquisition_function = acquisition_function
+        self.pca_components = pca_components
+        self.var_threshold = var_threshold
+        self.verbose = verbose
+        self.progress = progress and tqdm is not None
+
+        self.triggers = [ALWAYS]
+        self.logger_properties = [RAWYBEST]
+        self.instances = range(self.num_runs)
+        self.doe_params = {"criterion": "center", "iterations": 1000}
+
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
+        self.device = int(os.environ.get("LOCAL_RANK", "0"))
+        self.results = []                      # one dict per finished run (this rank)
+
+    # ---- run list and its shard -----------------------------------------------------------------------------------
+    def _my_runs(self):
+        """(problem_id, dim, instance) triples of this rank, in suite order (ExperimentRunner.py:90,131)."""
+        runs = _sharding.enumerate_runs(self.problem_ids, self.dimensions, self.num_runs)
+        if self.world_size == 1:
+            return runs
+        mine = set(_sharding.assign_runs(runs, self.world_size, budget_factor=self.budget_factor,
+                                          doe_factor=self.doe_factor)[self.rank])
+        return [r for r in runs if r in mine]
+
+    def _folder(self, algorithm: str) -> str:
+        base = f"{algorithm}-{self.experiment_name}"
+        return base if self.world_size == 1 else f"{base}-rank{self.rank}"
+
+    def _make_logger(self, algorithm: str):
+        kw = dict(root=self.root_dir, folder_name=self._folder(algorithm), algorithm_name=algorithm,
+                  algorithm_info=f"A {algorithm}-BO Implementation.", store_positions=True)
+        if HAVE_IOH:                           # pragma: no cover
+            return _IohAnalyzer(triggers=self.triggers, additional_properties=self.logger_properties, **kw)
+        from pcabo.iohlog import Analyzer
+        return Analyzer(**kw)
+
+    def _problems(self, logger):
+        """Yield attached problems for this rank's runs."""
+        mine = self._my_runs()
+        if HAVE_IOH:                           # pragma: no cover
+            wanted = set(mine)
+            suite = _IohBBOB(problem_ids=self.problem_ids, dimensions=self.dimensions, instances=self.instances)
+            suite.attach_logger(logger)
+            for problem in suite:
+                md = problem.meta_data
+                if (md.problem_id, md.n_variables, md.instance) in wanted:
+                    yield problem
+            suite.detach_logger()
+            return
+        from pcabo.bbob import BBOBProblem
+        from pcabo.iohlog import LoggedProblem
+        for pid, dim, inst in mine:
+            yield LoggedProblem(BBOBProblem(pid, inst, dim), logger)
+
+    # ---- the experiment --------------------------------------------------------------------------------------------
+    def run_experiment(self) -> None:
+        total_runs = len(self.algorithms) * len(self.problem_ids) * len(self.dimensions) * self.num_runs
+        my_total = len(self.algorithms) * len(self._my_runs())
+        if self.rank == 0:
+            print(f"\nRunning {total_runs} experiments ({len(self.algorithms)} algorithms × "
+                  f"{len(self.dimensions)} dimensions × {len(self.problem_ids)} problems × {self.num_runs} runs)"
+                  + (f" on {self.world_size} GPUs ({my_total} on rank 0)" if self.world_size > 1 else "") + "\n")
+        bar = tqdm if self.progress else _NoBar
+
+        with bar(total=my_total, position=0, desc="Total Progress") as ebar:
+            for algorithm in self.algorithms:
+                if algorithm not in ("vanilla", "pca"):
+                    raise ValueError(f"Invalid algorithm name: '{algorithm}'")
+                logger = self._make_logger(algorithm)
+                logger.set_experiment_attributes({
+                    "budget_factor": f"{self.budget_factor}",
+                    "doe_factor": f"{self.doe_factor}",
+                    "acquisition_function": f"{self.acquisition_function}"
+                })
+                if algorithm == "pca":
+                    logger.set_experiment_attributes({
+                        "pca_components": f"{self.pca_components}",
+                        "var_threshold": f"{self.var_threshold}"
+                    })
+                optimizer_class = Vanilla_BO if algorithm == "vanilla" else PCA_BO
+                for time_profile in getattr(optimizer_class, "TIME_PROFILES", []):
+                    logger.add_run_attribute(f"{time_profile}_time", 0.0)
+                logger.add_run_attribute("time", 0.0)
+
+                for problem in self._problems(logger):
+                    dim = problem.meta_data.n_variables
+                    problem_id = problem.meta_data.problem_id
+                    instance = problem.meta_data.instance
+                    maximization = bool(problem.meta_data.optimization_type.value)
+                    run_num = self.instances.index(instance)
+
+                    budget = self.budget_factor * dim + 50
+                    n_doe = int(self.doe_factor * dim)
+                    random_seed = 1000 * problem_id + 10 * dim + instance
+
+                    with bar(total=budget, position=1, desc="", leave=False) as pbar:
+                        pbar.set_description(f"{algorithm} | {dim}-dim | F-{problem_id} | run-{run_num + 1}")
+                        if self.verbose:
+                            pbar.write(f"\nRunning {algorithm} | {dim}-dim | F-{problem_id} | run-{run_num + 1}:\n")
+                        common = dict(budget=budget, n_DoE=n_doe, acquisition_function=self.acquisition_function,
+                                      random_seed=random_seed, maximization=maximization, verbose=self.verbose,
+                                      DoE_parameters=self.doe_params, pbar=pbar if self.progress else None,
+                                      device=self.device)
+                        if algorithm == "vanilla":
+                            optimizer = Vanilla_BO(**common)
+                        else:
+                            optimizer = PCA_BO(var_threshold=self.var_threshold, **common)
+
+                        start_time = time()
+                        optimizer(problem=problem)
+                        elapsed = time() - start_time
+                        logger.set_run_attribute("time", elapsed)
+                        for time_profile, total_profile_time in optimizer.total_times.items():
+                            logger.set_run_attribute(f"{time_profile}_time", total_profile_time)
+                        self.results.append({"algorithm": algorithm, "problem_id": problem_id, "dim": dim,
+                                             "instance": instance, "best": optimizer.current_best, "time": elapsed,
+                                             "iterations": budget - n_doe, **optimizer.total_times})
+                        if self.verbose:
+                            pbar.write(f"The distance from optimum is: "
+                                       f"{norm(problem.state.current_best.x - problem.optimum.x)}")
+                            pbar.write(f"The regret is: {problem.state.current_best.y - problem.optimum.y}")
+                        pbar.close()
+                        ebar.update(1)
+                logger.close()

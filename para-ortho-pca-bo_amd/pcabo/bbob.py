@@ -1,11 +1,14 @@
 """Host-side BBOB objectives used as synthetic workloads (problem side of the boundary).
 
+f15 (Rastrigin rotated, the function BASELINE.json names) and f20 (Schwefel, the second function of the
+reference's `--quick` configuration, main.py:103-109) are restated; both are pinned by the reference's own logged
+runs (tests/golden/ref_kats_dim5.json).
+
 The reference obtains its objectives from the third-party `ioh` package
 (reference: Algorithms/Experiment/ExperimentRunner.py:90, example.py:82-86), which is
-not installed here.  This module restates the COCO/IOH *legacy* definition of BBOB f15
-("Rastrigin rotated") so that `PCA_BO` can be driven without `ioh`; it is pinned by the
-known answers the reference itself ships in
-pca-experiment/data_f15_RastriginRotated/IOHprofiler_f15_DIM5.dat (tests/golden/).
+not installed here.  This module restates the COCO/IOH *legacy* definitions so that `PCA_BO` /
+`Vanilla_BO` can be driven without `ioh`; the known answers are the rows the reference itself ships in
+{pca,vanilla}-experiment/data_f*/IOHprofiler_f*_DIM5.dat and the best points of the matching .json files.
 
 The objective is *outside* the accelerated path: it runs on the
 host, one point at a time, exactly like `problem(x)` does in the reference
@@ -22,7 +25,7 @@ from types import SimpleNamespace
 
 import numpy as np
 
-__all__ = ["BBOBProblem", "bbob_uniform", "bbob_gauss", "bbob_rotation", "f15_raw", "get_problem"]
+__all__ = ["BBOBProblem", "bbob_uniform", "bbob_gauss", "bbob_rotation", "f15_raw", "f20_raw", "get_problem", "FUNCTIONS"]
 
 
 def bbob_uniform(n: int, seed: int) -> np.ndarray:
@@ -121,6 +124,34 @@ def f15_raw(x: np.ndarray, state: _F15State) -> float:
     return float(10.0 * (state.dim - np.sum(np.cos(2.0 * math.pi * z))) + np.dot(z, z))
 
 
+class _F20State:
+    """BBOB f20 (Schwefel): x_opt = +-4.2096874637/2 with the signs of a seeded uniform draw; the same draw decides
+    the sign flip of x; conditioning 10^(i / (2 (D-1)))."""
+
+    def __init__(self, dim: int, instance: int):
+        rseed = 20 + 10000 * instance
+        u = bbob_uniform(dim, rseed)
+        self.sign = np.where(u < 0.5, -1.0, 1.0)
+        self.xopt = self.sign * 0.5 * 4.2096874637
+        self.offset = 2.0 * np.abs(self.xopt)
+        self.cond = np.sqrt(10.0) ** (np.arange(dim) / (dim - 1.0))
+        self.dim = dim
+
+
+def f20_raw(x: np.ndarray, state: _F20State) -> float:
+    """Schwefel x sin(sqrt|x|) with the BBOB variable transformations, value before the f_opt shift."""
+    xh = 2.0 * state.sign * np.asarray(x, dtype=np.float64)
+    zh = xh.copy()
+    zh[1:] += 0.25 * (xh[:-1] - state.offset[:-1])
+    z = 100.0 * (state.cond * (zh - state.offset) + state.offset)
+    out = np.abs(z) - 500.0
+    penalty = float(np.sum(np.where(out > 0.0, out * out, 0.0)))
+    total = float(np.sum(z * np.sin(np.sqrt(np.abs(z)))))
+    return 0.01 * (penalty + 418.9828872724339 - total / state.dim)
+
+
+FUNCTIONS = {15: ("RastriginRotated", _F15State, f15_raw), 20: ("Schwefel", _F20State, f20_raw)}
+
 _MIN = SimpleNamespace(value=0, name="MIN")
 
 
@@ -128,15 +159,17 @@ class BBOBProblem:
     """Minimal ioh-like single-objective problem (minimisation, box [-5,5]^d)."""
 
     def __init__(self, function_id: int, instance: int, dimension: int, add_fopt: bool = True):
-        if function_id != 15:
-            raise NotImplementedError("only BBOB f15 is restated (the function BASELINE.json names)")
+        if function_id not in FUNCTIONS:
+            raise NotImplementedError(f"BBOB f{function_id} is not restated here (available: {sorted(FUNCTIONS)}); "
+                                      "pass an ioh problem instead")
+        name, state_cls, self._raw = FUNCTIONS[function_id]
         if dimension < 2:
             raise ValueError("BBOB problems need dimension >= 2")
-        self._state = _F15State(dimension, instance)
+        self._state = state_cls(dimension, instance)
         self.f_opt = _fopt(function_id, instance) if add_fopt else 0.0
         self.meta_data = SimpleNamespace(
             n_variables=int(dimension), problem_id=int(function_id), instance=int(instance),
-            name="RastriginRotated", optimization_type=_MIN)
+            name=name, optimization_type=_MIN)
         self.bounds = SimpleNamespace(lb=np.full(dimension, -5.0), ub=np.full(dimension, 5.0))
         self.optimum = SimpleNamespace(x=self._state.xopt.copy(), y=self.f_opt)
         self.evaluations = 0
@@ -144,11 +177,11 @@ class BBOBProblem:
         self.best_raw = math.inf
 
     def raw(self, x) -> float:
-        return f15_raw(np.asarray(x, dtype=np.float64).ravel(), self._state)
+        return self._raw(np.asarray(x, dtype=np.float64).ravel(), self._state)
 
     def __call__(self, x) -> float:
         x = np.asarray(x, dtype=np.float64).ravel()
-        r = f15_raw(x, self._state)
+        r = self._raw(x, self._state)
         self.evaluations += 1
         self.best_raw = min(self.best_raw, r)
         self.log.append((r, x.copy()))

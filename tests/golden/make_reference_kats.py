@@ -10,6 +10,12 @@ Outputs tests/golden/ref_kats_dim5.json holding DATA only (inputs + expected out
   * "f15_best": full-precision best x / y per run from the two f15 .json files
             -> pins BBOB f15 on off-grid points to ~1e-13.
   * "f15_bo_rows": a sample of BO-phase rows (x printed to 1e-6) -> pins f15 to ~1e-5.
+  * "f20_doe", "f20_best", "f20_bo_rows": the same three for BBOB f20 (Schwefel), the second function of the
+            reference's --quick configuration (main.py:103-109).
+  * "final_best": min raw_y of every committed run (alg, fid, instance) -> the end-to-end statistical check of
+            Vanilla_BO (the PCA_BO files come from an older, clipping revision of the reference: SURVEY.md fact 6).
+  * "dat_header", "json_keys": the layout of the IOHprofiler 0.3.18 files (column header of a .dat block, key order
+            of the .json) -> pins the writer in pcabo/iohlog.py.
 Source files: /root/reference/{pca,vanilla}-experiment/data_f*/IOHprofiler_f*_DIM5.dat and
 /root/reference/{pca,vanilla}-experiment/IOHprofiler_f15_RastriginRotated.json
 """
@@ -35,7 +41,7 @@ def read_runs(path):
 
 
 def main():
-    out = {"doe": [], "f15_doe": [], "f15_best": [], "f15_bo_rows": []}
+    out = {"doe": [], "f15_doe": [], "f15_best": [], "f15_bo_rows": [], "f20_doe": [], "f20_best": [], "f20_bo_rows": []}
     for alg in ("pca", "vanilla"):
         for fid, name in ((15, "RastriginRotated"), (20, "Schwefel")):
             meta = json.load(open(f"{REF}/{alg}-experiment/IOHprofiler_f{fid}_{name}.json"))
@@ -48,14 +54,21 @@ def main():
                 out["doe"].append({"alg": alg, "fid": fid, "dim": 5, "instance": inst,
                                    "seed": 1000 * fid + 10 * 5 + inst, "first_eval_index": first,
                                    "x": [r[3:] for r in doe]})
-                if fid == 15:
-                    out["f15_doe"].append({"alg": alg, "instance": inst, "raw_y": [r[1] for r in doe]})
-                    for r in run[10::13]:
-                        out["f15_bo_rows"].append({"instance": inst, "x": r[3:], "raw_y": r[1]})
-            if fid == 15:
-                for r in meta["scenarios"][0]["runs"]:
-                    out["f15_best"].append({"alg": alg, "instance": r["instance"],
+                out.setdefault("final_best", []).append({"alg": alg, "fid": fid, "instance": inst, "rows": len(run),
+                                                         "best": min(r[1] for r in run)})
+                out[f"f{fid}_doe"].append({"alg": alg, "instance": inst, "raw_y": [r[1] for r in doe]})
+                for r in run[10::13]:
+                    out[f"f{fid}_bo_rows"].append({"instance": inst, "x": r[3:], "raw_y": r[1]})
+            for r in meta["scenarios"][0]["runs"]:
+                out[f"f{fid}_best"].append({"alg": alg, "instance": r["instance"],
                                             "x": r["best"]["x"], "y": r["best"]["y"]})
+            if alg == "pca" and fid == 15:
+                out["dat_header"] = open(f"{REF}/{alg}-experiment/data_f{fid}_{name}/IOHprofiler_f{fid}_DIM5.dat").readline()
+                out["dat_first_row"] = open(f"{REF}/{alg}-experiment/data_f{fid}_{name}/IOHprofiler_f{fid}_DIM5.dat").readlines()[1]
+                out["json_keys"] = list(meta.keys())
+                out["json_scenario_keys"] = list(meta["scenarios"][0].keys())
+                out["json_run_keys"] = list(meta["scenarios"][0]["runs"][0].keys())
+                out["json_head"] = {k: meta[k] for k in meta if k != "scenarios"}
     json.dump(out, open(OUT, "w"))
     print(OUT, os.path.getsize(OUT), "bytes;", {k: len(v) for k, v in out.items()})
 

@@ -205,7 +205,7 @@ def test_optimize_acqf_teacher_forced(ctx, records):
             assert np.abs(x - rec.cand_x).max() < 1e-6 * max(1.0, np.abs(rec.cand_x).max())
 
 
-def _replay_with_oracle(opt, problem_factory, dim, lb=-5.0, ub=5.0):
+def _replay_with_oracle(opt, problem_factory, dim, lb=-5.0, ub=5.0, oracle_cls=O.OraclePCABO):
     """Teacher-force the oracle from every state the free-running GPU run went through (same X, f and the
     same numpy / torch RNG states) and compare what both produce for that iteration.
 
@@ -218,7 +218,7 @@ def _replay_with_oracle(opt, problem_factory, dim, lb=-5.0, ub=5.0):
     st = {"iters": 0, "ties": 0, "retries": 0, "dcand": [], "dval": [], "dx": [], "df": [], "count_equal": [], "dic": []}
     for it, tr in enumerate(opt.trace):
         n = tr["n"]
-        orc = O.OraclePCABO(budget=n + 1, n_DoE=n, random_seed=0, maximization=opt.maximization, record=True)
+        orc = oracle_cls(budget=n + 1, n_DoE=n, random_seed=0, maximization=opt.maximization, record=True)
         orc.x_evals = [row.copy() for row in X_all[:n]]
         orc.f_evals = [float(v) for v in f_all[:n]]
         orc._assign_new_best()
@@ -484,3 +484,80 @@ def test_full_reference_cpu_config_run_replayed(native):
     opt(BBOBProblem(15, 0, 10))
     assert len(opt.f_evals) == 150
     _check_replay(_replay_with_oracle(opt, lambda: BBOBProblem(15, 0, 10), 10), min_iters=100)
+
+
+def test_vanilla_bo_run_replayed_by_oracle(native):
+    """Vanilla_BO: GP on raw x, Normalize off, box-constrained search - replayed like PCA_BO."""
+    from Algorithms import Vanilla_BO
+    torch.set_num_threads(4)
+    opt = Vanilla_BO(budget=58, n_DoE=18, random_seed=15061, maximization=False, record_trace=True)
+    opt(BBOBProblem(15, 1, 6))
+    assert Vanilla_BO.TIME_PROFILES == ["SingleTaskGP", "optimize_acqf"]
+    assert len(opt.f_evals) == 58 and opt.current_best == min(opt.f_evals)
+    X = np.vstack(opt.x_evals)
+    assert (X >= -5.0).all() and (X <= 5.0).all()                  # candidates stay inside the box
+    st = _replay_with_oracle(opt, lambda: BBOBProblem(15, 1, 6), 6, oracle_cls=O.OracleVanillaBO)
+    _check_replay(st, min_iters=40)       # measured over these 40 iterations: end points q50 2e-12, q90 9e-6; counts equal 91 %
+
+
+def test_experiment_runner_quick_configuration(native, tmp_path):
+    """The reference's quick configuration (main.py:103-109) cut to 2 instances: pca + vanilla on f15 / f20, d=5,
+    budget 75, 10 DoE points; the files it writes have the layout of the reference's committed experiment folders
+    and the DoE rows are the reference's own (same seed formula, same LHS, same objective)."""
+    import json, os
+    from Algorithms import ExperimentRunner
+    from pcabo import iohlog
+    G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_kats_dim5.json")))
+    er = ExperimentRunner(algorithms=["pca", "vanilla"], dimensions=[5], problem_ids=[15, 20], num_runs=2,
+                          budget_factor=5, doe_factor=2.0, root_dir=str(tmp_path), experiment_name="experiment",
+                          pca_components=0, progress=False)
+    er.run_experiment()
+    assert len(er.results) == 8 and all(r["iterations"] == 65 for r in er.results)
+    for alg in ("pca", "vanilla"):
+        for fid, name in ((15, "RastriginRotated"), (20, "Schwefel")):
+            root = os.path.join(str(tmp_path), f"{alg}-experiment")
+            meta = json.load(open(os.path.join(root, f"IOHprofiler_f{fid}_{name}.json")))
+            assert meta["algorithm"]["name"] == alg and meta["function_id"] == fid
+            want_attrs = ["SingleTaskGP_time", "optimize_acqf_time"] + (["pca_time"] if alg == "pca" else []) + ["time"]
+            assert meta["run_attributes"] == want_attrs
+            runs = meta["scenarios"][0]["runs"]
+            assert [r["instance"] for r in runs] == [0, 1]
+            # Vanilla_BO evaluates every candidate; PCA_BO does not evaluate (or log) out-of-bounds ones (PCA_BO.py:255-263)
+            assert all(r["evals"] == 75 if alg == "vanilla" else 10 <= r["evals"] <= 75 for r in runs)
+            assert all(r["time"] > 0 and r["optimize_acqf_time"] > 0 for r in runs)
+            blocks = iohlog.read_dat(os.path.join(root, meta["scenarios"][0]["path"]))
+            assert [b.shape for b in blocks] == [(r["evals"], 8) for r in runs]
+            for inst, b in enumerate(blocks):
+                ref = [d for d in G["doe"] if (d["alg"], d["fid"], d["instance"]) == (alg, fid, inst)][0]
+                assert np.abs(b[:10, 3:] - np.array(ref["x"])).max() < 5e-7                # the reference's DoE rows
+                want = [r for r in G[f"f{fid}_doe"] if (r["alg"], r["instance"]) == (alg, inst)][0]["raw_y"]
+                assert np.abs(b[:10, 1] - np.array(want)).max() < 1e-9 * np.abs(want).max()   # and their raw_y
+                assert np.allclose(b[:, 2], np.minimum.accumulate(b[:, 1]))
+                assert abs(runs[inst]["best"]["y"] - b[:, 1].min()) < 1e-9
+                if alg == "vanilla":
+                    assert np.abs(b[:, 3:]).max() <= 5.0 + 1e-9
+
+
+def test_vanilla_bo_final_results_distributed_like_the_reference_runs(native):
+    """End-to-end statistical check against the reference's OWN committed runs (vanilla-experiment/, d=5, f15 and
+    f20, 30 instances each, budget 75): trajectories are chaotic, so the comparison is the
+    distribution of the final best raw_y over the 30 instances - same seeds, same DoE.  Measured: medians 40.3 vs
+    42.8 (f15) and 3.22 vs 2.98 (f20), Mann-Whitney p = 0.77 / 0.53."""
+    import json, os
+    from scipy.stats import mannwhitneyu
+    from Algorithms import Vanilla_BO
+    G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_kats_dim5.json")))
+    torch.set_num_threads(4)
+    for fid in (15, 20):
+        ref = {r["instance"]: r["best"] for r in G["final_best"] if r["alg"] == "vanilla" and r["fid"] == fid}
+        assert len(ref) == 30
+        mine = []
+        for inst in range(30):
+            prob = BBOBProblem(fid, inst, 5)
+            opt = Vanilla_BO(budget=75, n_DoE=10, random_seed=1000 * fid + 50 + inst, maximization=False,
+                             DoE_parameters={"criterion": "center", "iterations": 1000})
+            opt(prob)
+            mine.append(prob.best_raw)
+        rb, mb = np.array([ref[i] for i in range(30)]), np.array(mine)
+        assert mannwhitneyu(rb, mb).pvalue > 0.05, (fid, np.median(rb), np.median(mb))
+        assert abs(np.log10(mb).mean() - np.log10(rb).mean()) < 0.25

@@ -64,3 +64,29 @@ def test_problem_interface_and_fopt():
     assert p.raw(p.optimum.x) == pytest.approx(0.0, abs=1e-9)
     with pytest.raises(NotImplementedError):
         BBOBProblem(16, 0, 5)
+
+
+def test_f20_on_reference_rows():
+    """BBOB f20 (Schwefel), the second function of the reference's --quick configuration: exact DoE rows,
+    full-precision best points, printed BO rows."""
+    by_inst = {(r["alg"], r["instance"]): r for r in G["f20_doe"]}
+    worst = 0.0
+    for run in G["doe"]:
+        if run["fid"] != 20:
+            continue
+        np.random.seed(run["seed"])
+        x0 = 10.0 * lhs_center(5, 10) - 5.0
+        prob = BBOBProblem(20, run["instance"], 5)
+        for x, y in zip(x0, by_inst[(run["alg"], run["instance"])]["raw_y"]):
+            worst = max(worst, abs(prob.raw(x) - y) / max(1.0, abs(y)))
+    assert worst < 1e-12
+    assert len(G["f20_best"]) >= 50
+    for b in G["f20_best"]:
+        assert abs(BBOBProblem(20, b["instance"], 5).raw(b["x"]) - b["y"]) < 1e-12 * max(1.0, abs(b["y"]))
+    bad = 0
+    for r in G["f20_bo_rows"]:
+        v = BBOBProblem(20, r["instance"], 5).raw(r["x"])
+        bad += abs(v - r["raw_y"]) > 2e-3 * max(1.0, abs(r["raw_y"]))      # x printed with 6 decimals; f20 is steep
+    assert bad <= 3
+    p = BBOBProblem(20, 3, 5)
+    assert abs(p.raw(p.optimum.x)) < 1e-6 and p.meta_data.name == "Schwefel"       # f(x_opt) = 0 before the shift

@@ -17,13 +17,19 @@ Third-party code that IS present is executed for real, exactly as the reference 
   (botorch initialisers), numpy's legacy global RNG (PCA_BO.py:376).
 
 PARITY PIN STATUS
-  * pinned by the reference's own data: LHS design + seed formula (120 runs) and the BBOB f15
-    objective (tests/golden/ref_kats_dim5.json, tests/test_reference_kats.py).
-  * rows E-N (botorch/gpytorch semantics: model constants, log-EI, initial-condition
-    heuristic, joint 5-restart L-BFGS-B) are restated from the published algorithms; the
-    reference ships no tests or golden vectors for them and the packages cannot be imported
-    here => for those rows: **parity unpinned**.  Every constant that comes from memory of
-    those packages is a named module-level parameter below.
+  * pinned by the reference's own data (tests/golden/ref_kats_dim5.json): LHS design + seed formula (120 runs);
+    the BBOB f15 and f20 objectives (tests/test_reference_kats.py); and rows F-L for the un-projected GP
+    (Standardize, Matern-5/2 with lengthscale ln 2 and no output scale, noise e^-5, zero mean, log-EI, best_f):
+    every BO row of the reference's committed Vanilla_BO runs is a local maximum of this oracle's acquisition
+    surface to the 1e-6 the files print, and is NOT one when a constant is changed
+    (tests/test_oracle.py::test_reference_logged_vanilla_candidates_are_optima_of_the_oracle_surface).
+  * still **parity unpinned**: the pieces no committed output can pin - row E's bounds in PCA space and rows A-D as
+    a chain (the committed pca-experiment files come from an older revision of the reference that clipped
+    candidates; their rows are not reproducible from the current code), and the random-restart heuristic of rows
+    K-N (Sobol scrambling, `initialize_q_batch` temperature, arg-max over restarts: they select WHICH local optimum
+    is returned, and that is chaotic - DESIGN.md section 6).  These are restated from the published algorithms of
+    botorch 0.13 / gpytorch 1.14; sklearn, scipy and torch, which are present, are executed for real.  Every
+    constant that comes from memory of the absent packages is a named module-level parameter below.
 
 Row letters refer to SURVEY.md section 8(a).
 """

@@ -14,6 +14,9 @@ Outputs tests/golden/ref_kats_dim5.json holding DATA only (inputs + expected out
             reference's --quick configuration (main.py:103-109).
   * "final_best": min raw_y of every committed run (alg, fid, instance) -> the end-to-end statistical check of
             Vanilla_BO (the PCA_BO files come from an older, clipping revision of the reference: SURVEY.md fact 6).
+  * "vanilla_runs": all 75 logged rows (raw_y, x printed to 1e-6) of 12 committed Vanilla_BO runs -> each BO row is the
+            candidate the REFERENCE chose given the rows before it: it must be a local maximum of the acquisition
+            surface built from those rows (pins Standardize / Matern-5/2 / lengthscale / noise / log-EI / best_f).
   * "dat_header", "json_keys": the layout of the IOHprofiler 0.3.18 files (column header of a .dat block, key order
             of the .json) -> pins the writer in pcabo/iohlog.py.
 Source files: /root/reference/{pca,vanilla}-experiment/data_f*/IOHprofiler_f*_DIM5.dat and
@@ -56,6 +59,9 @@ def main():
                                    "x": [r[3:] for r in doe]})
                 out.setdefault("final_best", []).append({"alg": alg, "fid": fid, "instance": inst, "rows": len(run),
                                                          "best": min(r[1] for r in run)})
+                if alg == "vanilla" and inst % 5 == 0:
+                    out.setdefault("vanilla_runs", []).append({"fid": fid, "instance": inst,
+                                                               "rows": [[r[1]] + r[3:] for r in run]})
                 out[f"f{fid}_doe"].append({"alg": alg, "instance": inst, "raw_y": [r[1] for r in doe]})
                 for r in run[10::13]:
                     out[f"f{fid}_bo_rows"].append({"instance": inst, "x": r[3:], "raw_y": r[1]})

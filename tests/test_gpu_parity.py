@@ -561,3 +561,41 @@ def test_vanilla_bo_final_results_distributed_like_the_reference_runs(native):
         rb, mb = np.array([ref[i] for i in range(30)]), np.array(mine)
         assert mannwhitneyu(rb, mb).pvalue > 0.05, (fid, np.median(rb), np.median(mb))
         assert abs(np.log10(mb).mean() - np.log10(rb).mean()) < 0.25
+
+
+def test_reference_logged_vanilla_candidates_are_optima_of_the_device_surface(native):
+    """The HIP path against the reference's own outputs (no oracle involved): every BO row of the committed
+    Vanilla_BO runs must be a local maximum of the DEVICE log-EI surface conditioned on the rows before it.
+    Starting the device optimiser (C ABI: pcabo_gp_condition + pcabo_optimize_acqf) at the logged candidate must
+    leave it in place (x is printed to 1e-6); with lengthscale 1.0 instead of ln 2 it walks away."""
+    import json, os, math
+    G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_kats_dim5.json")))
+    ident, box = np.vstack([np.zeros(5), np.ones(5)]), np.vstack([np.full(5, -5.0), np.full(5, 5.0)])
+    c = native.Context(max_n=80, max_d=5, max_q=16)
+
+    def moves(lengthscale, every):
+        dx, dv = [], []
+        for run in G["vanilla_runs"]:
+            rows = np.array(run["rows"])
+            for t in range(10, 75, every):
+                X, f, xc = rows[:t, 1:], rows[:t, 0], rows[t, 1:]
+                c.gp_condition(f, Z=X, norm_bounds=ident, lengthscale=lengthscale, noise=math.exp(-5))
+                best = float(np.float32(f.min()))
+                v0, _ = c.acq_eval(xc.reshape(1, -1), best, False, native.ACQ_LOG_EI, grad=True)
+                cand, vals, info, failed = c.optimize_acqf(xc.reshape(1, -1), box, best)
+                assert not failed
+                dx.append(np.abs(cand[0] - xc).max())
+                dv.append(vals[0] - v0[0])
+        return np.array(dx), np.array(dv)
+
+    dx, dv = moves(math.log(2.0), 3)
+    assert len(dx) == 12 * 22
+    assert np.median(dx) < 1e-4 and np.quantile(dx, 0.9) < 5e-4, (np.median(dx), np.quantile(dx, 0.9))
+    # the reference optimises 5 restarts as ONE problem and stops on the reduction of their sum, so a single restart
+    # may be left ~1e-3 short of its optimum: allowed for <= 2 % of the rows (measured: 2 of 264, gains 8e-4)
+    far = dx >= 5e-3
+    assert far.mean() <= 0.02 and (dv[far] < 1e-2).all(), (dx[far], dv[far])
+    assert np.median(dv) < 1e-8 and np.quantile(dv, 0.9) < 1e-7 and dv.min() > -1e-12
+    dx_wrong, _ = moves(1.0, 13)
+    assert np.median(dx_wrong) > 0.1
+    c.close()

@@ -84,3 +84,47 @@ def test_oracle_loop_is_deterministic_and_respects_oob_rule():
         assert rec.oob == (np.any(rec.cand_x < -5) or np.any(rec.cand_x > 5))
         if rec.oob:
             assert rec.f_new == 1000.0
+
+
+def _logged_candidate_cases(G, every=6):
+    for run in G["vanilla_runs"]:
+        rows = np.array(run["rows"])
+        for t in range(10, 75, every):
+            yield run["fid"], run["instance"], t, rows[:t, 1:], rows[:t, 0], rows[t, 1:]
+
+
+def test_reference_logged_vanilla_candidates_are_optima_of_the_oracle_surface():
+    """Pin of rows F-L by the reference's OWN outputs: every BO row of the committed Vanilla_BO runs is the point the
+    reference's optimize_acqf returned for the GP built from the rows before it, so it has to be a local maximum of
+    the oracle's log-EI surface (x is printed to 1e-6, L-BFGS-B stops at a relative f-reduction of 2e-9).
+    The check has power: with lengthscale 1.0 instead of ln 2, or noise 1e-4 instead of e^-5, the same points are
+    NOT optima (moves of 0.5 / 3e-3 instead of 2e-5)."""
+    import json, os
+    from scipy.optimize import minimize
+    G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_kats_dim5.json")))
+    assert len(G["vanilla_runs"]) == 12
+    ident = np.vstack([np.zeros(5), np.ones(5)])
+
+    def moves(lengthscale, noise, every):
+        dx, dv = [], []
+        for fid, inst, t, X, f, xc in _logged_candidate_cases(G, every):
+            gp = O.ExactGP(X, f, ident, lengthscale=lengthscale, noise=noise)
+            acq = O.Acquisition(gp, float(f.min()), False, "expected_improvement")
+
+            def fg(x):
+                v, g = acq.value_and_grad(x.reshape(1, -1))
+                return -float(v[0]), -np.asarray(g).ravel()
+            v0 = -fg(xc)[0]
+            res = minimize(fg, xc, jac=True, method="L-BFGS-B", bounds=[(-5, 5)] * 5,
+                           options=dict(maxiter=200, ftol=1e7 * np.finfo(float).eps, gtol=1e-5))
+            dx.append(np.abs(res.x - xc).max())
+            dv.append(-res.fun - v0)
+        return np.array(dx), np.array(dv)
+
+    dx, dv = moves(O.LENGTHSCALE, O.NOISE, 6)
+    assert len(dx) == 12 * 11
+    assert np.median(dx) < 1e-4 and np.quantile(dx, 0.9) < 5e-4 and dx.max() < 5e-3, (np.median(dx), dx.max())
+    assert np.median(dv) < 1e-8 and np.quantile(dv, 0.9) < 1e-7
+    dx_ls, _ = moves(1.0, O.NOISE, 13)
+    dx_noise, _ = moves(O.LENGTHSCALE, 1e-4, 13)
+    assert np.median(dx_ls) > 0.1 and np.median(dx_noise) > 10 * np.median(dx)

@@ -33,6 +33,44 @@
 
 #define PSTRIDE (2 + 2 * PCABO_MAXD)   // doubles per (query, slab) partial record
 
+// Phase stamps for tests/gpu_acq_phases.py (diagnostic build only: `make timing` -> libpcabo_timing.so).
+#ifdef PCABO_ACQ_TIMING
+__device__ unsigned long long g_acq_stamps[16];
+#define STAMP(i) do { if (blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && threadIdx.x == 0) g_acq_stamps[i] = wall_clock64(); } while (0)
+#define STAMP_FIN(i) do { if (blockIdx.y == 0 && threadIdx.x == 0) g_acq_stamps[i] = wall_clock64(); } while (0)
+extern "C" int pcabo_debug_acq_stamps(unsigned long long* out16) {
+  return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_acq_stamps), sizeof(g_acq_stamps)) == hipSuccess ? 0 : -3;
+}
+#else
+#define STAMP(i)
+#define STAMP_FIN(i)
+#endif
+
+// Wave-wide sum without LDS traffic.  `__shfl_xor` compiles to ds_bpermute_b32 (two per double, each followed by an
+// lgkmcnt wait: ~100 cycles of dependent latency per step); in a kernel whose whole budget is ~15 us the reductions
+// were the largest single item.  DPP steps stay inside the VALU: quad_perm x2, row_half_mirror, row_mirror leave the
+// row sum in all 16 lanes; row_bcast15 / row_bcast31 carry it across the four rows into lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ inline double dpp_get(double v) {
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ inline double row_sum16(double v) {        // every lane: sum over its row of 16 lanes
+  v += dpp_get<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]
+  v += dpp_get<0x4E, 0xf>(v);      // quad_perm [2,3,0,1]
+  v += dpp_get<0x141, 0xf>(v);     // row_half_mirror
+  v += dpp_get<0x140, 0xf>(v);     // row_mirror
+  return v;
+}
+__device__ inline double wave_sum(double v) {         // uniform result: sum over all 64 lanes
+  v = row_sum16(v);
+  v += dpp_get<0x142, 0xa>(v);     // row_bcast15 -> rows 1, 3
+  v += dpp_get<0x143, 0xc>(v);     // row_bcast31 -> rows 2, 3
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63),
+                          __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
 // Write-through store (global_store ... sc1): the partial records are handed to another work-group inside
 // the launch; written this way they never sit dirty in this XCD's L2, so the hand-off needs no L2 write-back
 // (agent-scope release) on the producer side - only the drain + ticket, and the consumer's acquire.
@@ -69,6 +107,7 @@ __global__ __launch_bounds__(256) void k_acq_fused(
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
   const int s = blockIdx.x, q = blockIdx.y, S = gridDim.x;
   double* out = partial + ((size_t)q * S + s) * PSTRIDE;
+  STAMP(0);
 
   if (tid < k) {
     double lo = bounds4[tid], hi = bounds4[PCABO_MAXD + tid];
@@ -76,6 +115,7 @@ __global__ __launch_bounds__(256) void k_acq_fused(
     s_xn[tid] = (xv - lo) / (hi - lo);
   }
   __syncthreads();
+  STAMP(1);
   // kernel vector and the radial derivative factor
   const double s5 = 2.23606797749979;
   for (int j = tid; j < NP; j += 256) {
@@ -98,6 +138,7 @@ __global__ __launch_bounds__(256) void k_acq_fused(
     s_cf[j] = cf;
   }
   __syncthreads();
+  STAMP(2);
   // v_i = R[i][0..i] . ks for the slab's 16 rows: each wave owns 4 rows and streams them together (4
   // independent load streams in flight), then 64-lane shuffle reductions
   {
@@ -116,16 +157,14 @@ __global__ __launch_bounds__(256) void k_acq_fused(
       for (int u = 0; u < RW; ++u) acc[u] += Rr[u][j] * kj;      // R is exactly zero above its diagonal
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-      for (int u = 0; u < RW; ++u) acc[u] += __shfl_xor(acc[u], off, 64);
-    }
+    for (int u = 0; u < RW; ++u) acc[u] = wave_sum(acc[u]);
     if (l == 0) {
 #pragma unroll
       for (int u = 0; u < RW; ++u) s_v[w + 4 * u] = acc[u];
     }
   }
   __syncthreads();
+  STAMP(3);
   // slab contributions to |v|^2 and to mu_s = alpha . ks: 16 lanes, one round trip
   if (w == 0) {
     double vv = 0.0, mu = 0.0;
@@ -135,12 +174,13 @@ __global__ __launch_bounds__(256) void k_acq_fused(
       vv = vi * vi;
       if (i < n) mu = alpha[i] * s_ks[i];
     }
-#pragma unroll
-    for (int off = SLAB / 2; off > 0; off >>= 1) { vv += __shfl_xor(vv, off, 64); mu += __shfl_xor(mu, off, 64); }
+    vv = wave_sum(vv);        // lanes >= SLAB hold zeros
+    mu = wave_sum(mu);
     if (l == 0) { st_wt(out + 0, vv); st_wt(out + 1, mu); }
   }
   if (want_grad) {
   __syncthreads();   // thread 0 has finished reading s_ks before it is reused below
+  STAMP(4);
   // w_j (slab part) = sum_{i in slab} R[i][j] v_i (R[i][j] = 0 for j > i); fold in coef_j.  The 16 row
   // segments are read column-wise (coalesced over j), all loads independent.
   for (int j = tid; j < NP; j += 256) {
@@ -153,6 +193,7 @@ __global__ __launch_bounds__(256) void k_acq_fused(
     s_ks[j] = wj * cf;                    // ks no longer needed: reuse as t_sigma
   }
   __syncthreads();
+  STAMP(5);
   // contraction with (xn_c - zn_jc): a wave keeps 8 components in flight (c = c0 + w + 4u)
   for (int c0 = 0; c0 < k; c0 += 32) {
     double gs[8], gm[8], xc[8];
@@ -173,10 +214,7 @@ __global__ __launch_bounds__(256) void k_acq_fused(
       }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { gs[u] += __shfl_xor(gs[u], off, 64); gm[u] += __shfl_xor(gm[u], off, 64); }
-    }
+    for (int u = 0; u < 8; ++u) { gs[u] = wave_sum(gs[u]); gm[u] = wave_sum(gm[u]); }
     if (l == 0) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -190,8 +228,10 @@ __global__ __launch_bounds__(256) void k_acq_fused(
   // ---- in-launch combine: the last slab group of this query to arrive finishes it -----------------
   if (!combine) return;          // large batches: a follow-up k_acq_combine launch reads the partials instead
   int* s_flag = reinterpret_cast<int*>(s_v + SLAB);
+  STAMP(6);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  STAMP(7);
   if (tid == 0) {
     unsigned int t = __hip_atomic_fetch_add(&counters[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int last = ((t % (unsigned int)S) == (unsigned int)(S - 1));
@@ -203,12 +243,18 @@ __global__ __launch_bounds__(256) void k_acq_fused(
   }
   __syncthreads();
   if (!*s_flag) return;
+  STAMP_FIN(8);
   if (w == 0) {
     acq_finish_query(partial + (size_t)q * S * PSTRIDE, S, k, q, bounds4, ystats, prm, val, grad, host_val, host_grad, l);
     // publish: this query's sequence word follows its results with a system-scope release (one wave, so the
     // release store's drain covers every lane's host writes)
     if (hm && l == 0)
       __hip_atomic_store(const_cast<unsigned long long*>(&hm->qflag[q]), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    STAMP_FIN(9);
+#ifdef PCABO_ACQ_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP_FIN(10);
+#endif
   }
 }
 
@@ -246,8 +292,8 @@ __device__ void acq_finish_query(const double* base, int S, int k, int q, const 
   // lanes over slabs (S <= 128): two loads per lane, fixed shuffle tree -> deterministic
   double vv = 0.0, mus = 0.0;
   for (int s = l; s < S; s += 64) { vv += base[(size_t)s * PSTRIDE]; mus += base[(size_t)s * PSTRIDE + 1]; }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) { vv += __shfl_xor(vv, off, 64); mus += __shfl_xor(mus, off, 64); }
+  vv = wave_sum(vv);
+  mus = wave_sum(mus);
   const double ym = ystats[0], ysd = ystats[1];
   const double mu = ym + ysd * mus;
   double var = (1.0 - vv) * (ysd * ysd);

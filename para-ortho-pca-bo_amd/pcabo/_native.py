@@ -36,7 +36,8 @@ class PcaboError(RuntimeError):
 
 
 def lib_path() -> str:
-    return os.path.normpath(_LIB_PATH)
+    # PCABO_LIB selects another build of the SAME library (diagnostic builds such as libpcabo_timing.so)
+    return os.path.normpath(os.environ.get("PCABO_LIB") or _LIB_PATH)
 
 
 def _load() -> C.CDLL:

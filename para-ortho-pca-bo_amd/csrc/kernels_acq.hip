@@ -89,6 +89,44 @@ __device__ void acq_finish_query(const double* base, int S, int k, int q, const 
                                  const AcqParams& p, double* val, double* grad, double* host_val, double* host_grad,
                                  int lane);
 
+// ---- in-launch combine: the last slab group of a query to arrive finishes it ---------------------------
+template <int SLAB>
+__device__ inline void acq_tail(int combine, double* s_v, double* partial, unsigned int* counters, int q, int S, int k,
+                                const double* bounds4, const double* ystats, const AcqParams& prm, double* val,
+                                double* grad, double* host_val, double* host_grad, HostMirror* hm,
+                                unsigned long long seq, int tid, int w, int l) {
+  if (!combine) return;          // large batches: a follow-up k_acq_combine launch reads the partials instead
+  int* s_flag = reinterpret_cast<int*>(s_v + SLAB);
+  STAMP(6);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  STAMP(7);
+  if (tid == 0) {
+    unsigned int t = __hip_atomic_fetch_add(&counters[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int last = ((t % (unsigned int)S) == (unsigned int)(S - 1));
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    *s_flag = last;
+  }
+  __syncthreads();
+  if (!*s_flag) return;
+  STAMP_FIN(8);
+  if (w == 0) {
+    acq_finish_query(partial + (size_t)q * S * PSTRIDE, S, k, q, bounds4, ystats, prm, val, grad, host_val, host_grad, l);
+    // publish: this query's sequence word follows its results with a system-scope release (one wave, so the
+    // release store's drain covers every lane's host writes)
+    if (hm && l == 0)
+      __hip_atomic_store(const_cast<unsigned long long*>(&hm->qflag[q]), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    STAMP_FIN(9);
+#ifdef PCABO_ACQ_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP_FIN(10);
+#endif
+  }
+}
+
 template <int SLAB>
 __global__ __launch_bounds__(256) void k_acq_fused(
     QueryArgs qa, const double* __restrict__ Xq, int q_total, int n, int k, int NP, int ld,
@@ -225,37 +263,214 @@ __global__ __launch_bounds__(256) void k_acq_fused(
   }
   }  // want_grad
 
-  // ---- in-launch combine: the last slab group of this query to arrive finishes it -----------------
-  if (!combine) return;          // large batches: a follow-up k_acq_combine launch reads the partials instead
-  int* s_flag = reinterpret_cast<int*>(s_v + SLAB);
-  STAMP(6);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  acq_tail<SLAB>(combine, s_v, partial, counters, q, S, k, bounds4, ystats, prm, val, grad, host_val, host_grad, hm, seq, tid, w, l);
+}
+
+// ---- fast path: NP = 64 NB <= 512 and k <= 40, everything static ---------------------------------------------
+// The generic kernel above re-reads its operands (ZnT for ks and again for the gradient contraction, the R slab
+// row-wise for v and again column-wise for w) and pays an exposed round trip per loop trip.  Here trip counts are
+// template constants and the two big operands are read ONCE, at kernel entry, into registers:
+//   z[u][b] = ZnT[c = w + 4u][l + 64 b]    (wave w: components w + 4u, u < 10; lanes: columns)   <= 80 doubles
+//   r[u][b] = R[slab row w + 4u][l + 64 b] (wave w: rows w + 4u of the slab; lanes: columns)     <= 64 doubles
+// so the whole kernel has one exposed memory round trip; everything after it is LDS + VALU:
+//   ks        partial squared distances per wave (its components) -> LDS -> thread j adds the four partials in a
+//             fixed order and applies the radial function
+//   v         acc[u] = sum_b r[u][b] ks[l + 64 b], DPP wave sums
+//   w_j       per-wave partial sum_u r[u][b] v[w + 4u] -> LDS -> thread j adds the four partials, folds in coef_j
+//   gradient  gs[u] = sum_b t_sigma[l + 64 b] (xn_c - z[u][b]) from the SAME registers, DPP wave sums
+// Wave-uniform indices are forced into SGPRs (readfirstlane): row bases are scalar, loads need no vector address
+// arithmetic.  Columns j >= n hold zeros in ZnT (k_znorm) and get zero weights.
+template <int SLAB, int NB>
+__global__ __launch_bounds__(256) void k_acq_fast(
+    QueryArgs qa, const double* __restrict__ Xq, int q_total, int n, int k, int NP_rt, int ld,
+    const double* __restrict__ ZnT, const double* __restrict__ R, const double* __restrict__ alpha,
+    const double* __restrict__ bounds4, const double* __restrict__ ystats, AcqParams prm, double* partial,
+    unsigned int* counters, double* __restrict__ val, double* __restrict__ grad,
+    double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq, int combine) {
+  constexpr int NP = NB * 64;
+  constexpr int CU = 10;                 // components per wave
+  constexpr int RW = SLAB / 4;           // slab rows per wave
+  constexpr int NM = (NB + 3) / 4;       // columns per thread in the thread-per-column steps
+  const double inv_ls = prm.inv_ls;
+  const int kernel = prm.kernel, want_grad = prm.want_grad;
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+  double* s_ks = s_dyn;              // NP
+  double* s_cf = s_dyn + NP;         // NP  coef_j (dks_j/dxn = coef_j (xn - zn_j))
+  double* s_tm = s_dyn + 2 * NP;     // NP  alpha_j coef_j restricted to this slab's rows
+  double* s_xn = s_dyn + 3 * NP;     // PCABO_MAXD
+  double* s_v = s_xn + PCABO_MAXD;   // SLAB (+ flag word)
+  double* s_p4 = s_v + SLAB + 2;     // 4 NP per-wave partials (squared distances, then w_j)
+  const int tid = threadIdx.x, l = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int s = blockIdx.x, q = blockIdx.y, S = gridDim.x;
+  double* out = partial + ((size_t)q * S + s) * PSTRIDE;
+  STAMP(0);
+
+  // ---- every global operand, issued before anything waits ---------------------------------------------------
+  // Column block b of this group is physical block (b + rot) % NB: all groups of a launch read the same ZnT (and the
+  // ten groups of a slab the same R rows), so without the rotation they would all hit the same L2 lines at once.
+  double z[CU][NB], r[RW][NB], al[NM];
+  int col[NB];
+  {
+    const int rot = (s + q) % NB;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { const int pb = b + rot; col[b] = l + 64 * (pb >= NB ? pb - NB : pb); }
+  }
+#pragma unroll
+  for (int u = 0; u < CU; ++u) {
+    const int c = w + 4 * u;
+    const double* zr = ZnT + (size_t)(c < k ? c : k - 1) * ld;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) z[u][b] = zr[col[b]];
+  }
+#pragma unroll
+  for (int u = 0; u < RW; ++u) {
+    const int ri = slab_row<SLAB>(s, w + 4 * u, NP);
+    const double* Rr = R + (size_t)ri * ld;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) r[u][b] = (col[b] - l <= ri) ? Rr[col[b]] : 0.0;   // blocks above the diagonal are zero
+  }
+#pragma unroll
+  for (int m = 0; m < NM; ++m) { const int j = tid + 256 * m; al[m] = j < n ? alpha[j] : 0.0; }
+  if (tid < k) {
+    double lo = bounds4[tid], hi = bounds4[PCABO_MAXD + tid];
+    double xv = Xq ? Xq[(size_t)q * k + tid] : qa.x[q * k + tid];
+    s_xn[tid] = (xv - lo) / (hi - lo);
+  }
   __syncthreads();
-  STAMP(7);
-  if (tid == 0) {
-    unsigned int t = __hip_atomic_fetch_add(&counters[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int last = ((t % (unsigned int)S) == (unsigned int)(S - 1));
-    if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STAMP(1);
+  // ---- ks ------------------------------------------------------------------------------------------------------
+  double xc[CU];
+#pragma unroll
+  for (int u = 0; u < CU; ++u) xc[u] = s_xn[(w + 4 * u < k) ? w + 4 * u : k - 1];
+  {
+    double sq[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) sq[b] = 0.0;
+#pragma unroll
+    for (int u = 0; u < CU; ++u) {
+      if (w + 4 * u < k) {                  // wave-uniform
+#pragma unroll
+        for (int b = 0; b < NB; ++b) { const double d = xc[u] - z[u][b]; sq[b] += d * d; }
+      }
     }
-    *s_flag = last;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) s_p4[w * NP + col[b]] = sq[b];
   }
   __syncthreads();
-  if (!*s_flag) return;
-  STAMP_FIN(8);
-  if (w == 0) {
-    acq_finish_query(partial + (size_t)q * S * PSTRIDE, S, k, q, bounds4, ystats, prm, val, grad, host_val, host_grad, l);
-    // publish: this query's sequence word follows its results with a system-scope release (one wave, so the
-    // release store's drain covers every lane's host writes)
-    if (hm && l == 0)
-      __hip_atomic_store(const_cast<unsigned long long*>(&hm->qflag[q]), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    STAMP_FIN(9);
-#ifdef PCABO_ACQ_TIMING
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    STAMP_FIN(10);
-#endif
+  const double s5 = 2.23606797749979;
+#pragma unroll
+  for (int m = 0; m < NM; ++m) {
+    const int j = tid + 256 * m;
+    if (j < NP) {
+      double ks = 0.0, cf = 0.0;
+      if (j < n) {
+        double sq = ((s_p4[j] + s_p4[NP + j]) + s_p4[2 * NP + j]) + s_p4[3 * NP + j];
+        sq *= inv_ls * inv_ls;
+        if (kernel == 1) {
+          ks = exp(-0.5 * sq);
+          cf = -ks * inv_ls * inv_ls;
+        } else {
+          double dist = sqrt(fmax(sq, 1e-30));
+          double e = exp(-s5 * dist);
+          ks = ((s5 * dist + 1.0) + (5.0 / 3.0) * (dist * dist)) * e;
+          cf = -(5.0 / 3.0) * (1.0 + s5 * dist) * e * inv_ls * inv_ls;
+        }
+      }
+      s_ks[j] = ks;
+      s_cf[j] = cf;
+    }
   }
+  __syncthreads();
+  STAMP(2);
+  // ---- v_i = R[i][:] . ks for the slab's rows -------------------------------------------------------------------
+  {
+    double acc[RW];
+#pragma unroll
+    for (int u = 0; u < RW; ++u) acc[u] = 0.0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const double kj = s_ks[col[b]];
+#pragma unroll
+      for (int u = 0; u < RW; ++u) acc[u] += r[u][b] * kj;
+    }
+#pragma unroll
+    for (int u = 0; u < RW; ++u) acc[u] = wave_sum(acc[u]);
+    if (l == 0) {
+#pragma unroll
+      for (int u = 0; u < RW; ++u) s_v[w + 4 * u] = acc[u];
+    }
+  }
+  __syncthreads();
+  STAMP(3);
+  // slab contributions to |v|^2 and to mu_s = alpha . ks
+  if (w == 0) {
+    double vv = 0.0, mu = 0.0;
+    if (l < SLAB) {
+      const int i = slab_row<SLAB>(s, l, NP);
+      const double vi = s_v[l];
+      vv = vi * vi;
+      if (i < n) mu = alpha[i] * s_ks[i];
+    }
+    vv = wave_sum(vv);
+    mu = wave_sum(mu);
+    if (l == 0) { st_wt(out + 0, vv); st_wt(out + 1, mu); }
+  }
+  if (want_grad) {
+  // ---- w_j (slab part) = sum_{i in slab} R[i][j] v_i: per-wave partials from the same registers -----------------
+  {
+    double vw[RW];
+#pragma unroll
+    for (int u = 0; u < RW; ++u) vw[u] = s_v[w + 4 * u];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      double pw = 0.0;
+#pragma unroll
+      for (int u = 0; u < RW; ++u) pw += r[u][b] * vw[u];
+      s_p4[w * NP + col[b]] = pw;
+    }
+  }
+  __syncthreads();   // also: wave 0 has finished reading s_ks before it is reused below
+  STAMP(4);
+#pragma unroll
+  for (int m = 0; m < NM; ++m) {
+    const int j = tid + 256 * m;
+    if (j < NP) {
+      const double wj = ((s_p4[j] + s_p4[NP + j]) + s_p4[2 * NP + j]) + s_p4[3 * NP + j];
+      const bool mine = ((j / (SLAB / 2)) == s) || (((NP - 1 - j) / (SLAB / 2)) == s);
+      const double cf = s_cf[j];
+      s_tm[j] = mine ? al[m] * cf : 0.0;     // al = 0 beyond n
+      s_ks[j] = wj * cf;                     // ks no longer needed: reuse as t_sigma
+    }
+  }
+  __syncthreads();
+  STAMP(5);
+  // ---- contraction with (xn_c - zn_jc) -------------------------------------------------------------------------
+  {
+    double gs[CU], gm[CU];
+#pragma unroll
+    for (int u = 0; u < CU; ++u) { gs[u] = 0.0; gm[u] = 0.0; }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const double ts = s_ks[col[b]], tm = s_tm[col[b]];
+#pragma unroll
+      for (int u = 0; u < CU; ++u) {
+        const double dlt = xc[u] - z[u][b];
+        gs[u] += ts * dlt;
+        gm[u] += tm * dlt;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < CU; ++u) {
+      const int c = w + 4 * u;
+      if (c < k) {                          // wave-uniform
+        const double a = wave_sum(gs[u]), b2 = wave_sum(gm[u]);
+        if (l == 0) { st_wt(out + 2 + c, a); st_wt(out + 2 + PCABO_MAXD + c, b2); }
+      }
+    }
+  }
+  }  // want_grad
+  acq_tail<SLAB>(combine, s_v, partial, counters, q, S, k, bounds4, ystats, prm, val, grad, host_val, host_grad, hm, seq, tid, w, l);
 }
 
 // ---- scalar log-EI helper, value and derivative (botorch/acquisition/analytic.py::_log_ei_helper)
@@ -367,17 +582,35 @@ void launch_acq(hipStream_t st, const QueryArgs* qa, const double* Xq, int q, in
   if (slab_thr < 0) { const char* e = getenv("PCABO_SLAB32_NP"); slab_thr = e ? atoi(e) : 448; }
   const int slab = NP >= slab_thr ? 32 : 16;
   const int S = NP / slab;
-  size_t lds = (size_t)(3 * NP + PCABO_MAXD + 32 + 2) * sizeof(double);
   static const QueryArgs empty = {};
   const int combine = hm != nullptr;      // small batches: finish inside the launch and publish to the host
-  if (slab == 16)
-    hipLaunchKernelGGL(k_acq_fused<16>, dim3(S, q), dim3(256), lds, st, qa ? *qa : empty, Xq, q, n, k, NP, ld, ZnT, R,
-                       alpha, bounds4, ystats, p, partial, counters, val, grad, host_val, host_grad, hm,
-                       seq, combine);
-  else
-    hipLaunchKernelGGL(k_acq_fused<32>, dim3(S, q), dim3(256), lds, st, qa ? *qa : empty, Xq, q, n, k, NP, ld, ZnT, R,
-                       alpha, bounds4, ystats, p, partial, counters, val, grad, host_val, host_grad, hm,
-                       seq, combine);
+  const int nb = NP / 64;
+  static int use_fast = -1;
+  if (use_fast < 0) { const char* e = getenv("PCABO_ACQ_GENERIC"); use_fast = !(e && atoi(e)); }
+#define ACQ_ARGS qa ? *qa : empty, Xq, q, n, k, NP, ld, ZnT, R, alpha, bounds4, ystats, p, partial, counters, val, grad, \
+                 host_val, host_grad, hm, seq, combine
+#define ACQ_FAST(SL, NBV)                                                                                      \
+  case NBV:                                                                                                    \
+    hipLaunchKernelGGL((k_acq_fast<SL, NBV>), dim3(S, q), dim3(256),                                           \
+                       (size_t)(7 * NBV * 64 + PCABO_MAXD + SL + 4) * sizeof(double), st, ACQ_ARGS);           \
+    break;
+  if (use_fast && k <= 40 && nb <= 8) {
+    if (slab == 16) {
+      switch (nb) { ACQ_FAST(16, 1) ACQ_FAST(16, 2) ACQ_FAST(16, 3) ACQ_FAST(16, 4) ACQ_FAST(16, 5) ACQ_FAST(16, 6)
+                    ACQ_FAST(16, 7) ACQ_FAST(16, 8) }
+    } else {
+      switch (nb) { ACQ_FAST(32, 1) ACQ_FAST(32, 2) ACQ_FAST(32, 3) ACQ_FAST(32, 4) ACQ_FAST(32, 5) ACQ_FAST(32, 6)
+                    ACQ_FAST(32, 7) ACQ_FAST(32, 8) }
+    }
+  } else {
+    size_t lds = (size_t)(3 * NP + PCABO_MAXD + 32 + 2) * sizeof(double);
+    if (slab == 16)
+      hipLaunchKernelGGL(k_acq_fused<16>, dim3(S, q), dim3(256), lds, st, ACQ_ARGS);
+    else
+      hipLaunchKernelGGL(k_acq_fused<32>, dim3(S, q), dim3(256), lds, st, ACQ_ARGS);
+  }
+#undef ACQ_FAST
+#undef ACQ_ARGS
   if (!combine)
     hipLaunchKernelGGL(k_acq_combine, dim3((q + 3) / 4), dim3(256), 0, st, partial, q, S, k, bounds4, ystats, p, val,
                        grad);

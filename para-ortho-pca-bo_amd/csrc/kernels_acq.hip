@@ -89,6 +89,31 @@ __device__ void acq_finish_query(const double* base, int S, int k, int q, const 
                                  const AcqParams& p, double* val, double* grad, double* host_val, double* host_grad,
                                  int lane);
 
+// Sum of the gradient partials of slabs first, first + 3, ... for component c (fixed order; shared by the in-launch
+// finish, where waves 1-3 take first = 0, 1, 2, and by the large-batch combine pass -> identical bits on both paths).
+__device__ inline void grad_partial_sum(const double* base, int S, int c, int first, double* gs_out, double* gm_out) {
+  double gs = 0.0, gm = 0.0;
+  int sl = first;
+  for (; sl + 9 < S; sl += 12) {                  // four slabs at a time: 8 loads in flight
+    double a[4], b[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      a[t] = base[(size_t)(sl + 3 * t) * PSTRIDE + 2 + c];
+      b[t] = base[(size_t)(sl + 3 * t) * PSTRIDE + 2 + PCABO_MAXD + c];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { gs += a[t]; gm += b[t]; }
+  }
+  for (; sl < S; sl += 3) {
+    gs += base[(size_t)sl * PSTRIDE + 2 + c];
+    gm += base[(size_t)sl * PSTRIDE + 2 + PCABO_MAXD + c];
+  }
+  *gs_out = gs;
+  *gm_out = gm;
+}
+
+__device__ void acq_finish_scalar(const double* base, int S, int q, const double* ystats, const AcqParams& p, double* val,
+                                  double* host_val, double* coef, int lane);
 // ---- in-launch combine: the last slab group of a query to arrive finishes it ---------------------------
 template <int SLAB>
 __device__ inline void acq_tail(int combine, double* s_v, double* partial, unsigned int* counters, int q, int S, int k,
@@ -113,8 +138,34 @@ __device__ inline void acq_tail(int combine, double* s_v, double* partial, unsig
   __syncthreads();
   if (!*s_flag) return;
   STAMP_FIN(8);
+  // The partial records come from other XCDs (write-through stores): every read below is a trip to memory.  The four
+  // waves of the finishing group split the work so that those trips overlap: wave 0 reduces |v|^2 / mu_s and runs the
+  // scalar log-EI chain; waves 1-3 meanwhile sum the gradient partials of every third slab (fixed order).
+  const double* base = partial + (size_t)q * S * PSTRIDE;
+  double* s_fin = s_v + SLAB + 2;                 // [3][2][PCABO_MAXD] partial sums, then 2 coefficients
+  double* s_coef = s_fin + 6 * PCABO_MAXD;
   if (w == 0) {
-    acq_finish_query(partial + (size_t)q * S * PSTRIDE, S, k, q, bounds4, ystats, prm, val, grad, host_val, host_grad, l);
+    acq_finish_scalar(base, S, q, ystats, prm, val, host_val, s_coef, l);
+  } else if (prm.want_grad) {
+    for (int c = l; c < k; c += 64) {
+      double gs, gm;
+      grad_partial_sum(base, S, c, w - 1, &gs, &gm);
+      s_fin[(w - 1) * 2 * PCABO_MAXD + c] = gs;
+      s_fin[(w - 1) * 2 * PCABO_MAXD + PCABO_MAXD + c] = gm;
+    }
+  }
+  __syncthreads();
+  if (w == 0) {
+    if (prm.want_grad) {
+      const double c_mu = s_coef[0], c_sg = s_coef[1];
+      for (int c = l; c < k; c += 64) {
+        const double gs = (s_fin[c] + s_fin[2 * PCABO_MAXD + c]) + s_fin[4 * PCABO_MAXD + c];
+        const double gm = (s_fin[PCABO_MAXD + c] + s_fin[3 * PCABO_MAXD + c]) + s_fin[5 * PCABO_MAXD + c];
+        const double g = (c_mu * gm + c_sg * gs) / (bounds4[PCABO_MAXD + c] - bounds4[c]);
+        grad[(size_t)q * k + c] = g;
+        if (host_grad) host_grad[(size_t)q * k + c] = g;
+      }
+    }
     // publish: this query's sequence word follows its results with a system-scope release (one wave, so the
     // release store's drain covers every lane's host writes)
     if (hm && l == 0)
@@ -307,28 +358,26 @@ __global__ __launch_bounds__(256) void k_acq_fast(
   STAMP(0);
 
   // ---- every global operand, issued before anything waits ---------------------------------------------------
-  // Column block b of this group is physical block (b + rot) % NB: all groups of a launch read the same ZnT (and the
-  // ten groups of a slab the same R rows), so without the rotation they would all hit the same L2 lines at once.
+  // Addresses are (scalar row base) + (lane offset) + (immediate 512 b): no vector address arithmetic per load.
+  // (Rotating the block order per group to spread L2 lines made no difference and cost address arithmetic.)
   double z[CU][NB], r[RW][NB], al[NM];
-  int col[NB];
-  {
-    const int rot = (s + q) % NB;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) { const int pb = b + rot; col[b] = l + 64 * (pb >= NB ? pb - NB : pb); }
-  }
+  const unsigned lane8 = (unsigned)l * 8u;
 #pragma unroll
   for (int u = 0; u < CU; ++u) {
     const int c = w + 4 * u;
-    const double* zr = ZnT + (size_t)(c < k ? c : k - 1) * ld;
+    const char* zr = reinterpret_cast<const char*>(ZnT + (size_t)(c < k ? c : k - 1) * ld);
 #pragma unroll
-    for (int b = 0; b < NB; ++b) z[u][b] = zr[col[b]];
+    for (int b = 0; b < NB; ++b) z[u][b] = *reinterpret_cast<const double*>(zr + lane8 + 512 * b);
   }
 #pragma unroll
   for (int u = 0; u < RW; ++u) {
-    const int ri = slab_row<SLAB>(s, w + 4 * u, NP);
-    const double* Rr = R + (size_t)ri * ld;
+    const int ri = slab_row<SLAB>(s, w + 4 * u, NP);          // wave-uniform
+    const char* Rr = reinterpret_cast<const char*>(R + (size_t)ri * ld);
 #pragma unroll
-    for (int b = 0; b < NB; ++b) r[u][b] = (col[b] - l <= ri) ? Rr[col[b]] : 0.0;   // blocks above the diagonal are zero
+    for (int b = 0; b < NB; ++b) {
+      r[u][b] = 0.0;                                            // blocks above the diagonal are exactly zero
+      if (64 * b <= ri) r[u][b] = *reinterpret_cast<const double*>(Rr + lane8 + 512 * b);
+    }
   }
 #pragma unroll
   for (int m = 0; m < NM; ++m) { const int j = tid + 256 * m; al[m] = j < n ? alpha[j] : 0.0; }
@@ -355,7 +404,7 @@ __global__ __launch_bounds__(256) void k_acq_fast(
       }
     }
 #pragma unroll
-    for (int b = 0; b < NB; ++b) s_p4[w * NP + col[b]] = sq[b];
+    for (int b = 0; b < NB; ++b) s_p4[w * NP + l + 64 * b] = sq[b];
   }
   __syncthreads();
   const double s5 = 2.23606797749979;
@@ -390,7 +439,7 @@ __global__ __launch_bounds__(256) void k_acq_fast(
     for (int u = 0; u < RW; ++u) acc[u] = 0.0;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      const double kj = s_ks[col[b]];
+      const double kj = s_ks[l + 64 * b];
 #pragma unroll
       for (int u = 0; u < RW; ++u) acc[u] += r[u][b] * kj;
     }
@@ -427,7 +476,7 @@ __global__ __launch_bounds__(256) void k_acq_fast(
       double pw = 0.0;
 #pragma unroll
       for (int u = 0; u < RW; ++u) pw += r[u][b] * vw[u];
-      s_p4[w * NP + col[b]] = pw;
+      s_p4[w * NP + l + 64 * b] = pw;
     }
   }
   __syncthreads();   // also: wave 0 has finished reading s_ks before it is reused below
@@ -452,7 +501,7 @@ __global__ __launch_bounds__(256) void k_acq_fast(
     for (int u = 0; u < CU; ++u) { gs[u] = 0.0; gm[u] = 0.0; }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      const double ts = s_ks[col[b]], tm = s_tm[col[b]];
+      const double ts = s_ks[l + 64 * b], tm = s_tm[l + 64 * b];
 #pragma unroll
       for (int u = 0; u < CU; ++u) {
         const double dlt = xc[u] - z[u][b];
@@ -500,11 +549,10 @@ __device__ inline void log_ei_helper(double u, double* h, double* dh) {
   }
 }
 
-// Scalar tail for one query, executed by one wave (lanes over reduced components c, c + 64).
-__device__ void acq_finish_query(const double* base, int S, int k, int q, const double* bounds4, const double* ystats,
-                                 const AcqParams& p, double* val, double* grad, double* host_val, double* host_grad,
-                                 int l) {
-  // lanes over slabs (S <= 128): two loads per lane, fixed shuffle tree -> deterministic
+// Scalar chain of one query (one wave): slab sums of |v|^2 and mu_s -> mean, sigma, u -> value and the two
+// coefficients of the gradient's chain rule.  coef (LDS or registers' spill target) receives {c_mu, c_sg}.
+__device__ void acq_finish_scalar(const double* base, int S, int q, const double* ystats, const AcqParams& p, double* val,
+                                  double* host_val, double* coef, int l) {
   double vv = 0.0, mus = 0.0;
   for (int s = l; s < S; s += 64) { vv += base[(size_t)s * PSTRIDE]; mus += base[(size_t)s * PSTRIDE + 1]; }
   vv = wave_sum(vv);
@@ -531,28 +579,31 @@ __device__ void acq_finish_query(const double* base, int S, int k, int q, const 
     dv_du = 0.3989422804014327 * exp(-0.5 * u * u);
     dv_dsig = 0.0;
   }
-  if (l == 0) { val[q] = value; if (host_val) host_val[q] = value; }
-  if (p.want_grad) {
+  if (l == 0) {
+    val[q] = value;
+    if (host_val) host_val[q] = value;
     // du = sgn dmu/sigma - u dsigma/sigma ; dsigma = -s_y^2 g_sigma / sigma (0 where the variance was clamped)
-    const double c_mu = dv_du * sgn * ysd / sigma;
-    const double c_sg = clamped ? 0.0 : (dv_dsig - dv_du * u / sigma) * (-(ysd * ysd) / sigma);
+    coef[0] = dv_du * sgn * ysd / sigma;
+    coef[1] = clamped ? 0.0 : (dv_dsig - dv_du * u / sigma) * (-(ysd * ysd) / sigma);
+  }
+}
+
+// One query, one wave (the large-batch combine pass): scalar chain, then the gradient from all slabs in order.
+__device__ void acq_finish_query(const double* base, int S, int k, int q, const double* bounds4, const double* ystats,
+                                 const AcqParams& p, double* val, double* grad, double* host_val, double* host_grad,
+                                 int l) {
+  __shared__ double s_cf2[4][2];
+  double* coef = s_cf2[(threadIdx.x >> 6) & 3];
+  acq_finish_scalar(base, S, q, ystats, p, val, host_val, coef, l);
+  if (p.want_grad) {
+    __builtin_amdgcn_wave_barrier();
+    const double c_mu = coef[0], c_sg = coef[1];
     for (int c = l; c < k; c += 64) {
-      double gs = 0.0, gm = 0.0;
-      int s = 0;
-      for (; s + 8 <= S; s += 8) {                     // 16 independent loads in flight, summed in order
-        double a[8], b[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          a[u] = base[(size_t)(s + u) * PSTRIDE + 2 + c];
-          b[u] = base[(size_t)(s + u) * PSTRIDE + 2 + PCABO_MAXD + c];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { gs += a[u]; gm += b[u]; }
-      }
-      for (; s < S; ++s) {
-        gs += base[(size_t)s * PSTRIDE + 2 + c];
-        gm += base[(size_t)s * PSTRIDE + 2 + PCABO_MAXD + c];
-      }
+      double a0, b0, a1, b1, a2, b2;
+      grad_partial_sum(base, S, c, 0, &a0, &b0);
+      grad_partial_sum(base, S, c, 1, &a1, &b1);
+      grad_partial_sum(base, S, c, 2, &a2, &b2);
+      const double gs = (a0 + a1) + a2, gm = (b0 + b1) + b2;
       double g = (c_mu * gm + c_sg * gs) / (bounds4[PCABO_MAXD + c] - bounds4[c]);
       grad[(size_t)q * k + c] = g;
       if (host_grad) host_grad[(size_t)q * k + c] = g;
@@ -592,7 +643,7 @@ void launch_acq(hipStream_t st, const QueryArgs* qa, const double* Xq, int q, in
 #define ACQ_FAST(SL, NBV)                                                                                      \
   case NBV:                                                                                                    \
     hipLaunchKernelGGL((k_acq_fast<SL, NBV>), dim3(S, q), dim3(256),                                           \
-                       (size_t)(7 * NBV * 64 + PCABO_MAXD + SL + 4) * sizeof(double), st, ACQ_ARGS);           \
+                       (size_t)(3 * NBV * 64 + PCABO_MAXD + SL + 2 + (4 * NBV * 64 > 6 * PCABO_MAXD + 2 ? 4 * NBV * 64 : 6 * PCABO_MAXD + 2)) * sizeof(double), st, ACQ_ARGS); \
     break;
   if (use_fast && k <= 40 && nb <= 8) {
     if (slab == 16) {
@@ -603,7 +654,7 @@ void launch_acq(hipStream_t st, const QueryArgs* qa, const double* Xq, int q, in
                     ACQ_FAST(32, 7) ACQ_FAST(32, 8) }
     }
   } else {
-    size_t lds = (size_t)(3 * NP + PCABO_MAXD + 32 + 2) * sizeof(double);
+    size_t lds = (size_t)(3 * NP + PCABO_MAXD + 32 + 2 + 6 * PCABO_MAXD + 2) * sizeof(double);
     if (slab == 16)
       hipLaunchKernelGGL(k_acq_fused<16>, dim3(S, q), dim3(256), lds, st, ACQ_ARGS);
     else

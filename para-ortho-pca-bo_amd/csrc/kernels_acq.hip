@@ -89,24 +89,32 @@ __device__ void acq_finish_query(const double* base, int S, int k, int q, const 
                                  const AcqParams& p, double* val, double* grad, double* host_val, double* host_grad,
                                  int lane);
 
-// Sum of the gradient partials of slabs first, first + 3, ... for component c (fixed order; shared by the in-launch
+// Sum of the gradient partials of slabs first, first + 3, ... (zero if first >= S) for component c (fixed order; shared by the in-launch
 // finish, where waves 1-3 take first = 0, 1, 2, and by the large-batch combine pass -> identical bits on both paths).
 __device__ inline void grad_partial_sum(const double* base, int S, int c, int first, double* gs_out, double* gm_out) {
   double gs = 0.0, gm = 0.0;
   int sl = first;
-  for (; sl + 9 < S; sl += 12) {                  // four slabs at a time: 8 loads in flight
-    double a[4], b[4];
+  for (; sl + 21 < S; sl += 24) {                 // eight slabs at a time: 16 loads in flight, one round trip
+    double a[8], b[8];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < 8; ++t) {
       a[t] = base[(size_t)(sl + 3 * t) * PSTRIDE + 2 + c];
       b[t] = base[(size_t)(sl + 3 * t) * PSTRIDE + 2 + PCABO_MAXD + c];
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { gs += a[t]; gm += b[t]; }
+    for (int t = 0; t < 8; ++t) { gs += a[t]; gm += b[t]; }
   }
-  for (; sl < S; sl += 3) {
-    gs += base[(size_t)sl * PSTRIDE + 2 + c];
-    gm += base[(size_t)sl * PSTRIDE + 2 + PCABO_MAXD + c];
+  {                                               // the rest (< 8 slabs), still issued together
+    double a[8], b[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int si = sl + 3 * t;
+      const int sc = si < S ? si : 0;
+      a[t] = base[(size_t)sc * PSTRIDE + 2 + c];
+      b[t] = base[(size_t)sc * PSTRIDE + 2 + PCABO_MAXD + c];
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { if (sl + 3 * t < S) { gs += a[t]; gm += b[t]; } }
   }
   *gs_out = gs;
   *gm_out = gm;
@@ -144,7 +152,9 @@ __device__ inline void acq_tail(int combine, double* s_v, double* partial, unsig
   const double* base = partial + (size_t)q * S * PSTRIDE;
   double* s_fin = s_v + SLAB + 2;                 // [3][2][PCABO_MAXD] partial sums, then 2 coefficients
   double* s_coef = s_fin + 6 * PCABO_MAXD;
+  double rng_c = 1.0;
   if (w == 0) {
+    if (prm.want_grad && l < k) rng_c = bounds4[PCABO_MAXD + l] - bounds4[l];     // in flight during the scalar chain
     acq_finish_scalar(base, S, q, ystats, prm, val, host_val, s_coef, l);
   } else if (prm.want_grad) {
     for (int c = l; c < k; c += 64) {
@@ -161,7 +171,7 @@ __device__ inline void acq_tail(int combine, double* s_v, double* partial, unsig
       for (int c = l; c < k; c += 64) {
         const double gs = (s_fin[c] + s_fin[2 * PCABO_MAXD + c]) + s_fin[4 * PCABO_MAXD + c];
         const double gm = (s_fin[PCABO_MAXD + c] + s_fin[3 * PCABO_MAXD + c]) + s_fin[5 * PCABO_MAXD + c];
-        const double g = (c_mu * gm + c_sg * gs) / (bounds4[PCABO_MAXD + c] - bounds4[c]);
+        const double g = __fma_rn(c_mu, gm, c_sg * gs) / (c == l ? rng_c : bounds4[PCABO_MAXD + c] - bounds4[c]);
         grad[(size_t)q * k + c] = g;
         if (host_grad) host_grad[(size_t)q * k + c] = g;
       }
@@ -364,10 +374,13 @@ __global__ __launch_bounds__(256) void k_acq_fast(
   const unsigned lane8 = (unsigned)l * 8u;
 #pragma unroll
   for (int u = 0; u < CU; ++u) {
-    const int c = w + 4 * u;
-    const char* zr = reinterpret_cast<const char*>(ZnT + (size_t)(c < k ? c : k - 1) * ld);
+    const int c = w + 4 * u;                                    // wave-uniform
+    const char* zr = reinterpret_cast<const char*>(ZnT + (size_t)c * ld);
 #pragma unroll
-    for (int b = 0; b < NB; ++b) z[u][b] = *reinterpret_cast<const double*>(zr + lane8 + 512 * b);
+    for (int b = 0; b < NB; ++b) {
+      z[u][b] = 0.0;
+      if (c < k) z[u][b] = *reinterpret_cast<const double*>(zr + lane8 + 512 * b);
+    }
   }
 #pragma unroll
   for (int u = 0; u < RW; ++u) {
@@ -604,7 +617,7 @@ __device__ void acq_finish_query(const double* base, int S, int k, int q, const 
       grad_partial_sum(base, S, c, 1, &a1, &b1);
       grad_partial_sum(base, S, c, 2, &a2, &b2);
       const double gs = (a0 + a1) + a2, gm = (b0 + b1) + b2;
-      double g = (c_mu * gm + c_sg * gs) / (bounds4[PCABO_MAXD + c] - bounds4[c]);
+      double g = __fma_rn(c_mu, gm, c_sg * gs) / (bounds4[PCABO_MAXD + c] - bounds4[c]);
       grad[(size_t)q * k + c] = g;
       if (host_grad) host_grad[(size_t)q * k + c] = g;
     }

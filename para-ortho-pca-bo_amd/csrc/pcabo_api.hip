@@ -456,6 +456,7 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
   HIPCHK(hipSetDevice(ctx->device));
   const int k = ctx->k;
   const int ngroups = (num_restarts + batch_limit - 1) / batch_limit;
+  const auto t_enter = std::chrono::steady_clock::now();
   std::vector<Lbfgsb> opt(ngroups);
   std::vector<int> gstart(ngroups), gsize(ngroups), niter(ngroups, 0), nfev(ngroups, 0);
   std::vector<char> active(ngroups, 1);     // char, not vector<bool>: groups are touched from two threads
@@ -568,7 +569,7 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
       xc[gi] = x[gi]; gc[gi] = g[gi]; fc[gi] = fval[gi]; have_cache[gi] = 1;
     }
   }
-  if (trace) fprintf(stderr, "[pcabo] optimize: rounds %d, host L-BFGS-B %.1f us/round, eval %.1f us/round (n=%d k=%d)\n", rounds, 1e6 * t_step / std::max(1, rounds), 1e6 * t_eval / std::max(1, rounds), ctx->n, ctx->k);
+  const double t_loop_end = trace ? now() : 0.0;
   // final clamp and acquisition values at the candidates (no gradient)
   for (int gi = 0; gi < ngroups; ++gi) {
     for (int t = 0; t < gsize[gi] * k; ++t) {
@@ -586,6 +587,12 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
   if (rc != PCABO_OK) return rc;
   for (int j = 0; j < num_restarts; ++j) vals[j] = ctx->hVal[j];
   if (failed) *failed = any_failed;
+  if (trace) {
+    const double t0 = std::chrono::duration<double>(t_enter.time_since_epoch()).count();
+    fprintf(stderr, "[pcabo] optimize: rounds %d, host L-BFGS-B %.1f us/round, eval %.1f us/round (n=%d k=%d) total %.0f us, "
+            "after loop %.0f us\n", rounds, 1e6 * t_step / std::max(1, rounds), 1e6 * t_eval / std::max(1, rounds), ctx->n,
+            ctx->k, 1e6 * (now() - t0), 1e6 * (now() - t_loop_end));
+  }
   return PCABO_OK;
 }
 

@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.join(ROOT, "para-ortho-pca-bo_amd"))
 from pcabo import _native as N
 names = ["xn", "ks", "v", "vv/mu", "w", "contract", "drain+barrier", "ticket->finisher", "finish+publish", "host drain"]
 rng = np.random.default_rng(0)
-for n, k in ((120, 31), (250, 33), (449, 36)):
+for n, k in ((120, 31), (250, 33), (449, 36), (150, 27), (250, 17), (350, 10), (430, 8)):
     Z = rng.uniform(-1, 1, size=(n, k)); y = rng.normal(size=n)
     c = N.Context(max_n=450, max_d=40, max_q=512)
     c.gp_condition(y, Z=Z)

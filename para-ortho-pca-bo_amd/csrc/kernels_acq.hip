@@ -46,31 +46,6 @@ extern "C" int pcabo_debug_acq_stamps(unsigned long long* out16) {
 #define STAMP_FIN(i)
 #endif
 
-// Wave-wide sum without LDS traffic.  `__shfl_xor` compiles to ds_bpermute_b32 (two per double, each followed by an
-// lgkmcnt wait: ~100 cycles of dependent latency per step); in a kernel whose whole budget is ~15 us the reductions
-// were the largest single item.  DPP steps stay inside the VALU: quad_perm x2, row_half_mirror, row_mirror leave the
-// row sum in all 16 lanes; row_bcast15 / row_bcast31 carry it across the four rows into lane 63.
-template <int CTRL, int ROW_MASK>
-__device__ inline double dpp_get(double v) {
-  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
-  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-__device__ inline double row_sum16(double v) {        // every lane: sum over its row of 16 lanes
-  v += dpp_get<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]
-  v += dpp_get<0x4E, 0xf>(v);      // quad_perm [2,3,0,1]
-  v += dpp_get<0x141, 0xf>(v);     // row_half_mirror
-  v += dpp_get<0x140, 0xf>(v);     // row_mirror
-  return v;
-}
-__device__ inline double wave_sum(double v) {         // uniform result: sum over all 64 lanes
-  v = row_sum16(v);
-  v += dpp_get<0x142, 0xa>(v);     // row_bcast15 -> rows 1, 3
-  v += dpp_get<0x143, 0xc>(v);     // row_bcast31 -> rows 2, 3
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63),
-                          __builtin_amdgcn_readlane(__double2loint(v), 63));
-}
-
 // Write-through store (global_store ... sc1): the partial records are handed to another work-group inside
 // the launch; written this way they never sit dirty in this XCD's L2, so the hand-off needs no L2 write-back
 // (agent-scope release) on the producer side - only the drain + ticket, and the consumer's acquire.

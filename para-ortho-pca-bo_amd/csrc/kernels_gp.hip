@@ -129,14 +129,20 @@ __device__ inline void chol64_inplace(double* s_d, double (*s_col)[BS], int* bad
 // b_m -= x_c L[m][c] (unconditional for columns certainly beyond c; the boundary group is predicated).
 __device__ inline void trsm64_right_lt(const double* s_d, const double* s_rdiag, double* Bt, int ld) {
   const int tid = threadIdx.x;
-  const int ri = tid >> 2, part = tid & 3, lane = tid & 63;
+  const int ri = tid >> 2, part = tid & 3;
   double bb[16];
 #pragma unroll
   for (int u = 0; u < 16; ++u) bb[u] = Bt[(size_t)ri * ld + part + 4 * u];
 #pragma unroll
   for (int c = 0; c < BS; ++c) {
     const double own = bb[c >> 2] * s_rdiag[c];
-    const double xc = __shfl(own, (lane & ~3) | (c & 3), 64);
+    double xc;                                   // broadcast inside the quad by DPP (quad_perm [m,m,m,m]), no LDS
+    switch (c & 3) {
+      case 0: xc = dpp_get<0x00, 0xf>(own); break;
+      case 1: xc = dpp_get<0x55, 0xf>(own); break;
+      case 2: xc = dpp_get<0xAA, 0xf>(own); break;
+      default: xc = dpp_get<0xFF, 0xf>(own); break;
+    }
     if (part == (c & 3)) bb[c >> 2] = xc;
     if (part > (c & 3)) bb[c >> 2] -= xc * s_d[(part + 4 * (c >> 2)) * TLD + c];
 #pragma unroll
@@ -220,8 +226,8 @@ __global__ __launch_bounds__(256) void k_trinv_diag(const double* __restrict__ L
     double s = 0.0;
     if (r > c)
       for (int m = c + part; m < r; m += 4) s += s_l[r * TLD + m] * s_x[c * TLD + m];
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
+    s += dpp_get<0xB1, 0xf>(s);      // quad_perm [1,0,3,2]
+    s += dpp_get<0x4E, 0xf>(s);      // quad_perm [2,3,0,1]
     if (part == 0) s_x[c * TLD + r] = (r < c) ? 0.0 : (((r == c) ? 1.0 : 0.0) - s) / s_l[r * TLD + r];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(256) void k_rmatvec(const double* __restrict__ R, c
     double s = 0.0;
     if (i < n)
       for (int j = l; j <= i; j += 64) s += R[(size_t)i * ld + j] * y[j];
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    s = wave_sum(s);
     if (l == 0) t[i] = (i < n) ? s : 0.0;
   }
 }

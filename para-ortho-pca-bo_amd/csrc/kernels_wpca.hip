@@ -194,15 +194,29 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi(const double* __restrict
         if (q < d) {
           double* gp = s_g + p * LD;
           double* gq = s_g + q * LD;
+          // the lane's rows stay in registers between the dot products and the rotation (d <= 4 LP: 4 rows at most
+          // on the fast path; longer columns take the second loop)
+          double xr[4], yr[4];
           double a = 0.0, b = 0.0, g = 0.0;
-          for (int r = lane; r < d; r += LP) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int r = lane + t * LP;
+            xr[t] = r < d ? gp[r] : 0.0;
+            yr[t] = r < d ? gq[r] : 0.0;
+            a += xr[t] * xr[t]; b += yr[t] * yr[t]; g += xr[t] * yr[t];
+          }
+          for (int r = lane + 4 * LP; r < d; r += LP) {
             double x = gp[r], y = gq[r];
             a += x * x; b += y * y; g += x * y;
           }
-          for (int off = LP >> 1; off > 0; off >>= 1) {
-            a += __shfl_xor(a, off, 64);
-            b += __shfl_xor(b, off, 64);
-            g += __shfl_xor(g, off, 64);
+          if (LP == 16) {                       // the pair's 16 lanes are one DPP row: no LDS traffic, no waits
+            a = row_sum16(a); b = row_sum16(b); g = row_sum16(g);
+          } else {
+            for (int off = LP >> 1; off > 0; off >>= 1) {
+              a += __shfl_xor(a, off, 64);
+              b += __shfl_xor(b, off, 64);
+              g += __shfl_xor(g, off, 64);
+            }
           }
           const double ab = a * b;
           if (g * g > tol * tol * ab && fabs(g) > 1e-300) {
@@ -212,7 +226,12 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi(const double* __restrict
             const double t = (zeta >= 0.0 ? 1.0 : -1.0) * fast_rcp(fabs(zeta) + hyp * fast_rsq(hyp));
             const double cs = fast_rsq(1.0 + t * t);
             const double sn = cs * t;
-            for (int r = lane; r < d; r += LP) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int r = lane + u * LP;
+              if (r < d) { gp[r] = cs * xr[u] - sn * yr[u]; gq[r] = sn * xr[u] + cs * yr[u]; }
+            }
+            for (int r = lane + 4 * LP; r < d; r += LP) {
               double x = gp[r], y = gq[r];
               gp[r] = cs * x - sn * y;
               gq[r] = sn * x + cs * y;
@@ -234,7 +253,7 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi(const double* __restrict
     int l = tid & 63;
     double a = 0.0;
     for (int r = l; r < d; r += 64) { double x = s_g[col * LD + r]; a += x * x; }
-    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+    a = wave_sum(a);
     double nrm = sqrt(a);
     double inv = nrm > 0.0 ? 1.0 / nrm : 0.0;
     for (int r = l; r < d; r += 64) Gout[(size_t)col * d + r] = s_g[col * LD + r] * inv;

@@ -5,7 +5,12 @@
 
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <cstdio>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #define WS(i, p) ws_[(size_t)(p) * n_ + (i)]
 #define WY(i, p) wy_[(size_t)(p) * n_ + (i)]
@@ -19,6 +24,99 @@ namespace {
 
 // circular column index of the limited-memory matrices (avoids an integer division per use)
 inline int nxt(int p, int m) { return p + 1 == m ? 0 : p + 1; }
+
+// ---- vector kernels -----------------------------------------------------------------------------------------
+// The O(m n) loops of L-BFGS-B come in two shapes.  Both are vectorised WITHOUT changing what any single number
+// goes through (same operands, same order, separate multiply and add - no fma), so the iterates stay scipy's:
+//  (a) "reduce over variables": 2m accumulators  acc_j += coef_k * W(k, j), k in increasing order.  SIMD lanes =
+//      different j, which needs the j's of one variable side by side -> a row-major mirror `wr_` of WY|WS
+//      (row stride RS = 2 MP, MP = m rounded up to 4; physical circular-buffer columns, mapped to logical order
+//      afterwards).
+//  (b) "chain per variable": out_k = out_k + f(W(k, j)) for j = 0..col-1 in order.  SIMD lanes = different k, on the
+//      usual column-major WY / WS, for ALL variables (then gathered through the free-variable index).
+typedef void (*accum_fn)(const double* wr, int rs, int mp, const int* rows, const double* coef, int count, double* acc);
+typedef void (*chain_fn)(double* out, const double* wy, const double* ws, double a1, double a2, double th, int n);
+
+void accum_scalar(const double* wr, int rs, int mp, const int* rows, const double* coef, int count, double* acc) {
+  const int w = 2 * mp;
+  for (int t = 0; t < count; ++t) {
+    const double* row = wr + (size_t)(rows ? rows[t] : t) * rs;
+    const double c = coef[t];
+    for (int j = 0; j < w; ++j) acc[j] += c * row[j];
+  }
+}
+// cmprlb:  out = out + (wy a1 + ws a2)
+void chain_r_scalar(double* out, const double* wy, const double* ws, double a1, double a2, double, int n) {
+  for (int k = 0; k < n; ++k) out[k] += wy[k] * a1 + ws[k] * a2;
+}
+// subsm:   out = (out + wy a1 / theta) + ws a2
+void chain_d_scalar(double* out, const double* wy, const double* ws, double a1, double a2, double th, int n) {
+  for (int k = 0; k < n; ++k) out[k] = out[k] + wy[k] * a1 / th + ws[k] * a2;
+}
+
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) void accum_avx2(const double* wr, int rs, int mp, const int* rows, const double* coef,
+                                                int count, double* acc) {
+  if (mp == 12) {                      // m = 9..12 (scipy's default m = 10): six accumulators stay in registers
+    __m256d a0 = _mm256_loadu_pd(acc), a1 = _mm256_loadu_pd(acc + 4), a2 = _mm256_loadu_pd(acc + 8);
+    __m256d a3 = _mm256_loadu_pd(acc + 12), a4 = _mm256_loadu_pd(acc + 16), a5 = _mm256_loadu_pd(acc + 20);
+    for (int t = 0; t < count; ++t) {
+      const double* row = wr + (size_t)(rows ? rows[t] : t) * rs;
+      const __m256d c = _mm256_set1_pd(coef[t]);
+      a0 = _mm256_add_pd(a0, _mm256_mul_pd(c, _mm256_loadu_pd(row)));
+      a1 = _mm256_add_pd(a1, _mm256_mul_pd(c, _mm256_loadu_pd(row + 4)));
+      a2 = _mm256_add_pd(a2, _mm256_mul_pd(c, _mm256_loadu_pd(row + 8)));
+      a3 = _mm256_add_pd(a3, _mm256_mul_pd(c, _mm256_loadu_pd(row + 12)));
+      a4 = _mm256_add_pd(a4, _mm256_mul_pd(c, _mm256_loadu_pd(row + 16)));
+      a5 = _mm256_add_pd(a5, _mm256_mul_pd(c, _mm256_loadu_pd(row + 20)));
+    }
+    _mm256_storeu_pd(acc, a0); _mm256_storeu_pd(acc + 4, a1); _mm256_storeu_pd(acc + 8, a2);
+    _mm256_storeu_pd(acc + 12, a3); _mm256_storeu_pd(acc + 16, a4); _mm256_storeu_pd(acc + 20, a5);
+    return;
+  }
+  const int w = 2 * mp;
+  for (int t = 0; t < count; ++t) {
+    const double* row = wr + (size_t)(rows ? rows[t] : t) * rs;
+    const __m256d c = _mm256_set1_pd(coef[t]);
+    for (int j = 0; j < w; j += 4)
+      _mm256_storeu_pd(acc + j, _mm256_add_pd(_mm256_loadu_pd(acc + j), _mm256_mul_pd(c, _mm256_loadu_pd(row + j))));
+  }
+}
+__attribute__((target("avx2"))) void chain_r_avx2(double* out, const double* wy, const double* ws, double a1, double a2,
+                                                  double, int n) {
+  const __m256d v1 = _mm256_set1_pd(a1), v2 = _mm256_set1_pd(a2);
+  int k = 0;
+  for (; k + 4 <= n; k += 4) {
+    const __m256d t = _mm256_add_pd(_mm256_mul_pd(_mm256_loadu_pd(wy + k), v1), _mm256_mul_pd(_mm256_loadu_pd(ws + k), v2));
+    _mm256_storeu_pd(out + k, _mm256_add_pd(_mm256_loadu_pd(out + k), t));
+  }
+  for (; k < n; ++k) out[k] += wy[k] * a1 + ws[k] * a2;
+}
+__attribute__((target("avx2"))) void chain_d_avx2(double* out, const double* wy, const double* ws, double a1, double a2,
+                                                  double th, int n) {
+  const __m256d v1 = _mm256_set1_pd(a1), v2 = _mm256_set1_pd(a2), vt = _mm256_set1_pd(th);
+  int k = 0;
+  for (; k + 4 <= n; k += 4) {
+    __m256d t = _mm256_div_pd(_mm256_mul_pd(_mm256_loadu_pd(wy + k), v1), vt);
+    t = _mm256_add_pd(_mm256_loadu_pd(out + k), t);
+    _mm256_storeu_pd(out + k, _mm256_add_pd(t, _mm256_mul_pd(_mm256_loadu_pd(ws + k), v2)));
+  }
+  for (; k < n; ++k) out[k] = out[k] + wy[k] * a1 / th + ws[k] * a2;
+}
+#endif
+
+struct VecKernels { accum_fn accum; chain_fn chain_r, chain_d; };
+const VecKernels& vec_kernels() {
+  static const VecKernels k = [] {
+    VecKernels v{accum_scalar, chain_r_scalar, chain_d_scalar};
+#if defined(__x86_64__)
+    const char* off = std::getenv("PCABO_LBFGSB_SCALAR");
+    if (!(off && off[0] == '1') && __builtin_cpu_supports("avx2")) v = VecKernels{accum_avx2, chain_r_avx2, chain_d_avx2};
+#endif
+    return v;
+  }();
+  return k;
+}
 
 inline double ddot(int n, const double* x, const double* y) {
   double s = 0.0;
@@ -78,6 +176,8 @@ void Lbfgsb::init(int n, int m, const double* lower, const double* upper, double
     nbd_[i] = hl ? (hu ? 2 : 1) : (hu ? 3 : 0);
   }
   ws_.assign((size_t)n * m, 0.0); wy_.assign((size_t)n * m, 0.0);
+  mp_ = (m + 3) & ~3; rs_ = 2 * mp_;
+  wr_.assign((size_t)n * rs_, 0.0); sc_coef_.assign(n, 0.0); sc_full_.assign(n, 0.0); sc_rows_.assign(n, 0);
   sy_.assign((size_t)m * m, 0.0); ss_.assign((size_t)m * m, 0.0); wt_.assign((size_t)m * m, 0.0);
   wn_.assign((size_t)4 * m * m, 0.0); snd_.assign((size_t)4 * m * m, 0.0);
   z_.assign(n, 0.0); r_.assign(n, 0.0); d_.assign(n, 0.0); t_.assign(n, 0.0); xp_.assign(n, 0.0);
@@ -92,6 +192,23 @@ void Lbfgsb::reset_memory() {
 
 void Lbfgsb::projgr(const double* x, const double* g) {
   sbgnrm_ = 0.0;
+  if (boxed_) {
+    // every variable has both bounds: branch-free (the sign of g_i is unpredictable), four running maxima
+    // (max is exact and associative, the result is the same number)
+    double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
+    // (plain comparisons instead of fmax/fmin: those are libm calls without -ffinite-math; no NaN reaches this point)
+    auto proj = [&](int i) {
+      const double gi = g[i], hi = x[i] - u_[i], lo = x[i] - l_[i];
+      const double a = hi > gi ? hi : gi, b = lo < gi ? lo : gi;
+      return std::fabs(gi < 0.0 ? a : b);
+    };
+    auto mx = [](double p, double q) { return p > q ? p : q; };
+    int i = 0;
+    for (; i + 4 <= n_; i += 4) { m0 = mx(m0, proj(i)); m1 = mx(m1, proj(i + 1)); m2 = mx(m2, proj(i + 2)); m3 = mx(m3, proj(i + 3)); }
+    for (; i < n_; ++i) m0 = mx(m0, proj(i));
+    sbgnrm_ = mx(mx(m0, m1), mx(m2, m3));
+    return;
+  }
   for (int i = 0; i < n_; ++i) {
     double gi = g[i];
     if (nbd_[i] != 0) {
@@ -191,7 +308,7 @@ void Lbfgsb::cauchy(const double* x, const double* g) {
   int* iorder = indx2_.data();
   if (sbgnrm_ <= 0.0) { std::memcpy(xcp, x, sizeof(double) * n); return; }
   bool bnded = true;
-  int nfree = n, nbreak = 0, ibkmin = 0;
+  int nfree = n, nbreak = 0, ibkmin = 0, nmove = 0;
   double bkmin = 0.0;
   const int col2 = 2 * col;
   double f1 = 0.0;
@@ -209,17 +326,13 @@ void Lbfgsb::cauchy(const double* x, const double* g) {
       else if (xupper) { if (neggi >= 0.0) iwhere_[i] = 2; }
       else { if (std::fabs(neggi) <= 0.0) iwhere_[i] = -3; }
     }
-    int pointr = head_;
     if (iwhere_[i] != 0 && iwhere_[i] != -1) {
       d[i] = 0.0;
     } else {
       d[i] = neggi;
       f1 -= neggi * neggi;
-      for (int j = 0; j < col; ++j) {
-        p[j] += WY(i, pointr) * neggi;
-        p[col + j] += WS(i, pointr) * neggi;
-        pointr = nxt(pointr, m);
-      }
+      sc_rows_[nmove] = i;                    // p = W' d is accumulated after the loop, in this (increasing) order
+      sc_coef_[nmove++] = neggi;
       if (nbd_[i] <= 2 && nbd_[i] != 0 && neggi < 0.0) {
         iorder[nbreak] = i;
         t[nbreak] = tl / (-neggi);
@@ -236,6 +349,16 @@ void Lbfgsb::cauchy(const double* x, const double* g) {
         if (std::fabs(neggi) > 0.0) bnded = false;
       }
     }
+  }
+  if (col > 0) {
+    double acc[2 * LBFGSB_MAXM] = {0.0};
+    vec_kernels().accum(wr_.data(), rs_, mp_, sc_rows_.data(), sc_coef_.data(), nmove, acc);
+    int pointr = head_;
+    for (int j = 0; j < col; ++j) { p[j] = acc[pointr]; p[col + j] = acc[mp_ + pointr]; pointr = nxt(pointr, m); }
+#ifdef LBFGSB_CHECK
+    { int pr = head_; for (int j = 0; j < col; ++j) { double a = 0, b = 0; for (int i = 0; i < n; ++i) if (d[i] != 0.0 || true) { if (iwhere_[i]==0||iwhere_[i]==-1) { a += WY(i, pr) * d[i]; b += WS(i, pr) * d[i]; } }
+        if (a != p[j] || b != p[col + j]) fprintf(stderr, "cauchy mismatch j=%d %.17g %.17g | %.17g %.17g\n", j, a, p[j], b, p[col+j]); pr = nxt(pr, m); } }
+#endif
   }
   if (theta_ != 1.0)
     for (int j = 0; j < col; ++j) p[col + j] *= theta_;
@@ -368,32 +491,24 @@ void Lbfgsb::formk() {
     // Elements jy = 0..col-1 of the new rows: col independent dot products per block, accumulated side by
     // side (k outer) - every accumulator still sums k in increasing order, exactly like one-at-a-time ddots.
     {
-      double t1[LBFGSB_MAXM], t2[LBFGSB_MAXM], t3[LBFGSB_MAXM], t4[LBFGSB_MAXM];
-      int ptr[LBFGSB_MAXM];
+      // free variables: row col of Y'ZZ'Y (t1) and column col of R_z (t4) share the coefficient WY(k, ipntr);
+      // active variables: row col of S'AA'S (t2) and of L_a (t3) share WS(k, ipntr).  One pass over the mirror each.
+      double accf[2 * LBFGSB_MAXM] = {0.0}, acca[2 * LBFGSB_MAXM] = {0.0};
+      double* coef = sc_coef_.data();
+      for (int k = 0; k < nsub; ++k) coef[k] = WY(ind[k], ipntr);
+      for (int k = nsub; k < n; ++k) coef[k] = WS(ind[k], ipntr);
+      vec_kernels().accum(wr_.data(), rs_, mp_, ind, coef, nsub, accf);
+      vec_kernels().accum(wr_.data(), rs_, mp_, ind + nsub, coef + nsub, n - nsub, acca);
       int jp = head;
-      for (int jy = 0; jy < col; ++jy) { t1[jy] = t2[jy] = t3[jy] = t4[jy] = 0.0; ptr[jy] = jp; jp = nxt(jp, m); }
-      const int jlast = (head + col - 1) % m;
-      for (int k = 0; k < nsub; ++k) {
-        const int k1 = ind[k];
-        const double wyi = WY(k1, ipntr), wyl = WY(k1, jlast);
-        for (int jy = 0; jy < col; ++jy) {
-          t1[jy] += wyi * WY(k1, ptr[jy]);               // row col of Y'ZZ'Y
-          t4[jy] += WS(k1, ptr[jy]) * wyl;               // column col of R_z
-        }
-      }
-      for (int k = nsub; k < n; ++k) {
-        const int k1 = ind[k];
-        const double wsi = WS(k1, ipntr);
-        for (int jy = 0; jy < col; ++jy) {
-          t2[jy] += wsi * WS(k1, ptr[jy]);               // row col of S'AA'S
-          t3[jy] += wsi * WY(k1, ptr[jy]);               // row col of L_a
-        }
-      }
-      for (int jy = 0; jy < col; ++jy) {
-        WN1(iy, jy) = t1[jy]; WN1(is, m + jy) = t2[jy]; WN1(is, jy) = t3[jy];
-      }
       const int jyc = col - 1;
-      for (int i = 0; i < col; ++i) WN1(m + i, jyc) = t4[i];
+      for (int jy = 0; jy < col; ++jy) {
+        WN1(iy, jy) = accf[jp];            // t1
+        WN1(is, m + jy) = acca[mp_ + jp];  // t2
+        WN1(is, jy) = acca[jp];            // t3
+        jp = nxt(jp, m);
+      }
+      jp = head;                           // t4 last: element (m+col-1, col-1) is written by both t3 and t4, t4 stays
+      for (int jy = 0; jy < col; ++jy) { WN1(m + jy, jyc) = accf[mp_ + jp]; jp = nxt(jp, m); }
     }
     upcl = col - 1;
   } else {
@@ -463,15 +578,22 @@ void Lbfgsb::cmprlb(const double* x, const double* g) {
     for (int i = 0; i < n; ++i) r_[i] = -g[i];
     return;
   }
-  for (int i = 0; i < nfree_; ++i) { int k = index_[i]; r_[i] = -theta_ * (z_[k] - x[k]) - g[k]; }
+  const bool all_free = (nfree_ == n);
+  double* full = all_free ? r_.data() : sc_full_.data();
+  for (int k = 0; k < n; ++k) full[k] = -theta_ * (z_[k] - x[k]) - g[k];
   bmv(wa_.data() + 2 * m, wa_.data());
   if (info_ != 0) { info_ = -8; return; }
   int pointr = head_;
-  for (int j = 0; j < col; ++j) {
-    const double a1 = wa_[j], a2 = theta_ * wa_[col + j];
-    for (int i = 0; i < nfree_; ++i) { int k = index_[i]; r_[i] += WY(k, pointr) * a1 + WS(k, pointr) * a2; }
+  for (int j = 0; j < col; ++j) {                    // a chain per variable, all n side by side (see vec_kernels)
+    vec_kernels().chain_r(full, &WY(0, pointr), &WS(0, pointr), wa_[j], theta_ * wa_[col + j], 0.0, n);
     pointr = nxt(pointr, m);
   }
+  if (!all_free) for (int i = 0; i < nfree_; ++i) r_[i] = full[index_[i]];
+#ifdef LBFGSB_CHECK
+  { std::vector<double> rr(nfree_); for (int i = 0; i < nfree_; ++i) { int k = index_[i]; rr[i] = -theta_ * (z_[k] - x[k]) - g[k]; }
+    int pr = head_; for (int j = 0; j < col; ++j) { const double a1 = wa_[j], a2 = theta_ * wa_[col + j]; for (int i = 0; i < nfree_; ++i) { int k = index_[i]; rr[i] += WY(k, pr) * a1 + WS(k, pr) * a2; } pr = nxt(pr, m); }
+    for (int i = 0; i < nfree_; ++i) if (rr[i] != r_[i]) { fprintf(stderr, "cmprlb mismatch i=%d %.17g %.17g allfree=%d\n", i, rr[i], r_[i], (int)all_free); break; } }
+#endif
 }
 
 void Lbfgsb::subsm(const double* xx, const double* gg) {
@@ -483,15 +605,15 @@ void Lbfgsb::subsm(const double* xx, const double* gg) {
   if (nsub <= 0) return;
   int pointr = head_;
   {
-    double t1[LBFGSB_MAXM], t2[LBFGSB_MAXM];
-    int ptr[LBFGSB_MAXM];
-    for (int i = 0; i < col; ++i) { t1[i] = t2[i] = 0.0; ptr[i] = pointr; pointr = nxt(pointr, m); }
-    for (int j = 0; j < nsub; ++j) {
-      const int k = ind[j];
-      const double dj = d[j];
-      for (int i = 0; i < col; ++i) { t1[i] += WY(k, ptr[i]) * dj; t2[i] += WS(k, ptr[i]) * dj; }
-    }
-    for (int i = 0; i < col; ++i) { wv[i] = t1[i]; wv[col + i] = theta_ * t2[i]; }
+    // wv = W' Z d over the free variables (their order), all 2 col inner products in one pass over the mirror
+    double acc[2 * LBFGSB_MAXM] = {0.0};
+    vec_kernels().accum(wr_.data(), rs_, mp_, ind, d, nsub, acc);
+    for (int i = 0; i < col; ++i) { wv[i] = acc[pointr]; wv[col + i] = theta_ * acc[mp_ + pointr]; pointr = nxt(pointr, m); }
+#ifdef LBFGSB_CHECK
+    { int pr = head_; for (int i = 0; i < col; ++i) { double a = 0, b = 0; for (int j = 0; j < nsub; ++j) { a += WY(ind[j], pr) * d[j]; b += WS(ind[j], pr) * d[j]; }
+        if (a != wv[i] || theta_ * b != wv[col + i]) fprintf(stderr, "subsm1 mismatch i=%d\n", i); pr = nxt(pr, m); } }
+    for (int i = 0; i < nsub; ++i) sc_coef_[i] = d[i];
+#endif
   }
   const int m2 = 2 * m, col2 = 2 * col;
   info_ = dtrsl(wn_.data(), m2, col2, wv, 11);
@@ -500,13 +622,22 @@ void Lbfgsb::subsm(const double* xx, const double* gg) {
   info_ = dtrsl(wn_.data(), m2, col2, wv, 1);
   if (info_ != 0) return;
   pointr = head_;
-  for (int jy = 0; jy < col; ++jy) {
-    const int js = col + jy;
-    for (int i = 0; i < nsub; ++i) {
-      int k = ind[i];
-      d[i] = d[i] + WY(k, pointr) * wv[jy] / theta_ + WS(k, pointr) * wv[js];
+  {
+    // d_k = d_k + WY(k, j) wv_j / theta + WS(k, j) wv_{col+j}, j in order: a chain per variable, run for all n variables
+    // side by side on the column-major matrices, then read back through the free-variable index
+    const bool all_free = (nsub == n);               // freev lists the free variables in increasing order
+    double* full = all_free ? d : sc_full_.data();
+    if (!all_free) { for (int k = 0; k < n; ++k) full[k] = 0.0; for (int i = 0; i < nsub; ++i) full[ind[i]] = d[i]; }
+    for (int jy = 0; jy < col; ++jy) {
+      vec_kernels().chain_d(full, &WY(0, pointr), &WS(0, pointr), wv[jy], wv[col + jy], theta_, n);
+      pointr = nxt(pointr, m);
     }
-    pointr = nxt(pointr, m);
+    if (!all_free) for (int i = 0; i < nsub; ++i) d[i] = full[ind[i]];
+#ifdef LBFGSB_CHECK
+    { int pr = head_; std::vector<double> dd(sc_coef_.begin(), sc_coef_.begin() + nsub);
+      for (int jy = 0; jy < col; ++jy) { for (int i = 0; i < nsub; ++i) dd[i] = dd[i] + WY(ind[i], pr) * wv[jy] / theta_ + WS(ind[i], pr) * wv[col + jy]; pr = nxt(pr, m); }
+      for (int i = 0; i < nsub; ++i) if (dd[i] != d[i]) { fprintf(stderr, "subsm2 mismatch i=%d %.17g %.17g\n", i, dd[i], d[i]); break; } }
+#endif
   }
   const double inv_theta = 1.0 / theta_;
   for (int i = 0; i < nsub; ++i) d[i] *= inv_theta;
@@ -752,6 +883,10 @@ void Lbfgsb::matupd(double rr, double dr) {
   }
   std::memcpy(&WS(0, itail_), d_.data(), sizeof(double) * n);
   std::memcpy(&WY(0, itail_), r_.data(), sizeof(double) * n);
+  for (int i = 0; i < n; ++i) {                      // row-major mirror (see vec_kernels)
+    wr_[(size_t)i * rs_ + itail_] = r_[i];
+    wr_[(size_t)i * rs_ + mp_ + itail_] = d_[i];
+  }
   theta_ = rr / dr;
   const int col = col_;
   if (iupdat_ > m) {
@@ -761,15 +896,15 @@ void Lbfgsb::matupd(double rr, double dr) {
     }
   }
   {
-    double t1[LBFGSB_MAXM], t2[LBFGSB_MAXM];
-    int ptr[LBFGSB_MAXM];
+    // SY(col-1, j) = d . WY(:, j), SS(j, col-1) = WS(:, j) . d for the older columns j: one pass over the mirror
+    double acc[2 * LBFGSB_MAXM] = {0.0};
+    vec_kernels().accum(wr_.data(), rs_, mp_, nullptr, d_.data(), n, acc);
     int pointr = head_;
-    for (int j = 0; j < col - 1; ++j) { t1[j] = t2[j] = 0.0; ptr[j] = pointr; pointr = nxt(pointr, m); }
-    for (int k = 0; k < n; ++k) {
-      const double dk = d_[k];
-      for (int j = 0; j < col - 1; ++j) { t1[j] += dk * WY(k, ptr[j]); t2[j] += WS(k, ptr[j]) * dk; }
-    }
-    for (int j = 0; j < col - 1; ++j) { SY(col - 1, j) = t1[j]; SS(j, col - 1) = t2[j]; }
+    for (int j = 0; j < col - 1; ++j) { SY(col - 1, j) = acc[pointr]; SS(j, col - 1) = acc[mp_ + pointr]; pointr = nxt(pointr, m); }
+#ifdef LBFGSB_CHECK
+    { int pr = head_; for (int j = 0; j < col - 1; ++j) { double a = 0, b = 0; for (int k = 0; k < n; ++k) { a += d_[k] * WY(k, pr); b += WS(k, pr) * d_[k]; }
+        if (a != SY(col - 1, j) || b != SS(j, col - 1)) fprintf(stderr, "matupd mismatch j=%d\n", j); pr = nxt(pr, m); } }
+#endif
   }
   if (stp_ == 1.0) SS(col - 1, col - 1) = dtd_;
   else SS(col - 1, col - 1) = stp_ * stp_ * dtd_;

@@ -47,6 +47,9 @@ class Lbfgsb {
   std::vector<int> nbd_;
   // L-BFGS matrices (column-major, Fortran layout)
   std::vector<double> ws_, wy_, sy_, ss_, wt_, wn_, snd_;
+  std::vector<double> wr_, sc_coef_, sc_full_;   // row-major mirror of WY|WS (stride rs_) and scratch, see lbfgsb.cpp
+  std::vector<int> sc_rows_;
+  int mp_ = 0, rs_ = 0;
   std::vector<double> z_, r_, d_, t_, xp_, wa_;
   std::vector<int> index_, iwhere_, indx2_;
   // scalars of mainlb

@@ -132,6 +132,7 @@ class PCA_BO(AbstractBayesianOptimizer):
             warnings.warn("visualize=True: the GIF visualiser of the reference is not part of the MI355X path; ignored.")
         self.__z_evals = []
         self.__gp_pending = False
+        self.__X_buf, self.__X_rows = None, 0
         self.__ctx: Optional[_native.Context] = None
         self.lbfgsb_info = []          # per iteration: (iterations, evaluations, warnflag, task) per restart group
         self.trace = []                # record_trace=True: per iteration RNG states, restart candidates/values
@@ -166,6 +167,7 @@ class PCA_BO(AbstractBayesianOptimizer):
             self._pbar.update(self.n_DoE)
         self.__ctx = _native.Context(max_n=self.budget, max_d=self.dimension,
                                      max_q=max(self.__torch_config["RAW_SAMPLES"], 16), device=self.__device)
+        self.__X_buf, self.__X_rows = None, 0
 
     def _bo_iteration(self, problem, **kwargs) -> None:
         if self.__record_trace:
@@ -231,12 +233,25 @@ class PCA_BO(AbstractBayesianOptimizer):
         return pre / pre.sum()
 
     # ---- rows A-C ---------------------------------------------------------------------------------
+    def _design_matrix(self) -> np.ndarray:
+        """x_evals as one contiguous n x d array; rows already copied stay (the list only grows during a run), which
+        avoids re-stacking several hundred small arrays every iteration."""
+        n = len(self.x_evals)
+        buf = self.__X_buf
+        if buf is None or buf.shape[0] < n or self.__X_rows > n:
+            buf = np.empty((max(n, self.budget), self.dimension), dtype=np.float64)
+            self.__X_buf, self.__X_rows = buf, 0
+        for i in range(self.__X_rows, n):
+            buf[i] = self.x_evals[i]
+        self.__X_rows = n
+        return buf[:n]
+
     def _transform_points_to_reduced_space(self) -> None:
         if len(self.x_evals) < 2:
             if len(self.x_evals) == 1:
                 self.__z_evals = [np.zeros(1)]
             return
-        X = np.vstack(self.x_evals)
+        X = self._design_matrix()
         ranks = self._calculate_ranks()
         noise = np.random.normal(0, 1e-8, size=X.shape)        # same draw, same global RNG as the reference
         start = perf_counter()

@@ -8,6 +8,9 @@
 #include <atomic>
 #include <chrono>
 #include <thread>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <cstdlib>
 #include <cmath>
 #include <cstdio>
@@ -20,6 +23,49 @@
 #define PROF_POOL 4096
 
 struct ProfPair { hipEvent_t a, b; int group; double bytes, flops; };
+
+// One helper thread per context for the odd-numbered restart groups of pcabo_optimize_acqf.  It lives as long as the
+// context (creating and joining a thread per call cost ~0.1 ms per BO iteration), sleeps on a condition variable
+// between calls and spin-waits on `go` only while a call is active.  `go`/`done` are monotonic round counters.
+struct OptHelper {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::atomic<unsigned> go{0}, done{0};
+  std::atomic<bool> quit{false}, active{false};
+  std::function<void()> fn;          // written by the caller only while the helper is idle (done == go)
+  void run() {
+    unsigned seen = 0;
+    while (true) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return active.load(std::memory_order_acquire) || quit.load(std::memory_order_acquire); });
+      }
+      if (quit.load(std::memory_order_acquire)) return;
+      while (active.load(std::memory_order_acquire)) {
+        const unsigned cur = go.load(std::memory_order_acquire);
+        if (cur == seen) { __builtin_ia32_pause(); continue; }
+        seen = cur;
+        fn();
+        done.store(cur, std::memory_order_release);
+      }
+    }
+  }
+  void start() { if (!th.joinable()) th = std::thread([this] { run(); }); }
+  void begin(std::function<void()> f) {
+    start();
+    fn = std::move(f);
+    { std::lock_guard<std::mutex> lk(mu); active.store(true, std::memory_order_release); }
+    cv.notify_one();
+  }
+  void end() { active.store(false, std::memory_order_release); }
+  void shutdown() {
+    if (!th.joinable()) return;
+    { std::lock_guard<std::mutex> lk(mu); quit.store(true, std::memory_order_release); active.store(false, std::memory_order_release); }
+    cv.notify_one();
+    th.join();
+  }
+};
 
 struct pcabo_ctx {
   int device = 0;
@@ -49,6 +95,7 @@ struct pcabo_ctx {
   HostMirror* hm = nullptr;
   double *hXq = nullptr, *hVal = nullptr, *hGrad = nullptr, *hSmall = nullptr;
   unsigned long long seq = 0;
+  OptHelper helper;
   char err[512] = {0};
   // profiling
   bool prof = false;
@@ -186,6 +233,7 @@ int pcabo_ctx_destroy(pcabo_ctx* ctx) {
   void* host[] = {(void*)ctx->hm, ctx->hXq, ctx->hVal, ctx->hGrad, ctx->hSmall};
   for (void* p : host) if (p) hipHostFree(p);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
+  ctx->helper.shutdown();
   delete ctx;
   return PCABO_OK;
 }
@@ -510,36 +558,21 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
       return;
     }
   };
-  // The groups are independent between evaluations: odd-numbered groups advance on a helper thread while the
-  // calling thread advances the even ones (hand-off through two sequence counters, spin-waiting).
-  std::atomic<unsigned> go{0}, done{0};
-  std::atomic<bool> quit{false};
-  std::thread helper;
-  if (ngroups > 1) {
-    helper = std::thread([&] {
-      unsigned seen = 0;
-      while (true) {
-        unsigned cur;
-        while ((cur = go.load(std::memory_order_acquire)) == seen) {
-          if (quit.load(std::memory_order_acquire)) return;
-          __builtin_ia32_pause();
-        }
-        seen = cur;
-        for (int gi = 1; gi < ngroups; gi += 2) advance(gi);
-        done.store(cur, std::memory_order_release);
-      }
-    });
-  }
-  struct Joiner { std::thread& t; std::atomic<bool>& q; ~Joiner() { q.store(true, std::memory_order_release); if (t.joinable()) t.join(); } } joiner{helper, quit};
+  // The groups are independent between evaluations: odd-numbered groups advance on the context's helper thread
+  // while the calling thread advances the even ones (hand-off through two monotonic round counters, spin-waiting).
+  OptHelper& hp = ctx->helper;
+  if (ngroups > 1) hp.begin([&] { for (int gi = 1; gi < ngroups; gi += 2) advance(gi); });
+  struct Ender { OptHelper& h; bool on; ~Ender() { if (on) h.end(); } } ender{hp, ngroups > 1};
   unsigned round_no = 0;
   std::vector<int> qoff(ngroups, -1);
   while (true) {
     const double ta = trace ? now() : 0.0;
     ++round_no;
-    if (ngroups > 1) go.store(round_no, std::memory_order_release);
+    unsigned ticket = 0;
+    if (ngroups > 1) { ticket = hp.go.load(std::memory_order_relaxed) + 1; hp.go.store(ticket, std::memory_order_release); }
     for (int gi = 0; gi < ngroups; gi += 2) advance(gi);
     if (ngroups > 1)
-      while (done.load(std::memory_order_acquire) != round_no) __builtin_ia32_pause();
+      while (hp.done.load(std::memory_order_acquire) != ticket) __builtin_ia32_pause();
     int nq = 0;
     for (int gi = 0; gi < ngroups; ++gi) {
       qoff[gi] = -1;

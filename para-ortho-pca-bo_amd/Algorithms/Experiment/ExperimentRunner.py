@@ -80,7 +80,13 @@ class ExperimentRunner:
 
         self.rank = int(os.environ.get("RANK", "0"))
         self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
-        self.device = int(os.environ.get("LOCAL_RANK", "0"))
+        # one process per GPU is the normal launch; with more local ranks than GPUs the ranks share the devices
+        # round-robin (independent runs from several processes overlap well on one GPU: a single run keeps it busy
+        # for ~10 us out of every ~25 us round)
+        from pcabo import _native
+        ndev = _native.device_count()
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        self.device = local % ndev if ndev > 0 else local
         self.results = []                      # one dict per finished run (this rank)
 
     # ---- run list and its shard -----------------------------------------------------------------------------------

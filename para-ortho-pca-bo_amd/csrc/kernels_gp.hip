@@ -155,7 +155,13 @@ __device__ inline void trsm64_right_lt(const double* s_d, const double* s_rdiag,
   for (int u = 0; u < 16; ++u) Bt[(size_t)ri * ld + part + 4 * u] = bb[u];
 }
 
-__global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ A, int p, int ld, int* __restrict__ info) {
+// Block 0 must not store the factor over the diagonal block inside this launch: the other groups read that block as
+// INPUT at their start, and nothing orders their start before block 0's end (on a GPU shared with other processes a
+// group can start tens of microseconds late - seen as a spurious "not positive definite").  With more than one group
+// the factor goes to `diag_scratch`; the trailing-update launch that follows copies it into place (it does not touch
+// the diagonal block otherwise).
+__global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ A, int p, int ld, int* __restrict__ info,
+                                                    double* __restrict__ diag_scratch) {
   __shared__ __attribute__((aligned(16))) double s_d[BS * TLD];
   __shared__ __attribute__((aligned(16))) double s_col[2][BS];
   const int tid = threadIdx.x;
@@ -167,9 +173,11 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ A, int 
   chol64_inplace(s_d, s_col, &bad);
   if (bad && b == 0 && tid == 0) atomicCAS(info, 0, p * BS + bad);
   if (b == 0) {
+    const bool direct = gridDim.x == 1;              // last panel: nobody else reads the block
     for (int idx = tid; idx < BS * BS; idx += 256) {
       int r = idx >> 6, c = idx & 63;
-      Add[(size_t)r * ld + c] = s_d[r * TLD + c];
+      if (direct) Add[(size_t)r * ld + c] = s_d[r * TLD + c];
+      else diag_scratch[idx] = s_d[r * TLD + c];
     }
     return;
   }
@@ -181,9 +189,14 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ A, int 
 // Trailing update A[I][J] -= L[I][p] L[J][p]^T for p < J <= I on f64 MFMA.
 // Both 64x64 operand tiles are staged in LDS with coalesced loads; fragments are read with a
 // leading dimension of 66 doubles (conflict-free for ds_read_b64).
-__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int p, int nblk, int ld) {
+__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int p, int nblk, int ld,
+                                                     const double* __restrict__ diag_scratch) {
   __shared__ __attribute__((aligned(16))) double s_a[BS * TLD];
   __shared__ __attribute__((aligned(16))) double s_b[BS * TLD];
+  if (blockIdx.x == 0) {                             // put panel p's diagonal factor in place (see k_chol_panel)
+    double* Add = A + (size_t)(p * BS) * ld + p * BS;
+    for (int idx = threadIdx.x; idx < BS * BS; idx += 256) Add[(size_t)(idx >> 6) * ld + (idx & 63)] = diag_scratch[idx];
+  }
   // linear block id -> (I, J) in the lower triangle of the trailing (nblk-p-1)^2 tiles
   const int m = nblk - p - 1;
   int t = blockIdx.x, I = 0;
@@ -320,12 +333,12 @@ void launch_gram(hipStream_t s, const double* AT, const double* nrm, int n, int 
 void launch_add_jitter(hipStream_t s, double* K, int n, int ld, double jitter) {
   hipLaunchKernelGGL(k_add_jitter, dim3((n + 255) / 256), dim3(256), 0, s, K, n, ld, jitter);
 }
-void launch_cholesky(hipStream_t s, double* L, int NP, int ld, int* info) {
+void launch_cholesky(hipStream_t s, double* L, int NP, int ld, int* info, double* diag_scratch) {
   const int nblk = NP / BS;
   for (int p = 0; p < nblk; ++p) {
-    hipLaunchKernelGGL(k_chol_panel, dim3(nblk - p), dim3(256), 0, s, L, p, ld, info);
+    hipLaunchKernelGGL(k_chol_panel, dim3(nblk - p), dim3(256), 0, s, L, p, ld, info, diag_scratch);
     int m = nblk - p - 1;
-    if (m > 0) hipLaunchKernelGGL(k_chol_update, dim3(m * (m + 1) / 2), dim3(256), 0, s, L, p, nblk, ld);
+    if (m > 0) hipLaunchKernelGGL(k_chol_update, dim3(m * (m + 1) / 2), dim3(256), 0, s, L, p, nblk, ld, diag_scratch);
   }
 }
 void launch_trinv(hipStream_t s, const double* L, int NP, int ld, double* R) {

@@ -88,7 +88,7 @@ struct pcabo_ctx {
   int *dK = nullptr, *dSweeps = nullptr, *dInfo = nullptr;
   double *dY = nullptr, *dYs = nullptr, *dYstats = nullptr, *dBounds4 = nullptr, *dZnMean = nullptr, *dUserNB = nullptr;
   double *dZnT = nullptr, *dAT = nullptr, *dNrm = nullptr, *dGram = nullptr, *dL = nullptr, *dR = nullptr;
-  double *dTmp = nullptr, *dAlpha = nullptr;
+  double *dTmp = nullptr, *dAlpha = nullptr, *dDiag = nullptr;   // dDiag: 64x64 hand-over tile of the Cholesky panels
   double *dXq = nullptr, *dPartial = nullptr, *dVal = nullptr, *dGrad = nullptr, *dZq = nullptr, *dXout = nullptr;
   unsigned int* dCounters = nullptr;     // per-query tickets of the in-launch combine
   // pinned host
@@ -202,6 +202,7 @@ int pcabo_ctx_create(int device, int max_n, int max_d, int max_q, pcabo_ctx** ou
   HIPCHK(dalloc(&ctx->dNrm, N));
   HIPCHK(dalloc(&ctx->dGram, N * N));    HIPCHK(dalloc(&ctx->dL, N * N));    HIPCHK(dalloc(&ctx->dR, N * N));
   HIPCHK(dalloc(&ctx->dTmp, N));         HIPCHK(dalloc(&ctx->dAlpha, N));
+  HIPCHK(dalloc(&ctx->dDiag, (size_t)PCABO_BS * PCABO_BS));
   HIPCHK(dalloc(&ctx->dXq, Q * d));
   HIPCHK(dalloc(&ctx->dPartial, Q * (size_t)ctx->Scap * (2 + 2 * PCABO_MAXD)));
   HIPCHK(dalloc(&ctx->dVal, Q));         HIPCHK(dalloc(&ctx->dGrad, Q * d));
@@ -227,7 +228,7 @@ int pcabo_ctx_destroy(pcabo_ctx* ctx) {
   void* dev[] = {ctx->dX, ctx->dNoise, ctx->dF, ctx->dWeights, ctx->dWc, ctx->dRanks, ctx->dDataMean, ctx->dPcaMean,
                  ctx->dC, ctx->dGbuf[0], ctx->dGbuf[1], ctx->dLam, ctx->dComps, ctx->dEvr, ctx->dZ, ctx->dK, ctx->dSweeps, ctx->dInfo,
                  ctx->dY, ctx->dYs, ctx->dYstats, ctx->dBounds4, ctx->dZnMean, ctx->dUserNB, ctx->dZnT, ctx->dAT,
-                 ctx->dNrm, ctx->dGram, ctx->dL, ctx->dR, ctx->dTmp, ctx->dAlpha, ctx->dXq, ctx->dPartial, ctx->dVal,
+                 ctx->dNrm, ctx->dGram, ctx->dL, ctx->dR, ctx->dTmp, ctx->dAlpha, ctx->dDiag, ctx->dXq, ctx->dPartial, ctx->dVal,
                  ctx->dGrad, ctx->dZq, ctx->dXout, ctx->dCounters};
   for (void* p : dev) if (p) hipFree(p);
   void* host[] = {(void*)ctx->hm, ctx->hXq, ctx->hVal, ctx->hGrad, ctx->hSmall};
@@ -321,7 +322,7 @@ static int launch_factorisation(pcabo_ctx* ctx, double jitter) {
   HIPCHK(hipMemcpyAsync(ctx->dL, ctx->dGram, bytes, hipMemcpyDeviceToDevice, s));
   if (jitter > 0.0) launch_add_jitter(s, ctx->dL, ctx->n, ctx->ld, jitter);
   HIPCHK(hipMemsetAsync(ctx->dInfo, 0, sizeof(int), s));
-  { ProfScope ps(ctx, 2, 16.0 * ctx->n * ctx->n, (double)ctx->n * ctx->n * ctx->n / 3.0); launch_cholesky(s, ctx->dL, ctx->NP, ctx->ld, ctx->dInfo); }
+  { ProfScope ps(ctx, 2, 16.0 * ctx->n * ctx->n, (double)ctx->n * ctx->n * ctx->n / 3.0); launch_cholesky(s, ctx->dL, ctx->NP, ctx->ld, ctx->dInfo, ctx->dDiag); }
   {
     ProfScope ps(ctx, 3, 16.0 * ctx->n * ctx->n, (double)ctx->n * ctx->n * ctx->n / 3.0 + 2.0 * ctx->n * ctx->n);
     launch_trinv(s, ctx->dL, ctx->NP, ctx->ld, ctx->dR);

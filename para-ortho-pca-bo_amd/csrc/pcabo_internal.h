@@ -102,7 +102,7 @@ void launch_znorm(hipStream_t s, const double* Z, int n, int k, int NP, int KP, 
 void launch_gram(hipStream_t s, const double* AT, const double* nrm, int n, int NP, int KP, int ld, double noise,
                  int kernel, double* K);
 void launch_add_jitter(hipStream_t s, double* K, int n, int ld, double jitter);
-void launch_cholesky(hipStream_t s, double* L, int NP, int ld, int* info);
+void launch_cholesky(hipStream_t s, double* L, int NP, int ld, int* info, double* diag_scratch);
 void launch_trinv(hipStream_t s, const double* L, int NP, int ld, double* R);
 void launch_alpha(hipStream_t s, const double* R, const double* ys, int n, int NP, int ld, double* tmp, double* alpha);
 void launch_acq(hipStream_t s, const QueryArgs* qa, const double* Xq, int q, int n, int k, int NP, int ld,

@@ -608,3 +608,36 @@ def test_reference_logged_vanilla_candidates_are_optima_of_the_device_surface(na
     dx_wrong, _ = moves(1.0, 13)
     assert np.median(dx_wrong) > 0.1
     c.close()
+
+
+def test_concurrent_processes_share_one_gpu(native):
+    """Three processes drive the same GPU at once (runs are independent; a work-group of one process can then start
+    tens of microseconds after its siblings).  Every run must reproduce, bit for bit, what it produces alone - this
+    is the test that exposes ordering assumptions between the work-groups of one launch."""
+    import hashlib, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, os, hashlib
+import numpy as np
+sys.path.insert(0, os.path.join(%r, "para-ortho-pca-bo_amd"))
+from Algorithms import PCA_BO
+from pcabo.bbob import BBOBProblem
+inst = int(sys.argv[1])
+opt = PCA_BO(budget=330, n_DoE=120, random_seed=15400 + inst, maximization=False)
+opt(BBOBProblem(15, inst, 40))
+print("DIGEST", hashlib.md5(np.array(opt.f_evals).tobytes() + np.vstack(opt.x_evals).tobytes()).hexdigest())
+''' % root
+
+    def run(insts):
+        procs = [subprocess.Popen([sys.executable, "-c", code, str(i)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                  text=True) for i in insts]
+        out = []
+        for p in procs:
+            so, se = p.communicate(timeout=600)
+            assert p.returncode == 0, se[-3000:]
+            out.append([l for l in so.splitlines() if l.startswith("DIGEST")][-1])
+        return out
+
+    together = run([0, 1, 2])
+    alone = [run([i])[0] for i in (0, 1, 2)]
+    assert together == alone

@@ -3,7 +3,9 @@
 exchange is the final gather of best-so-far values (a few hundred bytes - pure latency)."""
 from __future__ import annotations
 
+import datetime
 import os
+import warnings
 from typing import List, Sequence
 
 import torch
@@ -23,8 +25,22 @@ def init(backend: str = None) -> tuple:
             # PCABO_DIST_BACKEND=gloo: rehearsal on a box with fewer GPUs than ranks (ranks then share a device)
             backend = os.environ.get("PCABO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=size)
+            # RCCL first; if it cannot come up on this node (IPC/driver trouble) the few scalar collectives of this
+            # package (barrier, max, sum, final gather - none of them on the data path) run over gloo instead.
+            try:
+                torch.cuda.set_device(local_rank)
+                dist.init_process_group(backend="nccl", rank=rank, world_size=size,
+                                        timeout=datetime.timedelta(seconds=180))
+                t = torch.zeros(1, dtype=torch.float64, device=torch.device("cuda", local_rank))
+                dist.all_reduce(t)
+                torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001
+                warnings.warn(f"RCCL initialisation failed ({type(e).__name__}: {e}); falling back to gloo", RuntimeWarning)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                dist.init_process_group(backend="gloo", rank=rank, world_size=size)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=size)
     return rank, local_rank, size
 
 

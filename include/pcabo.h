@@ -149,8 +149,10 @@ int pcabo_sobol_scramble(int64_t* state, const int64_t* ltm, int k);
 /* Device-time accounting: accumulated HIP-event time (ms, events recorded on the context's own
  * stream), launch count and ALGORITHMIC bytes / flops of the kernel groups since the last reset.
  * which: 0 wpca (5 kernels), 1 normalise+Gram (3 kernels), 2 Cholesky (2 kernels per 64-wide panel),
- * 3 root inverse + alpha (5 launches), 4 fused acquisition kernel (value+gradient+combine), 5 unused.
- * Enabled by pcabo_set_profiling(ctx, 1) (adds an event pair per bracketed group of launches). */
+ * 3 root inverse + alpha (5 launches), 4 acquisition kernel, single-launch evaluations (<= 32 queries: the L-BFGS-B
+ * rounds), 5 acquisition, large batches (two launches: partials + combine).
+ * Enabled by pcabo_set_profiling(ctx, 1) (adds an event pair per bracketed group of launches; the reading of two events
+ * recorded back to back, calibrated when profiling is switched on, is subtracted from every pair). */
 int pcabo_set_profiling(pcabo_ctx* ctx, int enabled);
 int pcabo_get_profile(pcabo_ctx* ctx, int which, double* ms, int64_t* launches, double* bytes, double* flops);
 int pcabo_reset_profile(pcabo_ctx* ctx);

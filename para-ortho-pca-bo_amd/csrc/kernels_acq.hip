@@ -140,6 +140,7 @@ __device__ inline void acq_tail(int combine, double* s_v, double* partial, unsig
     }
   }
   __syncthreads();
+  STAMP_FIN(13);
   if (w == 0) {
     if (prm.want_grad) {
       const double c_mu = s_coef[0], c_sg = s_coef[1];
@@ -543,11 +544,12 @@ __device__ inline void log_ei_helper(double u, double* h, double* dh) {
 // coefficients of the gradient's chain rule.  coef (LDS or registers' spill target) receives {c_mu, c_sg}.
 __device__ void acq_finish_scalar(const double* base, int S, int q, const double* ystats, const AcqParams& p, double* val,
                                   double* host_val, double* coef, int l) {
+  const double ym = ystats[0], ysd = ystats[1];            // issued with the partial loads, not after the reductions
   double vv = 0.0, mus = 0.0;
   for (int s = l; s < S; s += 64) { vv += base[(size_t)s * PSTRIDE]; mus += base[(size_t)s * PSTRIDE + 1]; }
   vv = wave_sum(vv);
   mus = wave_sum(mus);
-  const double ym = ystats[0], ysd = ystats[1];
+  STAMP_FIN(11);
   const double mu = ym + ysd * mus;
   double var = (1.0 - vv) * (ysd * ysd);
   bool clamped = false;
@@ -576,6 +578,7 @@ __device__ void acq_finish_scalar(const double* base, int S, int q, const double
     coef[0] = dv_du * sgn * ysd / sigma;
     coef[1] = clamped ? 0.0 : (dv_dsig - dv_du * u / sigma) * (-(ysd * ysd) / sigma);
   }
+  STAMP_FIN(12);
 }
 
 // One query, one wave (the large-batch combine pass): scalar chain, then the gradient from all slabs in order.

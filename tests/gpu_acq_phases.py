@@ -22,9 +22,12 @@ for n, k in ((120, 31), (250, 33), (449, 36), (150, 27), (250, 17), (350, 10), (
         t = np.array(list(st)[:11], dtype=np.float64)
         if it >= 10:
             acc += np.diff(t) * 0.01; cnt += 1          # us
+            fin = np.array([st[8], st[11], st[12], st[13], st[9]], dtype=np.float64)
+            facc = (facc if it > 10 else np.zeros(4)) + np.diff(fin) * 0.01
     t0 = time.perf_counter()
     for _ in range(200): c.acq_eval(Xq, 0.0)
     wall = (time.perf_counter() - t0) / 200 * 1e6
     print(f"n={n} k={k} q=10: host round trip {wall:.1f} us; in-kernel total {acc.sum()/cnt:.1f} us: " +
-          ", ".join(f"{nm} {v/cnt:.2f}" for nm, v in zip(names, acc)), flush=True)
+          ", ".join(f"{nm} {v/cnt:.2f}" for nm, v in zip(names, acc)) +
+          " | finish split: partial loads+sums %.2f, scalar chain %.2f, wait for waves 1-3 %.2f, gradient+stores+flag %.2f" % tuple(facc / cnt), flush=True)
     c.close()

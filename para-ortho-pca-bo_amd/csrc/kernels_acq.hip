@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void k_acq_fused(
     const double* __restrict__ ZnT, const double* __restrict__ R, const double* __restrict__ alpha,
     const double* __restrict__ bounds4, const double* __restrict__ ystats, AcqParams prm, double* partial,
     unsigned int* counters, double* __restrict__ val, double* __restrict__ grad,
-    double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq, int combine) {
+    double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq, int combine, int /*qb*/) {
   const double inv_ls = prm.inv_ls;
   const int kernel = prm.kernel, want_grad = prm.want_grad;
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void k_acq_fast(
     const double* __restrict__ ZnT, const double* __restrict__ R, const double* __restrict__ alpha,
     const double* __restrict__ bounds4, const double* __restrict__ ystats, AcqParams prm, double* partial,
     unsigned int* counters, double* __restrict__ val, double* __restrict__ grad,
-    double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq, int combine) {
+    double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq, int combine, int qb) {
   constexpr int NP = NB * 64;
   constexpr int CU = 10;                 // components per wave
   constexpr int RW = SLAB / 4;           // slab rows per wave
@@ -339,8 +339,7 @@ __global__ __launch_bounds__(256) void k_acq_fast(
   double* s_p4 = s_v + SLAB + 2;     // 4 NP per-wave partials (squared distances, then w_j)
   const int tid = threadIdx.x, l = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int s = blockIdx.x, q = blockIdx.y, S = gridDim.x;
-  double* out = partial + ((size_t)q * S + s) * PSTRIDE;
+  const int s = blockIdx.x, S = gridDim.x;
   STAMP(0);
 
   // ---- every global operand, issued before anything waits ---------------------------------------------------
@@ -370,6 +369,13 @@ __global__ __launch_bounds__(256) void k_acq_fast(
   }
 #pragma unroll
   for (int m = 0; m < NM; ++m) { const int j = tid + 256 * m; al[m] = j < n ? alpha[j] : 0.0; }
+  // ---- per query: large batches (value scoring of the raw samples, many-restart optimisation) give each group qb
+  // queries, so the register tiles above are loaded once for all of them; the in-launch combine uses qb = 1
+  int q = blockIdx.y * qb;
+  double* out = partial + ((size_t)q * S + s) * PSTRIDE;
+  for (int qi = 0; qi < qb; ++qi, ++q, out += (size_t)S * PSTRIDE) {
+  if (q >= q_total) break;
+  if (qi > 0) __syncthreads();          // the previous query's readers of s_xn / s_ks / s_tm / s_v are done
   if (tid < k) {
     double lo = bounds4[tid], hi = bounds4[PCABO_MAXD + tid];
     double xv = Xq ? Xq[(size_t)q * k + tid] : qa.x[q * k + tid];
@@ -508,6 +514,9 @@ __global__ __launch_bounds__(256) void k_acq_fast(
     }
   }
   }  // want_grad
+  }   // queries of this group
+  q = blockIdx.y * qb;                  // (combine: qb = 1)
+  out = partial + ((size_t)q * S + s) * PSTRIDE;
   acq_tail<SLAB>(combine, s_v, partial, counters, q, S, k, bounds4, ystats, prm, val, grad, host_val, host_grad, hm, seq, tid, w, l);
 }
 
@@ -631,14 +640,19 @@ void launch_acq(hipStream_t st, const QueryArgs* qa, const double* Xq, int q, in
   const int nb = NP / 64;
   static int use_fast = -1;
   if (use_fast < 0) { const char* e = getenv("PCABO_ACQ_GENERIC"); use_fast = !(e && atoi(e)); }
+  // large batches on the fast path: 8 queries per group share one load of the register tiles (qb); the generic
+  // kernel and the in-launch combine take one query per group
+  const bool fast = use_fast && k <= 40 && nb <= 8;
+  const int qb = (fast && !combine && q >= 64) ? 8 : 1;
+  const int gy = (q + qb - 1) / qb;
 #define ACQ_ARGS qa ? *qa : empty, Xq, q, n, k, NP, ld, ZnT, R, alpha, bounds4, ystats, p, partial, counters, val, grad, \
-                 host_val, host_grad, hm, seq, combine
+                 host_val, host_grad, hm, seq, combine, qb
 #define ACQ_FAST(SL, NBV)                                                                                      \
   case NBV:                                                                                                    \
-    hipLaunchKernelGGL((k_acq_fast<SL, NBV>), dim3(S, q), dim3(256),                                           \
+    hipLaunchKernelGGL((k_acq_fast<SL, NBV>), dim3(S, gy), dim3(256),                                           \
                        (size_t)(3 * NBV * 64 + PCABO_MAXD + SL + 2 + (4 * NBV * 64 > 6 * PCABO_MAXD + 2 ? 4 * NBV * 64 : 6 * PCABO_MAXD + 2)) * sizeof(double), st, ACQ_ARGS); \
     break;
-  if (use_fast && k <= 40 && nb <= 8) {
+  if (fast) {
     if (slab == 16) {
       switch (nb) { ACQ_FAST(16, 1) ACQ_FAST(16, 2) ACQ_FAST(16, 3) ACQ_FAST(16, 4) ACQ_FAST(16, 5) ACQ_FAST(16, 6)
                     ACQ_FAST(16, 7) ACQ_FAST(16, 8) }

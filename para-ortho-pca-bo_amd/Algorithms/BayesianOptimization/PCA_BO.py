@@ -101,6 +101,15 @@ class PCA_BO(AbstractBayesianOptimizer):
                  visualize: bool = False, **kwargs):
         self.__device = int(kwargs.pop("device", 0))
         self.__record_trace = bool(kwargs.pop("record_trace", False))
+        # prefetch_noise: draw the NEXT iteration's 1e-8 noise matrix (numpy's global RNG, PCA_BO.py:376) on a helper
+        # thread while the acquisition optimiser runs inside the library.  The numbers are the same, but they leave the
+        # global stream BEFORE the objective of this iteration is evaluated - harmless exactly when the objective does
+        # not draw from numpy's global RNG.  None = automatic: on for the in-repo BBOB problems, off otherwise.
+        self.__prefetch = kwargs.pop("prefetch_noise", None)
+        if self.__prefetch is None and os.environ.get("PCABO_PREFETCH_NOISE") in ("0", "1"):   # A/B diagnostics
+            self.__prefetch = os.environ["PCABO_PREFETCH_NOISE"] == "1"
+        self.__prefetch_on = False
+        self.__noise_thread, self.__noise_next = None, None
         # torch is only used for the Sobol / multinomial draws here; its default of one OpenMP worker per visible core
         # (hundreds on a GPU host) leaves spinning workers that starve the host threads driving the device loop
         # (measured: 300 us instead of 34 us per L-BFGS-B round).  Capped for the duration of a run; None = leave alone.
@@ -168,6 +177,13 @@ class PCA_BO(AbstractBayesianOptimizer):
         self.__ctx = _native.Context(max_n=self.budget, max_d=self.dimension,
                                      max_q=max(self.__torch_config["RAW_SAMPLES"], 16), device=self.__device)
         self.__X_buf, self.__X_rows = None, 0
+        if self.__prefetch is None:
+            from pcabo.bbob import BBOBProblem
+            self.__prefetch_on = isinstance(getattr(problem, "_problem", problem), BBOBProblem)
+        else:
+            self.__prefetch_on = bool(self.__prefetch)
+        if self.__record_trace:            # the recorded per-iteration RNG state must be the one BEFORE the draw
+            self.__prefetch_on = False
 
     def _bo_iteration(self, problem, **kwargs) -> None:
         if self.__record_trace:
@@ -204,6 +220,9 @@ class PCA_BO(AbstractBayesianOptimizer):
                   f"Best: x:{self.x_evals[self.current_best_index]} y:{self.current_best}", flush=True)
 
     def _finish(self) -> None:
+        if self.__noise_thread is not None:
+            self.__noise_thread.join()
+            self.__noise_thread, self.__noise_next = None, None
         if self.__saved_torch_threads is not None:
             import torch
             torch.set_num_threads(self.__saved_torch_threads)
@@ -246,6 +265,31 @@ class PCA_BO(AbstractBayesianOptimizer):
         self.__X_rows = n
         return buf[:n]
 
+    def _take_noise(self, shape) -> np.ndarray:
+        t = self.__noise_thread
+        if t is None:
+            return np.random.normal(0, 1e-8, size=shape)
+        t.join()
+        self.__noise_thread = None
+        nz, self.__noise_next = self.__noise_next, None
+        if nz is None or nz.shape != tuple(shape):
+            raise RuntimeError("noise prefetch out of step with the run (a draw of another shape left the RNG)")
+        return nz
+
+    def _prefetch_noise(self) -> None:
+        """Called once the current iteration's noise is consumed: the next iteration (if there is one) has one more
+        point."""
+        n = len(self.x_evals)
+        if not self.__prefetch_on or self.__noise_thread is not None or n + 1 >= self.budget:
+            return
+        import threading
+        shape = (n + 1, self.dimension)
+
+        def draw():
+            self.__noise_next = np.random.normal(0, 1e-8, size=shape)   # numpy releases the GIL while it generates
+        self.__noise_thread = threading.Thread(target=draw, daemon=True)
+        self.__noise_thread.start()
+
     def _transform_points_to_reduced_space(self) -> None:
         if len(self.x_evals) < 2:
             if len(self.x_evals) == 1:
@@ -253,7 +297,7 @@ class PCA_BO(AbstractBayesianOptimizer):
             return
         X = self._design_matrix()
         ranks = self._calculate_ranks()
-        noise = np.random.normal(0, 1e-8, size=X.shape)        # same draw, same global RNG as the reference
+        noise = self._take_noise(X.shape)                      # same draw, same global RNG as the reference
         start = perf_counter()
         res = self.__ctx.wpca(X, ranks=ranks, maximize=self.maximization, var_threshold=self.var_threshold,
                               n_components=self.n_components, noise=noise, want_Z=False, want_full=True)
@@ -295,6 +339,7 @@ class PCA_BO(AbstractBayesianOptimizer):
             self.__gp_pending = False
         bounds = ctx.acq_bounds()
 
+        self._prefetch_noise()             # overlaps with the optimiser's time inside the library
         new_z, cand, vals, info = _acqopt.optimize_acqf(
             ctx, bounds, acq.best_f, acq.maximize, acq.acq_code, num_restarts, raw_samples, batch_limit, 200,
             engine=engine, breakdown=self.phase_breakdown, trace=self.trace[-1] if self.__record_trace else None)

@@ -641,3 +641,17 @@ print("DIGEST", hashlib.md5(np.array(opt.f_evals).tobytes() + np.vstack(opt.x_ev
     together = run([0, 1, 2])
     alone = [run([i])[0] for i in (0, 1, 2)]
     assert together == alone
+
+
+def test_noise_prefetch_does_not_change_a_run(native):
+    """prefetch_noise draws the next iteration's noise matrix early on a helper thread; for an objective that does not
+    touch numpy's global RNG the run must be identical to the plain one, bit for bit."""
+    from Algorithms import PCA_BO
+    torch.set_num_threads(4)
+    runs = []
+    for pre in (True, False, None):
+        opt = PCA_BO(budget=70, n_DoE=30, random_seed=15101, maximization=False, prefetch_noise=pre)
+        opt(BBOBProblem(15, 1, 10))
+        runs.append((np.array(opt.f_evals), np.vstack(opt.x_evals)))
+    for f, x in runs[1:]:
+        assert np.array_equal(f, runs[0][0]) and np.array_equal(x, runs[0][1])

@@ -95,7 +95,9 @@ int pcabo_gp_condition_begin(pcabo_ctx* ctx, const double* Z, const double* y, i
                              const double* norm_bounds, double lengthscale, double noise, int kernel);
 int pcabo_gp_condition_end(pcabo_ctx* ctx);
 
-/* Row J: search box of the acquisition optimiser, PCA_BO.py:558-573. bounds[2*k] [host] (lo row, hi row). */
+/* Row J: search box of the acquisition optimiser, PCA_BO.py:558-573. bounds[2*k] [host] (lo row, hi row).
+ * May be called between pcabo_gp_condition_begin and _end: it then waits only for the statistics kernel, so the
+ * raw samples of the initial-condition draw can be generated while the factorisation is still running. */
 int pcabo_acq_bounds(pcabo_ctx* ctx, double* bounds);
 
 /* Row I: batched acquisition value (+ gradient) at q query points of the reduced space.

@@ -334,15 +334,18 @@ class PCA_BO(AbstractBayesianOptimizer):
         # Like the reference, where gpytorch's Gram/Cholesky happen lazily inside optimize_acqf, the wait for the
         # conditioning is accounted here; the scrambled Sobol engine (needs only k) is built meanwhile.
         engine = _init.scrambled_sobol_engine(ctx.k)
+        bounds = ctx.acq_bounds()          # needs only the statistics kernel, not the factorisation
+        t0 = perf_counter()
+        raw = _init.draw_sobol(bounds, raw_samples, engine)
+        self.phase_breakdown["sobol"] = self.phase_breakdown.get("sobol", 0.0) + perf_counter() - t0
         if self.__gp_pending:
             ctx.gp_wait()
             self.__gp_pending = False
-        bounds = ctx.acq_bounds()
 
         self._prefetch_noise()             # overlaps with the optimiser's time inside the library
         new_z, cand, vals, info = _acqopt.optimize_acqf(
             ctx, bounds, acq.best_f, acq.maximize, acq.acq_code, num_restarts, raw_samples, batch_limit, 200,
-            engine=engine, breakdown=self.phase_breakdown, trace=self.trace[-1] if self.__record_trace else None)
+            raw=raw, breakdown=self.phase_breakdown, trace=self.trace[-1] if self.__record_trace else None)
         self.timing_logs["optimize_acqf"].append(perf_counter() - start)
         self.lbfgsb_info.append(info)
         return new_z

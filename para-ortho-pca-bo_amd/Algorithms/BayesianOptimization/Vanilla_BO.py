@@ -132,11 +132,12 @@ class Vanilla_BO(AbstractBayesianOptimizer):
     def optimize_acqf_and_get_observation(self) -> np.ndarray:
         ctx, cfg, acq = self.__ctx, self.__torch_config, self.acquisition_function
         start = perf_counter()
-        engine = _init.scrambled_sobol_engine(self.dimension)      # built while the device conditions the GP
+        engine = _init.scrambled_sobol_engine(self.dimension)      # built and drawn while the device conditions the GP
+        raw = _init.draw_sobol(self.__box, cfg["RAW_SAMPLES"], engine)
         ctx.gp_wait()
         new_x, cand, vals, info = _acqopt.optimize_acqf(
             ctx, self.__box, acq.best_f, acq.maximize, acq.acq_code, cfg["NUM_RESTARTS"], cfg["RAW_SAMPLES"], 5, 200,
-            engine=engine, breakdown=self.phase_breakdown, trace=self.trace[-1] if self.__record_trace else None)
+            raw=raw, breakdown=self.phase_breakdown, trace=self.trace[-1] if self.__record_trace else None)
         self.timing_logs["optimize_acqf"].append(perf_counter() - start)
         self.lbfgsb_info.append(info)
         return new_x

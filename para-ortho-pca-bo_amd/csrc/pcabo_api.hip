@@ -70,6 +70,7 @@ struct OptHelper {
 struct pcabo_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipEvent_t evBounds = nullptr;         // recorded after k_zstats: the search box is on the host before the Cholesky ends
   int max_n = 0, max_d = 0, max_q = 0;
   int NPcap = 0, ld = 0, DPcap = 0, KPcap = 0, Scap = 0;
   int ptr_mode = PCABO_PTR_HOST;
@@ -190,6 +191,7 @@ int pcabo_ctx_create(int device, int max_n, int max_d, int max_q, pcabo_ctx** ou
   ctx->Scap = ctx->NPcap / PCABO_SLAB;
   HIPCHK(hipSetDevice(device));
   HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&ctx->evBounds, hipEventDisableTiming));
   const size_t N = ctx->NPcap, D = ctx->DPcap, n = max_n, d = max_d, Q = max_q;
   HIPCHK(dalloc(&ctx->dX, n * d));       HIPCHK(dalloc(&ctx->dNoise, n * d));
   HIPCHK(dalloc(&ctx->dF, n));           HIPCHK(dalloc(&ctx->dWeights, n));
@@ -238,6 +240,7 @@ int pcabo_ctx_destroy(pcabo_ctx* ctx) {
   for (void* p : dev) if (p) hipFree(p);
   void* host[] = {(void*)ctx->hm, ctx->hXq, ctx->hVal, ctx->hGrad, ctx->hSmall};
   for (void* p : host) if (p) hipHostFree(p);
+  if (ctx->evBounds) hipEventDestroy(ctx->evBounds);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   ctx->helper.shutdown();
   delete ctx;
@@ -364,6 +367,7 @@ int pcabo_gp_condition_begin(pcabo_ctx* ctx, const double* Z, const double* y, i
   {
     ProfScope ps(ctx, 1, 8.0 * n * k + 4.0 * n * (n + 1.0), 2.0 * n * n * k + 12.0 * n * n);
     launch_zstats(s, ctx->dZ, ctx->dY, n, k, unb, ctx->dBounds4, ctx->dZnMean, ctx->dYstats, ctx->dYs, ctx->hm);
+    HIPCHK(hipEventRecord(ctx->evBounds, s));
     launch_znorm(s, ctx->dZ, n, k, ctx->NP, ctx->KP, ctx->ld, ctx->dBounds4, ctx->dZnMean, 1.0 / lengthscale, ctx->dZnT,
                  ctx->dAT, ctx->dNrm);
     launch_gram(s, ctx->dAT, ctx->dNrm, n, ctx->NP, ctx->KP, ctx->ld, noise, kernel, ctx->dGram);
@@ -399,7 +403,12 @@ int pcabo_gp_condition(pcabo_ctx* ctx, const double* Z, const double* y, int n, 
 
 int pcabo_acq_bounds(pcabo_ctx* ctx, double* bounds) {
   if (!ctx || !bounds) return PCABO_ERR_ARG;
-  if (!ctx->have_gp) return set_err(ctx, PCABO_ERR_ARG, "pcabo_acq_bounds: call pcabo_gp_condition first%s", "");
+  if (ctx->gp_pending) {                   // conditioning in flight: the box only needs k_zstats, wait for that alone
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipEventSynchronize(ctx->evBounds));
+  } else if (!ctx->have_gp) {
+    return set_err(ctx, PCABO_ERR_ARG, "pcabo_acq_bounds: call pcabo_gp_condition first%s", "");
+  }
   for (int c = 0; c < ctx->k; ++c) { bounds[c] = ctx->hm->acq_lo[c]; bounds[ctx->k + c] = ctx->hm->acq_hi[c]; }
   return PCABO_OK;
 }

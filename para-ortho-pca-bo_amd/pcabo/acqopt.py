@@ -16,15 +16,17 @@ from . import initializers as _init
 
 def optimize_acqf(ctx: "_native.Context", bounds: np.ndarray, best_f: float, maximize: bool, acq_code: int,
                   num_restarts: int, raw_samples: int, batch_limit: int = 5, maxiter: int = 200, engine=None,
-                  breakdown: Optional[dict] = None, trace: Optional[dict] = None):
+                  breakdown: Optional[dict] = None, trace: Optional[dict] = None, raw: Optional[np.ndarray] = None):
     """Returns (candidate[1, k], all restart candidates, their values, L-BFGS-B info).  `engine`: a scrambled Sobol
-    engine prepared earlier (same RNG consumption, earlier in time); the retry path draws a fresh one."""
+    engine prepared earlier (same RNG consumption, earlier in time); `raw`: the raw samples already drawn from it
+    (while the device was still factorising).  The retry path draws afresh."""
     pb = breakdown if breakdown is not None else {}
-    engines = [engine] if engine is not None else []
+    engines = [engine] if engine is not None and raw is None else []
+    ready = [raw] if raw is not None else []
 
     def initial_conditions():
         t0 = perf_counter()
-        raw = _init.draw_sobol(bounds, raw_samples, engines.pop() if engines else None)
+        raw = ready.pop() if ready else _init.draw_sobol(bounds, raw_samples, engines.pop() if engines else None)
         t1 = perf_counter()
         vals = ctx.acq_eval(raw, best_f, maximize, acq_code, grad=False)
         t2 = perf_counter()

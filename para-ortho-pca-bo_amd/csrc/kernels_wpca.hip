@@ -6,6 +6,7 @@
 // "few launches, one work-group where a phase is sequential, MFMA for the one GEMM-like
 // contraction (the d x d covariance W^T W)".
 #include "pcabo_internal.h"
+#include <cstdlib>
 
 #define WP_THREADS 1024
 
@@ -211,6 +212,10 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi(const double* __restrict
           }
           if (LP == 16) {                       // the pair's 16 lanes are one DPP row: no LDS traffic, no waits
             a = row_sum16(a); b = row_sum16(b); g = row_sum16(g);
+          } else if (LP == 8) {                 // half a DPP row: quad_perm x2 + row_half_mirror
+            a += dpp_get<0xB1, 0xf>(a); b += dpp_get<0xB1, 0xf>(b); g += dpp_get<0xB1, 0xf>(g);
+            a += dpp_get<0x4E, 0xf>(a); b += dpp_get<0x4E, 0xf>(b); g += dpp_get<0x4E, 0xf>(g);
+            a += dpp_get<0x141, 0xf>(a); b += dpp_get<0x141, 0xf>(b); g += dpp_get<0x141, 0xf>(g);
           } else {
             for (int off = LP >> 1; off > 0; off >>= 1) {
               a += __shfl_xor(a, off, 64);
@@ -451,7 +456,9 @@ void launch_jacobi(hipStream_t s, const double* C, int d, int DP, const double* 
     attr_set = true;
   }
   const int npairs = ((d + 1) & ~1) / 2;
-  int threads = npairs * 16 <= JAC_THREADS ? npairs * 16 : npairs * 8;
+  static int lp_env = -1;
+  if (lp_env < 0) { const char* e = getenv("PCABO_JACOBI_LP"); lp_env = e ? atoi(e) : 0; }
+  int threads = (npairs * 16 <= JAC_THREADS && lp_env != 8) ? npairs * 16 : npairs * 8;
   threads = (threads + 63) & ~63;
   hipLaunchKernelGGL(k_jacobi, dim3(1), dim3(threads), lds, s, C, d, DP, V0, G, lam, sweeps);
 }

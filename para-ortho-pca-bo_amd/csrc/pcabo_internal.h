@@ -8,7 +8,7 @@
 #define PCABO_MAXD 128       // largest ambient / reduced dimension supported
 #define PCABO_TLD 66         // LDS leading dimension (doubles) of a 64x64 tile: conflict-free ds_read_b64
 
-#define PCABO_QA_MAX 384      // query coordinates that travel as kernel arguments (3 KB)
+#define PCABO_QA_MAX 448      // query coordinates that travel as kernel arguments (3.5 KB; 10 restarts x 40 dims = 400 fit)
 #define PCABO_CNT_DONE 0x3fff // capacity of the per-query ticket array
 #define PCABO_INLAUNCH_MAXQ 32 // largest batch finished inside the launch (results + flags straight to the host)
 

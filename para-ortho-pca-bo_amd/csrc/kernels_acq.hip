@@ -643,7 +643,9 @@ void launch_acq(hipStream_t st, const QueryArgs* qa, const double* Xq, int q, in
   // large batches on the fast path: 8 queries per group share one load of the register tiles (qb); the generic
   // kernel and the in-launch combine take one query per group
   const bool fast = use_fast && k <= 40 && nb <= 8;
-  const int qb = (fast && !combine && q >= 64) ? 8 : 1;
+  static int qb_large = -1;
+  if (qb_large < 0) { const char* e = getenv("PCABO_ACQ_QB"); qb_large = e ? atoi(e) : 8; if (qb_large < 1) qb_large = 1; }
+  const int qb = (fast && !combine && q >= 64) ? qb_large : 1;
   const int gy = (q + qb - 1) / qb;
 #define ACQ_ARGS qa ? *qa : empty, Xq, q, n, k, NP, ld, ZnT, R, alpha, bounds4, ystats, p, partial, counters, val, grad, \
                  host_val, host_grad, hm, seq, combine, qb

@@ -141,6 +141,12 @@ __global__ __launch_bounds__(256) void k_cov(const double* __restrict__ Wc, int 
 // eigenvectors.  Round-robin ordering gives d/2 independent pairs per round, each handled by a
 // group of LP lanes (shuffle reductions, no LDS traffic for the dot products).
 #define JAC_THREADS 1024
+#ifdef PCABO_ACQ_TIMING
+__device__ unsigned long long g_jac_stamps[4];
+extern "C" int pcabo_debug_jacobi_stamps(unsigned long long* out4) {
+  return hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_jac_stamps), sizeof(g_jac_stamps)) == hipSuccess ? 0 : -3;
+}
+#endif
 // Warm start: if the eigenvectors V0 of the previous BO iteration are given (and orthonormal), iterate on
 // G0 = C V0 instead of C: still G = C V with V orthogonal, but the columns start almost orthogonal, so two or
 // three sweeps suffice instead of ~8.  The result does not depend on the start beyond rounding.
@@ -185,6 +191,9 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi(const double* __restrict
   const int grp = tid / LP, lane = tid % LP;
   const double tol = 1e-15;
   int sweep = 0;
+#ifdef PCABO_ACQ_TIMING
+  const unsigned long long jc0 = clock64(), jw0 = wall_clock64();
+#endif
   for (; sweep < 40; ++sweep) {
     for (int round = 0; round < de - 1; ++round) {
       if (grp < npairs) {
@@ -253,6 +262,9 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi(const double* __restrict
     __syncthreads();
     if (!rot) { ++sweep; break; }
   }
+#ifdef PCABO_ACQ_TIMING
+  if (tid == 0) { g_jac_stamps[0] = clock64() - jc0; g_jac_stamps[1] = wall_clock64() - jw0; g_jac_stamps[2] = (unsigned long long)sweep; g_jac_stamps[3] = (unsigned long long)(de - 1); }
+#endif
   // eigenvalues = column norms; write normalised columns (eigenvectors), column-major d x d
   for (int col = tid / 64; col < d; col += (int)blockDim.x / 64) {
     int l = tid & 63;

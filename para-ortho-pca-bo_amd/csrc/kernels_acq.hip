@@ -11,23 +11,22 @@
 //   u = +-(mu - best_f)/sigma ;  logEI = h(u) + log sigma
 // and the reverse-mode gradient  w = R^T v,  grad = sum_j (c_mu alpha_j + c_s w_j) dks_j/dx.
 //
-// Work decomposition (latency-bound: ~1 MFLOP per query at n = 450):
-//   k_acq_fused    grid (S, q): work-group (s, q) owns 16 rows of R (8 from the top, 8 mirrored from
-//                  the bottom -> balanced triangular work) for query q.  It recomputes ks (n*k
-//                  flops, cheaper than a launch boundary), forms its 16 entries of v by
-//                  wave-per-row shuffle reductions, its contribution R_slab^T v_slab to w, and
-//                  contracts that with dks/dx.  Because the gradient is linear in w, partial
-//                  gradients of different slabs simply add.
-//                  The S partial records of a query are then combined INSIDE the launch by the
-//                  last work-group to arrive at a per-query ticket counter (split-K style hand-off:
-//                  write-through (sc1) stores -> vmcnt(0) -> barrier -> relaxed ticket;
-//                  the last arriver does one agent-scope acquire, then plain loads).  It sums the
-//                  partials in a fixed order (deterministic), applies the scalar log-EI chain rule
-//                  and writes value/gradient to device memory and to pinned host memory; the group
-//                  finishing the last query of the launch publishes a sequence number the host
-//                  polls.  One launch per L-BFGS-B evaluation, no second kernel, no memcpy.
-//                  Query points arrive as kernel arguments when they fit (<= 3 KB) so that no
-//                  work-group has to read host memory over PCIe.
+// Work decomposition (latency- and issue-bound: ~1 MFLOP per query at n = 450, 10-15 us per launch):
+//   grid (S, q): work-group (s, q) owns SLAB rows of R (half from the top, half mirrored from the bottom -> balanced
+//   triangular work) for query q.  It recomputes ks (n*k flops, cheaper than a launch boundary), forms its entries
+//   of v, its contribution R_slab^T v_slab to w, and contracts that with dks/dx.  Because the gradient is linear in w,
+//   partial gradients of different slabs simply add.
+//   k_acq_fast<SLAB,NB>   NP = 64 NB <= 512 and k <= 40 (every headline shape): all loops static, ZnT and the R slab
+//                  read once into registers, DPP reductions, scalar row bases (see the comment at the kernel).
+//   k_acq_fused<SLAB>     any size: the same phases with run-time loops.
+//   The S partial records of a query are combined INSIDE the launch by the last work-group to arrive at a per-query
+//   ticket counter (split-K style hand-off: write-through (sc1) stores -> vmcnt(0) -> barrier -> relaxed ticket; the
+//   last arriver does one agent-scope acquire, then plain loads).  Its four waves sum the partials in a fixed order
+//   (deterministic), apply the scalar log-EI chain rule and write value/gradient to device memory and to pinned host
+//   memory, followed per query by a sequence word the host polls.  One launch per L-BFGS-B evaluation, no second
+//   kernel, no memcpy.  Query points arrive as kernel arguments when they fit (<= 3.5 KB) so that no work-group has
+//   to read host memory over PCIe.  Batches of more than 32 queries use the launch boundary instead of tickets
+//   (k_acq_combine) and, on the fast path, give each group 8 queries per load of its register tiles.
 #include "pcabo_internal.h"
 #include <cstdlib>
 

@@ -169,7 +169,8 @@ __global__ __launch_bounds__(256) void k_acq_fused(
     const double* __restrict__ ZnT, const double* __restrict__ R, const double* __restrict__ alpha,
     const double* __restrict__ bounds4, const double* __restrict__ ystats, AcqParams prm, double* partial,
     unsigned int* counters, double* __restrict__ val, double* __restrict__ grad,
-    double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq, int combine, int /*qb*/) {
+    double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq, int combine, int /*qb*/,
+    const MailPair* /*host_mail*/, MailPair* /*dev_mail*/) {
   const double inv_ls = prm.inv_ls;
   const int kernel = prm.kernel, want_grad = prm.want_grad;
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
@@ -322,7 +323,8 @@ __global__ __launch_bounds__(256) void k_acq_fast(
     const double* __restrict__ ZnT, const double* __restrict__ R, const double* __restrict__ alpha,
     const double* __restrict__ bounds4, const double* __restrict__ ystats, AcqParams prm, double* partial,
     unsigned int* counters, double* __restrict__ val, double* __restrict__ grad,
-    double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq, int combine, int qb) {
+    double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq, int combine, int qb,
+    const MailPair* host_mail, MailPair* dev_mail) {
   constexpr int NP = NB * 64;
   constexpr int CU = 10;                 // components per wave
   constexpr int RW = SLAB / 4;           // slab rows per wave
@@ -370,17 +372,71 @@ __global__ __launch_bounds__(256) void k_acq_fast(
   for (int m = 0; m < NM; ++m) { const int j = tid + 256 * m; al[m] = j < n ? alpha[j] : 0.0; }
   // ---- per query: large batches (value scoring of the raw samples, many-restart optimisation) give each group qb
   // queries, so the register tiles above are loaded once for all of them; the in-launch combine uses qb = 1
+  // ---- resident mode (dev_mail != nullptr): the kernel stays for all the evaluations of one optimize call.  Round r
+  // carries sequence number seq + r - 1; its query points arrive through the mailbox (group (0,0) polls the host's
+  // pinned copy and relays it with 16-byte stores; every group polls the device copy), so a round costs neither a launch
+  // nor a refill of the register tiles.  Every wait is bounded (PCABO_SERVER_TIMEOUT_TICKS): a group that times out
+  // simply leaves, the host then times out on the missing result and ends the call.
+  const bool server = dev_mail != nullptr;
+  int* s_srv = reinterpret_cast<int*>(s_v + SLAB + 1);        // 0 continue, 1 leave (set by wave 0)
+  unsigned long long cur_seq = seq;
+  double b_lo = 0.0, b_hi = 1.0;
+  if (server && tid < k) { b_lo = bounds4[tid]; b_hi = bounds4[PCABO_MAXD + tid]; }
+  for (;;) {                                                  // rounds (one pass unless resident)
   int q = blockIdx.y * qb;
   double* out = partial + ((size_t)q * S + s) * PSTRIDE;
+  if (server) {
+    const unsigned long long t0 = wall_clock64();
+    if (tid == 0) *s_srv = 0;
+    __syncthreads();
+    if (blockIdx.x == 0 && blockIdx.y == 0) {                 // relay: host mailbox -> device mailbox
+      for (;;) {
+        bool ok = true;
+        pcabo_u4 mine[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int pi = tid + 256 * i;
+          if (pi <= q_total * k) { mine[i] = ld_pair_sys(host_mail + pi); ok = ok && pair_tag(mine[i]) == cur_seq; }
+        }
+        if (__syncthreads_and(ok)) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) { const int pi = tid + 256 * i; if (pi <= q_total * k) st_pair_sys(dev_mail + pi, mine[i]); }
+          break;
+        }
+        if (__syncthreads_or(wall_clock64() - t0 > PCABO_SERVER_TIMEOUT_TICKS)) { if (tid == 0) *s_srv = 1; break; }
+      }
+      __syncthreads();
+    }
+    if (w == 0) {                                             // header + this query's coordinates, one snapshot each
+      for (;;) {
+        const pcabo_u4 hd = ld_pair_sys(dev_mail);
+        bool ok = pair_tag(hd) == cur_seq;
+        pcabo_u4 xv = {0u, 0u, 0u, 0u};
+        if (l < k) { xv = ld_pair_sys(dev_mail + 1 + q * k + l); ok = ok && pair_tag(xv) == cur_seq; }
+        if (__all(ok)) {
+          const int nq_round = (int)pair_value(hd);
+          if (q >= nq_round) { if (l == 0) *s_srv = 1; }      // the call is over (0) or this query's group has finished
+          else if (l < k) s_xn[l] = (pair_value(xv) - b_lo) / (b_hi - b_lo);
+          break;
+        }
+        if (__any(wall_clock64() - t0 > PCABO_SERVER_TIMEOUT_TICKS)) { if (l == 0) *s_srv = 1; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    __syncthreads();
+    if (*s_srv) return;
+  }
   for (int qi = 0; qi < qb; ++qi, ++q, out += (size_t)S * PSTRIDE) {
   if (q >= q_total) break;
   if (qi > 0) __syncthreads();          // the previous query's readers of s_xn / s_ks / s_tm / s_v are done
+  if (!server) {
   if (tid < k) {
     double lo = bounds4[tid], hi = bounds4[PCABO_MAXD + tid];
     double xv = Xq ? Xq[(size_t)q * k + tid] : qa.x[q * k + tid];
     s_xn[tid] = (xv - lo) / (hi - lo);
   }
   __syncthreads();
+  }
   STAMP(1);
   // ---- ks ------------------------------------------------------------------------------------------------------
   double xc[CU];
@@ -516,7 +572,11 @@ __global__ __launch_bounds__(256) void k_acq_fast(
   }   // queries of this group
   q = blockIdx.y * qb;                  // (combine: qb = 1)
   out = partial + ((size_t)q * S + s) * PSTRIDE;
-  acq_tail<SLAB>(combine, s_v, partial, counters, q, S, k, bounds4, ystats, prm, val, grad, host_val, host_grad, hm, seq, tid, w, l);
+  acq_tail<SLAB>(combine, s_v, partial, counters, q, S, k, bounds4, ystats, prm, val, grad, host_val, host_grad, hm, cur_seq, tid, w, l);
+  if (!server) break;
+  ++cur_seq;
+  __syncthreads();                      // the finish of this round has let go of the shared arrays
+  }   // rounds
 }
 
 // ---- scalar log-EI helper, value and derivative (botorch/acquisition/analytic.py::_log_ei_helper)
@@ -623,10 +683,30 @@ __global__ __launch_bounds__(256) void k_acq_combine(const double* __restrict__ 
                      threadIdx.x & 63);
 }
 
+// Resident mode needs every group of the grid on the chip at the same time (groups wait for one another through the
+// mailbox and the tickets): one group per CU is always possible for these kernels, so S q <= number of CUs is enough.
+bool acq_server_possible(int q, int n, int k, int NP) {
+  static int enabled = -1, cus = 0;
+  if (enabled < 0) {
+    const char* e = getenv("PCABO_ACQ_SERVER");
+    enabled = !(e && atoi(e) == 0);
+    const char* g = getenv("PCABO_ACQ_GENERIC");
+    if (g && atoi(g)) enabled = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+  }
+  if (!enabled || k > 40 || NP > 512 || q < 1 || q > PCABO_INLAUNCH_MAXQ || (size_t)q * k > PCABO_QA_MAX) return false;
+  static int slab_thr = -1;
+  if (slab_thr < 0) { const char* e = getenv("PCABO_SLAB32_NP"); slab_thr = e ? atoi(e) : 448; }
+  const int S = NP / (NP >= slab_thr ? 32 : 16);
+  return S * q <= cus;
+}
+
 void launch_acq(hipStream_t st, const QueryArgs* qa, const double* Xq, int q, int n, int k, int NP, int ld,
                 const double* ZnT, const double* R, const double* alpha, const double* bounds4, const double* ystats,
                 AcqParams p, double* partial, unsigned int* counters, double* val,
-                double* grad, double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq) {
+                double* grad, double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq,
+                const MailPair* host_mail, MailPair* dev_mail) {
   // 16 rows per work-group while S*q groups fit the 256 CUs (NP <= 384 at q = 10), 32 rows beyond that: measured
   // on MI355X (q=10, with gradient) 16 rows win at n=120/250 (22.2 vs 23.0, 26.9 vs 27.8 us), 32 rows at n=449 (34.4 vs
   // 37.3 us).  PCABO_SLAB32_NP overrides the switch point (tuning only).
@@ -641,13 +721,13 @@ void launch_acq(hipStream_t st, const QueryArgs* qa, const double* Xq, int q, in
   if (use_fast < 0) { const char* e = getenv("PCABO_ACQ_GENERIC"); use_fast = !(e && atoi(e)); }
   // large batches on the fast path: 8 queries per group share one load of the register tiles (qb); the generic
   // kernel and the in-launch combine take one query per group
-  const bool fast = use_fast && k <= 40 && nb <= 8;
+  const bool fast = use_fast && k <= 40 && nb <= 8;      // (the resident mode is only requested when this holds)
   static int qb_large = -1;
   if (qb_large < 0) { const char* e = getenv("PCABO_ACQ_QB"); qb_large = e ? atoi(e) : 8; if (qb_large < 1) qb_large = 1; }
   const int qb = (fast && !combine && q >= 64) ? qb_large : 1;
   const int gy = (q + qb - 1) / qb;
 #define ACQ_ARGS qa ? *qa : empty, Xq, q, n, k, NP, ld, ZnT, R, alpha, bounds4, ystats, p, partial, counters, val, grad, \
-                 host_val, host_grad, hm, seq, combine, qb
+                 host_val, host_grad, hm, seq, combine, qb, host_mail, dev_mail
 #define ACQ_FAST(SL, NBV)                                                                                      \
   case NBV:                                                                                                    \
     hipLaunchKernelGGL((k_acq_fast<SL, NBV>), dim3(S, gy), dim3(256),                                           \

@@ -95,6 +95,7 @@ struct pcabo_ctx {
   // pinned host
   HostMirror* hm = nullptr;
   double *hXq = nullptr, *hVal = nullptr, *hGrad = nullptr, *hSmall = nullptr;
+  MailPair *hMail = nullptr, *dMail = nullptr;   // mailbox of the resident acquisition kernel (pinned host copy, device copy)
   unsigned long long seq = 0;
   OptHelper helper;
   char err[512] = {0};
@@ -223,6 +224,10 @@ int pcabo_ctx_create(int device, int max_n, int max_d, int max_q, pcabo_ctx** ou
   HIPCHK(hipHostMalloc((void**)&ctx->hVal, Q * sizeof(double), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&ctx->hGrad, Q * d * sizeof(double), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&ctx->hSmall, (d * d + 8 * d + 64) * sizeof(double), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&ctx->hMail, PCABO_MAIL_PAIRS * sizeof(MailPair), hipHostMallocMapped | hipHostMallocCoherent));
+  memset(ctx->hMail, 0, PCABO_MAIL_PAIRS * sizeof(MailPair));
+  HIPCHK(dalloc(&ctx->dMail, PCABO_MAIL_PAIRS));
+  HIPCHK(hipMemset(ctx->dMail, 0, PCABO_MAIL_PAIRS * sizeof(MailPair)));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return PCABO_OK;
 }
@@ -236,9 +241,9 @@ int pcabo_ctx_destroy(pcabo_ctx* ctx) {
                  ctx->dC, ctx->dGbuf[0], ctx->dGbuf[1], ctx->dLam, ctx->dComps, ctx->dEvr, ctx->dZ, ctx->dK, ctx->dSweeps, ctx->dInfo,
                  ctx->dY, ctx->dYs, ctx->dYstats, ctx->dBounds4, ctx->dZnMean, ctx->dUserNB, ctx->dZnT, ctx->dAT,
                  ctx->dNrm, ctx->dGram, ctx->dL, ctx->dR, ctx->dTmp, ctx->dAlpha, ctx->dDiag, ctx->dXq, ctx->dPartial, ctx->dVal,
-                 ctx->dGrad, ctx->dZq, ctx->dXout, ctx->dCounters};
+                 ctx->dGrad, ctx->dZq, ctx->dXout, ctx->dCounters, ctx->dMail};
   for (void* p : dev) if (p) hipFree(p);
-  void* host[] = {(void*)ctx->hm, ctx->hXq, ctx->hVal, ctx->hGrad, ctx->hSmall};
+  void* host[] = {(void*)ctx->hm, ctx->hXq, ctx->hVal, ctx->hGrad, ctx->hSmall, (void*)ctx->hMail};
   for (void* p : host) if (p) hipHostFree(p);
   if (ctx->evBounds) hipEventDestroy(ctx->evBounds);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -504,6 +509,30 @@ int pcabo_logei(pcabo_ctx* ctx, const double* Xq, int q, double best_f, int maxi
   return pcabo_acq_eval(ctx, Xq, q, best_f, maximize, PCABO_ACQ_LOG_EI, val, grad);
 }
 
+// ---- resident acquisition kernel: host side of the mailbox ---------------------------------------------------------
+// One round: all cap*k coordinate pairs get the round's tag (coordinates of queries that are no longer active are
+// whatever is left in hXq), then the header (number of active queries; 0 = leave).  Value before tag everywhere.
+static void server_post(pcabo_ctx* ctx, int cap, int nq, int k, unsigned long long tag) {
+  MailPair* m = ctx->hMail;
+  const int np = cap * k;
+  for (int i = 0; i < np; ++i) { m[1 + i].v = ctx->hXq[i]; __atomic_store_n(&m[1 + i].tag, tag, __ATOMIC_RELEASE); }
+  m[0].v = (double)nq;
+  __atomic_store_n(&m[0].tag, tag, __ATOMIC_RELEASE);
+}
+static int server_wait(pcabo_ctx* ctx, int nq, unsigned long long tag) {
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned long spins = 0;
+  for (int qi = 0; qi < nq; ++qi) {
+    while (__atomic_load_n(&ctx->hm->qflag[qi], __ATOMIC_ACQUIRE) != tag) {
+      if ((++spins & 0xFFFF) == 0) {
+        double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (el > 5.0) return set_err(ctx, PCABO_ERR_TIMEOUT, "resident acquisition kernel did not answer%s", "");
+      }
+    }
+  }
+  return PCABO_OK;
+}
+
 // ---- multi-start L-BFGS-B over the device acquisition ------------------------------------------
 // All restart groups advance in lock-step: per round every still-active group asks for one joint
 // value+gradient evaluation; the points of all groups go to the device in ONE launch whose results
@@ -580,6 +609,17 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
   struct Ender { OptHelper& h; bool on; ~Ender() { if (on) h.end(); } } ender{hp, ngroups > 1};
   unsigned round_no = 0;
   std::vector<int> qoff(ngroups, -1);
+  int srv_cap = 0;                       // > 0 while a resident kernel of that many queries is in flight
+  struct ServerStop {                    // whatever way the loop is left: tell the kernel to go, wait until it has gone
+    pcabo_ctx* c; int& cap; int k;
+    void stop() {
+      if (cap <= 0) return;
+      server_post(c, cap, 0, k, ++c->seq);
+      hipStreamSynchronize(c->stream);
+      cap = 0;
+    }
+    ~ServerStop() { stop(); }
+  } server_stop{ctx, srv_cap, k};
   while (true) {
     const double ta = trace ? now() : 0.0;
     ++round_no;
@@ -598,7 +638,26 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
     }
     if (nq == 0) break;
     const double tb = trace ? now() : 0.0;
-    int rc = eval_staged(ctx, nq, p);
+    int rc;
+    if (round_no == 1 && !ctx->prof && acq_server_possible(nq, ctx->n, k, ctx->NP)) {
+      // the evaluations of this call go to ONE resident launch (see k_acq_fast): no launch and no operand refill per round
+      srv_cap = nq;
+      launch_acq(ctx->stream, nullptr, nullptr, srv_cap, ctx->n, k, ctx->NP, ctx->ld, ctx->dZnT, ctx->dR, ctx->dAlpha,
+                 ctx->dBounds4, ctx->dYstats, p, ctx->dPartial, ctx->dCounters, ctx->dVal, ctx->dGrad, ctx->hVal, ctx->hGrad,
+                 ctx->hm, ctx->seq + 1, ctx->hMail, ctx->dMail);
+      HIPCHK(hipGetLastError());
+    }
+    if (srv_cap > 0) {
+      const unsigned long long tag = ++ctx->seq;
+      server_post(ctx, srv_cap, nq, k, tag);
+      rc = server_wait(ctx, nq, tag);
+      if (rc == PCABO_ERR_TIMEOUT) {       // e.g. this thread lost the CPU for longer than the kernel waits: plain launches from here on
+        server_stop.stop();
+        rc = eval_staged(ctx, nq, p);
+      }
+    } else {
+      rc = eval_staged(ctx, nq, p);
+    }
     if (rc != PCABO_OK) return rc;
     if (trace) { const double tc = now(); t_step += tb - ta; t_eval += tc - tb; ++rounds; }
     for (int gi = 0; gi < ngroups; ++gi) {
@@ -617,6 +676,7 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
       xc[gi] = x[gi]; gc[gi] = g[gi]; fc[gi] = fval[gi]; have_cache[gi] = 1;
     }
   }
+  server_stop.stop();
   const double t_loop_end = trace ? now() : 0.0;
   // final clamp and acquisition values at the candidates (no gradient)
   for (int gi = 0; gi < ngroups; ++gi) {

@@ -14,6 +14,12 @@
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 struct QueryArgs { double x[PCABO_QA_MAX]; };
+// Mailbox of the resident ("server") acquisition kernel: (value, tag) pairs of 16 bytes.  A pair is written value
+// first, tag second (one 16-byte store on the device) and read as one 16-byte snapshot, so a matching tag implies the
+// value.  Pair 0 is the header (value = number of queries of the round, 0 = leave), pairs 1.. the query coordinates.
+struct alignas(16) MailPair { double v; unsigned long long tag; };
+#define PCABO_MAIL_PAIRS (1 + PCABO_QA_MAX)
+#define PCABO_SERVER_TIMEOUT_TICKS 200000000ull // 2 s of wall_clock64 (100 MHz): every wait in the kernel is bounded
 
 #ifdef __HIPCC__
 // fp64 reciprocal / reciprocal square root from the hardware estimate (v_rcp_f64 / v_rsq_f64) plus two
@@ -59,6 +65,19 @@ struct HostMirror {
 
 // ---- launchers (defined in kernels_*.hip); all asynchronous on `s` -------------------
 #if defined(__HIPCC__)
+// 16-byte loads / stores that go to the fabric (system scope: no L1/L2 copy is trusted or left behind)
+typedef unsigned int pcabo_u4 __attribute__((ext_vector_type(4)));
+__device__ inline pcabo_u4 ld_pair_sys(const void* p) {
+  pcabo_u4 r;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
+  return r;
+}
+__device__ inline void st_pair_sys(void* p, pcabo_u4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ inline unsigned long long pair_tag(pcabo_u4 v) { return ((unsigned long long)v.w << 32) | v.z; }
+__device__ inline double pair_value(pcabo_u4 v) { return __hiloint2double((int)v.y, (int)v.x); }
+
 // Wave-wide sum without LDS traffic.  `__shfl_xor` compiles to ds_bpermute_b32 (two per double, each followed by an
 // lgkmcnt wait: ~100 cycles of dependent latency per step); in a kernel whose whole budget is ~15 us the reductions
 // were the largest single item.  DPP steps stay inside the VALU: quad_perm x2, row_half_mirror, row_mirror leave the
@@ -108,6 +127,9 @@ void launch_alpha(hipStream_t s, const double* R, const double* ys, int n, int N
 void launch_acq(hipStream_t s, const QueryArgs* qa, const double* Xq, int q, int n, int k, int NP, int ld,
                 const double* ZnT, const double* R, const double* alpha, const double* bounds4, const double* ystats,
                 AcqParams p, double* partial, unsigned int* counters, double* val,
-                double* grad, double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq);
+                double* grad, double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq,
+                const MailPair* host_mail = nullptr, MailPair* dev_mail = nullptr);
+// resident mode available for this shape? (fast path + every group of the grid co-resident)
+bool acq_server_possible(int q, int n, int k, int NP);
 void launch_inverse_map(hipStream_t s, const double* z, const double* comps, const double* data_mean,
                         const double* pca_mean, int k, int d, double* x);

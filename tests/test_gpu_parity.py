@@ -655,3 +655,31 @@ def test_noise_prefetch_does_not_change_a_run(native):
         runs.append((np.array(opt.f_evals), np.vstack(opt.x_evals)))
     for f, x in runs[1:]:
         assert np.array_equal(f, runs[0][0]) and np.array_equal(x, runs[0][1])
+
+
+def test_resident_kernel_reproduces_per_round_launches(native):
+    """The resident ("server") mode of the acquisition kernel - one launch per optimize call, query points through the
+    mailbox - runs the same arithmetic as one launch per evaluation: whole runs must agree bit for bit
+    (PCABO_ACQ_SERVER is read once per process, hence the subprocesses)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, os, hashlib
+import numpy as np
+sys.path.insert(0, os.path.join(%r, "para-ortho-pca-bo_amd"))
+from Algorithms import PCA_BO, Vanilla_BO
+from pcabo.bbob import BBOBProblem
+out = []
+for cls, kw, dim, budget, ndoe in ((PCA_BO, {}, 10, 70, 30), (PCA_BO, {}, 40, 150, 120), (Vanilla_BO, {}, 6, 40, 18)):
+    opt = cls(budget=budget, n_DoE=ndoe, random_seed=15000 + dim, maximization=False, **kw)
+    opt(BBOBProblem(15, 1, dim))
+    out.append(hashlib.md5(np.array(opt.f_evals).tobytes() + np.vstack(opt.x_evals).tobytes()).hexdigest())
+print("DIGESTS", " ".join(out))
+''' % root
+    res = []
+    for mode in ("1", "0"):
+        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PCABO_ACQ_SERVER=mode), capture_output=True,
+                           text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        res.append([l for l in p.stdout.splitlines() if l.startswith("DIGESTS")][-1])
+    assert res[0] == res[1]

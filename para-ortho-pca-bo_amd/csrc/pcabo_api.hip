@@ -17,6 +17,11 @@
 #include <cstring>
 #include <new>
 #include <vector>
+#include <dirent.h>
+#include <fcntl.h>
+#include <signal.h>
+#include <cerrno>
+#include <unistd.h>
 
 #define PCABO_ABI_VERSION 1
 #define PROF_GROUPS 6
@@ -96,8 +101,11 @@ struct pcabo_ctx {
   HostMirror* hm = nullptr;
   double *hXq = nullptr, *hVal = nullptr, *hGrad = nullptr, *hSmall = nullptr;
   MailPair *hMail = nullptr, *dMail = nullptr;   // mailbox of the resident acquisition kernel (pinned host copy, device copy)
+  int srv_penalty = 0;                   // > 0: the next calls use plain launches (the GPU looked shared, see pcabo_optimize_acqf)
   unsigned long long seq = 0;
   OptHelper helper;
+  bool registered = false;
+  bool alone = true; int alone_age = 0;   // cached answer of presence_alone(), refreshed every few calls
   char err[512] = {0};
   // profiling
   bool prof = false;
@@ -108,6 +116,50 @@ struct pcabo_ctx {
   int64_t prof_launches[PROF_GROUPS] = {0};
   double prof_bytes[PROF_GROUPS] = {0}, prof_flops[PROF_GROUPS] = {0};
 };
+
+// ---- who else drives this GPU?  ---------------------------------------------------------------------------------
+// The resident acquisition kernel holds most of the chip for a whole optimize call.  That is the fastest way to run ONE
+// process per GPU (the contract of this package), but when several processes share a device their resident kernels can
+// only run one after the other, whole calls at a time (measured: 4 processes 140 instead of 336 it/s in aggregate).
+// Every process therefore leaves a marker /dev/shm/pcabo.<device>.<pid> while it has a context on a device, and the
+// resident mode is used only by a process that finds itself alone there (markers of dead processes are removed).
+static std::mutex g_presence_mu;
+static int g_presence_refs[64] = {0};
+static void presence_path(char* buf, size_t n, int device, long pid) { snprintf(buf, n, "/dev/shm/pcabo.%d.%ld", device, pid); }
+static void presence_register(int device) {
+  if (device < 0 || device >= 64) return;
+  std::lock_guard<std::mutex> lk(g_presence_mu);
+  if (g_presence_refs[device]++ == 0) {
+    char path[128]; presence_path(path, sizeof(path), device, (long)getpid());
+    int fd = open(path, O_CREAT | O_WRONLY, 0644);
+    if (fd >= 0) close(fd);
+  }
+}
+static void presence_unregister(int device) {
+  if (device < 0 || device >= 64) return;
+  std::lock_guard<std::mutex> lk(g_presence_mu);
+  if (g_presence_refs[device] > 0 && --g_presence_refs[device] == 0) {
+    char path[128]; presence_path(path, sizeof(path), device, (long)getpid());
+    unlink(path);
+  }
+}
+static bool presence_alone(int device) {
+  DIR* d = opendir("/dev/shm");
+  if (!d) return true;
+  char prefix[64]; snprintf(prefix, sizeof(prefix), "pcabo.%d.", device);
+  const size_t pl = strlen(prefix);
+  bool alone = true;
+  while (struct dirent* e = readdir(d)) {
+    if (strncmp(e->d_name, prefix, pl) != 0) continue;
+    const long pid = atol(e->d_name + pl);
+    if (pid <= 0 || pid == (long)getpid()) continue;
+    if (kill((pid_t)pid, 0) == 0 || errno == EPERM) { alone = false; break; }
+    char path[300]; snprintf(path, sizeof(path), "/dev/shm/%s", e->d_name);
+    unlink(path);                                   // left behind by a process that is gone
+  }
+  closedir(d);
+  return alone;
+}
 
 static int set_err(pcabo_ctx* c, int code, const char* fmt, const char* a = "", int v = 0) {
   if (c) snprintf(c->err, sizeof(c->err), fmt, a, v);
@@ -192,6 +244,7 @@ int pcabo_ctx_create(int device, int max_n, int max_d, int max_q, pcabo_ctx** ou
   ctx->Scap = ctx->NPcap / PCABO_SLAB;
   HIPCHK(hipSetDevice(device));
   HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  presence_register(ctx->device); ctx->registered = true;
   HIPCHK(hipEventCreateWithFlags(&ctx->evBounds, hipEventDisableTiming));
   const size_t N = ctx->NPcap, D = ctx->DPcap, n = max_n, d = max_d, Q = max_q;
   HIPCHK(dalloc(&ctx->dX, n * d));       HIPCHK(dalloc(&ctx->dNoise, n * d));
@@ -248,6 +301,7 @@ int pcabo_ctx_destroy(pcabo_ctx* ctx) {
   if (ctx->evBounds) hipEventDestroy(ctx->evBounds);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   ctx->helper.shutdown();
+  if (ctx->registered) presence_unregister(ctx->device);
   delete ctx;
   return PCABO_OK;
 }
@@ -639,7 +693,9 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
     if (nq == 0) break;
     const double tb = trace ? now() : 0.0;
     int rc;
-    if (round_no == 1 && !ctx->prof && acq_server_possible(nq, ctx->n, k, ctx->NP)) {
+    if (round_no == 1 && (ctx->alone_age++ & 7) == 0) ctx->alone = presence_alone(ctx->device);
+    if (round_no == 1 && ctx->srv_penalty > 0) --ctx->srv_penalty;
+    else if (round_no == 1 && ctx->alone && !ctx->prof && acq_server_possible(nq, ctx->n, k, ctx->NP)) {
       // the evaluations of this call go to ONE resident launch (see k_acq_fast): no launch and no operand refill per round
       srv_cap = nq;
       launch_acq(ctx->stream, nullptr, nullptr, srv_cap, ctx->n, k, ctx->NP, ctx->ld, ctx->dZnT, ctx->dR, ctx->dAlpha,
@@ -649,11 +705,18 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
     }
     if (srv_cap > 0) {
       const unsigned long long tag = ++ctx->seq;
+      const double tp = now();
       server_post(ctx, srv_cap, nq, k, tag);
       rc = server_wait(ctx, nq, tag);
       if (rc == PCABO_ERR_TIMEOUT) {       // e.g. this thread lost the CPU for longer than the kernel waits: plain launches from here on
         server_stop.stop();
+        ctx->srv_penalty = 1000;
         rc = eval_staged(ctx, nq, p);
+      } else if (round_no == 1 && now() - tp > 1e-3) {
+        // A first answer after more than a millisecond (normal: ~20 us) means the grid could not become resident at once:
+        // another process holds the GPU with its own resident kernel.  Resident kernels of different processes then run
+        // one after the other, whole calls at a time; plain launches interleave much better, so use them for a while.
+        ctx->srv_penalty = 40;
       }
     } else {
       rc = eval_staged(ctx, nq, p);

@@ -28,6 +28,7 @@
 //   to read host memory over PCIe.  Batches of more than 32 queries use the launch boundary instead of tickets
 //   (k_acq_combine) and, on the fast path, give each group 8 queries per load of its register tiles.
 #include "pcabo_internal.h"
+#include <algorithm>
 #include <cstdlib>
 
 #define PSTRIDE (2 + 2 * PCABO_MAXD)   // doubles per (query, slab) partial record
@@ -96,6 +97,8 @@ __device__ inline void grad_partial_sum(const double* base, int S, int c, int fi
 
 __device__ void acq_finish_scalar(const double* base, int S, int q, const double* ystats, const AcqParams& p, double* val,
                                   double* host_val, double* coef, int lane);
+__device__ void acq_scalar_core(double vv, double mus, int q, double ym, double ysd, const AcqParams& p, double* val,
+                                double* host_val, double* coef, int l);
 // ---- in-launch combine: the last slab group of a query to arrive finishes it ---------------------------
 template <int SLAB>
 __device__ inline void acq_tail(int combine, double* s_v, double* partial, unsigned int* counters, int q, int S, int k,
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(256) void k_acq_fused(
     const double* __restrict__ bounds4, const double* __restrict__ ystats, AcqParams prm, double* partial,
     unsigned int* counters, double* __restrict__ val, double* __restrict__ grad,
     double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq, int combine, int /*qb*/,
-    const MailPair* /*host_mail*/, MailPair* /*dev_mail*/) {
+    const MailPair* /*host_mail*/, MailPair* /*dev_mail*/, MailPair* /*part_pairs*/) {
   const double inv_ls = prm.inv_ls;
   const int kernel = prm.kernel, want_grad = prm.want_grad;
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
@@ -303,6 +306,159 @@ __global__ __launch_bounds__(256) void k_acq_fused(
   acq_tail<SLAB>(combine, s_v, partial, counters, q, S, k, bounds4, ystats, prm, val, grad, host_val, host_grad, hm, seq, tid, w, l);
 }
 
+// ---- resident mode: the dedicated finishing group of a query -----------------------------------------------------
+// In resident mode the slab groups publish their partial records as (value, tag) pairs and go straight to the next
+// round; group (S, q) of the grid does nothing but finish query q.  It polls the records themselves (the data arrive
+// with their tags: no ticket, no drain, no acquire), and it starts the scalar log-EI chain as soon as the |v|^2 / mu_s
+// pairs are there - about 1.7 us before the gradient pairs - so the chain overlaps with the rest of the round:
+//   wave 0     |v|^2, mu_s of every slab (one lane per slab, S <= 64) -> sums -> scalar chain -> value, coefficients
+//   wave 1-3   gradient pairs of slabs w-1, w+2, ... (items spread over the 64 lanes, staged in LDS), then lanes over
+//              components add them in slab order: the same partial sums as grad_partial_sum
+//   wave 0     gradient = (c_mu gm + c_sg gs) / range, results and sequence word to the host.
+// Returns false on a timeout (the group then leaves the kernel).
+#define FIN_STAGE_PER_WAVE (11 * 2 * 40)      // doubles: ceil(32 / 3) slabs x {gs, gm} x k <= 40
+__device__ inline bool acq_server_finisher(const MailPair* rec, int S, int k, int q, unsigned long long seq,
+                                           const double* ystats, const AcqParams& prm, double* val, double* grad,
+                                           double* host_val, double* host_grad, HostMirror* hm, double rng_c,
+                                           double* s_fin, double* s_coef, double* s_stage, int* s_srv,
+                                           unsigned long long t0, int w, int l) {
+  if (w == 0) {
+    const double ym = ystats[0], ysd = ystats[1];
+    const void* ptr[8];
+    pcabo_u4 o[8];
+    const MailPair* mine = rec + (size_t)(l < S ? l : 0) * PSTRIDE;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) ptr[t] = mine + (t & 1);
+    for (;;) {
+      ld_pairs_sys8(ptr, o);
+      const bool ok = pair_tag(o[0]) == seq && pair_tag(o[1]) == seq;
+      if (__all(ok)) break;
+      if (__any(wall_clock64() - t0 > PCABO_SERVER_TIMEOUT_TICKS)) { if (l == 0) *s_srv = 1; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    double vv = l < S ? pair_value(o[0]) : 0.0, mus = l < S ? pair_value(o[1]) : 0.0;
+    vv = wave_sum(vv);
+    mus = wave_sum(mus);
+    acq_scalar_core(vv, mus, q, ym, ysd, prm, val, host_val, s_coef, l);
+  } else if (prm.want_grad) {
+    const int first = w - 1;
+    const int ns = first < S ? (S - first + 2) / 3 : 0;       // slabs first, first + 3, ...
+    const int total = ns * 2 * k;
+    double* stage = s_stage + (size_t)(w - 1) * FIN_STAGE_PER_WAVE;   // [slab][gs|gm][c]
+    for (int i0 = 0; i0 < total; i0 += 512) {
+      const void* ptr[8];
+      int item[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int i = i0 + l + 64 * t;
+        item[t] = i < total ? i : -1;
+        const int ii = i < total ? i : 0;
+        const int st = ii / (2 * k), rem = ii - st * 2 * k, which = rem >= k, c = rem - which * k;
+        ptr[t] = rec + (size_t)(first + 3 * st) * PSTRIDE + 2 + which * PCABO_MAXD + c;
+      }
+      pcabo_u4 o[8];
+      for (;;) {
+        ld_pairs_sys8(ptr, o);
+        bool ok = true;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) ok = ok && (item[t] < 0 || pair_tag(o[t]) == seq);
+        if (__all(ok)) break;
+        if (__any(wall_clock64() - t0 > PCABO_SERVER_TIMEOUT_TICKS)) { if (l == 0) *s_srv = 1; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) if (item[t] >= 0) stage[item[t]] = pair_value(o[t]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (l < k) {
+      double gs = 0.0, gm = 0.0;
+      for (int st = 0; st < ns; ++st) { gs += stage[st * 2 * k + l]; gm += stage[st * 2 * k + k + l]; }
+      s_fin[(w - 1) * 2 * PCABO_MAXD + l] = gs;
+      s_fin[(w - 1) * 2 * PCABO_MAXD + PCABO_MAXD + l] = gm;
+    }
+  }
+  __syncthreads();
+  if (*s_srv) return false;
+  if (w == 0) {
+    if (prm.want_grad && l < k) {
+      const double c_mu = s_coef[0], c_sg = s_coef[1];
+      const double gs = (s_fin[l] + s_fin[2 * PCABO_MAXD + l]) + s_fin[4 * PCABO_MAXD + l];
+      const double gm = (s_fin[PCABO_MAXD + l] + s_fin[3 * PCABO_MAXD + l]) + s_fin[5 * PCABO_MAXD + l];
+      const double g = __fma_rn(c_mu, gm, c_sg * gs) / rng_c;
+      grad[(size_t)q * k + l] = g;
+      if (host_grad) host_grad[(size_t)q * k + l] = g;
+    }
+    if (hm && l == 0)
+      __hip_atomic_store(const_cast<unsigned long long*>(&hm->qflag[q]), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  return true;
+}
+
+// Resident finishing groups: group (S, q) of the resident grid.  The whole role lives in this function, entered at the
+// very top of k_acq_fast before any register tile exists, so the kernel's register allocation is the maximum of the
+// two roles, not their sum.  (A separate kernel on a second stream would be simpler, but two streams of one process may
+// share a hardware queue, and then the two kernels wait for each other until they time out.)  Group (S, 0) also relays
+// the round's mailbox from the host's pinned copy to the device copy that everybody else polls.
+#define FIN_LDS_DOUBLES (6 * PCABO_MAXD + 2 + 3 * FIN_STAGE_PER_WAVE + 2)
+__device__ __noinline__ void acq_server_finish_main(double* s_mem, const MailPair* host_mail, MailPair* dev_mail, int npairs,
+                                                    const MailPair* part_pairs, int S, int k, int q,
+                                                    const double* __restrict__ bounds4, const double* __restrict__ ystats,
+                                                    const AcqParams& prm, double* val, double* grad, double* host_val,
+                                                    double* host_grad, HostMirror* hm, unsigned long long seq) {
+  double* s_fin = s_mem;
+  int* s_srvp = reinterpret_cast<int*>(s_mem + FIN_LDS_DOUBLES - 1);
+  const int tid = threadIdx.x, l = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  double rng_c = 1.0;
+  if (tid < k) rng_c = bounds4[PCABO_MAXD + tid] - bounds4[tid];
+  for (unsigned long long cur_seq = seq;; ++cur_seq) {
+    const unsigned long long t0 = wall_clock64();
+    if (tid == 0) *s_srvp = 0;
+    __syncthreads();
+    if (q == 0) {                                                // relay: host mailbox -> device mailbox
+      for (;;) {
+        bool ok = true;
+        pcabo_u4 mine[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int pi = tid + 256 * i;
+          if (pi <= npairs) { mine[i] = ld_pair_sys(host_mail + pi); ok = ok && pair_tag(mine[i]) == cur_seq; }
+        }
+        if (__syncthreads_and(ok)) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) { const int pi = tid + 256 * i; if (pi <= npairs) st_pair_sys(dev_mail + pi, mine[i]); }
+          break;
+        }
+        if (__syncthreads_or(wall_clock64() - t0 > PCABO_SERVER_TIMEOUT_TICKS)) { if (tid == 0) *s_srvp = 1; break; }
+      }
+      __syncthreads();
+    }
+    if (w == 0) {                                               // header of the round: how many queries are still active
+      for (;;) {
+        const pcabo_u4 hd = ld_pair_sys(dev_mail);
+        if (__all(pair_tag(hd) == cur_seq)) { if (q >= (int)pair_value(hd) && l == 0) *s_srvp = 1; break; }
+        if (__any(wall_clock64() - t0 > PCABO_SERVER_TIMEOUT_TICKS)) { if (l == 0) *s_srvp = 1; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    __syncthreads();
+    if (*s_srvp) return;
+    if (!acq_server_finisher(part_pairs + (size_t)q * S * PSTRIDE, S, k, q, cur_seq, ystats, prm, val, grad, host_val,
+                             host_grad, hm, rng_c, s_fin, s_fin + 6 * PCABO_MAXD, s_fin + 6 * PCABO_MAXD + 2, s_srvp, t0, w, l))
+      return;
+    __syncthreads();
+  }
+}
+
+// number of slab groups per query that launch_acq uses for this size
+int acq_slabs(int NP) {
+  static int slab_thr = -1;
+  if (slab_thr < 0) { const char* e = getenv("PCABO_SLAB32_NP"); slab_thr = e ? atoi(e) : 448; }
+  return NP / (NP >= slab_thr ? 32 : 16);
+}
+
 // ---- fast path: NP = 64 NB <= 512 and k <= 40, everything static ---------------------------------------------
 // The generic kernel above re-reads its operands (ZnT for ks and again for the gradient contraction, the R slab
 // row-wise for v and again column-wise for w) and pays an exposed round trip per loop trip.  Here trip counts are
@@ -324,7 +480,7 @@ __global__ __launch_bounds__(256) void k_acq_fast(
     const double* __restrict__ bounds4, const double* __restrict__ ystats, AcqParams prm, double* partial,
     unsigned int* counters, double* __restrict__ val, double* __restrict__ grad,
     double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq, int combine, int qb,
-    const MailPair* host_mail, MailPair* dev_mail) {
+    const MailPair* host_mail, MailPair* dev_mail, MailPair* part_pairs) {
   constexpr int NP = NB * 64;
   constexpr int CU = 10;                 // components per wave
   constexpr int RW = SLAB / 4;           // slab rows per wave
@@ -340,7 +496,13 @@ __global__ __launch_bounds__(256) void k_acq_fast(
   double* s_p4 = s_v + SLAB + 2;     // 4 NP per-wave partials (squared distances, then w_j)
   const int tid = threadIdx.x, l = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int s = blockIdx.x, S = gridDim.x;
+  const bool server = dev_mail != nullptr;                      // resident mode, see below
+  const int s = blockIdx.x, S = server ? (int)gridDim.x - 1 : (int)gridDim.x;
+  if (server && s == S) {                                        // the finishing group of query blockIdx.y
+    acq_server_finish_main(s_dyn, host_mail, dev_mail, q_total * k, part_pairs, S, k, blockIdx.y, bounds4, ystats, prm,
+                           val, grad, host_val, host_grad, hm, seq);
+    return;
+  }
   STAMP(0);
 
   // ---- every global operand, issued before anything waits ---------------------------------------------------
@@ -373,11 +535,10 @@ __global__ __launch_bounds__(256) void k_acq_fast(
   // ---- per query: large batches (value scoring of the raw samples, many-restart optimisation) give each group qb
   // queries, so the register tiles above are loaded once for all of them; the in-launch combine uses qb = 1
   // ---- resident mode (dev_mail != nullptr): the kernel stays for all the evaluations of one optimize call.  Round r
-  // carries sequence number seq + r - 1; its query points arrive through the mailbox (group (0,0) polls the host's
-  // pinned copy and relays it with 16-byte stores; every group polls the device copy), so a round costs neither a launch
+  // carries sequence number seq + r - 1; its query points arrive through the mailbox (group 0 of k_acq_server_finish polls the
+  // host's pinned copy and relays it with 16-byte stores; every group polls the device copy), so a round costs neither a launch
   // nor a refill of the register tiles.  Every wait is bounded (PCABO_SERVER_TIMEOUT_TICKS): a group that times out
   // simply leaves, the host then times out on the missing result and ends the call.
-  const bool server = dev_mail != nullptr;
   int* s_srv = reinterpret_cast<int*>(s_v + SLAB + 1);        // 0 continue, 1 leave (set by wave 0)
   unsigned long long cur_seq = seq;
   double b_lo = 0.0, b_hi = 1.0;
@@ -389,24 +550,6 @@ __global__ __launch_bounds__(256) void k_acq_fast(
     const unsigned long long t0 = wall_clock64();
     if (tid == 0) *s_srv = 0;
     __syncthreads();
-    if (blockIdx.x == 0 && blockIdx.y == 0) {                 // relay: host mailbox -> device mailbox
-      for (;;) {
-        bool ok = true;
-        pcabo_u4 mine[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int pi = tid + 256 * i;
-          if (pi <= q_total * k) { mine[i] = ld_pair_sys(host_mail + pi); ok = ok && pair_tag(mine[i]) == cur_seq; }
-        }
-        if (__syncthreads_and(ok)) {
-#pragma unroll
-          for (int i = 0; i < 2; ++i) { const int pi = tid + 256 * i; if (pi <= q_total * k) st_pair_sys(dev_mail + pi, mine[i]); }
-          break;
-        }
-        if (__syncthreads_or(wall_clock64() - t0 > PCABO_SERVER_TIMEOUT_TICKS)) { if (tid == 0) *s_srv = 1; break; }
-      }
-      __syncthreads();
-    }
     if (w == 0) {                                             // header + this query's coordinates, one snapshot each
       for (;;) {
         const pcabo_u4 hd = ld_pair_sys(dev_mail);
@@ -426,6 +569,7 @@ __global__ __launch_bounds__(256) void k_acq_fast(
     __syncthreads();
     if (*s_srv) return;
   }
+  MailPair* pout = server ? part_pairs + ((size_t)q * S + s) * PSTRIDE : nullptr;
   for (int qi = 0; qi < qb; ++qi, ++q, out += (size_t)S * PSTRIDE) {
   if (q >= q_total) break;
   if (qi > 0) __syncthreads();          // the previous query's readers of s_xn / s_ks / s_tm / s_v are done
@@ -513,7 +657,10 @@ __global__ __launch_bounds__(256) void k_acq_fast(
     }
     vv = wave_sum(vv);
     mu = wave_sum(mu);
-    if (l == 0) { st_wt(out + 0, vv); st_wt(out + 1, mu); }
+    if (l == 0) {
+      if (server) { st_pair_sys(pout + 0, make_pair(vv, cur_seq)); st_pair_sys(pout + 1, make_pair(mu, cur_seq)); }
+      else { st_wt(out + 0, vv); st_wt(out + 1, mu); }
+    }
   }
   if (want_grad) {
   // ---- w_j (slab part) = sum_{i in slab} R[i][j] v_i: per-wave partials from the same registers -----------------
@@ -564,7 +711,10 @@ __global__ __launch_bounds__(256) void k_acq_fast(
       const int c = w + 4 * u;
       if (c < k) {                          // wave-uniform
         const double a = wave_sum(gs[u]), b2 = wave_sum(gm[u]);
-        if (l == 0) { st_wt(out + 2 + c, a); st_wt(out + 2 + PCABO_MAXD + c, b2); }
+        if (l == 0) {
+          if (server) { st_pair_sys(pout + 2 + c, make_pair(a, cur_seq)); st_pair_sys(pout + 2 + PCABO_MAXD + c, make_pair(b2, cur_seq)); }
+          else { st_wt(out + 2 + c, a); st_wt(out + 2 + PCABO_MAXD + c, b2); }
+        }
       }
     }
   }
@@ -572,8 +722,10 @@ __global__ __launch_bounds__(256) void k_acq_fast(
   }   // queries of this group
   q = blockIdx.y * qb;                  // (combine: qb = 1)
   out = partial + ((size_t)q * S + s) * PSTRIDE;
-  acq_tail<SLAB>(combine, s_v, partial, counters, q, S, k, bounds4, ystats, prm, val, grad, host_val, host_grad, hm, cur_seq, tid, w, l);
-  if (!server) break;
+  if (!server) {
+    acq_tail<SLAB>(combine, s_v, partial, counters, q, S, k, bounds4, ystats, prm, val, grad, host_val, host_grad, hm, cur_seq, tid, w, l);
+    break;
+  }
   ++cur_seq;
   __syncthreads();                      // the finish of this round has let go of the shared arrays
   }   // rounds
@@ -608,16 +760,10 @@ __device__ inline void log_ei_helper(double u, double* h, double* dh) {
   }
 }
 
-// Scalar chain of one query (one wave): slab sums of |v|^2 and mu_s -> mean, sigma, u -> value and the two
-// coefficients of the gradient's chain rule.  coef (LDS or registers' spill target) receives {c_mu, c_sg}.
-__device__ void acq_finish_scalar(const double* base, int S, int q, const double* ystats, const AcqParams& p, double* val,
-                                  double* host_val, double* coef, int l) {
-  const double ym = ystats[0], ysd = ystats[1];            // issued with the partial loads, not after the reductions
-  double vv = 0.0, mus = 0.0;
-  for (int s = l; s < S; s += 64) { vv += base[(size_t)s * PSTRIDE]; mus += base[(size_t)s * PSTRIDE + 1]; }
-  vv = wave_sum(vv);
-  mus = wave_sum(mus);
-  STAMP_FIN(11);
+// Scalar chain of one query (one wave): mean, sigma, u -> value and the two coefficients of the gradient's chain
+// rule, from the summed |v|^2 and mu_s.  coef receives {c_mu, c_sg}.
+__device__ void acq_scalar_core(double vv, double mus, int q, double ym, double ysd, const AcqParams& p, double* val,
+                                double* host_val, double* coef, int l) {
   const double mu = ym + ysd * mus;
   double var = (1.0 - vv) * (ysd * ysd);
   bool clamped = false;
@@ -647,6 +793,18 @@ __device__ void acq_finish_scalar(const double* base, int S, int q, const double
     coef[1] = clamped ? 0.0 : (dv_dsig - dv_du * u / sigma) * (-(ysd * ysd) / sigma);
   }
   STAMP_FIN(12);
+}
+
+// The same, reading the slab sums from the partial records (lanes over slabs, S <= 128).
+__device__ void acq_finish_scalar(const double* base, int S, int q, const double* ystats, const AcqParams& p, double* val,
+                                  double* host_val, double* coef, int l) {
+  const double ym = ystats[0], ysd = ystats[1];            // issued with the partial loads, not after the reductions
+  double vv = 0.0, mus = 0.0;
+  for (int s = l; s < S; s += 64) { vv += base[(size_t)s * PSTRIDE]; mus += base[(size_t)s * PSTRIDE + 1]; }
+  vv = wave_sum(vv);
+  mus = wave_sum(mus);
+  STAMP_FIN(11);
+  acq_scalar_core(vv, mus, q, ym, ysd, p, val, host_val, coef, l);
 }
 
 // One query, one wave (the large-batch combine pass): scalar chain, then the gradient from all slabs in order.
@@ -699,14 +857,14 @@ bool acq_server_possible(int q, int n, int k, int NP) {
   static int slab_thr = -1;
   if (slab_thr < 0) { const char* e = getenv("PCABO_SLAB32_NP"); slab_thr = e ? atoi(e) : 448; }
   const int S = NP / (NP >= slab_thr ? 32 : 16);
-  return S * q <= cus;
+  return (S + 1) * q <= cus && S <= 32;      // slab groups + one finishing group per query (k_acq_server_finish)
 }
 
 void launch_acq(hipStream_t st, const QueryArgs* qa, const double* Xq, int q, int n, int k, int NP, int ld,
                 const double* ZnT, const double* R, const double* alpha, const double* bounds4, const double* ystats,
                 AcqParams p, double* partial, unsigned int* counters, double* val,
                 double* grad, double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq,
-                const MailPair* host_mail, MailPair* dev_mail) {
+                const MailPair* host_mail, MailPair* dev_mail, MailPair* part_pairs) {
   // 16 rows per work-group while S*q groups fit the 256 CUs (NP <= 384 at q = 10), 32 rows beyond that: measured
   // on MI355X (q=10, with gradient) 16 rows win at n=120/250 (22.2 vs 23.0, 26.9 vs 27.8 us), 32 rows at n=449 (34.4 vs
   // 37.3 us).  PCABO_SLAB32_NP overrides the switch point (tuning only).
@@ -727,11 +885,12 @@ void launch_acq(hipStream_t st, const QueryArgs* qa, const double* Xq, int q, in
   const int qb = (fast && !combine && q >= 64) ? qb_large : 1;
   const int gy = (q + qb - 1) / qb;
 #define ACQ_ARGS qa ? *qa : empty, Xq, q, n, k, NP, ld, ZnT, R, alpha, bounds4, ystats, p, partial, counters, val, grad, \
-                 host_val, host_grad, hm, seq, combine, qb, host_mail, dev_mail
+                 host_val, host_grad, hm, seq, combine, qb, host_mail, dev_mail, part_pairs
+  const int FIN_LDS = 6 * PCABO_MAXD + 2;   // finishing group's LDS beyond s_v
 #define ACQ_FAST(SL, NBV)                                                                                      \
   case NBV:                                                                                                    \
-    hipLaunchKernelGGL((k_acq_fast<SL, NBV>), dim3(S, gy), dim3(256),                                           \
-                       (size_t)(3 * NBV * 64 + PCABO_MAXD + SL + 2 + (4 * NBV * 64 > 6 * PCABO_MAXD + 2 ? 4 * NBV * 64 : 6 * PCABO_MAXD + 2)) * sizeof(double), st, ACQ_ARGS); \
+    hipLaunchKernelGGL((k_acq_fast<SL, NBV>), dim3(S + (dev_mail ? 1 : 0), gy), dim3(256),                                           \
+                       (size_t)std::max<int>(3 * NBV * 64 + PCABO_MAXD + SL + 2 + (4 * NBV * 64 > FIN_LDS ? 4 * NBV * 64 : FIN_LDS), dev_mail ? FIN_LDS_DOUBLES : 0) * sizeof(double), st, ACQ_ARGS); \
     break;
   if (fast) {
     if (slab == 16) {

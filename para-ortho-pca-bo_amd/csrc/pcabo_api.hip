@@ -101,6 +101,7 @@ struct pcabo_ctx {
   HostMirror* hm = nullptr;
   double *hXq = nullptr, *hVal = nullptr, *hGrad = nullptr, *hSmall = nullptr;
   MailPair *hMail = nullptr, *dMail = nullptr;   // mailbox of the resident acquisition kernel (pinned host copy, device copy)
+  MailPair* dPairs = nullptr;            // its partial records as (value, tag) pairs: 32 queries x 32 slabs
   int srv_penalty = 0;                   // > 0: the next calls use plain launches (the GPU looked shared, see pcabo_optimize_acqf)
   unsigned long long seq = 0;
   OptHelper helper;
@@ -280,8 +281,20 @@ int pcabo_ctx_create(int device, int max_n, int max_d, int max_q, pcabo_ctx** ou
   HIPCHK(hipHostMalloc((void**)&ctx->hMail, PCABO_MAIL_PAIRS * sizeof(MailPair), hipHostMallocMapped | hipHostMallocCoherent));
   memset(ctx->hMail, 0, PCABO_MAIL_PAIRS * sizeof(MailPair));
   HIPCHK(dalloc(&ctx->dMail, PCABO_MAIL_PAIRS));
-  HIPCHK(hipMemset(ctx->dMail, 0, PCABO_MAIL_PAIRS * sizeof(MailPair)));
+  HIPCHK(hipMemsetAsync(ctx->dMail, 0, PCABO_MAIL_PAIRS * sizeof(MailPair), ctx->stream));
+  {
+    const size_t np = (size_t)PCABO_INLAUNCH_MAXQ * 32 * (2 + 2 * PCABO_MAXD);
+    HIPCHK(dalloc(&ctx->dPairs, np));
+    HIPCHK(hipMemsetAsync(ctx->dPairs, 0, np * sizeof(MailPair), ctx->stream));   // on OUR stream: a memset on the
+    // null stream is not ordered with the non-blocking streams the resident kernels run on
+  }
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  // Sequence numbers double as mailbox tags.  Memory handed out by the allocator may come from a context that was
+  // destroyed earlier in this process, so every context numbers from its own base: a stale tag can never match.
+  {
+    static std::atomic<unsigned long long> ctx_counter{0};
+    ctx->seq = ((unsigned long long)(getpid() & 0xffff) << 44) + ((ctx_counter.fetch_add(1) + 1) << 30);
+  }
   return PCABO_OK;
 }
 
@@ -294,7 +307,7 @@ int pcabo_ctx_destroy(pcabo_ctx* ctx) {
                  ctx->dC, ctx->dGbuf[0], ctx->dGbuf[1], ctx->dLam, ctx->dComps, ctx->dEvr, ctx->dZ, ctx->dK, ctx->dSweeps, ctx->dInfo,
                  ctx->dY, ctx->dYs, ctx->dYstats, ctx->dBounds4, ctx->dZnMean, ctx->dUserNB, ctx->dZnT, ctx->dAT,
                  ctx->dNrm, ctx->dGram, ctx->dL, ctx->dR, ctx->dTmp, ctx->dAlpha, ctx->dDiag, ctx->dXq, ctx->dPartial, ctx->dVal,
-                 ctx->dGrad, ctx->dZq, ctx->dXout, ctx->dCounters, ctx->dMail};
+                 ctx->dGrad, ctx->dZq, ctx->dXout, ctx->dCounters, ctx->dMail, ctx->dPairs};
   for (void* p : dev) if (p) hipFree(p);
   void* host[] = {(void*)ctx->hm, ctx->hXq, ctx->hVal, ctx->hGrad, ctx->hSmall, (void*)ctx->hMail};
   for (void* p : host) if (p) hipHostFree(p);
@@ -700,7 +713,7 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
       srv_cap = nq;
       launch_acq(ctx->stream, nullptr, nullptr, srv_cap, ctx->n, k, ctx->NP, ctx->ld, ctx->dZnT, ctx->dR, ctx->dAlpha,
                  ctx->dBounds4, ctx->dYstats, p, ctx->dPartial, ctx->dCounters, ctx->dVal, ctx->dGrad, ctx->hVal, ctx->hGrad,
-                 ctx->hm, ctx->seq + 1, ctx->hMail, ctx->dMail);
+                 ctx->hm, ctx->seq + 1, ctx->hMail, ctx->dMail, ctx->dPairs);
       HIPCHK(hipGetLastError());
     }
     if (srv_cap > 0) {

@@ -75,6 +75,24 @@ __device__ inline pcabo_u4 ld_pair_sys(const void* p) {
 __device__ inline void st_pair_sys(void* p, pcabo_u4 v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
 }
+// up to 8 pair loads in flight, one wait (cnt <= 8; unused slots repeat slot 0)
+__device__ inline void ld_pairs_sys8(const void* const* p, pcabo_u4* o) {
+  asm volatile(
+      "global_load_dwordx4 %0, %8, off sc0 sc1\n\tglobal_load_dwordx4 %1, %9, off sc0 sc1\n\t"
+      "global_load_dwordx4 %2, %10, off sc0 sc1\n\tglobal_load_dwordx4 %3, %11, off sc0 sc1\n\t"
+      "global_load_dwordx4 %4, %12, off sc0 sc1\n\tglobal_load_dwordx4 %5, %13, off sc0 sc1\n\t"
+      "global_load_dwordx4 %6, %14, off sc0 sc1\n\tglobal_load_dwordx4 %7, %15, off sc0 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+      : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
+      : "memory");
+}
+__device__ inline pcabo_u4 make_pair(double v, unsigned long long tag) {
+  pcabo_u4 r;
+  r.x = (unsigned int)__double2loint(v); r.y = (unsigned int)__double2hiint(v);
+  r.z = (unsigned int)(tag & 0xffffffffull); r.w = (unsigned int)(tag >> 32);
+  return r;
+}
 __device__ inline unsigned long long pair_tag(pcabo_u4 v) { return ((unsigned long long)v.w << 32) | v.z; }
 __device__ inline double pair_value(pcabo_u4 v) { return __hiloint2double((int)v.y, (int)v.x); }
 
@@ -128,8 +146,9 @@ void launch_acq(hipStream_t s, const QueryArgs* qa, const double* Xq, int q, int
                 const double* ZnT, const double* R, const double* alpha, const double* bounds4, const double* ystats,
                 AcqParams p, double* partial, unsigned int* counters, double* val,
                 double* grad, double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq,
-                const MailPair* host_mail = nullptr, MailPair* dev_mail = nullptr);
+                const MailPair* host_mail = nullptr, MailPair* dev_mail = nullptr, MailPair* part_pairs = nullptr);
 // resident mode available for this shape? (fast path + every group of the grid co-resident)
 bool acq_server_possible(int q, int n, int k, int NP);
+int acq_slabs(int NP);
 void launch_inverse_map(hipStream_t s, const double* z, const double* comps, const double* data_mean,
                         const double* pca_mean, int k, int d, double* x);

@@ -473,7 +473,7 @@ int acq_slabs(int NP) {
 //   gradient  gs[u] = sum_b t_sigma[l + 64 b] (xn_c - z[u][b]) from the SAME registers, DPP wave sums
 // Wave-uniform indices are forced into SGPRs (readfirstlane): row bases are scalar, loads need no vector address
 // arithmetic.  Columns j >= n hold zeros in ZnT (k_znorm) and get zero weights.
-template <int SLAB, int NB>
+template <int SLAB, int NB, bool SRV>
 __global__ __launch_bounds__(256) void k_acq_fast(
     QueryArgs qa, const double* __restrict__ Xq, int q_total, int n, int k, int NP_rt, int ld,
     const double* __restrict__ ZnT, const double* __restrict__ R, const double* __restrict__ alpha,
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256) void k_acq_fast(
   double* s_p4 = s_v + SLAB + 2;     // 4 NP per-wave partials (squared distances, then w_j)
   const int tid = threadIdx.x, l = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool server = dev_mail != nullptr;                      // resident mode, see below
+  constexpr bool server = SRV;                                  // resident mode (own instantiation: the plain one keeps its registers), see below
   const int s = blockIdx.x, S = server ? (int)gridDim.x - 1 : (int)gridDim.x;
   if (server && s == S) {                                        // the finishing group of query blockIdx.y
     acq_server_finish_main(s_dyn, host_mail, dev_mail, q_total * k, part_pairs, S, k, blockIdx.y, bounds4, ystats, prm,
@@ -887,10 +887,15 @@ void launch_acq(hipStream_t st, const QueryArgs* qa, const double* Xq, int q, in
 #define ACQ_ARGS qa ? *qa : empty, Xq, q, n, k, NP, ld, ZnT, R, alpha, bounds4, ystats, p, partial, counters, val, grad, \
                  host_val, host_grad, hm, seq, combine, qb, host_mail, dev_mail, part_pairs
   const int FIN_LDS = 6 * PCABO_MAXD + 2;   // finishing group's LDS beyond s_v
+#define ACQ_LDS(SL, NBV) (3 * NBV * 64 + PCABO_MAXD + SL + 2 + (4 * NBV * 64 > FIN_LDS ? 4 * NBV * 64 : FIN_LDS))
 #define ACQ_FAST(SL, NBV)                                                                                      \
   case NBV:                                                                                                    \
-    hipLaunchKernelGGL((k_acq_fast<SL, NBV>), dim3(S + (dev_mail ? 1 : 0), gy), dim3(256),                                           \
-                       (size_t)std::max<int>(3 * NBV * 64 + PCABO_MAXD + SL + 2 + (4 * NBV * 64 > FIN_LDS ? 4 * NBV * 64 : FIN_LDS), dev_mail ? FIN_LDS_DOUBLES : 0) * sizeof(double), st, ACQ_ARGS); \
+    if (dev_mail)                                                                                              \
+      hipLaunchKernelGGL((k_acq_fast<SL, NBV, true>), dim3(S + 1, gy), dim3(256),                              \
+                         (size_t)std::max<int>(ACQ_LDS(SL, NBV), FIN_LDS_DOUBLES) * sizeof(double), st, ACQ_ARGS); \
+    else                                                                                                       \
+      hipLaunchKernelGGL((k_acq_fast<SL, NBV, false>), dim3(S, gy), dim3(256),                                 \
+                         (size_t)ACQ_LDS(SL, NBV) * sizeof(double), st, ACQ_ARGS);                             \
     break;
   if (fast) {
     if (slab == 16) {
@@ -908,6 +913,7 @@ void launch_acq(hipStream_t st, const QueryArgs* qa, const double* Xq, int q, in
       hipLaunchKernelGGL(k_acq_fused<32>, dim3(S, q), dim3(256), lds, st, ACQ_ARGS);
   }
 #undef ACQ_FAST
+#undef ACQ_LDS
 #undef ACQ_ARGS
   if (!combine)
     hipLaunchKernelGGL(k_acq_combine, dim3((q + 3) / 4), dim3(256), 0, st, partial, q, S, k, bounds4, ystats, p, val,

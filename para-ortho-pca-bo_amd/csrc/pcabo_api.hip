@@ -593,7 +593,7 @@ static int server_wait(pcabo_ctx* ctx, int nq, unsigned long long tag) {
     while (__atomic_load_n(&ctx->hm->qflag[qi], __ATOMIC_ACQUIRE) != tag) {
       if ((++spins & 0xFFFF) == 0) {
         double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        if (el > 5.0) return set_err(ctx, PCABO_ERR_TIMEOUT, "resident acquisition kernel did not answer%s", "");
+        if (el > 3.0) return set_err(ctx, PCABO_ERR_TIMEOUT, "resident acquisition kernel did not answer%s", "");
       }
     }
   }

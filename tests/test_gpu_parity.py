@@ -683,3 +683,39 @@ print("DIGESTS", " ".join(out))
         assert p.returncode == 0, p.stderr[-3000:]
         res.append([l for l in p.stdout.splitlines() if l.startswith("DIGESTS")][-1])
     assert res[0] == res[1]
+
+
+def test_resident_kernel_survives_a_stopped_host(native):
+    """The host process is stopped (SIGSTOP) for longer than the resident kernel waits (2 s): the kernel's groups time
+    out and leave, the host wakes up, gets no answer, ends the resident mode and goes on with plain launches.  The run
+    must finish with exactly the result of an undisturbed run."""
+    import os, signal, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, os, hashlib, threading, time, subprocess, signal
+import numpy as np
+sys.path.insert(0, os.path.join(%r, "para-ortho-pca-bo_amd"))
+from Algorithms import PCA_BO
+from pcabo.bbob import BBOBProblem
+disturb = sys.argv[1] == "1"
+opt = PCA_BO(budget=330, n_DoE=120, random_seed=15400, maximization=False)
+prob = BBOBProblem(15, 0, 40)
+opt._start(prob)
+t0 = time.time()
+for it in range(210):
+    if disturb and it == 100:
+        # a child wakes us up after 3.5 s; we stop ourselves from a thread while the main thread is inside the optimiser
+        subprocess.Popen([sys.executable, "-c", "import os,time,signal; time.sleep(3.5); os.kill(%%d, signal.SIGCONT)" %% os.getpid()])
+        threading.Timer(0.002, lambda: os.kill(os.getpid(), signal.SIGSTOP)).start()
+    opt._bo_iteration(prob)
+dt = time.time() - t0
+opt._finish()
+print("RESULT", hashlib.md5(np.array(opt.f_evals).tobytes() + np.vstack(opt.x_evals).tobytes()).hexdigest(), "%%.1f" %% dt)
+''' % root
+    out = []
+    for disturb in ("0", "1"):
+        p = subprocess.run([sys.executable, "-c", code, disturb], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-3000:]
+        out.append([l for l in p.stdout.splitlines() if l.startswith("RESULT")][-1].split())
+    assert out[0][1] == out[1][1]                  # same run
+    assert float(out[1][2]) > float(out[0][2]) + 3.0      # and it really was stopped for a while

@@ -670,7 +670,8 @@ sys.path.insert(0, os.path.join(%r, "para-ortho-pca-bo_amd"))
 from Algorithms import PCA_BO, Vanilla_BO
 from pcabo.bbob import BBOBProblem
 out = []
-for cls, kw, dim, budget, ndoe in ((PCA_BO, {}, 10, 70, 30), (PCA_BO, {}, 40, 150, 120), (Vanilla_BO, {}, 6, 40, 18)):
+for cls, kw, dim, budget, ndoe in ((PCA_BO, {}, 10, 70, 30), (PCA_BO, {}, 40, 150, 120), (Vanilla_BO, {}, 6, 40, 18),
+                                    (Vanilla_BO, {}, 40, 140, 120)):      # k = 40: the widest mailbox (400 coordinates)
     opt = cls(budget=budget, n_DoE=ndoe, random_seed=15000 + dim, maximization=False, **kw)
     opt(BBOBProblem(15, 1, dim))
     out.append(hashlib.md5(np.array(opt.f_evals).tobytes() + np.vstack(opt.x_evals).tobytes()).hexdigest())

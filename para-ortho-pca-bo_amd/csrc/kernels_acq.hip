@@ -401,7 +401,7 @@ __device__ inline bool acq_server_finisher(const MailPair* rec, int S, int k, in
 // two roles, not their sum.  (A separate kernel on a second stream would be simpler, but two streams of one process may
 // share a hardware queue, and then the two kernels wait for each other until they time out.)  Group (S, 0) also relays
 // the round's mailbox from the host's pinned copy to the device copy that everybody else polls.
-#define FIN_LDS_DOUBLES (6 * PCABO_MAXD + 2 + 3 * FIN_STAGE_PER_WAVE + 2)
+#define FIN_LDS_DOUBLES (6 * PCABO_MAXD + 2 + 3 * FIN_STAGE_PER_WAVE + 2)   // ... + two flag words in the last double
 __device__ __noinline__ void acq_server_finish_main(double* s_mem, const MailPair* host_mail, MailPair* dev_mail, int npairs,
                                                     const MailPair* part_pairs, int S, int k, int q,
                                                     const double* __restrict__ bounds4, const double* __restrict__ ystats,
@@ -415,23 +415,31 @@ __device__ __noinline__ void acq_server_finish_main(double* s_mem, const MailPai
   if (tid < k) rng_c = bounds4[PCABO_MAXD + tid] - bounds4[tid];
   for (unsigned long long cur_seq = seq;; ++cur_seq) {
     const unsigned long long t0 = wall_clock64();
-    if (tid == 0) *s_srvp = 0;
+    if (tid == 0) { s_srvp[0] = 0; s_srvp[1] = 0; }
     __syncthreads();
     if (q == 0) {                                                // relay: host mailbox -> device mailbox
-      for (;;) {
-        bool ok = true;
-        pcabo_u4 mine[2];
+      // Wave 0 polls ALL pairs (<= 8 per lane, one asm block = one PCIe round trip) and stores a complete round to the
+      // device copy.  (All four waves polling a quarter of a round trip apart was tried: the extra traffic made every
+      // poll slower, 13-15 instead of 11-12.5 us per evaluation.)
+      volatile int* flags = s_srvp;                              // [0] leave
+      if (w == 0) {
+        const void* ptr[8];
+        int idx[8];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int pi = tid + 256 * i;
-          if (pi <= npairs) { mine[i] = ld_pair_sys(host_mail + pi); ok = ok && pair_tag(mine[i]) == cur_seq; }
-        }
-        if (__syncthreads_and(ok)) {
+        for (int t = 0; t < 8; ++t) { const int pi = l + 64 * t; idx[t] = pi <= npairs ? pi : -1; ptr[t] = host_mail + (pi <= npairs ? pi : 0); }
+        for (;;) {
+          pcabo_u4 o[8];
+          ld_pairs_sys8(ptr, o);
+          bool ok = true;
 #pragma unroll
-          for (int i = 0; i < 2; ++i) { const int pi = tid + 256 * i; if (pi <= npairs) st_pair_sys(dev_mail + pi, mine[i]); }
-          break;
+          for (int t = 0; t < 8; ++t) ok = ok && (idx[t] < 0 || pair_tag(o[t]) == cur_seq);
+          if (__all(ok)) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) if (idx[t] >= 0) st_pair_sys(dev_mail + idx[t], o[t]);
+            break;
+          }
+          if (__any(wall_clock64() - t0 > PCABO_SERVER_TIMEOUT_TICKS)) { if (l == 0) flags[0] = 1; break; }
         }
-        if (__syncthreads_or(wall_clock64() - t0 > PCABO_SERVER_TIMEOUT_TICKS)) { if (tid == 0) *s_srvp = 1; break; }
       }
       __syncthreads();
     }
@@ -542,27 +550,30 @@ __global__ __launch_bounds__(256) void k_acq_fast(
   int* s_srv = reinterpret_cast<int*>(s_v + SLAB + 1);        // 0 continue, 1 leave (set by wave 0)
   unsigned long long cur_seq = seq;
   double b_lo = 0.0, b_hi = 1.0;
-  if (server && tid < k) { b_lo = bounds4[tid]; b_hi = bounds4[PCABO_MAXD + tid]; }
+  if (server && l < k) { b_lo = bounds4[l]; b_hi = bounds4[PCABO_MAXD + l]; }
   for (;;) {                                                  // rounds (one pass unless resident)
   int q = blockIdx.y * qb;
   double* out = partial + ((size_t)q * S + s) * PSTRIDE;
   if (server) {
     const unsigned long long t0 = wall_clock64();
-    if (tid == 0) *s_srv = 0;
+    if (tid == 0) { s_srv[0] = 0; s_srv[1] = 0; }
     __syncthreads();
-    if (w == 0) {                                             // header + this query's coordinates, one snapshot each
+    if (w == 0) {                                             // header + this query's coordinates: one round trip per poll
+      volatile int* flags = s_srv;
+      const void* ptr[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) ptr[t] = (t & 1) && l < k ? (const void*)(dev_mail + 1 + q * k + l) : (const void*)dev_mail;
       for (;;) {
-        const pcabo_u4 hd = ld_pair_sys(dev_mail);
-        bool ok = pair_tag(hd) == cur_seq;
-        pcabo_u4 xv = {0u, 0u, 0u, 0u};
-        if (l < k) { xv = ld_pair_sys(dev_mail + 1 + q * k + l); ok = ok && pair_tag(xv) == cur_seq; }
+        pcabo_u4 o[8];
+        ld_pairs_sys8(ptr, o);
+        const bool ok = pair_tag(o[0]) == cur_seq && (l >= k || pair_tag(o[1]) == cur_seq);
         if (__all(ok)) {
-          const int nq_round = (int)pair_value(hd);
-          if (q >= nq_round) { if (l == 0) *s_srv = 1; }      // the call is over (0) or this query's group has finished
-          else if (l < k) s_xn[l] = (pair_value(xv) - b_lo) / (b_hi - b_lo);
+          const int nq_round = (int)pair_value(o[0]);
+          if (q >= nq_round) { if (l == 0) flags[0] = 1; }    // the call is over (0) or this query's group has finished
+          else if (l < k) s_xn[l] = (pair_value(o[1]) - b_lo) / (b_hi - b_lo);
           break;
         }
-        if (__any(wall_clock64() - t0 > PCABO_SERVER_TIMEOUT_TICKS)) { if (l == 0) *s_srv = 1; break; }
+        if (__any(wall_clock64() - t0 > PCABO_SERVER_TIMEOUT_TICKS)) { if (l == 0) flags[0] = 1; break; }
         __builtin_amdgcn_s_sleep(1);
       }
     }

@@ -95,6 +95,17 @@ int pcabo_gp_condition_begin(pcabo_ctx* ctx, const double* Z, const double* y, i
                              const double* norm_bounds, double lengthscale, double noise, int kernel);
 int pcabo_gp_condition_end(pcabo_ctx* ctx);
 
+/* Rows A-H as ONE enqueue: pcabo_wpca immediately followed by pcabo_gp_condition_begin(Z = NULL,
+ * norm_bounds = NULL), i.e. PCA_BO._transform_points_to_reduced_space + _initialize_model of one iteration
+ * (PCA_BO.py:343-408 and :502-545) without the host round trip between them: the conditioning launches are queued
+ * behind the projection before the host has seen k (the kernels read it on the device).  Arguments as in the two
+ * calls (gp_noise = the likelihood noise, `noise` = the PCA_BO.py:376 draw).  Returns when the wPCA results are on the
+ * host, with the conditioning still in flight: finish with pcabo_gp_condition_end(). */
+int pcabo_wpca_gp_condition_begin(pcabo_ctx* ctx, const double* X, const double* f, const int64_t* ranks, int n,
+                                  int d, int maximize, double var_threshold, int n_components, const double* noise,
+                                  const double* y, double lengthscale, double gp_noise, int kernel,
+                                  double* data_mean, double* pca_mean, double* comps, double* evr, int* k);
+
 /* Row J: search box of the acquisition optimiser, PCA_BO.py:558-573. bounds[2*k] [host] (lo row, hi row).
  * May be called between pcabo_gp_condition_begin and _end: it then waits only for the statistics kernel, so the
  * raw samples of the initial-condition draw can be generated while the factorisation is still running. */

@@ -547,6 +547,7 @@ class IterationRecord:
     oob: bool
     f_new: float
     torch_rng_before: Optional[torch.Tensor] = None
+    acq: Optional["Acquisition"] = None       # the iteration's acquisition (tests evaluate it at the device's points)
 
 
 class OraclePCABO:
@@ -618,7 +619,7 @@ class OraclePCABO:
         self.f_evals.append(f_new)
         self._assign_new_best()
         rec = IterationRecord(n, wp.k, X, np.array(self.f_evals[:-1], dtype=np.float64), ranks, noise, best_before,
-                              wp, nb, ab, trace, z_new, x_new, oob, float(f_new), rng_before)
+                              wp, nb, ab, trace, z_new, x_new, oob, float(f_new), rng_before, acq)
         if self.record:
             self.records.append(rec)
         return rec
@@ -669,7 +670,7 @@ class OracleVanillaBO(OraclePCABO):
         self.f_evals.append(f_new)
         self._assign_new_best()
         rec = IterationRecord(n, d, X, f, np.zeros(n, dtype=np.int64), np.zeros((0, d)), best_before, None, identity, box,
-                              trace, x_new, x_new, False, float(f_new), rng_before)
+                              trace, x_new, x_new, False, float(f_new), rng_before, acq)
         if self.record:
             self.records.append(rec)
         return rec

@@ -109,7 +109,8 @@ class PCA_BO(AbstractBayesianOptimizer):
         if self.__prefetch is None and os.environ.get("PCABO_PREFETCH_NOISE") in ("0", "1"):   # A/B diagnostics
             self.__prefetch = os.environ["PCABO_PREFETCH_NOISE"] == "1"
         self.__prefetch_on = False
-        self.__noise_thread, self.__noise_next = None, None
+        self.__noise_thread, self.__noise_pending = None, False
+        self.__noise_req = self.__noise_res = None
         # torch is only used for the Sobol / multinomial draws here; its default of one OpenMP worker per visible core
         # (hundreds on a GPU host) leaves spinning workers that starve the host threads driving the device loop
         # (measured: 300 us instead of 34 us per L-BFGS-B round).  Capped for the duration of a run; None = leave alone.
@@ -141,6 +142,7 @@ class PCA_BO(AbstractBayesianOptimizer):
             warnings.warn("visualize=True: the GIF visualiser of the reference is not part of the MI355X path; ignored.")
         self.__z_evals = []
         self.__gp_pending = False
+        self.__fused = os.environ.get("PCABO_NO_FUSED_ENQUEUE") is None
         self.__X_buf, self.__X_rows = None, 0
         self.__ctx: Optional[_native.Context] = None
         self.lbfgsb_info = []          # per iteration: (iterations, evaluations, warnflag, task) per restart group
@@ -220,9 +222,7 @@ class PCA_BO(AbstractBayesianOptimizer):
                   f"Best: x:{self.x_evals[self.current_best_index]} y:{self.current_best}", flush=True)
 
     def _finish(self) -> None:
-        if self.__noise_thread is not None:
-            self.__noise_thread.join()
-            self.__noise_thread, self.__noise_next = None, None
+        self._stop_noise_worker()
         if self.__saved_torch_threads is not None:
             import torch
             torch.set_num_threads(self.__saved_torch_threads)
@@ -266,29 +266,49 @@ class PCA_BO(AbstractBayesianOptimizer):
         return buf[:n]
 
     def _take_noise(self, shape) -> np.ndarray:
-        t = self.__noise_thread
-        if t is None:
+        if not self.__noise_pending:
             return np.random.normal(0, 1e-8, size=shape)
-        t.join()
-        self.__noise_thread = None
-        nz, self.__noise_next = self.__noise_next, None
-        if nz is None or nz.shape != tuple(shape):
+        nz = self.__noise_res.get()
+        self.__noise_pending = False
+        if isinstance(nz, BaseException):
+            raise nz
+        if nz.shape != tuple(shape):
             raise RuntimeError("noise prefetch out of step with the run (a draw of another shape left the RNG)")
         return nz
 
+    def _noise_worker(self, req, res) -> None:
+        while True:
+            shape = req.get()
+            if shape is None:
+                return
+            try:
+                res.put(np.random.normal(0, 1e-8, size=shape))   # numpy releases the GIL while it generates
+            except BaseException as e:  # noqa: BLE001 - handed to the thread that asked
+                res.put(e)
+
     def _prefetch_noise(self) -> None:
         """Called once the current iteration's noise is consumed: the next iteration (if there is one) has one more
-        point."""
+        point.  One worker thread per run (creating a thread per iteration cost 0.24 ms of every iteration)."""
         n = len(self.x_evals)
-        if not self.__prefetch_on or self.__noise_thread is not None or n + 1 >= self.budget:
+        if not self.__prefetch_on or self.__noise_pending or n + 1 >= self.budget:
             return
-        import threading
-        shape = (n + 1, self.dimension)
+        if self.__noise_thread is None:
+            import queue
+            import threading
+            self.__noise_req, self.__noise_res = queue.SimpleQueue(), queue.SimpleQueue()
+            self.__noise_thread = threading.Thread(target=self._noise_worker, args=(self.__noise_req, self.__noise_res),
+                                                   daemon=True)
+            self.__noise_thread.start()
+        self.__noise_pending = True
+        self.__noise_req.put((n + 1, self.dimension))
 
-        def draw():
-            self.__noise_next = np.random.normal(0, 1e-8, size=shape)   # numpy releases the GIL while it generates
-        self.__noise_thread = threading.Thread(target=draw, daemon=True)
-        self.__noise_thread.start()
+    def _stop_noise_worker(self) -> None:
+        if self.__noise_thread is None:
+            return
+        self.__noise_req.put(None)
+        self.__noise_thread.join()
+        self.__noise_thread, self.__noise_pending = None, False
+        self.__noise_req = self.__noise_res = None
 
     def _transform_points_to_reduced_space(self) -> None:
         if len(self.x_evals) < 2:
@@ -299,8 +319,17 @@ class PCA_BO(AbstractBayesianOptimizer):
         ranks = self._calculate_ranks()
         noise = self._take_noise(X.shape)                      # same draw, same global RNG as the reference
         start = perf_counter()
-        res = self.__ctx.wpca(X, ranks=ranks, maximize=self.maximization, var_threshold=self.var_threshold,
-                              n_components=self.n_components, noise=noise, want_Z=False, want_full=True)
+        if self.__fused:
+            # rows A-H in one enqueue: the GP conditioning is queued right behind the projection and runs while the
+            # wPCA results travel back (`_initialize_model` then has nothing left to launch)
+            res = self.__ctx.wpca_gp_condition(
+                X, np.array(self.f_evals, dtype=np.float64), ranks=ranks, maximize=self.maximization,
+                var_threshold=self.var_threshold, n_components=self.n_components, noise=noise,
+                lengthscale=LENGTHSCALE, gp_noise=NOISE, kernel=_native.KERNEL_MATERN52)
+            self.__gp_pending = True
+        else:
+            res = self.__ctx.wpca(X, ranks=ranks, maximize=self.maximization, var_threshold=self.var_threshold,
+                                  n_components=self.n_components, noise=noise, want_Z=False, want_full=True)
         self.timing_logs["pca"].append(perf_counter() - start)
         self.data_mean = res["data_mean"]
         self.component_matrix = res["components"]
@@ -319,6 +348,9 @@ class PCA_BO(AbstractBayesianOptimizer):
         if not self.__z_evals:
             return
         start = perf_counter()
+        if self.__gp_pending:              # already enqueued together with the wPCA
+            self.timing_logs["SingleTaskGP"].append(perf_counter() - start)
+            return
         # enqueue only: the device conditions the GP while the host prepares the Sobol engine (gp_wait below)
         self.__ctx.gp_condition(np.array(self.f_evals, dtype=np.float64), lengthscale=LENGTHSCALE, noise=NOISE,
                                 kernel=_native.KERNEL_MATERN52, wait=False)

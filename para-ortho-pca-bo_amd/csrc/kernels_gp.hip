@@ -8,6 +8,7 @@
 // The padding block is the identity, so every kernel works on whole 64 x 64 tiles and the
 // padded rows/columns never influence the leading n x n part.
 #include "pcabo_internal.h"
+#include <cstdlib>
 
 #define BS PCABO_BS
 #define TLD PCABO_TLD
@@ -20,9 +21,11 @@
 // Operands are read straight from AT (KP x ld, point index contiguous): each MFMA operand load is
 // four 128-byte rows, fully coalesced; the whole AT (<= 36 x 512 doubles) is L2 resident.
 __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ AT, const double* __restrict__ nrm, int n,
-                                              int KP, int ld, double noise, int kernel, double* __restrict__ K) {
+                                              int KP, int ld, double noise, int kernel, double* __restrict__ K,
+                                              const int* __restrict__ k_dev) {
   const int ti = blockIdx.x, tj = blockIdx.y;
   if (tj > ti) return;
+  if (k_dev) KP = (*k_dev + 3) & ~3;
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int i0 = ti * BS + 16 * w, j0 = tj * BS;
   double4_t acc[4];
@@ -326,17 +329,19 @@ __global__ __launch_bounds__(256) void k_rtmatvec(const double* __restrict__ R, 
 
 // ---- launchers --------------------------------------------------------------------------------
 void launch_gram(hipStream_t s, const double* AT, const double* nrm, int n, int NP, int KP, int ld, double noise,
-                 int kernel, double* K) {
+                 int kernel, double* K, const int* k_dev) {
   int nb = NP / BS;
-  hipLaunchKernelGGL(k_gram, dim3(nb, nb), dim3(256), 0, s, AT, nrm, n, KP, ld, noise, kernel, K);
+  hipLaunchKernelGGL(k_gram, dim3(nb, nb), dim3(256), 0, s, AT, nrm, n, KP, ld, noise, kernel, K, k_dev);
 }
 void launch_add_jitter(hipStream_t s, double* K, int n, int ld, double jitter) {
   hipLaunchKernelGGL(k_add_jitter, dim3((n + 255) / 256), dim3(256), 0, s, K, n, ld, jitter);
 }
 void launch_cholesky(hipStream_t s, double* L, int NP, int ld, int* info, double* diag_scratch) {
   const int nblk = NP / BS;
+  static const bool lanes4 = getenv("PCABO_GP_FOUR_LANE_ROWS") != nullptr;      // A/B: the earlier panel / inverse kernels
   for (int p = 0; p < nblk; ++p) {
-    hipLaunchKernelGGL(k_chol_panel, dim3(nblk - p), dim3(256), 0, s, L, p, ld, info, diag_scratch);
+    if (lanes4) hipLaunchKernelGGL(k_chol_panel, dim3(nblk - p), dim3(256), 0, s, L, p, ld, info, diag_scratch);
+    else launch_chol_panel_w(s, L, p, nblk - p, ld, info, diag_scratch);
     int m = nblk - p - 1;
     if (m > 0) hipLaunchKernelGGL(k_chol_update, dim3(m * (m + 1) / 2), dim3(256), 0, s, L, p, nblk, ld, diag_scratch);
   }
@@ -344,7 +349,9 @@ void launch_cholesky(hipStream_t s, double* L, int NP, int ld, int* info, double
 void launch_trinv(hipStream_t s, const double* L, int NP, int ld, double* R) {
   const int nblk = NP / BS;
   hipMemsetAsync(R, 0, (size_t)NP * ld * sizeof(double), s);
-  hipLaunchKernelGGL(k_trinv_diag, dim3(nblk), dim3(256), 0, s, L, ld, R);
+  static const bool lanes4 = getenv("PCABO_GP_FOUR_LANE_ROWS") != nullptr;
+  if (lanes4) hipLaunchKernelGGL(k_trinv_diag, dim3(nblk), dim3(256), 0, s, L, ld, R);
+  else launch_trinv_diag_w(s, L, nblk, ld, R);
   hipLaunchKernelGGL(k_trinv_cols, dim3(NP / 16), dim3(256), 0, s, L, nblk, ld, R);
 }
 void launch_alpha(hipStream_t s, const double* R, const double* ys, int n, int NP, int ld, double* tmp, double* alpha) {

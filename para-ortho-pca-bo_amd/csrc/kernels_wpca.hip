@@ -364,7 +364,8 @@ __global__ __launch_bounds__(WP_THREADS) void k_zstats(const double* __restrict_
                                                        int n, int k, const double* __restrict__ user_nb,
                                                        double* __restrict__ bounds4, double* __restrict__ zn_mean,
                                                        double* __restrict__ ystats, double* __restrict__ ys,
-                                                       HostMirror* hm) {
+                                                       HostMirror* hm, const int* __restrict__ k_dev) {
+  if (k_dev) k = *k_dev;          // enqueued behind the wPCA: the reduced dimension is not on the host yet
   __shared__ double s_red[WP_THREADS];
   __shared__ double s_min[WP_THREADS];
   __shared__ double s_max[WP_THREADS];
@@ -417,7 +418,8 @@ __global__ __launch_bounds__(WP_THREADS) void k_zstats(const double* __restrict_
 __global__ __launch_bounds__(256) void k_znorm(const double* __restrict__ Z, int n, int k, int NP, int KP, int ld,
                                                const double* __restrict__ bounds4, const double* __restrict__ zn_mean,
                                                double inv_ls, double* __restrict__ ZnT, double* __restrict__ AT,
-                                               double* __restrict__ nrm) {
+                                               double* __restrict__ nrm, const int* __restrict__ k_dev) {
+  if (k_dev) { k = *k_dev; KP = (k + 3) & ~3; }
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= NP) return;
   double s = 0.0;
@@ -484,14 +486,14 @@ void launch_project(hipStream_t s, const double* X, const double* data_mean, con
   hipLaunchKernelGGL(k_project, dim3((n + 7) / 8), dim3(256), 0, s, X, data_mean, pca_mean, comps, k_dev, n, d, Z);
 }
 void launch_zstats(hipStream_t s, const double* Z, const double* y, int n, int k, const double* user_norm_bounds,
-                   double* bounds4, double* zn_mean, double* ystats, double* ys, HostMirror* hm) {
+                   double* bounds4, double* zn_mean, double* ystats, double* ys, HostMirror* hm, const int* k_dev) {
   hipLaunchKernelGGL(k_zstats, dim3(1), dim3(WP_THREADS), 0, s, Z, y, n, k, user_norm_bounds, bounds4, zn_mean,
-                     ystats, ys, hm);
+                     ystats, ys, hm, k_dev);
 }
 void launch_znorm(hipStream_t s, const double* Z, int n, int k, int NP, int KP, int ld, const double* bounds4,
-                  const double* zn_mean, double inv_ls, double* ZnT, double* AT, double* nrm) {
+                  const double* zn_mean, double inv_ls, double* ZnT, double* AT, double* nrm, const int* k_dev) {
   hipLaunchKernelGGL(k_znorm, dim3((NP + 255) / 256), dim3(256), 0, s, Z, n, k, NP, KP, ld, bounds4, zn_mean, inv_ls,
-                     ZnT, AT, nrm);
+                     ZnT, AT, nrm, k_dev);
 }
 void launch_inverse_map(hipStream_t s, const double* z, const double* comps, const double* data_mean,
                         const double* pca_mean, int k, int d, double* x) {

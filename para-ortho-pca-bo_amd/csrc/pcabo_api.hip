@@ -76,6 +76,7 @@ struct pcabo_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t evBounds = nullptr;         // recorded after k_zstats: the search box is on the host before the Cholesky ends
+  hipEvent_t evPca = nullptr;            // recorded after the wPCA results left for the host (conditioning may follow it)
   int max_n = 0, max_d = 0, max_q = 0;
   int NPcap = 0, ld = 0, DPcap = 0, KPcap = 0, Scap = 0;
   int ptr_mode = PCABO_PTR_HOST;
@@ -91,6 +92,8 @@ struct pcabo_ctx {
   double* dGbuf[2] = {nullptr, nullptr};   // eigenvector ping-pong: the previous result warm-starts the next Jacobi
   int gcur = 0, vprev_d = 0;
   double *dComps = nullptr, *dEvr = nullptr, *dZ = nullptr;
+  double* dPcaOut = nullptr;             // [data_mean | pca_mean | evr | comps]: one allocation, one copy to the host
+  double *dIn = nullptr, *hIn = nullptr; // host-pointer mode: X, noise, ranks (or f) and y travel packed in ONE copy
   int *dK = nullptr, *dSweeps = nullptr, *dInfo = nullptr;
   double *dY = nullptr, *dYs = nullptr, *dYstats = nullptr, *dBounds4 = nullptr, *dZnMean = nullptr, *dUserNB = nullptr;
   double *dZnT = nullptr, *dAT = nullptr, *dNrm = nullptr, *dGram = nullptr, *dL = nullptr, *dR = nullptr;
@@ -247,15 +250,18 @@ int pcabo_ctx_create(int device, int max_n, int max_d, int max_q, pcabo_ctx** ou
   HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   presence_register(ctx->device); ctx->registered = true;
   HIPCHK(hipEventCreateWithFlags(&ctx->evBounds, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&ctx->evPca, hipEventDisableTiming));
   const size_t N = ctx->NPcap, D = ctx->DPcap, n = max_n, d = max_d, Q = max_q;
   HIPCHK(dalloc(&ctx->dX, n * d));       HIPCHK(dalloc(&ctx->dNoise, n * d));
   HIPCHK(dalloc(&ctx->dF, n));           HIPCHK(dalloc(&ctx->dWeights, n));
   HIPCHK(dalloc(&ctx->dWc, (n + 4) * D)); HIPCHK(dalloc(&ctx->dRanks, n));
-  HIPCHK(dalloc(&ctx->dDataMean, d));    HIPCHK(dalloc(&ctx->dPcaMean, d));
+  HIPCHK(dalloc(&ctx->dPcaOut, 3 * d + d * d));
+  ctx->dDataMean = ctx->dPcaOut; ctx->dPcaMean = ctx->dPcaOut + d; ctx->dEvr = ctx->dPcaOut + 2 * d;
+  ctx->dComps = ctx->dPcaOut + 3 * d;
+  HIPCHK(dalloc(&ctx->dIn, n * (2 * d + 2)));
   HIPCHK(dalloc(&ctx->dC, D * D));       HIPCHK(dalloc(&ctx->dGbuf[0], d * d));  HIPCHK(dalloc(&ctx->dGbuf[1], d * d));
   ctx->dG = ctx->dGbuf[0];
-  HIPCHK(dalloc(&ctx->dLam, d));         HIPCHK(dalloc(&ctx->dComps, d * d));
-  HIPCHK(dalloc(&ctx->dEvr, d));         HIPCHK(dalloc(&ctx->dZ, n * d));
+  HIPCHK(dalloc(&ctx->dLam, d));         HIPCHK(dalloc(&ctx->dZ, n * d));
   HIPCHK(dalloc(&ctx->dK, 1));           HIPCHK(dalloc(&ctx->dSweeps, 1));   HIPCHK(dalloc(&ctx->dInfo, 1));
   HIPCHK(dalloc(&ctx->dY, n));           HIPCHK(dalloc(&ctx->dYs, N));
   HIPCHK(dalloc(&ctx->dYstats, 2));      HIPCHK(dalloc(&ctx->dBounds4, 4 * PCABO_MAXD));
@@ -278,6 +284,7 @@ int pcabo_ctx_create(int device, int max_n, int max_d, int max_q, pcabo_ctx** ou
   HIPCHK(hipHostMalloc((void**)&ctx->hVal, Q * sizeof(double), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&ctx->hGrad, Q * d * sizeof(double), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&ctx->hSmall, (d * d + 8 * d + 64) * sizeof(double), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&ctx->hIn, n * (2 * d + 2) * sizeof(double), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&ctx->hMail, PCABO_MAIL_PAIRS * sizeof(MailPair), hipHostMallocMapped | hipHostMallocCoherent));
   memset(ctx->hMail, 0, PCABO_MAIL_PAIRS * sizeof(MailPair));
   HIPCHK(dalloc(&ctx->dMail, PCABO_MAIL_PAIRS));
@@ -303,15 +310,16 @@ int pcabo_ctx_destroy(pcabo_ctx* ctx) {
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   for (auto& p : ctx->pairs) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
-  void* dev[] = {ctx->dX, ctx->dNoise, ctx->dF, ctx->dWeights, ctx->dWc, ctx->dRanks, ctx->dDataMean, ctx->dPcaMean,
-                 ctx->dC, ctx->dGbuf[0], ctx->dGbuf[1], ctx->dLam, ctx->dComps, ctx->dEvr, ctx->dZ, ctx->dK, ctx->dSweeps, ctx->dInfo,
+  void* dev[] = {ctx->dX, ctx->dNoise, ctx->dF, ctx->dWeights, ctx->dWc, ctx->dRanks, ctx->dPcaOut, ctx->dIn,
+                 ctx->dC, ctx->dGbuf[0], ctx->dGbuf[1], ctx->dLam, ctx->dZ, ctx->dK, ctx->dSweeps, ctx->dInfo,
                  ctx->dY, ctx->dYs, ctx->dYstats, ctx->dBounds4, ctx->dZnMean, ctx->dUserNB, ctx->dZnT, ctx->dAT,
                  ctx->dNrm, ctx->dGram, ctx->dL, ctx->dR, ctx->dTmp, ctx->dAlpha, ctx->dDiag, ctx->dXq, ctx->dPartial, ctx->dVal,
                  ctx->dGrad, ctx->dZq, ctx->dXout, ctx->dCounters, ctx->dMail, ctx->dPairs};
   for (void* p : dev) if (p) hipFree(p);
-  void* host[] = {(void*)ctx->hm, ctx->hXq, ctx->hVal, ctx->hGrad, ctx->hSmall, (void*)ctx->hMail};
+  void* host[] = {(void*)ctx->hm, ctx->hXq, ctx->hVal, ctx->hGrad, ctx->hSmall, ctx->hIn, (void*)ctx->hMail};
   for (void* p : host) if (p) hipHostFree(p);
   if (ctx->evBounds) hipEventDestroy(ctx->evBounds);
+  if (ctx->evPca) hipEventDestroy(ctx->evPca);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   ctx->helper.shutdown();
   if (ctx->registered) presence_unregister(ctx->device);
@@ -348,27 +356,46 @@ int pcabo_last_error(pcabo_ctx* ctx, char* buf, int buflen) {
 #define HOST_OUT(dst, src, count, T) \
   HIPCHK(hipMemcpyAsync((void*)(dst), (const void*)(src), (size_t)(count) * sizeof(T), hipMemcpyDeviceToHost, ctx->stream))
 
-int pcabo_wpca(pcabo_ctx* ctx, const double* X, const double* f, const int64_t* ranks, int n, int d, int maximize,
-               double var_threshold, int n_components, const double* noise, double* data_mean, double* pca_mean,
-               double* comps, double* evr, int* k, double* Z) {
-  if (!ctx) return PCABO_ERR_ARG;
-  if (!X || (!f && !ranks) || n < 2 || n > ctx->max_n || d < 1 || d > ctx->max_d)
-    return set_err(ctx, PCABO_ERR_ARG, "pcabo_wpca: bad argument or size beyond context capacity%s", "");
-  HIPCHK(hipSetDevice(ctx->device));
+// ---- rows A-C (+ D-H behind them) ---------------------------------------------------------------------------------
+// Inputs of one BO iteration.  Host-pointer mode: X, the noise block, the ranks (or f) and y are packed into one pinned
+// buffer and cross in ONE copy (four pageable copies cost 60-170 us of host time per iteration); device-pointer mode:
+// device-to-device copies into the context's own buffers as before.
+struct WpcaInputs { const double *X, *noise, *y; const long long* ranks; };
+static int stage_inputs(pcabo_ctx* ctx, const double* X, const double* f, const int64_t* ranks, const double* noise,
+                        const double* y, int n, int d, int maximize, WpcaInputs* in) {
+  hipStream_t s = ctx->stream;
+  const size_t nd = (size_t)n * d;
+  if (ctx->ptr_mode == PCABO_PTR_HOST) {
+    double* h = ctx->hIn;
+    size_t off = 0;
+    memcpy(h, X, nd * sizeof(double));                               in->X = ctx->dIn; off += nd;
+    if (noise) { memcpy(h + off, noise, nd * sizeof(double));        in->noise = ctx->dIn + off; off += nd; }
+    const size_t off_r = off;
+    memcpy(h + off, ranks ? (const void*)ranks : (const void*)f, (size_t)n * 8); off += n;
+    if (y) { memcpy(h + off, y, (size_t)n * sizeof(double));         in->y = ctx->dIn + off; off += n; }
+    // (segments are only 8-byte aligned: none of the consumers uses wider loads on them)
+    HIPCHK(hipMemcpyAsync(ctx->dIn, h, off * sizeof(double), hipMemcpyHostToDevice, s));
+    if (ranks) in->ranks = (const long long*)(ctx->dIn + off_r);
+    else { launch_rank(s, ctx->dIn + off_r, n, maximize, ctx->dRanks); in->ranks = ctx->dRanks; }
+    return PCABO_OK;
+  }
+  STAGE_IN(ctx->dX, X, nd, double);                                  in->X = ctx->dX;
+  if (ranks) { STAGE_IN(ctx->dRanks, ranks, n, long long); }
+  else { STAGE_IN(ctx->dF, f, n, double); launch_rank(s, ctx->dF, n, maximize, ctx->dRanks); }
+  in->ranks = ctx->dRanks;
+  if (noise) { STAGE_IN(ctx->dNoise, noise, nd, double);             in->noise = ctx->dNoise; }
+  if (y) { STAGE_IN(ctx->dY, y, n, double);                          in->y = ctx->dY; }
+  return PCABO_OK;
+}
+
+// wPCA launches, then ONE copy of [data_mean | pca_mean | evr | comps] to pinned memory and the event that says it
+// arrived.  k arrives through the HostMirror (written by k_pca_finalize).
+static int enqueue_wpca(pcabo_ctx* ctx, const WpcaInputs& in, int n, int d, double var_threshold, int n_components) {
   hipStream_t s = ctx->stream;
   const int DP = round_up(d, 16);
-  STAGE_IN(ctx->dX, X, (size_t)n * d, double);
-  if (ranks) {
-    STAGE_IN(ctx->dRanks, ranks, n, long long);
-  } else {
-    STAGE_IN(ctx->dF, f, n, double);
-    launch_rank(s, ctx->dF, n, maximize, ctx->dRanks);
-  }
-  if (noise) STAGE_IN(ctx->dNoise, noise, (size_t)n * d, double);
   {
     ProfScope ps(ctx, 0, 8.0 * n * d * 2 + 8.0 * n * d, 2.0 * n * d * d + 9.0 * d * d * d + 2.0 * n * d * d);
-    launch_wpca_prep(s, ctx->dX, ctx->dRanks, noise ? ctx->dNoise : nullptr, n, d, DP, ctx->dWeights, ctx->dDataMean,
-                     ctx->dPcaMean, ctx->dWc);
+    launch_wpca_prep(s, in.X, in.ranks, in.noise, n, d, DP, ctx->dWeights, ctx->dDataMean, ctx->dPcaMean, ctx->dWc);
     launch_cov(s, ctx->dWc, n, DP, ctx->dC);
     const double* v0 = (ctx->vprev_d == d) ? ctx->dGbuf[ctx->gcur] : nullptr;
     ctx->gcur ^= 1;
@@ -377,18 +404,51 @@ int pcabo_wpca(pcabo_ctx* ctx, const double* X, const double* f, const int64_t* 
     ctx->vprev_d = d;
     launch_pca_finalize(s, ctx->dG, ctx->dLam, n, d, var_threshold, n_components, ctx->dComps, ctx->dEvr, ctx->dK,
                         ctx->hm);
-    launch_project(s, ctx->dX, ctx->dDataMean, ctx->dPcaMean, ctx->dComps, ctx->dK, n, d, ctx->dZ);
+    launch_project(s, in.X, ctx->dDataMean, ctx->dPcaMean, ctx->dComps, ctx->dK, n, d, ctx->dZ);
   }
   const int rcount = n < d ? n : d;
-  if (data_mean) HOST_OUT(data_mean, ctx->dDataMean, d, double);
-  if (pca_mean) HOST_OUT(pca_mean, ctx->dPcaMean, d, double);
-  if (comps) HOST_OUT(comps, ctx->dComps, (size_t)rcount * d, double);
-  if (evr) HOST_OUT(evr, ctx->dEvr, rcount, double);
-  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipMemcpyAsync(ctx->hSmall, ctx->dPcaOut, ((size_t)3 * ctx->max_d + (size_t)rcount * d) * sizeof(double),
+                        hipMemcpyDeviceToHost, s));
+  HIPCHK(hipEventRecord(ctx->evPca, s));
+  return PCABO_OK;
+}
+
+// wait for the wPCA results only (whatever was enqueued behind them keeps running) and hand them out
+static int collect_wpca(pcabo_ctx* ctx, int n, int d, double* data_mean, double* pca_mean, double* comps, double* evr,
+                        int* k) {
+  HIPCHK(hipEventSynchronize(ctx->evPca));
   HIPCHK(hipGetLastError());
-  ctx->n = n; ctx->d = d; ctx->k = ctx->hm->k;
-  ctx->have_wpca = true; ctx->have_gp = false;
+  const int rcount = n < d ? n : d;
+  const double* h = ctx->hSmall;
+  const size_t D = ctx->max_d;
+  if (data_mean) memcpy(data_mean, h, (size_t)d * sizeof(double));
+  if (pca_mean) memcpy(pca_mean, h + D, (size_t)d * sizeof(double));
+  if (evr) memcpy(evr, h + 2 * D, (size_t)rcount * sizeof(double));
+  if (comps) memcpy(comps, h + 3 * D, (size_t)rcount * d * sizeof(double));
+  ctx->d = d; ctx->k = ctx->hm->k;
+  ctx->have_wpca = true;
   if (k) *k = ctx->k;
+  return PCABO_OK;
+}
+
+int pcabo_wpca(pcabo_ctx* ctx, const double* X, const double* f, const int64_t* ranks, int n, int d, int maximize,
+               double var_threshold, int n_components, const double* noise, double* data_mean, double* pca_mean,
+               double* comps, double* evr, int* k, double* Z) {
+  if (!ctx) return PCABO_ERR_ARG;
+  if (!X || (!f && !ranks) || n < 2 || n > ctx->max_n || d < 1 || d > ctx->max_d)
+    return set_err(ctx, PCABO_ERR_ARG, "pcabo_wpca: bad argument or size beyond context capacity%s", "");
+  if (ctx->gp_pending) return set_err(ctx, PCABO_ERR_ARG, "pcabo_wpca: a conditioning is in flight, call pcabo_gp_condition_end first%s", "");
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  WpcaInputs in{nullptr, nullptr, nullptr, nullptr};
+  int rc = stage_inputs(ctx, X, f, ranks, noise, nullptr, n, d, maximize, &in);
+  if (rc != PCABO_OK) return rc;
+  rc = enqueue_wpca(ctx, in, n, d, var_threshold, n_components);
+  if (rc != PCABO_OK) return rc;
+  ctx->have_gp = false;
+  rc = collect_wpca(ctx, n, d, data_mean, pca_mean, comps, evr, k);
+  if (rc != PCABO_OK) return rc;
+  ctx->n = n;
   if (Z) {
     STAGE_OUT(Z, ctx->dZ, (size_t)n * ctx->k, double);
     HIPCHK(hipStreamSynchronize(s));
@@ -412,11 +472,40 @@ static int launch_factorisation(pcabo_ctx* ctx, double jitter) {
   return PCABO_OK;
 }
 
+// Rows D-H on the stream, inputs on the device.  k < 0: the reduced dimension is still on its way (the launches sit
+// right behind the wPCA) - the three kernels that need it read it from ctx->dK.
+static int enqueue_condition(pcabo_ctx* ctx, const double* y_dev, int n, int k, const double* unb, double lengthscale,
+                             double noise, int kernel) {
+  hipStream_t s = ctx->stream;
+  const int* k_dev = k < 0 ? ctx->dK : nullptr;
+  const int kk = k < 0 ? ctx->max_d : k;              // work model only
+  ctx->n = n;
+  ctx->NP = round_up(n, PCABO_BS);
+  if (k >= 0) { ctx->k = k; ctx->KP = round_up(k, 4); }
+  ctx->lengthscale = lengthscale; ctx->noise = noise; ctx->kernel = kernel;
+  ctx->have_gp = false;
+  ctx->gp_pending = true;
+  HIPCHK(hipMemsetAsync(ctx->dCounters, 0, (PCABO_CNT_DONE + 1) * sizeof(unsigned int), s));
+  {
+    ProfScope ps(ctx, 1, 8.0 * n * kk + 4.0 * n * (n + 1.0), 2.0 * n * n * kk + 12.0 * n * n);
+    launch_zstats(s, ctx->dZ, y_dev, n, k, unb, ctx->dBounds4, ctx->dZnMean, ctx->dYstats, ctx->dYs, ctx->hm, k_dev);
+    HIPCHK(hipEventRecord(ctx->evBounds, s));
+    launch_znorm(s, ctx->dZ, n, k, ctx->NP, ctx->KP, ctx->ld, ctx->dBounds4, ctx->dZnMean, 1.0 / lengthscale, ctx->dZnT,
+                 ctx->dAT, ctx->dNrm, k_dev);
+    launch_gram(s, ctx->dAT, ctx->dNrm, n, ctx->NP, ctx->KP, ctx->ld, noise, kernel, ctx->dGram, k_dev);
+  }
+  return launch_factorisation(ctx, 0.0);       // asynchronous: pcabo_gp_condition_end() waits and checks
+}
+
+static bool gp_args_ok(const pcabo_ctx* ctx, int n, double lengthscale, double noise, int kernel) {
+  return n >= 2 && n <= ctx->max_n && lengthscale > 0.0 && noise >= 0.0 &&
+         (kernel == PCABO_KERNEL_MATERN52 || kernel == PCABO_KERNEL_RBF);
+}
+
 int pcabo_gp_condition_begin(pcabo_ctx* ctx, const double* Z, const double* y, int n, int k, const double* norm_bounds,
                              double lengthscale, double noise, int kernel) {
   if (!ctx) return PCABO_ERR_ARG;
-  if (!y || n < 2 || n > ctx->max_n || k < 1 || k > ctx->max_d || !(lengthscale > 0.0) || !(noise >= 0.0) ||
-      (kernel != PCABO_KERNEL_MATERN52 && kernel != PCABO_KERNEL_RBF))
+  if (!y || k < 1 || k > ctx->max_d || !gp_args_ok(ctx, n, lengthscale, noise, kernel))
     return set_err(ctx, PCABO_ERR_ARG, "pcabo_gp_condition: bad argument or size beyond context capacity%s", "");
   if (!Z && (!ctx->have_wpca || ctx->n != n || ctx->k != k))
     return set_err(ctx, PCABO_ERR_ARG, "pcabo_gp_condition: Z == NULL needs a matching pcabo_wpca call first%s", "");
@@ -429,22 +518,38 @@ int pcabo_gp_condition_begin(pcabo_ctx* ctx, const double* Z, const double* y, i
     HIPCHK(hipMemcpyAsync(ctx->dUserNB, norm_bounds, (size_t)2 * k * sizeof(double), hipMemcpyHostToDevice, s));
     unb = ctx->dUserNB;
   }
-  ctx->n = n; ctx->k = k;
-  ctx->NP = round_up(n, PCABO_BS);
-  ctx->KP = round_up(k, 4);
-  ctx->lengthscale = lengthscale; ctx->noise = noise; ctx->kernel = kernel;
-  ctx->have_gp = false;
-  ctx->gp_pending = true;
-  HIPCHK(hipMemsetAsync(ctx->dCounters, 0, (PCABO_CNT_DONE + 1) * sizeof(unsigned int), s));
-  {
-    ProfScope ps(ctx, 1, 8.0 * n * k + 4.0 * n * (n + 1.0), 2.0 * n * n * k + 12.0 * n * n);
-    launch_zstats(s, ctx->dZ, ctx->dY, n, k, unb, ctx->dBounds4, ctx->dZnMean, ctx->dYstats, ctx->dYs, ctx->hm);
-    HIPCHK(hipEventRecord(ctx->evBounds, s));
-    launch_znorm(s, ctx->dZ, n, k, ctx->NP, ctx->KP, ctx->ld, ctx->dBounds4, ctx->dZnMean, 1.0 / lengthscale, ctx->dZnT,
-                 ctx->dAT, ctx->dNrm);
-    launch_gram(s, ctx->dAT, ctx->dNrm, n, ctx->NP, ctx->KP, ctx->ld, noise, kernel, ctx->dGram);
+  return enqueue_condition(ctx, ctx->dY, n, k, unb, lengthscale, noise, kernel);
+}
+
+// pcabo_wpca followed by pcabo_gp_condition_begin(Z = NULL, norm_bounds = NULL) as ONE enqueue: the conditioning
+// launches go onto the stream right behind the projection, before the host has seen k, so the device does not idle
+// while the wPCA results travel and the caller prepares the second call.  Returns as soon as the wPCA results are on
+// the host; finish with pcabo_gp_condition_end().
+int pcabo_wpca_gp_condition_begin(pcabo_ctx* ctx, const double* X, const double* f, const int64_t* ranks, int n, int d,
+                                  int maximize, double var_threshold, int n_components, const double* noise,
+                                  const double* y, double lengthscale, double gp_noise, int kernel, double* data_mean,
+                                  double* pca_mean, double* comps, double* evr, int* k) {
+  if (!ctx) return PCABO_ERR_ARG;
+  if (!X || !y || (!f && !ranks) || d < 1 || d > ctx->max_d || !gp_args_ok(ctx, n, lengthscale, gp_noise, kernel))
+    return set_err(ctx, PCABO_ERR_ARG, "pcabo_wpca_gp_condition_begin: bad argument or size beyond context capacity%s", "");
+  if (ctx->gp_pending) return set_err(ctx, PCABO_ERR_ARG, "pcabo_wpca_gp_condition_begin: a conditioning is in flight, call pcabo_gp_condition_end first%s", "");
+  HIPCHK(hipSetDevice(ctx->device));
+  WpcaInputs in{nullptr, nullptr, nullptr, nullptr};
+  int rc = stage_inputs(ctx, X, f, ranks, noise, y, n, d, maximize, &in);
+  if (rc != PCABO_OK) return rc;
+  rc = enqueue_wpca(ctx, in, n, d, var_threshold, n_components);
+  if (rc != PCABO_OK) return rc;
+  if (ctx->prof) {                       // profiled runs keep the two phases apart (the work model of group 1 needs k)
+    rc = collect_wpca(ctx, n, d, data_mean, pca_mean, comps, evr, k);
+    if (rc != PCABO_OK) return rc;
+    return enqueue_condition(ctx, in.y, n, ctx->k, nullptr, lengthscale, gp_noise, kernel);
   }
-  return launch_factorisation(ctx, 0.0);       // asynchronous: pcabo_gp_condition_end() waits and checks
+  rc = enqueue_condition(ctx, in.y, n, -1, nullptr, lengthscale, gp_noise, kernel);
+  if (rc != PCABO_OK) return rc;
+  rc = collect_wpca(ctx, n, d, data_mean, pca_mean, comps, evr, k);
+  if (rc != PCABO_OK) return rc;
+  ctx->KP = round_up(ctx->k, 4);
+  return PCABO_OK;
 }
 
 int pcabo_gp_condition_end(pcabo_ctx* ctx) {

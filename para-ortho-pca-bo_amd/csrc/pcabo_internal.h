@@ -133,14 +133,17 @@ void launch_project(hipStream_t s, const double* X, const double* data_mean, con
                     const double* comps, const int* k_dev, int n, int d, double* Z);
 void launch_zstats(hipStream_t s, const double* Z, const double* y, int n, int k, const double* user_norm_bounds,
                    double* bounds4 /*norm_lo,norm_hi,acq_lo,acq_hi each MAXD*/, double* zn_mean, double* ystats,
-                   double* ys, HostMirror* hm);
+                   double* ys, HostMirror* hm, const int* k_dev = nullptr);
 void launch_znorm(hipStream_t s, const double* Z, int n, int k, int NP, int KP, int ld, const double* bounds4,
-                  const double* zn_mean, double inv_ls, double* ZnT, double* AT, double* nrm);
+                  const double* zn_mean, double inv_ls, double* ZnT, double* AT, double* nrm,
+                  const int* k_dev = nullptr);   // k_dev != NULL: k (and KP) are read on the device, the arguments ignored
 void launch_gram(hipStream_t s, const double* AT, const double* nrm, int n, int NP, int KP, int ld, double noise,
-                 int kernel, double* K);
+                 int kernel, double* K, const int* k_dev = nullptr);
 void launch_add_jitter(hipStream_t s, double* K, int n, int ld, double jitter);
 void launch_cholesky(hipStream_t s, double* L, int NP, int ld, int* info, double* diag_scratch);
 void launch_trinv(hipStream_t s, const double* L, int NP, int ld, double* R);
+void launch_chol_panel_w(hipStream_t s, double* L, int p, int nblocks, int ld, int* info, double* diag_scratch);
+void launch_trinv_diag_w(hipStream_t s, const double* L, int nblk, int ld, double* R);
 void launch_alpha(hipStream_t s, const double* R, const double* ys, int n, int NP, int ld, double* tmp, double* alpha);
 void launch_acq(hipStream_t s, const QueryArgs* qa, const double* Xq, int q, int n, int k, int NP, int ld,
                 const double* ZnT, const double* R, const double* alpha, const double* bounds4, const double* ystats,

@@ -5,20 +5,65 @@
 #define BS PCABO_BS
 #define WLD 65   // LDS leading dimension of the transposing tile (row reads and column writes both conflict-free)
 
-// ---- Cholesky panel: one wave per 64x64 block, a matrix ROW per lane ------------------------------------------------
+// ---- Cholesky panel: two waves per 64x64 block, a matrix ROW per lane ---------------------------------------------
 // The panel step is a chain of 64 dependent pivots; with four lanes per row (k_chol_panel) every link of the chain
-// costs a work-group barrier and two LDS round trips (44-48 us per panel).  Here lane r keeps row r of the diagonal
-// block D AND row r of its own off-diagonal block A in registers, the factor column of a step is broadcast lane by
-// lane with v_readlane (SGPR operand of the FMAs) and the triangular solve A <- A L^-T rides along in the same loop:
-// no barrier and no LDS between the loads and the stores.  Sub-panels of 16 columns: after each one the register
-// arrays shift down by 16 so that the loop body (static register indices) is the same for all four.
+// costs a work-group barrier and two LDS round trips (44-48 us per panel).  Here a lane keeps a whole row in
+// registers (static indices after unrolling; after every 16-column sub-panel the array shifts down by 16 so that the
+// loop body is the same for all four sub-panels):
+//   wave 0, lane r: row r of the diagonal block D.  Inside a sub-panel the factor column of a step is broadcast lane
+//     by lane with v_readlane (SGPR operand of the FMAs); the finished 16 columns go to the LDS tile, one barrier,
+//     then the trailing columns take their multipliers from that tile as LDS broadcasts.
+//   wave 1, lane r: row r of the work-group's off-diagonal block A.  It solves A <- A L^-T one sub-panel BEHIND wave 0
+//     with every multiplier an LDS broadcast - no cross-lane traffic at all.
+// Four barriers per panel instead of 64, and the two chains run on two SIMDs side by side.  LDS multipliers are
+// double-buffered by hand: left to itself the compiler emits read - wait - use, a full LDS latency per pair of FMAs.
 __device__ inline double lane_get(double v, int lane) {          // lane: wave-uniform
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
                           __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
 
-template <bool TRSM>
-__device__ inline void panel_rows(double (&dr)[BS], double (&ar)[BS], double* s_d, double* s_a, int r, int& bad) {
+// a[c] -= sum_j a[j] * L[base+c][base+j] for the 16 columns c = 16g.. of the shifted array, j = 0..15.
+// ltile = &L[base+16g][base] in the LDS tile.  Batches of 4 columns x 4 multiplier columns (16 LDS values, 4 independent
+// FMA chains); the reads of batch t+1 are issued before the FMAs of batch t.
+template <int G>
+__device__ inline void trailing16(double (&a)[BS], const double* ltile) {
+  double sb[2][16];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) sb[0][u * 4 + jj] = ltile[u * WLD + jj];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int c4 = 4 * (t >> 2), j4 = 4 * (t & 3);
+    if (t + 1 < 16) {
+      const int nc4 = 4 * ((t + 1) >> 2), nj4 = 4 * ((t + 1) & 3);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) sb[(t + 1) & 1][u * 4 + jj] = ltile[(nc4 + u) * WLD + nj4 + jj];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = 16 * G + c4 + u, j = j4 + jj;
+        a[c] = fma(-a[j], sb[t & 1][u * 4 + jj], a[c]);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+__device__ inline void trailing_all(double (&a)[BS], const double* s_d, int jb) {
+  const int base = 16 * jb;
+  if (jb + 1 < BS / 16) trailing16<1>(a, s_d + (base + 16) * WLD + base);       // uniform branches
+  if (jb + 2 < BS / 16) trailing16<2>(a, s_d + (base + 32) * WLD + base);
+  if (jb + 3 < BS / 16) trailing16<3>(a, s_d + (base + 48) * WLD + base);
+#pragma unroll
+  for (int c = 0; c < BS - 16; ++c) a[c] = a[c + 16];                            // everything else moves down
+}
+
+// wave 0: factor D.  s_rs[j] = 1/sqrt(pivot j) for wave 1.
+__device__ inline void panel_diag_rows(double (&dr)[BS], double* s_d, double* s_rs, int r, int& bad) {
   for (int jb = 0; jb < BS / 16; ++jb) {
     const int base = 16 * jb;
 #pragma unroll
@@ -26,145 +71,140 @@ __device__ inline void panel_rows(double (&dr)[BS], double (&ar)[BS], double* s_
       double piv = lane_get(dr[j], base + j);
       if (!(piv > 0.0)) { if (bad == 0) bad = base + j + 1; piv = 1.0; }      // uniform
       const double rs = fast_rsq(piv);
+      if (r == 0) s_rs[base + j] = rs;
       const double dl = dr[j] * rs;                // lanes r >= base+j: L[r][base+j] (lane base+j: sqrt(piv))
       dr[j] = dl;
-      double al = 0.0;
-      if (TRSM) { al = ar[j] * rs; ar[j] = al; }
 #pragma unroll
-      for (int c = j + 1; c < 16; ++c) {
-        const double s = lane_get(dl, base + c);   // L[base+c][base+j]
-        dr[c] = fma(-dl, s, dr[c]);
-        if (TRSM) ar[c] = fma(-al, s, ar[c]);
-      }
+      for (int c = j + 1; c < 16; ++c) dr[c] = fma(-dl, lane_get(dl, base + c), dr[c]);   // L[base+c][base+j]
       __builtin_amdgcn_sched_barrier(0);
     }
-    // the 16 finished columns go to the LDS tile (they leave through it anyway) ...
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      s_d[r * WLD + base + j] = (base + j <= r) ? dr[j] : 0.0;
-      if (TRSM) s_a[r * WLD + base + j] = ar[j];
-    }
-    __syncthreads();
-    // ... and the trailing columns of the panel read their multipliers L[base+c][base+j] from there as LDS broadcasts
-    // (one address for the whole wave): no v_readlane / SGPR hazard on this, the larger, part.  16 columns at a time,
-    // 4 independent accumulation chains between scheduling barriers.
-    // Batches of 4 columns x 4 multiplier columns (16 LDS values, 4..8 independent FMA chains), double-buffered by
-    // hand: the reads of batch t+1 are issued before the FMAs of batch t (left to itself the compiler emits
-    // read - wait - use, one full LDS latency per pair of FMAs).
-#pragma unroll
-    for (int g = 1; g < BS / 16; ++g) {
-      if (jb + g < BS / 16) {                      // uniform
-        const double* ltile = s_d + (base + 16 * g) * WLD + base;        // rows base+16g.., columns base..
-        double sb[2][16];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) sb[0][u * 4 + jj] = ltile[u * WLD + jj];
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-          const int c4 = 4 * (t >> 2), j4 = 4 * (t & 3);
-          if (t + 1 < 16) {
-            const int nc4 = 4 * ((t + 1) >> 2), nj4 = 4 * ((t + 1) & 3);
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-              for (int jj = 0; jj < 4; ++jj) sb[(t + 1) & 1][u * 4 + jj] = ltile[(nc4 + u) * WLD + nj4 + jj];
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const int c = 16 * g + c4 + u, j = j4 + jj;
-              const double sv = sb[t & 1][u * 4 + jj];
-              dr[c] = fma(-dr[j], sv, dr[c]);
-              if (TRSM) ar[c] = fma(-ar[j], sv, ar[c]);
-            }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    }
-    // everything else moves down
-#pragma unroll
-    for (int c = 0; c < BS - 16; ++c) {
-      dr[c] = dr[c + 16];
-      if (TRSM) ar[c] = ar[c + 16];
-    }
+    for (int j = 0; j < 16; ++j) s_d[r * WLD + base + j] = (base + j <= r) ? dr[j] : 0.0;
+    __syncthreads();                               // sub-panel jb is published
+    trailing_all(dr, s_d, jb);
   }
 }
 
-__global__ __launch_bounds__(64) void k_chol_panel_w(double* __restrict__ A, int p, int ld, int* __restrict__ info,
-                                                     double* __restrict__ diag_scratch) {
+// wave 1: A <- A L^-T, sub-panel by sub-panel behind wave 0.
+__device__ inline void panel_solve_rows(double (&ar)[BS], const double* s_d, const double* s_rs, double* s_a, int r) {
+  for (int jb = 0; jb < BS / 16; ++jb) {
+    const int base = 16 * jb;
+    __syncthreads();                               // wait for sub-panel jb of the factor
+    const double* tri = s_d + base * WLD + base;   // the 16x16 triangle: L[base+c][base+j] = tri[c*WLD + j]
+    double rsv[16], tb[3][16];                     // tb[j % 3][c]: column j of the triangle, prefetched two steps ahead
+#pragma unroll
+    for (int j = 0; j < 16; ++j) rsv[j] = s_rs[base + j];
+#pragma unroll
+    for (int c = 1; c < 16; ++c) tb[0][c] = tri[c * WLD];
+#pragma unroll
+    for (int c = 2; c < 16; ++c) tb[1][c] = tri[c * WLD + 1];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (j + 2 < 15) {
+#pragma unroll
+        for (int c = j + 3; c < 16; ++c) tb[(j + 2) % 3][c] = tri[c * WLD + j + 2];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const double al = ar[j] * rsv[j];
+      ar[j] = al;
+#pragma unroll
+      for (int c = j + 1; c < 16; ++c) ar[c] = fma(-al, tb[j % 3][c], ar[c]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s_a[r * WLD + base + j] = ar[j];
+    trailing_all(ar, s_d, jb);
+  }
+}
+
+__global__ __launch_bounds__(128) void k_chol_panel_w(double* __restrict__ A, int p, int ld, int* __restrict__ info,
+                                                      double* __restrict__ diag_scratch) {
   __shared__ double s_d[BS * WLD];
   __shared__ double s_a[BS * WLD];
-  const int r = threadIdx.x, b = blockIdx.x;
+  __shared__ double s_rs[BS];
+  const int r = threadIdx.x & 63, role = threadIdx.x >> 6, b = blockIdx.x;
   double* Add = A + (size_t)(p * BS) * ld + p * BS;
   double* Abd = A + (size_t)((p + b) * BS) * ld + p * BS;
-  double dr[BS], ar[BS];
-  // coalesced (lane = column), every load of the tile(s) in flight before the first use
+  double a[BS];
+  // coalesced (lane = column), every load of the tile in flight before the first use; transposed through LDS
+  if (role == 0) {
 #pragma unroll
-  for (int i = 0; i < BS; ++i) dr[i] = Add[(size_t)i * ld + r];
-  if (b > 0) {
+    for (int i = 0; i < BS; ++i) a[i] = Add[(size_t)i * ld + r];
 #pragma unroll
-    for (int i = 0; i < BS; ++i) ar[i] = Abd[(size_t)i * ld + r];
-  }
+    for (int i = 0; i < BS; ++i) s_d[i * WLD + r] = a[i];
+  } else if (b > 0) {
 #pragma unroll
-  for (int i = 0; i < BS; ++i) s_d[i * WLD + r] = dr[i];
-  if (b > 0) {
+    for (int i = 0; i < BS; ++i) a[i] = Abd[(size_t)i * ld + r];
 #pragma unroll
-    for (int i = 0; i < BS; ++i) s_a[i * WLD + r] = ar[i];
+    for (int i = 0; i < BS; ++i) s_a[i * WLD + r] = a[i];
   }
   __syncthreads();
+  if (role == 0) {
 #pragma unroll
-  for (int c = 0; c < BS; ++c) dr[c] = s_d[r * WLD + c];
-  int bad = 0;
+    for (int c = 0; c < BS; ++c) a[c] = s_d[r * WLD + c];
+    int bad = 0;
+    panel_diag_rows(a, s_d, s_rs, r, bad);
+    if (bad && b == 0 && r == 0) atomicCAS(info, 0, p * BS + bad);
+  } else if (b > 0) {
+#pragma unroll
+    for (int c = 0; c < BS; ++c) a[c] = s_a[r * WLD + c];
+    panel_solve_rows(a, s_d, s_rs, s_a, r);
+  } else {
+    for (int jb = 0; jb < BS / 16; ++jb) __syncthreads();      // block 0 has no off-diagonal block: keep the barriers paired
+  }
+  __syncthreads();
   if (b == 0) {
-    __syncthreads();
-    panel_rows<false>(dr, ar, s_d, s_a, r, bad);
-    if (bad && r == 0) atomicCAS(info, 0, p * BS + bad);
-    __syncthreads();
-    const bool direct = gridDim.x == 1;              // last panel: nobody else reads the block (see k_chol_panel)
+    if (role == 0) {
+      const bool direct = gridDim.x == 1;            // last panel: nobody else reads the block (see k_chol_panel)
 #pragma unroll 8
-    for (int i = 0; i < BS; ++i) {
-      if (direct) Add[(size_t)i * ld + r] = s_d[i * WLD + r];
-      else diag_scratch[i * BS + r] = s_d[i * WLD + r];
+      for (int i = 0; i < BS; ++i) {
+        if (direct) Add[(size_t)i * ld + r] = s_d[i * WLD + r];
+        else diag_scratch[i * BS + r] = s_d[i * WLD + r];
+      }
     }
-    return;
-  }
-#pragma unroll
-  for (int c = 0; c < BS; ++c) ar[c] = s_a[r * WLD + c];
-  __syncthreads();
-  panel_rows<true>(dr, ar, s_d, s_a, r, bad);
-  __syncthreads();
+  } else if (role == 1) {
 #pragma unroll 8
-  for (int i = 0; i < BS; ++i) Abd[(size_t)i * ld + r] = s_a[i * WLD + r];
+    for (int i = 0; i < BS; ++i) Abd[(size_t)i * ld + r] = s_a[i * WLD + r];
+  }
 }
 
 // Inverse of the 64x64 diagonal blocks of L, a COLUMN of the inverse per lane: right-looking forward substitution,
 //   x[m] = acc[m] / L[m][m];  acc[r] -= L[r][m] x[m]  (r > m),
 // all of x in registers, the L[r][m] are LDS broadcasts (same address for every lane, contiguous in r), no cross-lane
 // traffic and no barrier inside the chain.
-// step M: x[M] final, then x[r] -= L[r][M] x[M] for r > M.  The multipliers of step M+1 are read from LDS into the other
-// half of `lb` BEFORE the FMAs of step M (explicit double buffering, see panel_rows).
-template <int M>
-struct InvSteps {
-  static __device__ inline void run(double (&x)[BS], double (&lb)[2][BS], const double* s_lt, const double* s_rd) {
-    if (M + 1 < BS) {
+// Step M: x[M] final, then x[r] -= L[r][M] x[M] for r > M, in chunks of 16 rows.  The chunks of all steps form one
+// compile-time sequence; the multipliers of the chunk after the next are read from LDS into the free third of `lb` before
+// the FMAs of the current one (explicit double buffering, see panel_rows; 16-value buffers keep everything in the 256
+// architectural VGPRs - whole-column buffers ended up in AGPRs with a v_accvgpr_read per operand).
+constexpr bool inv_last(int m, int ch) { return m + 1 + 16 * ch + 16 >= BS; }
+constexpr int inv_next_m(int m, int ch) { return inv_last(m, ch) ? m + 1 : m; }
+constexpr int inv_next_ch(int m, int ch) { return inv_last(m, ch) ? 0 : ch + 1; }
+template <int M, int CH, int P>          // P: buffer (of 3) holding this chunk's multipliers; prefetch distance 2
+struct InvChunk {
+  static constexpr int r0 = M + 1 + 16 * CH;
+  static constexpr int NM = inv_next_m(M, CH), NCH = inv_next_ch(M, CH);
+  static constexpr int N2M = inv_next_m(NM, NCH), N2CH = inv_next_ch(NM, NCH), n2r0 = N2M + 1 + 16 * N2CH;
+  static __device__ inline void run(double (&x)[BS], double (&lb)[3][16], const double* s_lt, const double* s_rd,
+                                    double& xm) {
+    if (N2M < BS - 1) {
 #pragma unroll
-      for (int r = M + 2; r < BS; ++r) lb[(M + 1) & 1][r] = s_lt[(M + 1) * BS + r];
+      for (int i = 0; i < 16; ++i)
+        if (n2r0 + i < BS) lb[(P + 2) % 3][i] = s_lt[N2M * BS + n2r0 + i];
     }
     __builtin_amdgcn_sched_barrier(0);
-    const double xm = x[M] * s_rd[M];
-    x[M] = xm;
+    if (CH == 0) { xm = x[M] * s_rd[M]; x[M] = xm; }
 #pragma unroll
-    for (int r = M + 1; r < BS; ++r) x[r] = fma(-lb[M & 1][r], xm, x[r]);
+    for (int i = 0; i < 16; ++i)
+      if (r0 + i < BS) x[r0 + i] = fma(-lb[P][i], xm, x[r0 + i]);
     __builtin_amdgcn_sched_barrier(0);
-    InvSteps<M + 1>::run(x, lb, s_lt, s_rd);
+    InvChunk<NM, NCH, (P + 1) % 3>::run(x, lb, s_lt, s_rd, xm);
   }
 };
-template <>
-struct InvSteps<BS> {
-  static __device__ inline void run(double (&)[BS], double (&)[2][BS], const double*, const double*) {}
+template <int CH, int P>
+struct InvChunk<BS - 1, CH, P> {
+  static __device__ inline void run(double (&x)[BS], double (&)[3][16], const double*, const double* s_rd, double&) {
+    x[BS - 1] *= s_rd[BS - 1];
+  }
 };
 
 __global__ __launch_bounds__(64) void k_trinv_diag_w(const double* __restrict__ L, int ld, double* __restrict__ R) {
@@ -182,10 +222,10 @@ __global__ __launch_bounds__(64) void k_trinv_diag_w(const double* __restrict__ 
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < BS; ++r) x[r] = (r == c) ? 1.0 : 0.0;
-  double lb[2][BS];
+  double lb[3][16], xm = 0.0;
 #pragma unroll
-  for (int r = 1; r < BS; ++r) lb[0][r] = s_lt[r];
-  InvSteps<0>::run(x, lb, s_lt, s_rd);
+  for (int i = 0; i < 16; ++i) { lb[0][i] = s_lt[1 + i]; lb[1][i] = s_lt[17 + i]; }     // chunks (0,0) and (0,1)
+  InvChunk<0, 0, 0>::run(x, lb, s_lt, s_rd, xm);
   double* dst = R + (size_t)(b * BS) * ld + b * BS;
 #pragma unroll
   for (int r = 0; r < BS; ++r) dst[(size_t)r * ld + c] = (r >= c) ? x[r] : 0.0;
@@ -193,7 +233,7 @@ __global__ __launch_bounds__(64) void k_trinv_diag_w(const double* __restrict__ 
 
 
 void launch_chol_panel_w(hipStream_t s, double* L, int p, int nblocks, int ld, int* info, double* diag_scratch) {
-  hipLaunchKernelGGL(k_chol_panel_w, dim3(nblocks), dim3(64), 0, s, L, p, ld, info, diag_scratch);
+  hipLaunchKernelGGL(k_chol_panel_w, dim3(nblocks), dim3(128), 0, s, L, p, ld, info, diag_scratch);
 }
 void launch_trinv_diag_w(hipStream_t s, const double* L, int nblk, int ld, double* R) {
   hipLaunchKernelGGL(k_trinv_diag_w, dim3(nblk), dim3(64), 0, s, L, ld, R);

@@ -141,8 +141,10 @@ __global__ __launch_bounds__(256) void k_cov(const double* __restrict__ Wc, int 
 // eigenvectors.  Round-robin ordering gives d/2 independent pairs per round, each handled by a
 // group of LP lanes (shuffle reductions, no LDS traffic for the dot products).
 #define JAC_THREADS 1024
+__device__ inline double rcp_1nr(double x) { double r = __builtin_amdgcn_rcp(x); return fma(fma(-x, r, 1.0), r, r); }
+__device__ inline double rsq_1nr(double x) { double y = __builtin_amdgcn_rsq(x); return y * fma(-0.5 * x * y, y, 1.5); }
 #ifdef PCABO_ACQ_TIMING
-__device__ unsigned long long g_jac_stamps[4];
+__device__ unsigned long long g_jac_stamps[8];
 extern "C" int pcabo_debug_jacobi_stamps(unsigned long long* out4) {
   return hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_jac_stamps), sizeof(g_jac_stamps)) == hipSuccess ? 0 : -3;
 }
@@ -159,10 +161,23 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi(const double* __restrict
   volatile int& s_rot = *reinterpret_cast<volatile int*>(s_g + (size_t)d * LD);   // flag lives after the matrix
   if (tid == 0) s_rot = 0;
   __syncthreads();
+  // Warm start from LDS copies of C and V0 when they fit (3 d^2 doubles; d <= 64): read once, coalesced - the d-long
+  // loops below otherwise walk global memory (50 us of the kernel at d = 40).
+  const bool staged = V0 && d <= 64;           // the launcher sizes the dynamic LDS for it
+  double* s_c = s_g + (size_t)d * LD + 2;      // C row-major, stride LD      (after the matrix and the flag)
+  double* s_v = s_c + (size_t)d * LD;          // V0: column `col` contiguous, stride LD
+  if (staged) {
+    for (int idx = tid; idx < d * d; idx += (int)blockDim.x) {
+      const int a = idx / d, b = idx % d;
+      s_c[a * LD + b] = C[(size_t)a * DP + b];
+      s_v[a * LD + b] = V0[(size_t)a * d + b];
+    }
+    __syncthreads();
+  }
   if (V0) {                                  // usable only if every column has unit norm (none collapsed to zero)
     for (int col = tid; col < d; col += (int)blockDim.x) {
       double a = 0.0;
-      for (int r = 0; r < d; ++r) { double v = V0[(size_t)col * d + r]; a += v * v; }
+      for (int r = 0; r < d; ++r) { double v = staged ? s_v[col * LD + r] : V0[(size_t)col * d + r]; a += v * v; }
       if (!(fabs(a - 1.0) < 1e-8)) s_rot = 1;
     }
   }
@@ -172,7 +187,12 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi(const double* __restrict
   for (int idx = tid; idx < d * d; idx += (int)blockDim.x) {
     int col = idx / d, row = idx % d;
     double v;
-    if (warm) {
+    if (warm && staged) {
+      v = 0.0;
+      const double* crow = s_c + row * LD;
+      const double* vcol = s_v + col * LD;
+      for (int j = 0; j < d; ++j) v += crow[j] * vcol[j];
+    } else if (warm) {
       v = 0.0;
       const double* crow = C + (size_t)row * DP;
       const double* vcol = V0 + (size_t)col * d;
@@ -190,16 +210,28 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi(const double* __restrict
   const int LP = (int)blockDim.x >= npairs * 16 ? 16 : 8;      // lanes per column pair (launcher sizes the block)
   const int grp = tid / LP, lane = tid % LP;
   const double tol = 1e-15;
+  // round-robin schedule: group g > 0 plays p = (round + g) mod m against q = (round - g) mod m, group 0 plays
+  // `round` against the fixed last player; both indices advance by one (mod m) per round - kept incrementally
+  // (two runtime modulo operations per round were ~15 % of the round)
+  const int m_rr = de - 1;
+  int pr = grp < npairs ? grp % m_rr : 0, qr = grp < npairs ? (m_rr - grp % m_rr) % m_rr : 0;
   int sweep = 0;
 #ifdef PCABO_ACQ_TIMING
   const unsigned long long jc0 = clock64(), jw0 = wall_clock64();
+  unsigned long long ph_dot = 0, ph_rot = 0, ph_wr = 0, ph_bar = 0, ph_t = 0;
+#define JSTAMP(acc) do { if (tid == 0) { __builtin_amdgcn_s_waitcnt(0); unsigned long long n_ = clock64(); acc += n_ - ph_t; ph_t = n_; } } while (0)
+#else
+#define JSTAMP(acc) do {} while (0)
 #endif
   for (; sweep < 40; ++sweep) {
     for (int round = 0; round < de - 1; ++round) {
+#ifdef PCABO_ACQ_TIMING
+      if (tid == 0) ph_t = clock64();
+#endif
       if (grp < npairs) {
-        int p, q;
-        if (grp == 0) { p = round; q = de - 1; }
-        else { p = (round + grp) % (de - 1); q = (round - grp + (de - 1)) % (de - 1); }
+        int p = pr, q = grp == 0 ? de - 1 : qr;
+        pr = pr + 1 == m_rr ? 0 : pr + 1;
+        qr = qr + 1 == m_rr ? 0 : qr + 1;
         if (p > q) { int t = p; p = q; q = t; }
         if (q < d) {
           double* gp = s_g + p * LD;
@@ -233,13 +265,18 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi(const double* __restrict
             }
           }
           const double ab = a * b;
+          JSTAMP(ph_dot);
           if (g * g > tol * tol * ab && fabs(g) > 1e-300) {
             // rotation from hardware rcp/rsq estimates + Newton steps (c^2 + s^2 = 1 to ~1 ulp is what matters)
-            const double zeta = (b - a) * 0.5 * fast_rcp(g);
+            // (the ANGLE only needs ~1e-12: an error there is removed by the next rotation of the pair - one Newton
+            // step on the estimates; cs below keeps two)
+            const double zeta = (b - a) * 0.5 * rcp_1nr(g);
             const double hyp = 1.0 + zeta * zeta;
-            const double t = (zeta >= 0.0 ? 1.0 : -1.0) * fast_rcp(fabs(zeta) + hyp * fast_rsq(hyp));
+            const double t = (zeta >= 0.0 ? 1.0 : -1.0) * rcp_1nr(fabs(zeta) + hyp * rsq_1nr(hyp));
             const double cs = fast_rsq(1.0 + t * t);
             const double sn = cs * t;
+            if (cs == 123.456) s_rot = 2;      // (timing build only) keeps cs live before the stamp
+            JSTAMP(ph_rot);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
               const int r = lane + u * LP;
@@ -251,10 +288,12 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi(const double* __restrict
               gq[r] = sn * x + cs * y;
             }
             if (lane == 0 && g * g > 1e-16 * ab) s_rot = 1;   // a further sweep is needed
+            JSTAMP(ph_wr);
           }
         }
       }
       __syncthreads();
+      JSTAMP(ph_bar);
     }
     int rot = s_rot;
     __syncthreads();
@@ -263,7 +302,8 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi(const double* __restrict
     if (!rot) { ++sweep; break; }
   }
 #ifdef PCABO_ACQ_TIMING
-  if (tid == 0) { g_jac_stamps[0] = clock64() - jc0; g_jac_stamps[1] = wall_clock64() - jw0; g_jac_stamps[2] = (unsigned long long)sweep; g_jac_stamps[3] = (unsigned long long)(de - 1); }
+  if (tid == 0) { g_jac_stamps[0] = clock64() - jc0; g_jac_stamps[1] = wall_clock64() - jw0; g_jac_stamps[2] = (unsigned long long)sweep; g_jac_stamps[3] = (unsigned long long)(de - 1);
+    g_jac_stamps[4] = ph_dot; g_jac_stamps[5] = ph_rot; g_jac_stamps[6] = ph_wr; g_jac_stamps[7] = ph_bar; }
 #endif
   // eigenvalues = column norms; write normalised columns (eigenvectors), column-major d x d
   for (int col = tid / 64; col < d; col += (int)blockDim.x / 64) {
@@ -464,6 +504,7 @@ void launch_cov(hipStream_t s, const double* Wc, int n, int DP, double* C) {
 }
 void launch_jacobi(hipStream_t s, const double* C, int d, int DP, const double* V0, double* G, double* lam, int* sweeps) {
   size_t lds = ((size_t)d * (d | 1) + 2) * sizeof(double);
+  if (V0 && d <= 64) lds += (size_t)2 * d * (d | 1) * sizeof(double);      // LDS copies of C and V0 for the warm start
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)k_jacobi, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

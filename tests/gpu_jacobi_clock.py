@@ -13,7 +13,7 @@ for it in range(12):
     X = np.vstack([X, rng.uniform(-5, 5, size=(1, d))]); f = np.append(f, rng.normal())
     ranks = np.argsort(np.argsort(f)) + 1
     c.wpca(X, ranks=ranks, noise=rng.normal(0, 1e-8, X.shape), want_Z=False)
-    st = (C.c_ulonglong * 4)(); assert N.LIB.pcabo_debug_jacobi_stamps(st) == 0
-    cyc, wall, sweeps, rounds = [int(v) for v in st]
+    st = (C.c_ulonglong * 8)(); assert N.LIB.pcabo_debug_jacobi_stamps(st) == 0
+    cyc, wall, sweeps, rounds = [int(v) for v in st[:4]]
     print(f"n={X.shape[0]}: sweeps {sweeps}, {sweeps*rounds} rounds, {wall*0.01:.1f} us, {cyc/(sweeps*rounds):.0f} cycles/round, shader clock {cyc/(wall*0.01):.0f} MHz", flush=True)
 c.close()

@@ -674,6 +674,45 @@ def test_noise_prefetch_does_not_change_a_run(native):
         assert np.array_equal(f, runs[0][0]) and np.array_equal(x, runs[0][1])
 
 
+def test_single_enqueue_of_wpca_and_conditioning_equals_the_two_calls(native, monkeypatch):
+    """pcabo_wpca_gp_condition_begin queues the conditioning behind the projection before the host knows k (the kernels
+    read it on the device) and moves all inputs in one packed copy: same kernels, same operands - whole runs must
+    agree bit for bit with pcabo_wpca + pcabo_gp_condition_begin, and so must the state after one direct call."""
+    from Algorithms import PCA_BO
+    torch.set_num_threads(4)
+    runs = []
+    for fused in (True, False):
+        if fused:
+            monkeypatch.delenv("PCABO_NO_FUSED_ENQUEUE", raising=False)
+        else:
+            monkeypatch.setenv("PCABO_NO_FUSED_ENQUEUE", "1")
+        opt = PCA_BO(budget=60, n_DoE=30, random_seed=15101, maximization=False)
+        opt(BBOBProblem(15, 1, 10))
+        runs.append((np.array(opt.f_evals), np.vstack(opt.x_evals)))
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+    rng = np.random.default_rng(5)
+    n, d = 77, 12
+    X, y = rng.uniform(-5, 5, (n, d)), rng.normal(size=n)
+    ranks = np.argsort(np.argsort(y)) + 1
+    noise = rng.normal(0, 1e-8, (n, d))
+    states = []
+    for fused in (True, False):
+        ctx = native.Context(max_n=128, max_d=d, max_q=16)
+        if fused:
+            res = ctx.wpca_gp_condition(X, y, ranks=ranks, noise=noise)
+        else:
+            res = ctx.wpca(X, ranks=ranks, noise=noise, want_Z=False)
+            ctx.gp_condition(y, wait=False)
+        box = ctx.acq_bounds()                      # allowed while the conditioning is in flight
+        ctx.gp_wait()
+        val, grad = ctx.acq_eval(np.tile(box.mean(0), (3, 1)) + np.arange(3)[:, None] * 0.01, float(y.min()))
+        states.append((res["k"], res["components"], res["evr"], res["data_mean"], res["pca_mean"], box, ctx.gram(),
+                       *[v for _, v in sorted(ctx.gp_state().items())], val, grad))
+        ctx.close()
+    for a, b in zip(states[0], states[1]):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
 def test_resident_kernel_reproduces_per_round_launches(native):
     """The resident ("server") mode of the acquisition kernel - one launch per optimize call, query points through the
     mailbox - runs the same arithmetic as one launch per evaluation: whole runs must agree bit for bit

@@ -95,6 +95,13 @@ int pcabo_gp_condition_begin(pcabo_ctx* ctx, const double* Z, const double* y, i
                              const double* norm_bounds, double lengthscale, double noise, int kernel);
 int pcabo_gp_condition_end(pcabo_ctx* ctx);
 
+/* pcabo_gp_condition_end followed by pcabo_acq_eval(values only) with the evaluation enqueued behind the conditioning
+ * instead of after the host has seen it finish (the 512 raw samples of botorch's gen_batch_initial_conditions,
+ * PCA_BO.py:607-614, are drawn from the search box, which is known long before the factorisation ends).
+ * Same results as the two calls. Xq[q*k] [host], val[q] [host]. */
+int pcabo_gp_condition_end_eval(pcabo_ctx* ctx, const double* Xq, int q, double best_f, int maximize, int acq,
+                                double* val);
+
 /* Rows A-H as ONE enqueue: pcabo_wpca immediately followed by pcabo_gp_condition_begin(Z = NULL,
  * norm_bounds = NULL), i.e. PCA_BO._transform_points_to_reduced_space + _initialize_model of one iteration
  * (PCA_BO.py:343-408 and :502-545) without the host round trip between them: the conditioning launches are queued

@@ -134,10 +134,13 @@ class Vanilla_BO(AbstractBayesianOptimizer):
         start = perf_counter()
         engine = _init.scrambled_sobol_engine(self.dimension)      # built and drawn while the device conditions the GP
         raw = _init.draw_sobol(self.__box, cfg["RAW_SAMPLES"], engine)
-        ctx.gp_wait()
+        t0 = perf_counter()                # the raw samples are scored right behind the conditioning: one wait for both
+        raw_vals = ctx.gp_wait_eval(raw, acq.best_f, acq.maximize, acq.acq_code)
+        self.phase_breakdown["raw_eval"] = self.phase_breakdown.get("raw_eval", 0.0) + perf_counter() - t0
         new_x, cand, vals, info = _acqopt.optimize_acqf(
             ctx, self.__box, acq.best_f, acq.maximize, acq.acq_code, cfg["NUM_RESTARTS"], cfg["RAW_SAMPLES"], 5, 200,
-            raw=raw, breakdown=self.phase_breakdown, trace=self.trace[-1] if self.__record_trace else None)
+            raw=raw, raw_vals=raw_vals, breakdown=self.phase_breakdown,
+            trace=self.trace[-1] if self.__record_trace else None)
         self.timing_logs["optimize_acqf"].append(perf_counter() - start)
         self.lbfgsb_info.append(info)
         return new_x

@@ -175,6 +175,35 @@ static int set_err(pcabo_ctx* c, int code, const char* fmt, const char* a = "", 
     if (e_ != hipSuccess) return set_err(ctx, PCABO_ERR_HIP, "HIP error: %s (line %d)", hipGetErrorString(e_), __LINE__); \
   } while (0)
 
+// ---- waiting for the device -----------------------------------------------------------------------------------
+// hipStreamSynchronize / hipEventSynchronize put the calling thread to sleep once the wait lasts longer than the
+// runtime's short active-wait window; it then comes back late and cold (measured: the first ~0.15 ms of host work after a
+// 0.2 ms wait ran several times slower).  The waits of a BO iteration are 0.1-0.4 ms, so they poll instead, and only a
+// wait that lasts longer than 2 ms falls back to the blocking call.
+static const bool g_blocking_waits = getenv("PCABO_BLOCKING_WAITS") != nullptr;      // A/B switch
+static hipError_t wait_stream(hipStream_t s) {
+  if (g_blocking_waits) return hipStreamSynchronize(s);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 1;; ++spins) {
+    hipError_t e = hipStreamQuery(s);
+    if (e != hipErrorNotReady) return e == hipSuccess ? hipStreamSynchronize(s) : e;
+    if ((spins & 63) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    __builtin_ia32_pause();
+  }
+  return hipStreamSynchronize(s);
+}
+static hipError_t wait_event(hipEvent_t ev) {
+  if (g_blocking_waits) return hipEventSynchronize(ev);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 1;; ++spins) {
+    hipError_t e = hipEventQuery(ev);
+    if (e != hipErrorNotReady) return e;
+    if ((spins & 63) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    __builtin_ia32_pause();
+  }
+  return hipEventSynchronize(ev);
+}
+
 // ---- profiling helpers ------------------------------------------------------------------------
 __global__ void k_nop() {}
 
@@ -416,7 +445,7 @@ static int enqueue_wpca(pcabo_ctx* ctx, const WpcaInputs& in, int n, int d, doub
 // wait for the wPCA results only (whatever was enqueued behind them keeps running) and hand them out
 static int collect_wpca(pcabo_ctx* ctx, int n, int d, double* data_mean, double* pca_mean, double* comps, double* evr,
                         int* k) {
-  HIPCHK(hipEventSynchronize(ctx->evPca));
+  HIPCHK(wait_event(ctx->evPca));
   HIPCHK(hipGetLastError());
   const int rcount = n < d ? n : d;
   const double* h = ctx->hSmall;
@@ -559,7 +588,7 @@ int pcabo_gp_condition_end(pcabo_ctx* ctx) {
   ctx->gp_pending = false;
   double jitter = 0.0;
   for (int attempt = 0; attempt < 4; ++attempt) {       // psd_safe_cholesky: 0, 1e-8, 1e-7, 1e-6
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(wait_stream(ctx->stream));
     HIPCHK(hipGetLastError());
     if (ctx->hm->chol_info == 0) { ctx->have_gp = true; return PCABO_OK; }
     if (attempt == 3) break;
@@ -582,7 +611,7 @@ int pcabo_acq_bounds(pcabo_ctx* ctx, double* bounds) {
   if (!ctx || !bounds) return PCABO_ERR_ARG;
   if (ctx->gp_pending) {                   // conditioning in flight: the box only needs k_zstats, wait for that alone
     HIPCHK(hipSetDevice(ctx->device));
-    HIPCHK(hipEventSynchronize(ctx->evBounds));
+    HIPCHK(wait_event(ctx->evBounds));
   } else if (!ctx->have_gp) {
     return set_err(ctx, PCABO_ERR_ARG, "pcabo_acq_bounds: call pcabo_gp_condition first%s", "");
   }
@@ -626,7 +655,7 @@ static int eval_staged(pcabo_ctx* ctx, int nq, AcqParams& p) {
   if (!small) {
     HIPCHK(hipMemcpyAsync(ctx->hVal, ctx->dVal, (size_t)nq * sizeof(double), hipMemcpyDeviceToHost, s));
     if (p.want_grad) HIPCHK(hipMemcpyAsync(ctx->hGrad, ctx->dGrad, (size_t)nq * k * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(wait_stream(s));
     HIPCHK(hipGetLastError());
     return PCABO_OK;
   }
@@ -674,6 +703,39 @@ int pcabo_acq_eval(pcabo_ctx* ctx, const double* Xq, int q, double best_f, int m
     if (grad) HIPCHK(hipMemcpyAsync(grad, ctx->dGrad, nx * sizeof(double), hipMemcpyDeviceToDevice, s));
     HIPCHK(hipStreamSynchronize(s));
   }
+  return PCABO_OK;
+}
+
+// pcabo_gp_condition_end + pcabo_acq_eval (values only) with the evaluation ENQUEUED BEHIND the conditioning: the raw
+// samples of the initial-condition draw are known before the factorisation has finished, so their copy and launches
+// need not wait for the host to see it end.  If the factorisation turns out to have needed jitter, the values are
+// computed again after the retries.
+int pcabo_gp_condition_end_eval(pcabo_ctx* ctx, const double* Xq, int q, double best_f, int maximize, int acq,
+                                double* val) {
+  if (!ctx) return PCABO_ERR_ARG;
+  if (!Xq || !val || q < 1 || q > ctx->max_q || (acq != PCABO_ACQ_LOG_EI && acq != PCABO_ACQ_PI))
+    return set_err(ctx, PCABO_ERR_ARG, "pcabo_gp_condition_end_eval: bad argument or q beyond context capacity%s", "");
+  if (!ctx->gp_pending) return set_err(ctx, PCABO_ERR_ARG, "pcabo_gp_condition_end_eval: no conditioning in flight%s", "");
+  if (q <= PCABO_INLAUNCH_MAXQ || ctx->ptr_mode != PCABO_PTR_HOST) {      // nothing to gain: the two calls in a row
+    int rc = pcabo_gp_condition_end(ctx);
+    if (rc != PCABO_OK) return rc;
+    return pcabo_acq_eval(ctx, Xq, q, best_f, maximize, acq, val, nullptr);
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  memcpy(ctx->hXq, Xq, (size_t)q * ctx->k * sizeof(double));
+  AcqParams p = make_params(ctx, best_f, maximize, acq, 0);
+  int rc = eval_staged(ctx, q, p);                  // ends with a stream synchronisation: the conditioning is over too
+  if (rc != PCABO_OK) { ctx->gp_pending = false; return rc; }
+  if (ctx->hm->chol_info != 0) {                    // rare: jitter retries, then the evaluation again
+    rc = pcabo_gp_condition_end(ctx);
+    if (rc != PCABO_OK) return rc;
+    rc = eval_staged(ctx, q, p);
+    if (rc != PCABO_OK) return rc;
+  } else {
+    ctx->gp_pending = false;
+    ctx->have_gp = true;
+  }
+  memcpy(val, ctx->hVal, (size_t)q * sizeof(double));
   return PCABO_OK;
 }
 

@@ -23,7 +23,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "lib"
 EXPORTS = [
     "pcabo_abi_version", "pcabo_device_count", "pcabo_ctx_create", "pcabo_ctx_destroy",
     "pcabo_set_pointer_mode", "pcabo_last_error", "pcabo_wpca", "pcabo_gp_condition", "pcabo_gp_condition_begin",
-    "pcabo_gp_condition_end", "pcabo_wpca_gp_condition_begin", "pcabo_acq_bounds",
+    "pcabo_gp_condition_end", "pcabo_gp_condition_end_eval", "pcabo_wpca_gp_condition_begin", "pcabo_acq_bounds",
     "pcabo_acq_eval", "pcabo_logei", "pcabo_optimize_acqf", "pcabo_inverse_map", "pcabo_get_gp_state",
     "pcabo_get_gram", "pcabo_lbfgsb_minimize", "pcabo_sobol_scramble", "pcabo_set_profiling", "pcabo_get_profile", "pcabo_reset_profile",
 ]
@@ -61,6 +61,7 @@ def _load() -> C.CDLL:
     lib.pcabo_gp_condition.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_double, C.c_double, C.c_int]
     lib.pcabo_gp_condition_begin.argtypes = lib.pcabo_gp_condition.argtypes
     lib.pcabo_gp_condition_end.argtypes = [vp]
+    lib.pcabo_gp_condition_end_eval.argtypes = [vp, vp, C.c_int, C.c_double, C.c_int, C.c_int, vp]
     lib.pcabo_wpca_gp_condition_begin.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp,
                                                   vp, C.c_double, C.c_double, C.c_int, vp, vp, vp, vp, ip]
     lib.pcabo_acq_bounds.argtypes = [vp, vp]
@@ -201,6 +202,16 @@ class Context:
     def gp_wait(self) -> None:
         self._chk(LIB.pcabo_gp_condition_end(self._h))
         self._keep = None
+
+    def gp_wait_eval(self, Xq, best_f, maximize=False, acq=ACQ_LOG_EI) -> np.ndarray:
+        """gp_wait() + acq_eval(Xq, grad=False) with the evaluation enqueued behind the conditioning."""
+        Xq = _f64(Xq).reshape(-1, self.k)
+        q = Xq.shape[0]
+        val = np.empty(q)
+        self._chk(LIB.pcabo_gp_condition_end_eval(self._h, _ptr(Xq), q, float(best_f), int(bool(maximize)), int(acq),
+                                                  _ptr(val)))
+        self._keep = None
+        return val
 
     def acq_bounds(self) -> np.ndarray:
         b = np.empty((2, self.k))

@@ -16,19 +16,23 @@ from . import initializers as _init
 
 def optimize_acqf(ctx: "_native.Context", bounds: np.ndarray, best_f: float, maximize: bool, acq_code: int,
                   num_restarts: int, raw_samples: int, batch_limit: int = 5, maxiter: int = 200, engine=None,
-                  breakdown: Optional[dict] = None, trace: Optional[dict] = None, raw: Optional[np.ndarray] = None):
+                  breakdown: Optional[dict] = None, trace: Optional[dict] = None, raw: Optional[np.ndarray] = None,
+                  raw_vals: Optional[np.ndarray] = None, before_lbfgsb=None):
     """Returns (candidate[1, k], all restart candidates, their values, L-BFGS-B info).  `engine`: a scrambled Sobol
     engine prepared earlier (same RNG consumption, earlier in time); `raw`: the raw samples already drawn from it
-    (while the device was still factorising).  The retry path draws afresh."""
+    (while the device was still factorising); `raw_vals`: their acquisition values if the caller already has them
+    (`Context.gp_wait_eval`).  The retry path draws and scores afresh.  `before_lbfgsb()`: called once, after the
+    initial conditions are picked (where PCA_BO starts the next iteration's noise draw on its worker thread)."""
     pb = breakdown if breakdown is not None else {}
     engines = [engine] if engine is not None and raw is None else []
     ready = [raw] if raw is not None else []
+    ready_vals = [raw_vals] if raw is not None and raw_vals is not None else []
 
     def initial_conditions():
         t0 = perf_counter()
         raw = ready.pop() if ready else _init.draw_sobol(bounds, raw_samples, engines.pop() if engines else None)
         t1 = perf_counter()
-        vals = ctx.acq_eval(raw, best_f, maximize, acq_code, grad=False)
+        vals = ready_vals.pop() if ready_vals else ctx.acq_eval(raw, best_f, maximize, acq_code, grad=False)
         t2 = perf_counter()
         if acq_code == _native.ACQ_PI:
             idx = _init.initialize_q_batch_nonneg(vals, num_restarts)
@@ -43,6 +47,8 @@ def optimize_acqf(ctx: "_native.Context", bounds: np.ndarray, best_f: float, max
         return raw[idx]
 
     ics = initial_conditions()
+    if before_lbfgsb is not None:
+        before_lbfgsb()
     t_opt = perf_counter()
     cand, vals, info, failed = ctx.optimize_acqf(ics, bounds, best_f, maximize, acq_code, batch_limit=batch_limit,
                                                  maxiter=maxiter)

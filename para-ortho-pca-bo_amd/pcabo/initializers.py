@@ -52,6 +52,7 @@ def draw_sobol(bounds: np.ndarray, n: int, engine=None) -> np.ndarray:
     return (lo + rng * u).numpy()
 
 
+@torch.inference_mode()
 def initialize_q_batch(acq_vals: np.ndarray, n: int, eta: float = INIT_ETA) -> np.ndarray:
     """Boltzmann sampling of n restart indices (without replacement) + forced arg-max."""
     v = torch.from_numpy(np.ascontiguousarray(acq_vals, dtype=np.float64))

@@ -186,6 +186,38 @@ def test_not_positive_definite_is_reported(native):
     c.close()
 
 
+def test_scoring_enqueued_behind_the_conditioning_equals_wait_then_score(native):
+    """pcabo_gp_condition_end_eval = pcabo_gp_condition_end + pcabo_acq_eval with the evaluation queued behind the
+    conditioning: bit-identical values - also when the factorisation needed jitter (the early evaluation then ran on an
+    unusable factor and is repeated after the retries)."""
+    rng = np.random.default_rng(11)
+    cases = []
+    Z = rng.uniform(-2, 2, (150, 6)); cases.append((Z, rng.normal(size=150), 0.006737946999085467))
+    Zd = np.tile(np.array([[0.1, 0.2]]), (40, 1)); Zd[::2] += 0.5                  # duplicates, zero noise: jitter path
+    cases.append((Zd, np.arange(40.0), 0.0))
+    for Zc, y, noise in cases:
+        n, k = Zc.shape
+        Xq = rng.uniform(Zc.min(0) - 0.5, Zc.max(0) + 0.5, (512, k))
+        out = []
+        for early in (True, False):
+            c = native.Context(max_n=192, max_d=8, max_q=512)
+            try:
+                c.gp_condition(y, Z=Zc, noise=noise, wait=False)
+                if early:
+                    v = c.gp_wait_eval(Xq, float(y.min()))
+                else:
+                    c.gp_wait()
+                    v = c.acq_eval(Xq, float(y.min()), grad=False)
+                out.append(v)
+            except native.PcaboError as e:
+                assert e.code == -2 and noise == 0.0
+                out.append(None)
+            c.close()
+        assert (out[0] is None) == (out[1] is None)
+        if out[0] is not None:
+            assert np.array_equal(out[0], out[1], equal_nan=True)
+
+
 def test_optimize_acqf_teacher_forced(ctx, records):
     """Same state + same initial conditions in -> same 10 candidates out (rows M, N)."""
     for key in ("d10", "d40"):

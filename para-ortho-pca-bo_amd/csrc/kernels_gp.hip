@@ -348,7 +348,7 @@ void launch_cholesky(hipStream_t s, double* L, int NP, int ld, int* info, double
 }
 void launch_trinv(hipStream_t s, const double* L, int NP, int ld, double* R) {
   const int nblk = NP / BS;
-  hipMemsetAsync(R, 0, (size_t)NP * ld * sizeof(double), s);
+  (void)hipMemsetAsync(R, 0, (size_t)NP * ld * sizeof(double), s);    // an error surfaces at the next checked call
   static const bool lanes4 = getenv("PCABO_GP_FOUR_LANE_ROWS") != nullptr;
   if (lanes4) hipLaunchKernelGGL(k_trinv_diag, dim3(nblk), dim3(256), 0, s, L, ld, R);
   else launch_trinv_diag_w(s, L, nblk, ld, R);

@@ -327,7 +327,6 @@ __global__ __launch_bounds__(128) void k_pca_finalize(const double* __restrict__
                                                        int* __restrict__ k_dev, HostMirror* hm) {
   __shared__ int s_order[PCABO_MAXD];
   __shared__ double s_lam[PCABO_MAXD];
-  __shared__ double s_tot;
   const int tid = threadIdx.x;
   if (tid < d) s_lam[tid] = lam[tid];
   __syncthreads();
@@ -342,7 +341,6 @@ __global__ __launch_bounds__(128) void k_pca_finalize(const double* __restrict__
   if (tid == 0) {
     double tot = 0.0;
     for (int r = 0; r < rcount; ++r) tot += s_lam[s_order[r]];
-    s_tot = tot;
     int k;
     double cum = 0.0;
     int cnt = 0;
@@ -507,7 +505,7 @@ void launch_jacobi(hipStream_t s, const double* C, int d, int DP, const double* 
   if (V0 && d <= 64) lds += (size_t)2 * d * (d | 1) * sizeof(double);      // LDS copies of C and V0 for the warm start
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)k_jacobi, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_jacobi, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   const int npairs = ((d + 1) & ~1) / 2;

@@ -209,7 +209,7 @@ __global__ void k_nop() {}
 
 static void prof_resolve(pcabo_ctx* c) {
   if (c->pairs_used == 0) return;
-  hipStreamSynchronize(c->stream);
+  (void)hipStreamSynchronize(c->stream);
   for (size_t i = 0; i < c->pairs_used; ++i) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, c->pairs[i].a, c->pairs[i].b) == hipSuccess) {
@@ -231,9 +231,9 @@ struct ProfScope {
     if (c->pairs_used == c->pairs.size()) prof_resolve(c);
     p = &c->pairs[c->pairs_used++];
     p->group = group; p->bytes = bytes; p->flops = flops;
-    hipEventRecord(p->a, c->stream);
+    (void)hipEventRecord(p->a, c->stream);
   }
-  ~ProfScope() { if (p) hipEventRecord(p->b, c->stream); }
+  ~ProfScope() { if (p) (void)hipEventRecord(p->b, c->stream); }
 };
 
 // ---- algorithmic work models (per launch), see DESIGN.md section 4 ----------------------------
@@ -336,20 +336,20 @@ int pcabo_ctx_create(int device, int max_n, int max_d, int max_q, pcabo_ctx** ou
 
 int pcabo_ctx_destroy(pcabo_ctx* ctx) {
   if (!ctx) return PCABO_ERR_ARG;
-  hipSetDevice(ctx->device);
-  if (ctx->stream) hipStreamSynchronize(ctx->stream);
-  for (auto& p : ctx->pairs) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+  (void)hipSetDevice(ctx->device);        // tear-down: nothing useful to do with an error from here on
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (auto& p : ctx->pairs) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   void* dev[] = {ctx->dX, ctx->dNoise, ctx->dF, ctx->dWeights, ctx->dWc, ctx->dRanks, ctx->dPcaOut, ctx->dIn,
                  ctx->dC, ctx->dGbuf[0], ctx->dGbuf[1], ctx->dLam, ctx->dZ, ctx->dK, ctx->dSweeps, ctx->dInfo,
                  ctx->dY, ctx->dYs, ctx->dYstats, ctx->dBounds4, ctx->dZnMean, ctx->dUserNB, ctx->dZnT, ctx->dAT,
                  ctx->dNrm, ctx->dGram, ctx->dL, ctx->dR, ctx->dTmp, ctx->dAlpha, ctx->dDiag, ctx->dXq, ctx->dPartial, ctx->dVal,
                  ctx->dGrad, ctx->dZq, ctx->dXout, ctx->dCounters, ctx->dMail, ctx->dPairs};
-  for (void* p : dev) if (p) hipFree(p);
+  for (void* p : dev) if (p) (void)hipFree(p);
   void* host[] = {(void*)ctx->hm, ctx->hXq, ctx->hVal, ctx->hGrad, ctx->hSmall, ctx->hIn, (void*)ctx->hMail};
-  for (void* p : host) if (p) hipHostFree(p);
-  if (ctx->evBounds) hipEventDestroy(ctx->evBounds);
-  if (ctx->evPca) hipEventDestroy(ctx->evPca);
-  if (ctx->stream) hipStreamDestroy(ctx->stream);
+  for (void* p : host) if (p) (void)hipHostFree(p);
+  if (ctx->evBounds) (void)hipEventDestroy(ctx->evBounds);
+  if (ctx->evPca) (void)hipEventDestroy(ctx->evPca);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   ctx->helper.shutdown();
   if (ctx->registered) presence_unregister(ctx->device);
   delete ctx;
@@ -849,7 +849,7 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
     void stop() {
       if (cap <= 0) return;
       server_post(c, cap, 0, k, ++c->seq);
-      hipStreamSynchronize(c->stream);
+      (void)hipStreamSynchronize(c->stream);
       cap = 0;
     }
     ~ServerStop() { stop(); }

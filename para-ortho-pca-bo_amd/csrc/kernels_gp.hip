@@ -22,8 +22,11 @@
 // four 128-byte rows, fully coalesced; the whole AT (<= 36 x 512 doubles) is L2 resident.
 __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ AT, const double* __restrict__ nrm, int n,
                                               int KP, int ld, double noise, int kernel, double* __restrict__ K,
-                                              const int* __restrict__ k_dev) {
+                                              const int* __restrict__ k_dev, double* __restrict__ K2,
+                                              int* __restrict__ info_reset) {
   const int ti = blockIdx.x, tj = blockIdx.y;
+  // K2: the copy the factorisation works on in place; info_reset: its failure flag (saves a copy and a fill launch)
+  if (info_reset && ti == 0 && tj == 0 && threadIdx.x == 0) *info_reset = 0;
   if (tj > ti) return;
   if (k_dev) KP = (*k_dev + 3) & ~3;
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -59,6 +62,7 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ AT, con
         if (i == j) v += noise;
       }
       K[(size_t)i * ld + j] = v;
+      if (K2) K2[(size_t)i * ld + j] = v;
     }
   }
 }
@@ -207,10 +211,19 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int
   const int J = t;
   if (I >= m) return;
   const int gi = p + 1 + I, gj = p + 1 + J;
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  // the 16 elements of the target tile this thread updates are fetched up front, together with the operand tiles: read
+  // after the MFMAs in a load-subtract-store loop they cost 16 dependent global round trips (the compiler cannot
+  // hoist the loads over the stores to the same array), which was most of the kernel's 15.8 us
+  double* dst = A + (size_t)(gi * BS) * ld + gj * BS;
+  double cold[4][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cold[q][r] = dst[(size_t)(16 * w + (l >> 4) + 4 * r) * ld + 16 * q + (l & 15)];
   load_tile(A + (size_t)(gi * BS) * ld + p * BS, ld, s_a);
   load_tile(A + (size_t)(gj * BS) * ld + p * BS, ld, s_b);
   __syncthreads();
-  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   double4_t acc[4];
   for (int q = 0; q < 4; ++q) acc[q] = (double4_t){0.0, 0.0, 0.0, 0.0};
   for (int kk = 0; kk < BS; kk += 4) {
@@ -220,11 +233,12 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int
       acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[q], 0, 0, 0);
     }
   }
-  double* dst = A + (size_t)(gi * BS) * ld + gj * BS;
+#pragma unroll
   for (int q = 0; q < 4; ++q)
+#pragma unroll
     for (int r = 0; r < 4; ++r) {
       size_t off = (size_t)(16 * w + (l >> 4) + 4 * r) * ld + 16 * q + (l & 15);
-      dst[off] -= acc[q][r];
+      dst[off] = cold[q][r] - acc[q][r];
     }
 }
 
@@ -263,20 +277,42 @@ __global__ __launch_bounds__(256) void k_trinv_diag(const double* __restrict__ L
 //   X_I = Rdiag_I S
 // Column chunks are independent: NP/16 work-groups, no inter-group synchronisation.  X_K tiles
 // written earlier by this same work-group are re-read from global memory after a barrier.
+// The operand tiles of the NEXT step (a 64x64 tile of L or of the diagonal inverses, a 64x16 block of X) travel in
+// registers while the MFMAs of the current step run: the walk is a chain of ~35 short steps for the first block column,
+// and each used to pay a full global-load latency (2 us per step, 62 us per call on average).
 __global__ __launch_bounds__(256) void k_trinv_cols(const double* __restrict__ L, int nblk, int ld,
                                                     double* R) {
   __shared__ __attribute__((aligned(16))) double s_t[BS * TLD];   // 64x64 operand tile
   __shared__ __attribute__((aligned(16))) double s_xk[BS * 16];   // 64x16 block of X (or S)
+  const int tid = threadIdx.x;
   const int c0 = blockIdx.x * 16;
   const int J = c0 / BS;
-  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int w = tid >> 6, l = tid & 63;
+  double pt[16], px[4];                                            // prefetched tile / X block (this thread's share)
+  auto fetch_tile = [&](const double* src) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { const int idx = tid + 256 * u; pt[u] = src[(size_t)(idx >> 6) * ld + (idx & 63)]; }
+  };
+  auto fetch_x = [&](int Kb) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int idx = tid + 256 * u; px[u] = R[(size_t)(Kb * BS + (idx >> 4)) * ld + c0 + (idx & 15)]; }
+  };
+  auto put_tile = [&]() {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { const int idx = tid + 256 * u; s_t[(idx >> 6) * TLD + (idx & 63)] = pt[u]; }
+  };
+  auto put_x = [&]() {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s_xk[tid + 256 * u] = px[u];
+  };
+  if (J + 1 < nblk) { fetch_tile(L + (size_t)((J + 1) * BS) * ld + J * BS); fetch_x(J); }
   for (int I = J + 1; I < nblk; ++I) {
     double4_t acc = {0.0, 0.0, 0.0, 0.0};
     for (int Kb = J; Kb < I; ++Kb) {
-      __syncthreads();
-      load_tile(L + (size_t)(I * BS) * ld + Kb * BS, ld, s_t);
-      for (int idx = threadIdx.x; idx < BS * 16; idx += 256)
-        s_xk[idx] = R[(size_t)(Kb * BS + (idx >> 4)) * ld + c0 + (idx & 15)];
+      __syncthreads();                         // the previous step's MFMAs have read the LDS tiles
+      put_tile(); put_x();
+      if (Kb + 1 < I) { fetch_tile(L + (size_t)(I * BS) * ld + (Kb + 1) * BS); fetch_x(Kb + 1); }
+      else fetch_tile(R + (size_t)(I * BS) * ld + I * BS);         // Rdiag_I from step 1, for the closing product
       __syncthreads();
       for (int kk = 0; kk < BS; kk += 4) {
         double a = s_t[(16 * w + (l & 15)) * TLD + kk + (l >> 4)];
@@ -286,7 +322,8 @@ __global__ __launch_bounds__(256) void k_trinv_cols(const double* __restrict__ L
     }
     __syncthreads();
     for (int r = 0; r < 4; ++r) s_xk[(16 * w + (l >> 4) + 4 * r) * 16 + (l & 15)] = -acc[r];
-    load_tile(R + (size_t)(I * BS) * ld + I * BS, ld, s_t);     // Rdiag_I from step 1
+    put_tile();
+    if (I + 1 < nblk) { fetch_tile(L + (size_t)((I + 1) * BS) * ld + J * BS); fetch_x(J); }
     __syncthreads();
     double4_t x = {0.0, 0.0, 0.0, 0.0};
     for (int kk = 0; kk < BS; kk += 4) {
@@ -315,23 +352,39 @@ __global__ __launch_bounds__(256) void k_rmatvec(const double* __restrict__ R, c
   }
 }
 
-__global__ __launch_bounds__(256) void k_rtmatvec(const double* __restrict__ R, const double* __restrict__ t, int n,
-                                                  int ld, double* __restrict__ out) {
-  __shared__ double s_p[4][64];
+// out = R^T t, 64 columns per group, 16 waves walking down the rows: every wave reads whole 512-byte row segments
+// (the same row for all its lanes; rows above the group's first column hold only zeros of the lower-triangular R and are
+// skipped group-wise).  Fixed summation order: 4 interleaved accumulators per wave, then the 16 waves in order.
+#define RTM_WAVES 16
+__global__ __launch_bounds__(64 * RTM_WAVES) void k_rtmatvec(const double* __restrict__ R, const double* __restrict__ t,
+                                                             int n, int ld, double* __restrict__ out) {
+  __shared__ double s_p[RTM_WAVES][64];
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-  const int j = blockIdx.x * 64 + l;
-  double s = 0.0;
-  for (int i = j + w; i < n; i += 4) s += R[(size_t)i * ld + j] * t[i];
-  s_p[w][l] = s;
+  const int j0 = blockIdx.x * 64, j = j0 + l;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int i = j0 + w;
+  for (; i + 3 * RTM_WAVES < n; i += 4 * RTM_WAVES) {
+    a0 = fma(R[(size_t)i * ld + j], t[i], a0);
+    a1 = fma(R[(size_t)(i + RTM_WAVES) * ld + j], t[i + RTM_WAVES], a1);
+    a2 = fma(R[(size_t)(i + 2 * RTM_WAVES) * ld + j], t[i + 2 * RTM_WAVES], a2);
+    a3 = fma(R[(size_t)(i + 3 * RTM_WAVES) * ld + j], t[i + 3 * RTM_WAVES], a3);
+  }
+  for (; i < n; i += RTM_WAVES) a0 = fma(R[(size_t)i * ld + j], t[i], a0);
+  s_p[w][l] = (a0 + a1) + (a2 + a3);
   __syncthreads();
-  if (w == 0) out[j] = (j < n) ? ((s_p[0][l] + s_p[1][l]) + s_p[2][l]) + s_p[3][l] : 0.0;
+  if (w == 0) {
+    double s = 0.0;
+#pragma unroll
+    for (int u = 0; u < RTM_WAVES; ++u) s += s_p[u][l];
+    out[j] = (j < n) ? s : 0.0;
+  }
 }
 
 // ---- launchers --------------------------------------------------------------------------------
 void launch_gram(hipStream_t s, const double* AT, const double* nrm, int n, int NP, int KP, int ld, double noise,
-                 int kernel, double* K, const int* k_dev) {
+                 int kernel, double* K, const int* k_dev, double* K2, int* info_reset) {
   int nb = NP / BS;
-  hipLaunchKernelGGL(k_gram, dim3(nb, nb), dim3(256), 0, s, AT, nrm, n, KP, ld, noise, kernel, K, k_dev);
+  hipLaunchKernelGGL(k_gram, dim3(nb, nb), dim3(256), 0, s, AT, nrm, n, KP, ld, noise, kernel, K, k_dev, K2, info_reset);
 }
 void launch_add_jitter(hipStream_t s, double* K, int n, int ld, double jitter) {
   hipLaunchKernelGGL(k_add_jitter, dim3((n + 255) / 256), dim3(256), 0, s, K, n, ld, jitter);
@@ -348,7 +401,7 @@ void launch_cholesky(hipStream_t s, double* L, int NP, int ld, int* info, double
 }
 void launch_trinv(hipStream_t s, const double* L, int NP, int ld, double* R) {
   const int nblk = NP / BS;
-  (void)hipMemsetAsync(R, 0, (size_t)NP * ld * sizeof(double), s);    // an error surfaces at the next checked call
+  // (blocks above the diagonal are never written by anything: they keep the zeros of pcabo_ctx_create)
   static const bool lanes4 = getenv("PCABO_GP_FOUR_LANE_ROWS") != nullptr;
   if (lanes4) hipLaunchKernelGGL(k_trinv_diag, dim3(nblk), dim3(256), 0, s, L, ld, R);
   else launch_trinv_diag_w(s, L, nblk, ld, R);
@@ -356,5 +409,5 @@ void launch_trinv(hipStream_t s, const double* L, int NP, int ld, double* R) {
 }
 void launch_alpha(hipStream_t s, const double* R, const double* ys, int n, int NP, int ld, double* tmp, double* alpha) {
   hipLaunchKernelGGL(k_rmatvec, dim3(NP / 16), dim3(256), 0, s, R, ys, n, ld, tmp);
-  hipLaunchKernelGGL(k_rtmatvec, dim3(NP / 64), dim3(256), 0, s, R, tmp, n, ld, alpha);
+  hipLaunchKernelGGL(k_rtmatvec, dim3(NP / 64), dim3(64 * RTM_WAVES), 0, s, R, tmp, n, ld, alpha);
 }

@@ -100,6 +100,7 @@ struct pcabo_ctx {
   double *dTmp = nullptr, *dAlpha = nullptr, *dDiag = nullptr;   // dDiag: 64x64 hand-over tile of the Cholesky panels
   double *dXq = nullptr, *dPartial = nullptr, *dVal = nullptr, *dGrad = nullptr, *dZq = nullptr, *dXout = nullptr;
   unsigned int* dCounters = nullptr;     // per-query tickets of the in-launch combine
+  int cnt_S = 0; bool cnt_dirty = true;  // slab-group count the tickets are consistent with / a launch may have died
   // pinned host
   HostMirror* hm = nullptr;
   double *hXq = nullptr, *hVal = nullptr, *hGrad = nullptr, *hSmall = nullptr;
@@ -167,6 +168,7 @@ static bool presence_alone(int device) {
 
 static int set_err(pcabo_ctx* c, int code, const char* fmt, const char* a = "", int v = 0) {
   if (c) snprintf(c->err, sizeof(c->err), fmt, a, v);
+  if (c && (code == PCABO_ERR_TIMEOUT || code == PCABO_ERR_HIP)) c->cnt_dirty = true;   // a launch may have died half-way
   return code;
 }
 #define HIPCHK(call)                                                                         \
@@ -307,6 +309,7 @@ int pcabo_ctx_create(int device, int max_n, int max_d, int max_q, pcabo_ctx** ou
   HIPCHK(dalloc(&ctx->dCounters, PCABO_CNT_DONE + 1));
   HIPCHK(hipMemsetAsync(ctx->dCounters, 0, (PCABO_CNT_DONE + 1) * sizeof(unsigned int), ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->dYs, 0, N * sizeof(double), ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->dR, 0, N * N * sizeof(double), ctx->stream));   // the blocks above the diagonal stay zero for good
   HIPCHK(hipHostMalloc((void**)&ctx->hm, sizeof(HostMirror), hipHostMallocDefault));
   memset((void*)ctx->hm, 0, sizeof(HostMirror));
   HIPCHK(hipHostMalloc((void**)&ctx->hXq, Q * d * sizeof(double), hipHostMallocDefault));
@@ -487,10 +490,12 @@ int pcabo_wpca(pcabo_ctx* ctx, const double* X, const double* f, const int64_t* 
 
 static int launch_factorisation(pcabo_ctx* ctx, double jitter) {
   hipStream_t s = ctx->stream;
-  const size_t bytes = (size_t)ctx->NP * ctx->ld * sizeof(double);
-  HIPCHK(hipMemcpyAsync(ctx->dL, ctx->dGram, bytes, hipMemcpyDeviceToDevice, s));
-  if (jitter > 0.0) launch_add_jitter(s, ctx->dL, ctx->n, ctx->ld, jitter);
-  HIPCHK(hipMemsetAsync(ctx->dInfo, 0, sizeof(int), s));
+  if (jitter > 0.0) {      // a retry: the first attempt got its copy of K and a cleared flag from k_gram itself
+    const size_t bytes = (size_t)ctx->NP * ctx->ld * sizeof(double);
+    HIPCHK(hipMemcpyAsync(ctx->dL, ctx->dGram, bytes, hipMemcpyDeviceToDevice, s));
+    launch_add_jitter(s, ctx->dL, ctx->n, ctx->ld, jitter);
+    HIPCHK(hipMemsetAsync(ctx->dInfo, 0, sizeof(int), s));
+  }
   { ProfScope ps(ctx, 2, 16.0 * ctx->n * ctx->n, (double)ctx->n * ctx->n * ctx->n / 3.0); launch_cholesky(s, ctx->dL, ctx->NP, ctx->ld, ctx->dInfo, ctx->dDiag); }
   {
     ProfScope ps(ctx, 3, 16.0 * ctx->n * ctx->n, (double)ctx->n * ctx->n * ctx->n / 3.0 + 2.0 * ctx->n * ctx->n);
@@ -514,14 +519,20 @@ static int enqueue_condition(pcabo_ctx* ctx, const double* y_dev, int n, int k, 
   ctx->lengthscale = lengthscale; ctx->noise = noise; ctx->kernel = kernel;
   ctx->have_gp = false;
   ctx->gp_pending = true;
-  HIPCHK(hipMemsetAsync(ctx->dCounters, 0, (PCABO_CNT_DONE + 1) * sizeof(unsigned int), s));
+  // the per-query tickets count modulo the number of slab groups: they only need a reset when that number changes
+  // (every 64th iteration) or after a launch that did not complete
+  if (acq_slabs(ctx->NP) != ctx->cnt_S || ctx->cnt_dirty) {
+    HIPCHK(hipMemsetAsync(ctx->dCounters, 0, (PCABO_CNT_DONE + 1) * sizeof(unsigned int), s));
+    ctx->cnt_S = acq_slabs(ctx->NP); ctx->cnt_dirty = false;
+  }
   {
     ProfScope ps(ctx, 1, 8.0 * n * kk + 4.0 * n * (n + 1.0), 2.0 * n * n * kk + 12.0 * n * n);
     launch_zstats(s, ctx->dZ, y_dev, n, k, unb, ctx->dBounds4, ctx->dZnMean, ctx->dYstats, ctx->dYs, ctx->hm, k_dev);
     HIPCHK(hipEventRecord(ctx->evBounds, s));
     launch_znorm(s, ctx->dZ, n, k, ctx->NP, ctx->KP, ctx->ld, ctx->dBounds4, ctx->dZnMean, 1.0 / lengthscale, ctx->dZnT,
                  ctx->dAT, ctx->dNrm, k_dev);
-    launch_gram(s, ctx->dAT, ctx->dNrm, n, ctx->NP, ctx->KP, ctx->ld, noise, kernel, ctx->dGram, k_dev);
+    launch_gram(s, ctx->dAT, ctx->dNrm, n, ctx->NP, ctx->KP, ctx->ld, noise, kernel, ctx->dGram, k_dev, ctx->dL,
+                ctx->dInfo);
   }
   return launch_factorisation(ctx, 0.0);       // asynchronous: pcabo_gp_condition_end() waits and checks
 }

@@ -138,7 +138,7 @@ void launch_znorm(hipStream_t s, const double* Z, int n, int k, int NP, int KP, 
                   const double* zn_mean, double inv_ls, double* ZnT, double* AT, double* nrm,
                   const int* k_dev = nullptr);   // k_dev != NULL: k (and KP) are read on the device, the arguments ignored
 void launch_gram(hipStream_t s, const double* AT, const double* nrm, int n, int NP, int KP, int ld, double noise,
-                 int kernel, double* K, const int* k_dev = nullptr);
+                 int kernel, double* K, const int* k_dev = nullptr, double* K2 = nullptr, int* info_reset = nullptr);
 void launch_add_jitter(hipStream_t s, double* K, int n, int ld, double jitter);
 void launch_cholesky(hipStream_t s, double* L, int NP, int ld, int* info, double* diag_scratch);
 void launch_trinv(hipStream_t s, const double* L, int NP, int ld, double* R);

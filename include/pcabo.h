@@ -98,7 +98,7 @@ int pcabo_gp_condition_end(pcabo_ctx* ctx);
 /* pcabo_gp_condition_end followed by pcabo_acq_eval(values only) with the evaluation enqueued behind the conditioning
  * instead of after the host has seen it finish (the 512 raw samples of botorch's gen_batch_initial_conditions,
  * PCA_BO.py:607-614, are drawn from the search box, which is known long before the factorisation ends).
- * Same results as the two calls. Xq[q*k] [host], val[q] [host]. */
+ * Same results as the two calls. Xq[q*k] [bulk], val[q] [bulk] (device-pointer mode simply runs the two calls). */
 int pcabo_gp_condition_end_eval(pcabo_ctx* ctx, const double* Xq, int q, double best_f, int maximize, int acq,
                                 double* val);
 

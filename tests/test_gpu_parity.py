@@ -218,6 +218,62 @@ def test_scoring_enqueued_behind_the_conditioning_equals_wait_then_score(native)
             assert np.array_equal(out[0], out[1], equal_nan=True)
 
 
+def test_device_pointer_mode_equals_host_pointer_mode(native):
+    """pcabo_set_pointer_mode(PCABO_PTR_DEVICE): the [bulk] arguments are device pointers (torch-ROCm tensors through
+    .data_ptr()), the small results still arrive on the host.  Same numbers as with host pointers, bit for bit - for the
+    separate calls, the single enqueue of rows A-H and the scoring queued behind the conditioning."""
+    import ctypes as C
+    lib = native.LIB
+    rng = np.random.default_rng(3)
+    n, d, q = 90, 9, 40
+    X, y = rng.uniform(-5, 5, (n, d)), rng.normal(size=n)
+    ranks = (np.argsort(np.argsort(y)) + 1).astype(np.int64)
+    noise = rng.normal(0, 1e-8, (n, d))
+    dev = torch.device("cuda", 0)
+    tX, ty, tr, tn = (torch.from_numpy(a).to(dev) for a in (X, y, ranks, noise))
+    torch.cuda.synchronize()             # the context's stream is not ordered with torch's: hand over finished tensors
+    P = lambda a: C.c_void_p(a.ctypes.data)                 # host pointer of a numpy array
+    DP = lambda t: C.c_void_p(t.data_ptr())                 # device pointer of a torch tensor
+
+    def run(device_ptrs: bool, fused: bool, early: bool):
+        c = native.Context(max_n=128, max_d=d, max_q=64)
+        h = c._h
+        assert lib.pcabo_set_pointer_mode(h, native.PTR_DEVICE if device_ptrs else native.PTR_HOST) == 0
+        dm, pm, comps, evr, k = np.empty(d), np.empty(d), np.empty((d, d)), np.empty(d), C.c_int(0)
+        aX, ar, an, ay = (DP(tX), DP(tr), DP(tn), DP(ty)) if device_ptrs else (P(X), P(ranks), P(noise), P(y))
+        if fused:
+            rc = lib.pcabo_wpca_gp_condition_begin(h, aX, None, ar, n, d, 0, 0.95, 0, an, ay, np.log(2.0), np.exp(-5.0), 0,
+                                                   P(dm), P(pm), P(comps), P(evr), C.byref(k))
+            assert rc == 0, c._err()
+        else:
+            assert lib.pcabo_wpca(h, aX, None, ar, n, d, 0, 0.95, 0, an, P(dm), P(pm), P(comps), P(evr), C.byref(k), None) == 0
+            assert lib.pcabo_gp_condition_begin(h, None, ay, n, k.value, None, np.log(2.0), np.exp(-5.0), 0) == 0, c._err()
+        c.n, c.d, c.k = n, d, k.value
+        box = c.acq_bounds()
+        Xq = box[0] + (box[1] - box[0]) * np.random.default_rng(4).uniform(size=(q, k.value))
+        tXq = torch.from_numpy(Xq).to(dev)
+        val, tval = np.empty(q), torch.empty(q, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        if early:
+            rc = lib.pcabo_gp_condition_end_eval(h, DP(tXq) if device_ptrs else P(Xq), q, float(y.min()), 0, 0,
+                                                 DP(tval) if device_ptrs else P(val))
+        else:
+            assert lib.pcabo_gp_condition_end(h) == 0, c._err()
+            rc = lib.pcabo_acq_eval(h, DP(tXq) if device_ptrs else P(Xq), q, float(y.min()), 0, 0,
+                                    DP(tval) if device_ptrs else P(val), None)
+        assert rc == 0, c._err()
+        torch.cuda.synchronize()
+        out = (k.value, dm, pm, comps[:min(n, d)].copy(), evr, box, tval.cpu().numpy() if device_ptrs else val, c.gram())
+        c.close()
+        return out
+
+    ref = run(False, False, False)
+    for variant in ((True, False, False), (True, True, True), (False, True, True), (True, True, False)):
+        got = run(*variant)
+        for a, b in zip(ref, got):
+            assert np.array_equal(np.asarray(a), np.asarray(b)), variant
+
+
 def test_optimize_acqf_teacher_forced(ctx, records):
     """Same state + same initial conditions in -> same 10 candidates out (rows M, N)."""
     for key in ("d10", "d40"):

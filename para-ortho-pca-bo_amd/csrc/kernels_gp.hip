@@ -200,9 +200,10 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int
                                                      const double* __restrict__ diag_scratch) {
   __shared__ __attribute__((aligned(16))) double s_a[BS * TLD];
   __shared__ __attribute__((aligned(16))) double s_b[BS * TLD];
-  if (blockIdx.x == 0) {                             // put panel p's diagonal factor in place (see k_chol_panel)
-    double* Add = A + (size_t)(p * BS) * ld + p * BS;
+  if (blockIdx.x == gridDim.x - 1) {                 // one extra group puts panel p's diagonal factor in place (see
+    double* Add = A + (size_t)(p * BS) * ld + p * BS;  // k_chol_panel): off the critical path of the tile groups
     for (int idx = threadIdx.x; idx < BS * BS; idx += 256) Add[(size_t)(idx >> 6) * ld + (idx & 63)] = diag_scratch[idx];
+    return;
   }
   // linear block id -> (I, J) in the lower triangle of the trailing (nblk-p-1)^2 tiles
   const int m = nblk - p - 1;
@@ -396,7 +397,7 @@ void launch_cholesky(hipStream_t s, double* L, int NP, int ld, int* info, double
     if (lanes4) hipLaunchKernelGGL(k_chol_panel, dim3(nblk - p), dim3(256), 0, s, L, p, ld, info, diag_scratch);
     else launch_chol_panel_w(s, L, p, nblk - p, ld, info, diag_scratch);
     int m = nblk - p - 1;
-    if (m > 0) hipLaunchKernelGGL(k_chol_update, dim3(m * (m + 1) / 2), dim3(256), 0, s, L, p, nblk, ld, diag_scratch);
+    if (m > 0) hipLaunchKernelGGL(k_chol_update, dim3(m * (m + 1) / 2 + 1), dim3(256), 0, s, L, p, nblk, ld, diag_scratch);
   }
 }
 void launch_trinv(hipStream_t s, const double* L, int NP, int ld, double* R) {

@@ -66,9 +66,28 @@ __global__ __launch_bounds__(WP_THREADS) void k_wpca_prep(
   __syncthreads();   // weights[] written by other threads are read below
 
   // column means of X (PCA_BO.py:364)
+  // Up to WP_ROWS rows per thread the thread's elements stay in registers from here to the single store of Wc: one
+  // pass over X with all loads in flight instead of three dependent passes (the last one a load-subtract-store loop
+  // on Wc, i.e. one global round trip per row).  Same operations in the same order, so the same bits.
+  constexpr int WP_ROWS = 32;
+  const bool in_regs = (n4 + G - 1) / G <= WP_ROWS;
+  double xr[WP_ROWS];
   double acc = 0.0;
-  if (c < d)
+  if (in_regs) {
+#pragma unroll
+    for (int u = 0; u < WP_ROWS; ++u) {
+      const int i = g + u * G;
+      xr[u] = (c < d && i < n) ? X[(size_t)i * d + c] : 0.0;
+      if ((u & 7) == 7) __builtin_amdgcn_sched_barrier(0);       // 8 loads in flight at a time (128-VGPR budget)
+    }
+    if (c < d) {
+#pragma unroll
+      for (int u = 0; u < WP_ROWS; ++u)
+        if (g + u * G < n) acc += xr[u];
+    }
+  } else if (c < d) {
     for (int i = g; i < n; i += G) acc += X[(size_t)i * d + c];
+  }
   s_red[tid] = acc;
   __syncthreads();
   if (tid < CP) {
@@ -83,7 +102,22 @@ __global__ __launch_bounds__(WP_THREADS) void k_wpca_prep(
 
   // W = (X - mu) * sqrt(w_i) + noise (PCA_BO.py:365-377), column sums of W
   acc = 0.0;
-  if (c < DP) {
+  if (in_regs) {
+    if (c < DP) {
+#pragma unroll
+      for (int u = 0; u < WP_ROWS; ++u) {
+        const int i = g + u * G;
+        double w = 0.0;
+        if (c < d && i < n) {
+          w = (xr[u] - mu) * sqrt(weights[i]);
+          if (noise) w += noise[(size_t)i * d + c];
+        }
+        xr[u] = w;
+        if (i < n4) acc += w;
+        if ((u & 7) == 7) __builtin_amdgcn_sched_barrier(0);     // 8 rows' loads in flight at a time (128-VGPR budget)
+      }
+    }
+  } else if (c < DP) {
     for (int i = g; i < n4; i += G) {
       double w = 0.0;
       if (c < d && i < n) {
@@ -104,8 +138,18 @@ __global__ __launch_bounds__(WP_THREADS) void k_wpca_prep(
   }
   __syncthreads();
   const double mw = (c < d) ? s_col[c] : 0.0;
-  if (c < d)
+  if (in_regs) {
+    if (c < DP) {
+#pragma unroll
+      for (int u = 0; u < WP_ROWS; ++u) {
+        const int i = g + u * G;
+        if (i < n4) Wc[(size_t)i * DP + c] = (c < d && i < n) ? xr[u] - mw : 0.0;
+        if ((u & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  } else if (c < d) {
     for (int i = g; i < n; i += G) Wc[(size_t)i * DP + c] -= mw;
+  }
 }
 
 // Row C (covariance): C = Wc^T Wc / (n-1), DP x DP, one 16x16 tile per work-group; the four waves
@@ -152,10 +196,16 @@ extern "C" int pcabo_debug_jacobi_stamps(unsigned long long* out4) {
 // Warm start: if the eigenvectors V0 of the previous BO iteration are given (and orthonormal), iterate on
 // G0 = C V0 instead of C: still G = C V with V orthogonal, but the columns start almost orthogonal, so two or
 // three sweeps suffice instead of ~8.  The result does not depend on the start beyond rounding.
+struct PcaSelect {        // arguments of the selection step that ends the kernel (rows C, PCA_BO.py:389-399)
+  int n; double var_threshold; int n_components; double* comps; double* evr; int* k_dev; HostMirror* hm;
+};
 __global__ __launch_bounds__(JAC_THREADS) void k_jacobi(const double* __restrict__ C, int d, int DP,
                                                         const double* __restrict__ V0, double* __restrict__ Gout,
-                                                        double* __restrict__ lam, int* __restrict__ sweeps_out) {
+                                                        double* __restrict__ lam, int* __restrict__ sweeps_out,
+                                                        PcaSelect sel) {
   extern __shared__ __attribute__((aligned(16))) double s_g[];   // d columns of length d, column-major, stride LD
+  __shared__ double s_lam[PCABO_MAXD], s_sgn[PCABO_MAXD];
+  __shared__ int s_order[PCABO_MAXD];
   const int tid = threadIdx.x;
   const int LD = d | 1;                    // odd stride: column p and q of a pair never share banks systematically
   volatile int& s_rot = *reinterpret_cast<volatile int*>(s_g + (size_t)d * LD);   // flag lives after the matrix
@@ -313,31 +363,25 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi(const double* __restrict
     a = wave_sum(a);
     double nrm = sqrt(a);
     double inv = nrm > 0.0 ? 1.0 / nrm : 0.0;
-    for (int r = l; r < d; r += 64) Gout[(size_t)col * d + r] = s_g[col * LD + r] * inv;
-    if (l == 0) lam[col] = nrm;
+    for (int r = l; r < d; r += 64) {
+      const double v = s_g[col * LD + r] * inv;
+      Gout[(size_t)col * d + r] = v;
+      s_g[col * LD + r] = v;                                     // the selection below works on the normalised columns
+    }
+    if (l == 0) { lam[col] = nrm; s_lam[col] = nrm; }
   }
   if (tid == 0) *sweeps_out = sweep;
-}
-
-// Row C (selection): sort eigenpairs by decreasing variance, explained-variance ratios, k from the
-// variance threshold (PCA_BO.py:389-394), sign rule svd_flip(u_based_decision=False).
-__global__ __launch_bounds__(128) void k_pca_finalize(const double* __restrict__ G, const double* __restrict__ lam,
-                                                       int n, int d, double var_threshold, int n_components,
-                                                       double* __restrict__ comps, double* __restrict__ evr,
-                                                       int* __restrict__ k_dev, HostMirror* hm) {
-  __shared__ int s_order[PCABO_MAXD];
-  __shared__ double s_lam[PCABO_MAXD];
-  const int tid = threadIdx.x;
-  if (tid < d) s_lam[tid] = lam[tid];
+  // ---- selection (was a launch of its own: k_pca_finalize): eigenpairs by decreasing variance, explained-variance
+  // ratios, k from the variance threshold (PCA_BO.py:389-394), sign rule svd_flip(u_based_decision=False)
   __syncthreads();
   if (tid < d) {
-    double me = s_lam[tid];
+    const double me = s_lam[tid];
     int r = 0;
     for (int j = 0; j < d; ++j) r += (s_lam[j] > me) || (s_lam[j] == me && j < tid);
     s_order[r] = tid;
   }
   __syncthreads();
-  const int rcount = n < d ? n : d;           // sklearn keeps min(n, d) components
+  const int rcount = sel.n < d ? sel.n : d;           // sklearn keeps min(n, d) components
   if (tid == 0) {
     double tot = 0.0;
     for (int r = 0; r < rcount; ++r) tot += s_lam[s_order[r]];
@@ -346,27 +390,32 @@ __global__ __launch_bounds__(128) void k_pca_finalize(const double* __restrict__
     int cnt = 0;
     for (int r = 0; r < rcount; ++r) {
       double e = s_lam[s_order[r]] / tot;
-      evr[r] = e;
+      sel.evr[r] = e;
       cum += e;
-      cnt += (cum <= var_threshold);
+      cnt += (cum <= sel.var_threshold);
     }
-    if (n_components > 0) k = n_components < rcount ? n_components : rcount;
+    if (sel.n_components > 0) k = sel.n_components < rcount ? sel.n_components : rcount;
     else {
       k = cnt + 1;
       if (k > rcount) k = rcount;
       if (k < 1) k = 1;
     }
-    *k_dev = k;
-    hm->k = k;
+    *sel.k_dev = k;
+    sel.hm->k = k;
   }
-  if (tid < rcount) {
-    const double* v = G + (size_t)s_order[tid] * d;
+  if (tid < rcount) {                                   // sign of each component: its max-|.| entry positive
+    const double* v = s_g + s_order[tid] * LD;
     double best = -1.0, sgn = 1.0;
     for (int j = 0; j < d; ++j) {
       double a = fabs(v[j]);
       if (a > best) { best = a; sgn = v[j] < 0.0 ? -1.0 : 1.0; }
     }
-    for (int j = 0; j < d; ++j) comps[(size_t)tid * d + j] = sgn * v[j];
+    s_sgn[tid] = sgn;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < rcount * d; idx += (int)blockDim.x) {
+    const int r = idx / d, j = idx % d;
+    sel.comps[idx] = s_sgn[r] * s_g[s_order[r] * LD + j];
   }
 }
 
@@ -500,12 +549,14 @@ void launch_cov(hipStream_t s, const double* Wc, int n, int DP, double* C) {
   int n4 = (n + 3) & ~3;
   hipLaunchKernelGGL(k_cov, dim3(DP / 16, DP / 16), dim3(256), 0, s, Wc, n4, DP, 1.0 / (double)(n - 1), C);
 }
-void launch_jacobi(hipStream_t s, const double* C, int d, int DP, const double* V0, double* G, double* lam, int* sweeps) {
+void launch_jacobi(hipStream_t s, const double* C, int d, int DP, const double* V0, double* G, double* lam, int* sweeps,
+                   int n, double var_threshold, int n_components, double* comps, double* evr, int* k_dev, HostMirror* hm) {
   size_t lds = ((size_t)d * (d | 1) + 2) * sizeof(double);
   if (V0 && d <= 64) lds += (size_t)2 * d * (d | 1) * sizeof(double);      // LDS copies of C and V0 for the warm start
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_jacobi, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // 160 KB per work-group minus the kernel's static arrays (2.5 KB); d = 128 needs 132 KB of dynamic LDS
+    (void)hipFuncSetAttribute((const void*)k_jacobi, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     attr_set = true;
   }
   const int npairs = ((d + 1) & ~1) / 2;
@@ -513,12 +564,9 @@ void launch_jacobi(hipStream_t s, const double* C, int d, int DP, const double* 
   if (lp_env < 0) { const char* e = getenv("PCABO_JACOBI_LP"); lp_env = e ? atoi(e) : 0; }
   int threads = (npairs * 16 <= JAC_THREADS && lp_env != 8) ? npairs * 16 : npairs * 8;
   threads = (threads + 63) & ~63;
-  hipLaunchKernelGGL(k_jacobi, dim3(1), dim3(threads), lds, s, C, d, DP, V0, G, lam, sweeps);
-}
-void launch_pca_finalize(hipStream_t s, const double* G, const double* lam, int n, int d, double var_threshold,
-                         int n_components, double* comps, double* evr, int* k_dev, HostMirror* hm) {
-  hipLaunchKernelGGL(k_pca_finalize, dim3(1), dim3(128), 0, s, G, lam, n, d, var_threshold, n_components, comps, evr,
-                     k_dev, hm);
+  if (threads < d) threads = (d + 63) & ~63;          // the selection step at the end uses one thread per component
+  PcaSelect sel{n, var_threshold, n_components, comps, evr, k_dev, hm};
+  hipLaunchKernelGGL(k_jacobi, dim3(1), dim3(threads), lds, s, C, d, DP, V0, G, lam, sweeps, sel);
 }
 void launch_project(hipStream_t s, const double* X, const double* data_mean, const double* pca_mean,
                     const double* comps, const int* k_dev, int n, int d, double* Z) {

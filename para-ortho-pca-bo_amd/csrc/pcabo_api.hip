@@ -421,7 +421,7 @@ static int stage_inputs(pcabo_ctx* ctx, const double* X, const double* f, const 
 }
 
 // wPCA launches, then ONE copy of [data_mean | pca_mean | evr | comps] to pinned memory and the event that says it
-// arrived.  k arrives through the HostMirror (written by k_pca_finalize).
+// arrived.  k arrives through the HostMirror (written by the selection step at the end of k_jacobi).
 static int enqueue_wpca(pcabo_ctx* ctx, const WpcaInputs& in, int n, int d, double var_threshold, int n_components) {
   hipStream_t s = ctx->stream;
   const int DP = round_up(d, 16);
@@ -432,10 +432,9 @@ static int enqueue_wpca(pcabo_ctx* ctx, const WpcaInputs& in, int n, int d, doub
     const double* v0 = (ctx->vprev_d == d) ? ctx->dGbuf[ctx->gcur] : nullptr;
     ctx->gcur ^= 1;
     ctx->dG = ctx->dGbuf[ctx->gcur];
-    launch_jacobi(s, ctx->dC, d, DP, v0, ctx->dG, ctx->dLam, ctx->dSweeps);
+    launch_jacobi(s, ctx->dC, d, DP, v0, ctx->dG, ctx->dLam, ctx->dSweeps, n, var_threshold, n_components, ctx->dComps,
+                  ctx->dEvr, ctx->dK, ctx->hm);
     ctx->vprev_d = d;
-    launch_pca_finalize(s, ctx->dG, ctx->dLam, n, d, var_threshold, n_components, ctx->dComps, ctx->dEvr, ctx->dK,
-                        ctx->hm);
     launch_project(s, in.X, ctx->dDataMean, ctx->dPcaMean, ctx->dComps, ctx->dK, n, d, ctx->dZ);
   }
   const int rcount = n < d ? n : d;

@@ -126,9 +126,9 @@ void launch_rank(hipStream_t s, const double* f, int n, int maximize, long long*
 void launch_wpca_prep(hipStream_t s, const double* X, const long long* ranks, const double* noise, int n, int d,
                       int DP, double* weights, double* data_mean, double* pca_mean, double* Wc);
 void launch_cov(hipStream_t s, const double* Wc, int n, int DP, double* C);
-void launch_jacobi(hipStream_t s, const double* C, int d, int DP, const double* V0, double* G, double* lam, int* sweeps);
-void launch_pca_finalize(hipStream_t s, const double* G, const double* lam, int n, int d, double var_threshold,
-                         int n_components, double* comps, double* evr, int* k_dev, HostMirror* hm);
+// eigen-decomposition + selection (components sorted by variance, evr, k, sign rule) in one launch
+void launch_jacobi(hipStream_t s, const double* C, int d, int DP, const double* V0, double* G, double* lam, int* sweeps,
+                   int n, double var_threshold, int n_components, double* comps, double* evr, int* k_dev, HostMirror* hm);
 void launch_project(hipStream_t s, const double* X, const double* data_mean, const double* pca_mean,
                     const double* comps, const int* k_dev, int n, int d, double* Z);
 void launch_zstats(hipStream_t s, const double* Z, const double* y, int n, int k, const double* user_norm_bounds,

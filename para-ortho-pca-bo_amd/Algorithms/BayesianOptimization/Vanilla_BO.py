@@ -19,6 +19,7 @@ import numpy as np
 
 from pcabo import _native
 from pcabo import acqopt as _acqopt
+from pcabo import gcguard as _gcguard
 from pcabo import initializers as _init
 from .AbstractBayesianOptimizer import AbstractBayesianOptimizer
 from .PCA_BO import (ALLOWED_ACQUISITION_FUNCTION_STRINGS, ALLOWED_SHORTHAND_ACQUISITION_FUNCTION_STRINGS,
@@ -35,6 +36,8 @@ class Vanilla_BO(AbstractBayesianOptimizer):
         self.__record_trace = bool(kwargs.pop("record_trace", False))
         self.__torch_threads = kwargs.pop("torch_threads", 4)      # see PCA_BO: spinning OpenMP workers starve the loop
         self.__saved_torch_threads = None
+        self.__gc_freeze = bool(kwargs.pop("gc_freeze", _gcguard.enabled_by_default()))      # see pcabo/gcguard.py
+        self.__gc_entered = False
         super().__init__(budget, n_DoE, **kwargs)
         self.random_seed = random_seed
         smoke_test = os.environ.get("SMOKE_TEST")
@@ -72,6 +75,9 @@ class Vanilla_BO(AbstractBayesianOptimizer):
             self.__saved_torch_threads = torch.get_num_threads()
             if self.__saved_torch_threads > int(self.__torch_threads):
                 torch.set_num_threads(int(self.__torch_threads))
+        if self.__gc_freeze and not self.__gc_entered:
+            _gcguard.enter()
+            self.__gc_entered = True
         self.impose_random_seed()
         AbstractBayesianOptimizer.__call__(self, problem, dim, bounds, **kwargs)
         if self._pbar is not None:
@@ -107,6 +113,9 @@ class Vanilla_BO(AbstractBayesianOptimizer):
                   f"Best: x:{self.x_evals[self.current_best_index]} y:{self.current_best}", flush=True)
 
     def _finish(self) -> None:
+        if self.__gc_entered:
+            _gcguard.leave()
+            self.__gc_entered = False
         if self.__saved_torch_threads is not None:
             import torch
             torch.set_num_threads(self.__saved_torch_threads)

@@ -107,11 +107,19 @@ int pcabo_gp_condition_end_eval(pcabo_ctx* ctx, const double* Xq, int q, double 
  * (PCA_BO.py:343-408 and :502-545) without the host round trip between them: the conditioning launches are queued
  * behind the projection before the host has seen k (the kernels read it on the device).  Arguments as in the two
  * calls (gp_noise = the likelihood noise, `noise` = the PCA_BO.py:376 draw).  Returns when the wPCA results are on the
- * host, with the conditioning still in flight: finish with pcabo_gp_condition_end(). */
+ * host, with the conditioning still in flight: finish with pcabo_gp_condition_end().  With all five output pointers NULL
+ * it returns right after the enqueue; pcabo_wpca_results() then waits for and delivers the wPCA results. */
 int pcabo_wpca_gp_condition_begin(pcabo_ctx* ctx, const double* X, const double* f, const int64_t* ranks, int n,
                                   int d, int maximize, double var_threshold, int n_components, const double* noise,
                                   const double* y, double lengthscale, double gp_noise, int kernel,
                                   double* data_mean, double* pca_mean, double* comps, double* evr, int* k);
+
+/* Second half of pcabo_wpca_gp_condition_begin when that was called with all five output pointers NULL (enqueue only):
+ * waits for the wPCA results - the conditioning keeps running - and hands them out.  Between the two calls the host can
+ * do work that only needs a guess of k (PCA_BO builds the scrambled Sobol engine of botorch's initial-condition draw with
+ * the previous iteration's k while the eigen-decomposition runs, and rebuilds it in the rare case that k changed).
+ * Must precede pcabo_acq_bounds / pcabo_gp_condition_end(_eval). */
+int pcabo_wpca_results(pcabo_ctx* ctx, double* data_mean, double* pca_mean, double* comps, double* evr, int* k);
 
 /* Row J: search box of the acquisition optimiser, PCA_BO.py:558-573. bounds[2*k] [host] (lo row, hi row).
  * May be called between pcabo_gp_condition_begin and _end: it then waits only for the statistics kernel, so the

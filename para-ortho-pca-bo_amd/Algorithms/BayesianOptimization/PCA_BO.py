@@ -149,6 +149,8 @@ class PCA_BO(AbstractBayesianOptimizer):
         self.__gp_pending = False
         self.__fused = os.environ.get("PCABO_NO_FUSED_ENQUEUE") is None
         self.__early_scoring = os.environ.get("PCABO_NO_EARLY_SCORING") is None
+        self.__speculate_engine = os.environ.get("PCABO_NO_ENGINE_GUESS") is None
+        self.__engine_ready = None
         self.__X_buf, self.__X_rows = None, 0
         self.__ctx: Optional[_native.Context] = None
         self.lbfgsb_info = []          # per iteration: (iterations, evaluations, warnflag, task) per restart group
@@ -334,11 +336,28 @@ class PCA_BO(AbstractBayesianOptimizer):
         if self.__fused:
             # rows A-H in one enqueue: the GP conditioning is queued right behind the projection and runs while the
             # wPCA results travel back (`_initialize_model` then has nothing left to launch)
-            res = self.__ctx.wpca_gp_condition(
+            self.__ctx.wpca_gp_condition(
                 X, np.array(self.f_evals, dtype=np.float64), ranks=ranks, maximize=self.maximization,
                 var_threshold=self.var_threshold, n_components=self.n_components, noise=noise,
-                lengthscale=LENGTHSCALE, gp_noise=NOISE, kernel=_native.KERNEL_MATERN52)
+                lengthscale=LENGTHSCALE, gp_noise=NOISE, kernel=_native.KERNEL_MATERN52, collect=False)
             self.__gp_pending = True
+            # While the device runs the eigen-decomposition the host builds the scrambled Sobol engine of this
+            # iteration's initial-condition draw (0.15 ms) - with LAST iteration's k, which is this iteration's k
+            # almost always.  Same draws from torch's global generator at the same place of its stream (nothing else
+            # consumes it between here and the optimiser); if k did change the generator is put back and the engine
+            # is built later, as without the guess.
+            self.__engine_ready, guess, saved = None, None, None
+            k_prev = self.reduced_space_dim_num
+            if self.__speculate_engine and k_prev:
+                import torch
+                saved = torch.get_rng_state()
+                guess = _init.scrambled_sobol_engine(int(k_prev))
+            res = self.__ctx.wpca_results()
+            if guess is not None:
+                if res["k"] == k_prev:
+                    self.__engine_ready = guess
+                else:
+                    torch.set_rng_state(saved)
         else:
             res = self.__ctx.wpca(X, ranks=ranks, maximize=self.maximization, var_threshold=self.var_threshold,
                                   n_components=self.n_components, noise=noise, want_Z=False, want_full=True)
@@ -377,7 +396,9 @@ class PCA_BO(AbstractBayesianOptimizer):
         start = perf_counter()
         # Like the reference, where gpytorch's Gram/Cholesky happen lazily inside optimize_acqf, the wait for the
         # conditioning is accounted here; the scrambled Sobol engine (needs only k) is built meanwhile.
-        engine = _init.scrambled_sobol_engine(ctx.k)
+        engine, self.__engine_ready = self.__engine_ready, None
+        if engine is None:
+            engine = _init.scrambled_sobol_engine(ctx.k)
         bounds = ctx.acq_bounds()          # needs only the statistics kernel, not the factorisation
         t0 = perf_counter()
         raw = _init.draw_sobol(bounds, raw_samples, engine)

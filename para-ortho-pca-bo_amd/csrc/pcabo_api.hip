@@ -83,6 +83,7 @@ struct pcabo_ctx {
   // problem state
   int n = 0, d = 0, k = 0, NP = 0, KP = 0;
   bool have_wpca = false, have_gp = false, gp_pending = false;
+  int wpca_n = 0, wpca_d = 0; bool wpca_uncollected = false;   // a wPCA whose results have not been waited for yet
   double lengthscale = 0.0, noise = 0.0;
   int kernel = 0;
   // device buffers
@@ -578,6 +579,7 @@ int pcabo_wpca_gp_condition_begin(pcabo_ctx* ctx, const double* X, const double*
   if (rc != PCABO_OK) return rc;
   rc = enqueue_wpca(ctx, in, n, d, var_threshold, n_components);
   if (rc != PCABO_OK) return rc;
+  ctx->wpca_n = n; ctx->wpca_d = d;
   if (ctx->prof) {                       // profiled runs keep the two phases apart (the work model of group 1 needs k)
     rc = collect_wpca(ctx, n, d, data_mean, pca_mean, comps, evr, k);
     if (rc != PCABO_OK) return rc;
@@ -585,8 +587,22 @@ int pcabo_wpca_gp_condition_begin(pcabo_ctx* ctx, const double* X, const double*
   }
   rc = enqueue_condition(ctx, in.y, n, -1, nullptr, lengthscale, gp_noise, kernel);
   if (rc != PCABO_OK) return rc;
-  rc = collect_wpca(ctx, n, d, data_mean, pca_mean, comps, evr, k);
+  ctx->wpca_n = n; ctx->wpca_d = d; ctx->wpca_uncollected = true;
+  if (!data_mean && !pca_mean && !comps && !evr && !k) return PCABO_OK;      // enqueue only: pcabo_wpca_results() waits
+  return pcabo_wpca_results(ctx, data_mean, pca_mean, comps, evr, k);
+}
+
+// Second half of pcabo_wpca_gp_condition_begin when that was called without output pointers: waits for the wPCA
+// results (the conditioning keeps running) and hands them out.  Lets the host do work that only needs a GUESS of k (the
+// scrambled Sobol engine of the initial-condition draw, with last iteration's k) while the eigen-decomposition runs.
+int pcabo_wpca_results(pcabo_ctx* ctx, double* data_mean, double* pca_mean, double* comps, double* evr, int* k) {
+  if (!ctx) return PCABO_ERR_ARG;
+  if (!ctx->wpca_uncollected && !ctx->have_wpca)
+    return set_err(ctx, PCABO_ERR_ARG, "pcabo_wpca_results: no weighted PCA enqueued%s", "");
+  HIPCHK(hipSetDevice(ctx->device));
+  int rc = collect_wpca(ctx, ctx->wpca_n, ctx->wpca_d, data_mean, pca_mean, comps, evr, k);
   if (rc != PCABO_OK) return rc;
+  ctx->wpca_uncollected = false;
   ctx->KP = round_up(ctx->k, 4);
   return PCABO_OK;
 }
@@ -595,6 +611,7 @@ int pcabo_gp_condition_end(pcabo_ctx* ctx) {
   if (!ctx) return PCABO_ERR_ARG;
   if (!ctx->gp_pending) return set_err(ctx, PCABO_ERR_ARG, "pcabo_gp_condition_end: no conditioning in flight%s", "");
   HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->wpca_uncollected) { int rc0 = pcabo_wpca_results(ctx, nullptr, nullptr, nullptr, nullptr, nullptr); if (rc0 != PCABO_OK) return rc0; }
   ctx->gp_pending = false;
   double jitter = 0.0;
   for (int attempt = 0; attempt < 4; ++attempt) {       // psd_safe_cholesky: 0, 1e-8, 1e-7, 1e-6
@@ -619,6 +636,7 @@ int pcabo_gp_condition(pcabo_ctx* ctx, const double* Z, const double* y, int n, 
 
 int pcabo_acq_bounds(pcabo_ctx* ctx, double* bounds) {
   if (!ctx || !bounds) return PCABO_ERR_ARG;
+  if (ctx->wpca_uncollected) { int rc0 = pcabo_wpca_results(ctx, nullptr, nullptr, nullptr, nullptr, nullptr); if (rc0 != PCABO_OK) return rc0; }
   if (ctx->gp_pending) {                   // conditioning in flight: the box only needs k_zstats, wait for that alone
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(wait_event(ctx->evBounds));
@@ -726,6 +744,7 @@ int pcabo_gp_condition_end_eval(pcabo_ctx* ctx, const double* Xq, int q, double 
   if (!Xq || !val || q < 1 || q > ctx->max_q || (acq != PCABO_ACQ_LOG_EI && acq != PCABO_ACQ_PI))
     return set_err(ctx, PCABO_ERR_ARG, "pcabo_gp_condition_end_eval: bad argument or q beyond context capacity%s", "");
   if (!ctx->gp_pending) return set_err(ctx, PCABO_ERR_ARG, "pcabo_gp_condition_end_eval: no conditioning in flight%s", "");
+  if (ctx->wpca_uncollected) { int rc0 = pcabo_wpca_results(ctx, nullptr, nullptr, nullptr, nullptr, nullptr); if (rc0 != PCABO_OK) return rc0; }
   if (q <= PCABO_INLAUNCH_MAXQ || ctx->ptr_mode != PCABO_PTR_HOST) {      // nothing to gain: the two calls in a row
     int rc = pcabo_gp_condition_end(ctx);
     if (rc != PCABO_OK) return rc;

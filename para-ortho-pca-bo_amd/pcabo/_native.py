@@ -23,7 +23,8 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "lib"
 EXPORTS = [
     "pcabo_abi_version", "pcabo_device_count", "pcabo_ctx_create", "pcabo_ctx_destroy",
     "pcabo_set_pointer_mode", "pcabo_last_error", "pcabo_wpca", "pcabo_gp_condition", "pcabo_gp_condition_begin",
-    "pcabo_gp_condition_end", "pcabo_gp_condition_end_eval", "pcabo_wpca_gp_condition_begin", "pcabo_acq_bounds",
+    "pcabo_gp_condition_end", "pcabo_gp_condition_end_eval", "pcabo_wpca_gp_condition_begin", "pcabo_wpca_results",
+    "pcabo_acq_bounds",
     "pcabo_acq_eval", "pcabo_logei", "pcabo_optimize_acqf", "pcabo_inverse_map", "pcabo_get_gp_state",
     "pcabo_get_gram", "pcabo_lbfgsb_minimize", "pcabo_sobol_scramble", "pcabo_set_profiling", "pcabo_get_profile", "pcabo_reset_profile",
 ]
@@ -61,6 +62,7 @@ def _load() -> C.CDLL:
     lib.pcabo_gp_condition.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_double, C.c_double, C.c_int]
     lib.pcabo_gp_condition_begin.argtypes = lib.pcabo_gp_condition.argtypes
     lib.pcabo_gp_condition_end.argtypes = [vp]
+    lib.pcabo_wpca_results.argtypes = [vp, vp, vp, vp, vp, ip]
     lib.pcabo_gp_condition_end_eval.argtypes = [vp, vp, C.c_int, C.c_double, C.c_int, C.c_int, vp]
     lib.pcabo_wpca_gp_condition_begin.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp,
                                                   vp, C.c_double, C.c_double, C.c_int, vp, vp, vp, vp, ip]
@@ -163,23 +165,30 @@ class Context:
     # ---- rows A-H in one enqueue -------------------------------------------------------------
     def wpca_gp_condition(self, X, y, f=None, ranks=None, maximize=False, var_threshold=0.95, n_components=0,
                           noise=None, lengthscale=0.6931471805599453, gp_noise=0.006737946999085467,
-                          kernel=KERNEL_MATERN52):
+                          kernel=KERNEL_MATERN52, collect=True):
         """wpca(...) + gp_condition(y, wait=False) without the host round trip between them: returns the wPCA results
-        while the conditioning is still running; call gp_wait() before using the GP."""
+        while the conditioning is still running; call gp_wait() before using the GP.  collect=False only enqueues
+        (returns None); wpca_results() then waits for the wPCA and returns its results."""
         X = _f64(X)
         n, d = X.shape
         y = _f64(y, (n,))
         f_a = None if f is None else _f64(f, (n,))
         r_a = None if ranks is None else np.ascontiguousarray(ranks, dtype=np.int64).reshape(n)
         nz = None if noise is None else _f64(noise, (n, d))
+        self._chk(LIB.pcabo_wpca_gp_condition_begin(
+            self._h, _ptr(X), _ptr(f_a), _ptr(r_a), n, d, int(bool(maximize)), float(var_threshold),
+            int(n_components), _ptr(nz), _ptr(y), float(lengthscale), float(gp_noise), int(kernel), None, None, None, None,
+            None))
+        self.n, self.d = n, d
+        return self.wpca_results() if collect else None
+
+    def wpca_results(self):
+        n, d = self.n, self.d
         rc_ = min(n, d)
         data_mean, pca_mean, comps, evr = np.empty(d), np.empty(d), np.empty((rc_, d)), np.empty(rc_)
         k = C.c_int(0)
-        self._chk(LIB.pcabo_wpca_gp_condition_begin(
-            self._h, _ptr(X), _ptr(f_a), _ptr(r_a), n, d, int(bool(maximize)), float(var_threshold),
-            int(n_components), _ptr(nz), _ptr(y), float(lengthscale), float(gp_noise), int(kernel), _ptr(data_mean),
-            _ptr(pca_mean), _ptr(comps), _ptr(evr), C.byref(k)))
-        self.n, self.d, self.k = n, d, k.value
+        self._chk(LIB.pcabo_wpca_results(self._h, _ptr(data_mean), _ptr(pca_mean), _ptr(comps), _ptr(evr), C.byref(k)))
+        self.k = k.value
         return {"data_mean": data_mean, "pca_mean": pca_mean, "components": comps, "evr": evr, "k": k.value, "Z": None}
 
     # ---- rows D-H -----------------------------------------------------------------------------

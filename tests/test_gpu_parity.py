@@ -774,10 +774,19 @@ def test_single_enqueue_of_wpca_and_conditioning_equals_the_two_calls(native, mo
             monkeypatch.delenv("PCABO_NO_FUSED_ENQUEUE", raising=False)
         else:
             monkeypatch.setenv("PCABO_NO_FUSED_ENQUEUE", "1")
-        opt = PCA_BO(budget=60, n_DoE=30, random_seed=15101, maximization=False)
-        opt(BBOBProblem(15, 1, 10))
-        runs.append((np.array(opt.f_evals), np.vstack(opt.x_evals)))
+        opt = PCA_BO(budget=70, n_DoE=30, random_seed=15101, maximization=False)
+        prob = BBOBProblem(15, 1, 10)
+        opt._start(prob)
+        ks = []
+        for _ in range(40):
+            opt._bo_iteration(prob)
+            ks.append(opt.reduced_space_dim_num)
+        opt._finish()
+        runs.append((np.array(opt.f_evals), np.vstack(opt.x_evals), ks))
     assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+    # the single enqueue also builds the Sobol engine early with the previous iteration's k: the run must contain
+    # iterations where that guess was wrong (generator put back, engine rebuilt)
+    assert runs[0][2] == runs[1][2] and len(set(runs[0][2])) > 1
     rng = np.random.default_rng(5)
     n, d = 77, 12
     X, y = rng.uniform(-5, 5, (n, d)), rng.normal(size=n)

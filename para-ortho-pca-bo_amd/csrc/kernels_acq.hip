@@ -417,7 +417,8 @@ __device__ __noinline__ void acq_server_finish_main(double* s_mem, const MailPai
     const unsigned long long t0 = wall_clock64();
     if (tid == 0) { s_srvp[0] = 0; s_srvp[1] = 0; }
     __syncthreads();
-    if (q == 0) {                                                // relay: host mailbox -> device mailbox
+    if (q == 0 && host_mail) {                                   // relay: host mailbox -> device mailbox (host_mail == NULL:
+      // the host writes the device mailbox itself, through the PCIe BAR - nothing to relay)
       // Wave 0 polls ALL pairs (<= 8 per lane, one asm block = one PCIe round trip) and stores a complete round to the
       // device copy.  (All four waves polling a quarter of a round trip apart was tried: the extra traffic made every
       // poll slower, 13-15 instead of 11-12.5 us per evaluation.)
@@ -432,7 +433,7 @@ __device__ __noinline__ void acq_server_finish_main(double* s_mem, const MailPai
           ld_pairs_sys8(ptr, o);
           bool ok = true;
 #pragma unroll
-          for (int t = 0; t < 8; ++t) ok = ok && (idx[t] < 0 || pair_tag(o[t]) == cur_seq);
+          for (int t = 0; t < 8; ++t) ok = ok && (idx[t] < 0 || mail_seq(o[t]) == cur_seq);
           if (__all(ok)) {
 #pragma unroll
             for (int t = 0; t < 8; ++t) if (idx[t] >= 0) st_pair_sys(dev_mail + idx[t], o[t]);
@@ -446,7 +447,7 @@ __device__ __noinline__ void acq_server_finish_main(double* s_mem, const MailPai
     if (w == 0) {                                               // header of the round: how many queries are still active
       for (;;) {
         const pcabo_u4 hd = ld_pair_sys(dev_mail);
-        if (__all(pair_tag(hd) == cur_seq)) { if (q >= (int)pair_value(hd) && l == 0) *s_srvp = 1; break; }
+        if (__all(mail_seq(hd) == cur_seq)) { if (q >= (int)pair_value(hd) && l == 0) *s_srvp = 1; break; }
         if (__any(wall_clock64() - t0 > PCABO_SERVER_TIMEOUT_TICKS)) { if (l == 0) *s_srvp = 1; break; }
         __builtin_amdgcn_s_sleep(1);
       }
@@ -566,7 +567,7 @@ __global__ __launch_bounds__(256) void k_acq_fast(
       for (;;) {
         pcabo_u4 o[8];
         ld_pairs_sys8(ptr, o);
-        const bool ok = pair_tag(o[0]) == cur_seq && (l >= k || pair_tag(o[1]) == cur_seq);
+        const bool ok = mail_seq(o[0]) == cur_seq && (l >= k || mail_seq(o[1]) == cur_seq);
         if (__all(ok)) {
           const int nq_round = (int)pair_value(o[0]);
           if (q >= nq_round) { if (l == 0) flags[0] = 1; }    // the call is over (0) or this query's group has finished

@@ -22,6 +22,8 @@
 #include <signal.h>
 #include <cerrno>
 #include <unistd.h>
+#include <csetjmp>
+#include <emmintrin.h>
 
 #define PCABO_ABI_VERSION 1
 #define PROF_GROUPS 6
@@ -106,6 +108,7 @@ struct pcabo_ctx {
   HostMirror* hm = nullptr;
   double *hXq = nullptr, *hVal = nullptr, *hGrad = nullptr, *hSmall = nullptr;
   MailPair *hMail = nullptr, *dMail = nullptr;   // mailbox of the resident acquisition kernel (pinned host copy, device copy)
+  bool mail_bar = false;                 // the host writes dMail itself through the PCIe BAR (no relay group, no hMail)
   MailPair* dPairs = nullptr;            // its partial records as (value, tag) pairs: 32 queries x 32 slabs
   int srv_penalty = 0;                   // > 0: the next calls use plain launches (the GPU looked shared, see pcabo_optimize_acqf)
   unsigned long long seq = 0;
@@ -205,6 +208,46 @@ static hipError_t wait_event(hipEvent_t ev) {
     __builtin_ia32_pause();
   }
   return hipEventSynchronize(ev);
+}
+
+// ---- the resident kernel's mailbox, written by the host straight into device memory --------------------------------
+// With a large PCIe BAR the CPU can address device memory.  The host then stores the round's (value, tag) pairs into the
+// DEVICE mailbox itself (16-byte stores, write-combined, one sfence) and the relay work-group that used to fetch them
+// from pinned host memory over PCIe has nothing to do: 5.5 -> 4.6 us per round trip in profiles/tools/bar_mailbox_rtt.hip.
+// Used when the device reports a large BAR AND a probe store is seen by the device (PCABO_MAIL_BAR=0/1 overrides).
+static inline void put_mail_pair(MailPair* dst, double v, unsigned long long seq) {
+  unsigned long long vb; memcpy(&vb, &v, 8);
+  const __m128i x = _mm_set_epi64x((long long)(seq ^ mail_mix(vb)), (long long)vb);
+  _mm_store_si128(reinterpret_cast<__m128i*>(dst), x);        // value and tag leave in one store
+}
+static sigjmp_buf g_probe_jmp;
+static void probe_fault(int) { siglongjmp(g_probe_jmp, 1); }
+static bool mail_bar_usable(pcabo_ctx* ctx) {
+  const char* e = getenv("PCABO_MAIL_BAR");
+  if (e && atoi(e) == 0) return false;
+  int large = 0;
+  if (hipDeviceGetAttribute(&large, hipDeviceAttributeIsLargeBar, ctx->device) != hipSuccess) { (void)hipGetLastError(); large = 0; }
+  if (!large && !(e && atoi(e) == 1)) return false;
+  static std::mutex mu;                                        // the probe swaps process-wide signal handlers for a moment
+  std::lock_guard<std::mutex> lk(mu);
+  MailPair* probe = ctx->dMail + (PCABO_MAIL_PAIRS - 1);
+  struct sigaction old_segv, old_bus, sa;
+  memset(&sa, 0, sizeof(sa)); sa.sa_handler = probe_fault; sigemptyset(&sa.sa_mask);
+  sigaction(SIGSEGV, &sa, &old_segv); sigaction(SIGBUS, &sa, &old_bus);
+  bool ok = false;
+  if (sigsetjmp(g_probe_jmp, 1) == 0) {
+    put_mail_pair(probe, 42.5, 0x1234ull);
+    _mm_sfence();
+    ok = true;
+  }
+  sigaction(SIGSEGV, &old_segv, nullptr); sigaction(SIGBUS, &old_bus, nullptr);
+  if (!ok) return false;
+  MailPair back{0.0, 0};
+  if (hipMemcpy(&back, probe, sizeof(back), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return false; }
+  unsigned long long vb; const double v = 42.5; memcpy(&vb, &v, 8);
+  const bool seen = back.v == 42.5 && back.tag == (0x1234ull ^ mail_mix(vb));
+  put_mail_pair(probe, 0.0, 0); _mm_sfence();
+  return seen;
 }
 
 // ---- profiling helpers ------------------------------------------------------------------------
@@ -320,7 +363,10 @@ int pcabo_ctx_create(int device, int max_n, int max_d, int max_q, pcabo_ctx** ou
   HIPCHK(hipHostMalloc((void**)&ctx->hIn, n * (2 * d + 2) * sizeof(double), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&ctx->hMail, PCABO_MAIL_PAIRS * sizeof(MailPair), hipHostMallocMapped | hipHostMallocCoherent));
   memset(ctx->hMail, 0, PCABO_MAIL_PAIRS * sizeof(MailPair));
-  HIPCHK(dalloc(&ctx->dMail, PCABO_MAIL_PAIRS));
+  if (hipExtMallocWithFlags((void**)&ctx->dMail, PCABO_MAIL_PAIRS * sizeof(MailPair), hipDeviceMallocFinegrained) != hipSuccess) {
+    (void)hipGetLastError();
+    HIPCHK(dalloc(&ctx->dMail, PCABO_MAIL_PAIRS));
+  }
   HIPCHK(hipMemsetAsync(ctx->dMail, 0, PCABO_MAIL_PAIRS * sizeof(MailPair), ctx->stream));
   {
     const size_t np = (size_t)PCABO_INLAUNCH_MAXQ * 32 * (2 + 2 * PCABO_MAXD);
@@ -329,6 +375,7 @@ int pcabo_ctx_create(int device, int max_n, int max_d, int max_q, pcabo_ctx** ou
     // null stream is not ordered with the non-blocking streams the resident kernels run on
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->mail_bar = mail_bar_usable(ctx);
   // Sequence numbers double as mailbox tags.  Memory handed out by the allocator may come from a context that was
   // destroyed earlier in this process, so every context numbers from its own base: a stale tag can never match.
   {
@@ -774,13 +821,14 @@ int pcabo_logei(pcabo_ctx* ctx, const double* Xq, int q, double best_f, int maxi
 
 // ---- resident acquisition kernel: host side of the mailbox ---------------------------------------------------------
 // One round: all cap*k coordinate pairs get the round's tag (coordinates of queries that are no longer active are
-// whatever is left in hXq), then the header (number of active queries; 0 = leave).  Value before tag everywhere.
+// whatever is left in hXq), then the header (number of active queries; 0 = leave).  A pair leaves in one 16-byte store and
+// its tag is mixed with the value's bits (mail_mix), so a reader never takes a value that does not belong to its tag.
 static void server_post(pcabo_ctx* ctx, int cap, int nq, int k, unsigned long long tag) {
-  MailPair* m = ctx->hMail;
+  MailPair* m = ctx->mail_bar ? ctx->dMail : ctx->hMail;       // device memory through the BAR, or the pinned copy
   const int np = cap * k;
-  for (int i = 0; i < np; ++i) { m[1 + i].v = ctx->hXq[i]; __atomic_store_n(&m[1 + i].tag, tag, __ATOMIC_RELEASE); }
-  m[0].v = (double)nq;
-  __atomic_store_n(&m[0].tag, tag, __ATOMIC_RELEASE);
+  for (int i = 0; i < np; ++i) put_mail_pair(m + 1 + i, ctx->hXq[i], tag);
+  put_mail_pair(m, (double)nq, tag);
+  if (ctx->mail_bar) _mm_sfence();                             // flush the write-combining buffers now
 }
 static int server_wait(pcabo_ctx* ctx, int nq, unsigned long long tag) {
   const auto t0 = std::chrono::steady_clock::now();
@@ -909,7 +957,7 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
       srv_cap = nq;
       launch_acq(ctx->stream, nullptr, nullptr, srv_cap, ctx->n, k, ctx->NP, ctx->ld, ctx->dZnT, ctx->dR, ctx->dAlpha,
                  ctx->dBounds4, ctx->dYstats, p, ctx->dPartial, ctx->dCounters, ctx->dVal, ctx->dGrad, ctx->hVal, ctx->hGrad,
-                 ctx->hm, ctx->seq + 1, ctx->hMail, ctx->dMail, ctx->dPairs);
+                 ctx->hm, ctx->seq + 1, ctx->mail_bar ? nullptr : ctx->hMail, ctx->dMail, ctx->dPairs);
       HIPCHK(hipGetLastError());
     }
     if (srv_cap > 0) {

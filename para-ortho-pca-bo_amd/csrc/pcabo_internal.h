@@ -18,6 +18,13 @@ struct QueryArgs { double x[PCABO_QA_MAX]; };
 // first, tag second (one 16-byte store on the device) and read as one 16-byte snapshot, so a matching tag implies the
 // value.  Pair 0 is the header (value = number of queries of the round, 0 = leave), pairs 1.. the query coordinates.
 struct alignas(16) MailPair { double v; unsigned long long tag; };
+// Pairs WRITTEN BY THE HOST carry tag = sequence number XOR mail_mix(bits of the value): a reader that sees a pair torn
+// between two rounds (new tag, old value - possible in principle when a write-combining buffer of the host is flushed in
+// pieces) computes a different sequence number and simply polls again.
+static inline __host__ __device__ unsigned long long mail_mix(unsigned long long vbits) {
+  const unsigned int lo = (unsigned int)vbits, hi = (unsigned int)(vbits >> 32);
+  return (unsigned long long)((lo ^ hi ^ (hi >> 11)) & 0xFFFFFFu);
+}
 #define PCABO_MAIL_PAIRS (1 + PCABO_QA_MAX)
 #define PCABO_SERVER_TIMEOUT_TICKS 200000000ull // 2 s of wall_clock64 (100 MHz): every wait in the kernel is bounded
 
@@ -95,6 +102,10 @@ __device__ inline pcabo_u4 make_pair(double v, unsigned long long tag) {
 }
 __device__ inline unsigned long long pair_tag(pcabo_u4 v) { return ((unsigned long long)v.w << 32) | v.z; }
 __device__ inline double pair_value(pcabo_u4 v) { return __hiloint2double((int)v.y, (int)v.x); }
+// sequence number of a host-written pair (see mail_mix)
+__device__ inline unsigned long long mail_seq(pcabo_u4 v) {
+  return pair_tag(v) ^ mail_mix(((unsigned long long)v.y << 32) | v.x);
+}
 
 // Wave-wide sum without LDS traffic.  `__shfl_xor` compiles to ds_bpermute_b32 (two per double, each followed by an
 // lgkmcnt wait: ~100 cycles of dependent latency per step); in a kernel whose whole budget is ~15 us the reductions

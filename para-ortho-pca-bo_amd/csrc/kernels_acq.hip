@@ -403,7 +403,7 @@ __device__ inline bool acq_server_finisher(const MailPair* rec, int S, int k, in
 // the round's mailbox from the host's pinned copy to the device copy that everybody else polls.
 #define FIN_LDS_DOUBLES (6 * PCABO_MAXD + 2 + 3 * FIN_STAGE_PER_WAVE + 2)   // ... + two flag words in the last double
 __device__ __noinline__ void acq_server_finish_main(double* s_mem, const MailPair* host_mail, MailPair* dev_mail, int npairs,
-                                                    const MailPair* part_pairs, int S, int k, int q,
+                                                    int ctrl_idx, const MailPair* part_pairs, int S, int k, int q,
                                                     const double* __restrict__ bounds4, const double* __restrict__ ystats,
                                                     const AcqParams& prm, double* val, double* grad, double* host_val,
                                                     double* host_grad, HostMirror* hm, unsigned long long seq) {
@@ -427,7 +427,7 @@ __device__ __noinline__ void acq_server_finish_main(double* s_mem, const MailPai
         const void* ptr[8];
         int idx[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) { const int pi = l + 64 * t; idx[t] = pi <= npairs ? pi : -1; ptr[t] = host_mail + (pi <= npairs ? pi : 0); }
+        for (int t = 0; t < 8; ++t) { const int pi = 1 + l + 64 * t; idx[t] = pi <= npairs ? pi : -1; ptr[t] = host_mail + (pi <= npairs ? pi : 1); }
         for (;;) {
           pcabo_u4 o[8];
           ld_pairs_sys8(ptr, o);
@@ -444,10 +444,10 @@ __device__ __noinline__ void acq_server_finish_main(double* s_mem, const MailPai
       }
       __syncthreads();
     }
-    if (w == 0) {                                               // header of the round: how many queries are still active
+    if (w == 0) {                                               // this query's control pair of the round: 1 evaluate, 0 leave
       for (;;) {
-        const pcabo_u4 hd = ld_pair_sys(dev_mail);
-        if (__all(mail_seq(hd) == cur_seq)) { if (q >= (int)pair_value(hd) && l == 0) *s_srvp = 1; break; }
+        const pcabo_u4 hd = ld_pair_sys(dev_mail + ctrl_idx);
+        if (__all(mail_seq(hd) == cur_seq)) { if (pair_value(hd) == 0.0 && l == 0) *s_srvp = 1; break; }
         if (__any(wall_clock64() - t0 > PCABO_SERVER_TIMEOUT_TICKS)) { if (l == 0) *s_srvp = 1; break; }
         __builtin_amdgcn_s_sleep(1);
       }
@@ -508,8 +508,8 @@ __global__ __launch_bounds__(256) void k_acq_fast(
   constexpr bool server = SRV;                                  // resident mode (own instantiation: the plain one keeps its registers), see below
   const int s = blockIdx.x, S = server ? (int)gridDim.x - 1 : (int)gridDim.x;
   if (server && s == S) {                                        // the finishing group of query blockIdx.y
-    acq_server_finish_main(s_dyn, host_mail, dev_mail, q_total * k, part_pairs, S, k, blockIdx.y, bounds4, ystats, prm,
-                           val, grad, host_val, host_grad, hm, seq);
+    acq_server_finish_main(s_dyn, host_mail, dev_mail, q_total * (k + 1), 1 + q_total * k + (int)blockIdx.y, part_pairs, S, k,
+                           blockIdx.y, bounds4, ystats, prm, val, grad, host_val, host_grad, hm, seq);
     return;
   }
   STAMP(0);
@@ -559,18 +559,19 @@ __global__ __launch_bounds__(256) void k_acq_fast(
     const unsigned long long t0 = wall_clock64();
     if (tid == 0) { s_srv[0] = 0; s_srv[1] = 0; }
     __syncthreads();
-    if (w == 0) {                                             // header + this query's coordinates: one round trip per poll
+    if (w == 0) {                                             // control pair + this query's coordinates: one round trip per poll
       volatile int* flags = s_srv;
       const void* ptr[8];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) ptr[t] = (t & 1) && l < k ? (const void*)(dev_mail + 1 + q * k + l) : (const void*)dev_mail;
+      for (int t = 0; t < 8; ++t) ptr[t] = (t & 1) && l < k ? (const void*)(dev_mail + 1 + q * k + l) : (const void*)(dev_mail + 1 + q_total * k + q);
       for (;;) {
         pcabo_u4 o[8];
         ld_pairs_sys8(ptr, o);
-        const bool ok = mail_seq(o[0]) == cur_seq && (l >= k || mail_seq(o[1]) == cur_seq);
+        const bool ctl = mail_seq(o[0]) == cur_seq;           // the same pair for every lane
+        const bool bye = ctl && pair_value(o[0]) == 0.0;      // leaving needs no coordinates
+        const bool ok = ctl && (bye || l >= k || mail_seq(o[1]) == cur_seq);
         if (__all(ok)) {
-          const int nq_round = (int)pair_value(o[0]);
-          if (q >= nq_round) { if (l == 0) flags[0] = 1; }    // the call is over (0) or this query's group has finished
+          if (pair_value(o[0]) == 0.0) { if (l == 0) flags[0] = 1; }    // control pair 0: the call is over or this query's restart group has finished
           else if (l < k) s_xn[l] = (pair_value(o[1]) - b_lo) / (b_hi - b_lo);
           break;
         }

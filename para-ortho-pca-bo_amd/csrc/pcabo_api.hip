@@ -821,13 +821,13 @@ int pcabo_logei(pcabo_ctx* ctx, const double* Xq, int q, double best_f, int maxi
 
 // ---- resident acquisition kernel: host side of the mailbox ---------------------------------------------------------
 // One round: all cap*k coordinate pairs get the round's tag (coordinates of queries that are no longer active are
-// whatever is left in hXq), then the header (number of active queries; 0 = leave).  A pair leaves in one 16-byte store and
+// whatever is left in hXq), then one control pair per query (1 = evaluate, 0 = leave for good).  A pair leaves in one 16-byte store and
 // its tag is mixed with the value's bits (mail_mix), so a reader never takes a value that does not belong to its tag.
 static void server_post(pcabo_ctx* ctx, int cap, int nq, int k, unsigned long long tag) {
   MailPair* m = ctx->mail_bar ? ctx->dMail : ctx->hMail;       // device memory through the BAR, or the pinned copy
   const int np = cap * k;
   for (int i = 0; i < np; ++i) put_mail_pair(m + 1 + i, ctx->hXq[i], tag);
-  put_mail_pair(m, (double)nq, tag);
+  for (int q = 0; q < cap; ++q) put_mail_pair(m + 1 + np + q, q < nq ? 1.0 : 0.0, tag);     // control pairs: evaluate / leave
   if (ctx->mail_bar) _mm_sfence();                             // flush the write-combining buffers now
 }
 static int server_wait(pcabo_ctx* ctx, int nq, unsigned long long tag) {
@@ -891,8 +891,10 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
   // scipy wraps the objective in a ScalarFunction that memoises the last evaluated point: when a shrinking
   // line-search step underflows and the trial point repeats, the function is neither called nor counted.
   // Same here (xc/fc/gc = last evaluated point of the group and its value/gradient).
+  std::vector<char> pending(ngroups, 0);    // x[gi] waits for its evaluation (left so by the free-running mode below)
   auto advance = [&](int gi) {
     if (!active[gi]) return;
+    if (pending[gi]) { pending[gi] = 0; return; }
     while (true) {
       int task = opt[gi].step(x[gi].data(), &fval[gi], g[gi].data());
       if (task == LBFGSB_FG) {
@@ -959,6 +961,84 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
                  ctx->dBounds4, ctx->dYstats, p, ctx->dPartial, ctx->dCounters, ctx->dVal, ctx->dGrad, ctx->hVal, ctx->hGrad,
                  ctx->hm, ctx->seq + 1, ctx->mail_bar ? nullptr : ctx->hMail, ctx->dMail, ctx->dPairs);
       HIPCHK(hipGetLastError());
+      static const bool free_env = !(getenv("PCABO_FREE_GROUPS") && atoi(getenv("PCABO_FREE_GROUPS")) == 0);
+      if (free_env && ctx->mail_bar && ngroups == 2 && active[0] && active[1] && nq == num_restarts) {
+        // ---- the two restart groups free of each other ------------------------------------------------------------
+        // Each group has its own slots, control pairs and round counter in the mailbox, so each host thread drives its
+        // own group (post - wait - L-BFGS-B step) without meeting the other: a round no longer waits for the slower of
+        // the two steps and there is no hand-off between the threads.  Same evaluations, same order per group.
+        const unsigned long long seq0 = ctx->seq;
+        MailPair* m = ctx->dMail;
+        const int cap = srv_cap;
+        std::atomic<int> abort_flag{0};
+        int timed_out[2] = {0, 0}, got_nan[2] = {0, 0}, left[2] = {0, 0}, slow_first[2] = {0, 0};
+        unsigned long long used[2] = {0, 0};
+        auto free_loop = [&](int gi) {
+          const int q0 = gstart[gi], nqg = gsize[gi];
+          unsigned long long r = 0;
+          for (;;) {
+            if (abort_flag.load(std::memory_order_relaxed)) { pending[gi] = 1; break; }
+            const unsigned long long tag = seq0 + (++r);
+            for (int t = 0; t < nqg * k; ++t) put_mail_pair(m + 1 + q0 * k + t, x[gi][t], tag);
+            for (int j = 0; j < nqg; ++j) put_mail_pair(m + 1 + cap * k + q0 + j, 1.0, tag);
+            _mm_sfence();
+            const auto t0 = std::chrono::steady_clock::now();
+            unsigned long spins = 0;
+            bool ok = true;
+            for (int j = 0; j < nqg && ok; ++j) {
+              while (__atomic_load_n(&ctx->hm->qflag[q0 + j], __ATOMIC_ACQUIRE) != tag) {
+                if ((++spins & 0xFFF) == 0) {
+                  if (abort_flag.load(std::memory_order_relaxed)) { ok = false; break; }
+                  if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(3)) {
+                    timed_out[gi] = 1; abort_flag.store(1, std::memory_order_relaxed); ok = false; break;
+                  }
+                }
+              }
+            }
+            if (!ok) { pending[gi] = 1; break; }
+            if (r == 1 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(1)) slow_first[gi] = 1;
+            double fs = 0.0;
+            bool nan = false;
+            for (int j = 0; j < nqg; ++j) fs += ctx->hVal[q0 + j];
+            for (int t = 0; t < nqg * k; ++t) {
+              const double gv = -ctx->hGrad[(size_t)q0 * k + t];
+              if (gv != gv) nan = true;
+              g[gi][t] = gv;
+            }
+            if (nan) { got_nan[gi] = 1; abort_flag.store(1, std::memory_order_relaxed); break; }
+            fval[gi] = -fs;
+            nfev[gi] += 1;
+            xc[gi] = x[gi]; gc[gi] = g[gi]; fc[gi] = fval[gi]; have_cache[gi] = 1;
+            advance(gi);
+            if (!active[gi]) break;
+          }
+          // this group's slab and finishing groups may go (they wait for round r + 1 of their own count)
+          const unsigned long long bye = seq0 + r + 1;
+          for (int j = 0; j < nqg; ++j) put_mail_pair(m + 1 + cap * k + q0 + j, 0.0, bye);
+          _mm_sfence();
+          left[gi] = 1;
+          used[gi] = r + 1;
+        };
+        static const bool fdbg = getenv("PCABO_FREE_DEBUG") != nullptr;
+        if (fdbg) fprintf(stderr, "[free] enter n=%d k=%d cap=%d seq0=%llx\n", ctx->n, k, cap, seq0);
+        hp.fn = [&] { free_loop(1); };                 // the helper is idle here (its ticket of this round is done)
+        const unsigned fticket = hp.go.load(std::memory_order_relaxed) + 1;
+        hp.go.store(fticket, std::memory_order_release);
+        free_loop(0);
+        if (fdbg) fprintf(stderr, "[free] main loop done r=%llu timed_out=%d\n", used[0], timed_out[0]);
+        while (hp.done.load(std::memory_order_acquire) != fticket) __builtin_ia32_pause();
+        if (fdbg) fprintf(stderr, "[free] helper done r=%llu timed_out=%d\n", used[1], timed_out[1]);
+        hp.fn = [&] { for (int gi = 1; gi < ngroups; gi += 2) advance(gi); };
+        HIPCHK(hipStreamSynchronize(ctx->stream));      // every group of the grid has been told to leave
+        if (fdbg) fprintf(stderr, "[free] kernel gone\n");
+        ctx->seq = seq0 + std::max(used[0], used[1]) + 1;
+        srv_cap = 0;
+        if (got_nan[0] || got_nan[1]) return set_err(ctx, PCABO_ERR_NAN, "NaN in acquisition gradient%s", "");
+        if (timed_out[0] || timed_out[1]) ctx->srv_penalty = 1000;      // plain launches from here on (see below)
+        else if (slow_first[0] || slow_first[1]) ctx->srv_penalty = 40;
+        if (!active[0] && !active[1]) break;            // the normal end: both groups ran to their stop
+        continue;                                       // a wait failed: the lock-step loop below finishes the call
+      }
     }
     if (srv_cap > 0) {
       const unsigned long long tag = ++ctx->seq;

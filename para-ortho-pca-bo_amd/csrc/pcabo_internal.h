@@ -25,7 +25,7 @@ static inline __host__ __device__ unsigned long long mail_mix(unsigned long long
   const unsigned int lo = (unsigned int)vbits, hi = (unsigned int)(vbits >> 32);
   return (unsigned long long)((lo ^ hi ^ (hi >> 11)) & 0xFFFFFFu);
 }
-#define PCABO_MAIL_PAIRS (1 + PCABO_QA_MAX)
+#define PCABO_MAIL_PAIRS (1 + PCABO_QA_MAX + PCABO_INLAUNCH_MAXQ + 1)   // [0] unused, coordinates, one control pair per query, probe
 #define PCABO_SERVER_TIMEOUT_TICKS 200000000ull // 2 s of wall_clock64 (100 MHz): every wait in the kernel is bounded
 
 #ifdef __HIPCC__

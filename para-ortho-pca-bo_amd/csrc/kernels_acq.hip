@@ -543,11 +543,13 @@ __global__ __launch_bounds__(256) void k_acq_fast(
   for (int m = 0; m < NM; ++m) { const int j = tid + 256 * m; al[m] = j < n ? alpha[j] : 0.0; }
   // ---- per query: large batches (value scoring of the raw samples, many-restart optimisation) give each group qb
   // queries, so the register tiles above are loaded once for all of them; the in-launch combine uses qb = 1
-  // ---- resident mode (dev_mail != nullptr): the kernel stays for all the evaluations of one optimize call.  Round r
-  // carries sequence number seq + r - 1; its query points arrive through the mailbox (group 0 of k_acq_server_finish polls the
-  // host's pinned copy and relays it with 16-byte stores; every group polls the device copy), so a round costs neither a launch
-  // nor a refill of the register tiles.  Every wait is bounded (PCABO_SERVER_TIMEOUT_TICKS): a group that times out
-  // simply leaves, the host then times out on the missing result and ends the call.
+  // ---- resident mode (dev_mail != nullptr): the kernel stays for all the evaluations of one optimize call.  Round r of
+  // a query carries sequence number seq + r - 1; its coordinates and its control pair (1 evaluate, 0 leave) arrive
+  // through the device mailbox, which the host fills through the PCIe BAR (or, host_mail != NULL, finishing group 0 relays
+  // from the host's pinned copy).  Every query counts its own rounds - the host may drive the restart groups
+  // independently of each other.  A round costs neither a launch nor a refill of the register tiles.  Every wait is
+  // bounded (PCABO_SERVER_TIMEOUT_TICKS): a group that times out simply leaves, the host then times out on the
+  // missing result and finishes the call with plain launches.
   int* s_srv = reinterpret_cast<int*>(s_v + SLAB + 1);        // 0 continue, 1 leave (set by wave 0)
   unsigned long long cur_seq = seq;
   double b_lo = 0.0, b_hi = 1.0;

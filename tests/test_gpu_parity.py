@@ -812,8 +812,9 @@ def test_single_enqueue_of_wpca_and_conditioning_equals_the_two_calls(native, mo
 
 def test_resident_kernel_reproduces_per_round_launches(native):
     """The resident ("server") mode of the acquisition kernel - one launch per optimize call, query points through the
-    mailbox - runs the same arithmetic as one launch per evaluation: whole runs must agree bit for bit
-    (PCABO_ACQ_SERVER is read once per process, hence the subprocesses)."""
+    mailbox - runs the same arithmetic as one launch per evaluation, whoever fills the mailbox and however the host
+    threads drive the restart groups: whole runs must agree bit for bit (the switches are read once per process, hence
+    the subprocesses)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = r'''
@@ -831,12 +832,16 @@ for cls, kw, dim, budget, ndoe in ((PCA_BO, {}, 10, 70, 30), (PCA_BO, {}, 40, 15
 print("DIGESTS", " ".join(out))
 ''' % root
     res = []
-    for mode in ("1", "0"):
-        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PCABO_ACQ_SERVER=mode), capture_output=True,
+    # resident with the host writing the device mailbox through the BAR and the restart groups free of each other (the
+    # default where the device has a large BAR); the same in lock-step; mailbox through pinned memory + relay group;
+    # one launch per evaluation
+    for env in ({"PCABO_ACQ_SERVER": "1"}, {"PCABO_ACQ_SERVER": "1", "PCABO_FREE_GROUPS": "0"},
+                {"PCABO_ACQ_SERVER": "1", "PCABO_MAIL_BAR": "0"}, {"PCABO_ACQ_SERVER": "0"}):
+        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True,
                            text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-3000:]
         res.append([l for l in p.stdout.splitlines() if l.startswith("DIGESTS")][-1])
-    assert res[0] == res[1]
+    assert res[0] == res[1] == res[2] == res[3]
 
 
 def test_resident_kernel_survives_a_stopped_host(native):

@@ -865,7 +865,7 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
   std::vector<char> active(ngroups, 1);     // char, not vector<bool>: groups are touched from two threads
   std::vector<std::vector<double>> x(ngroups), g(ngroups), lo(ngroups), hi(ngroups);
   std::vector<double> fval(ngroups, 0.0), fc(ngroups, 0.0);
-  std::vector<std::vector<double>> xc(ngroups), gc(ngroups);
+  std::vector<std::vector<double>> xc(ngroups), gc(ngroups), vc(ngroups);   // vc: per-restart values of the cached evaluation
   std::vector<char> have_cache(ngroups, 0);
   for (int gi = 0; gi < ngroups; ++gi) {
     gstart[gi] = gi * batch_limit;
@@ -1009,6 +1009,7 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
             fval[gi] = -fs;
             nfev[gi] += 1;
             xc[gi] = x[gi]; gc[gi] = g[gi]; fc[gi] = fval[gi]; have_cache[gi] = 1;
+            vc[gi].assign(ctx->hVal + q0, ctx->hVal + q0 + nqg);
             advance(gi);
             if (!active[gi]) break;
           }
@@ -1074,6 +1075,7 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
       fval[gi] = -fs;
       nfev[gi] += 1;
       xc[gi] = x[gi]; gc[gi] = g[gi]; fc[gi] = fval[gi]; have_cache[gi] = 1;
+      vc[gi].assign(ctx->hVal + qoff[gi], ctx->hVal + qoff[gi] + gsize[gi]);
     }
   }
   server_stop.stop();
@@ -1090,10 +1092,22 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
     if (info) { info[4 * gi] = niter[gi]; info[4 * gi + 1] = nfev[gi]; info[4 * gi + 2] = wf; info[4 * gi + 3] = opt[gi].task(); }
     if (wf == 2) any_failed = 1;
   }
-  AcqParams pv = make_params(ctx, best_f, maximize, acq, 0);
-  int rc = eval_staged(ctx, num_restarts, pv);
-  if (rc != PCABO_OK) return rc;
-  for (int j = 0; j < num_restarts; ++j) vals[j] = ctx->hVal[j];
+  // botorch evaluates the acquisition once more at the clamped end points.  An L-BFGS-B run normally ends ON the last point
+  // it had evaluated (the accepted trial of its last line search), whose per-restart values are still here - the same
+  // kernel arithmetic, so the same bits; only a run that ended elsewhere (abnormal line search) needs the launch.
+  bool reuse = true;
+  for (int gi = 0; gi < ngroups && reuse; ++gi)
+    reuse = have_cache[gi] && (int)vc[gi].size() == gsize[gi] &&
+            memcmp(cand + (size_t)gstart[gi] * k, xc[gi].data(), (size_t)gsize[gi] * k * sizeof(double)) == 0;
+  if (reuse) {
+    for (int gi = 0; gi < ngroups; ++gi)
+      for (int j = 0; j < gsize[gi]; ++j) vals[gstart[gi] + j] = vc[gi][j];
+  } else {
+    AcqParams pv = make_params(ctx, best_f, maximize, acq, 0);
+    int rc = eval_staged(ctx, num_restarts, pv);
+    if (rc != PCABO_OK) return rc;
+    for (int j = 0; j < num_restarts; ++j) vals[j] = ctx->hVal[j];
+  }
   if (failed) *failed = any_failed;
   if (trace) {
     const double t0 = std::chrono::duration<double>(t_enter.time_since_epoch()).count();

@@ -94,3 +94,20 @@ def test_host_initializers_consume_torch_rng_like_the_oracle():
     ic = O.initialize_q_batch(c, torch.from_numpy(np.sin(c.numpy()).sum(1)), 10)
     assert np.array_equal(a, c.numpy()) and np.array_equal(ia, ic.numpy())
     assert int(np.argmax(va)) in ia
+
+
+def test_gc_guard_is_reference_counted_and_undone():
+    """pcabo/gcguard.py: freeze + raised young-generation threshold while at least one run is open, everything back to
+    what it was afterwards (nested runs: the outermost leave restores)."""
+    import gc
+    from pcabo import gcguard
+    before, frozen_before = gc.get_threshold(), gc.get_freeze_count()
+    gcguard.enter()
+    assert gc.get_threshold()[0] >= 50000 and gc.get_freeze_count() > 0 and gc.isenabled()
+    gcguard.enter()
+    gcguard.leave()
+    assert gc.get_threshold()[0] >= 50000          # still one run open
+    gcguard.leave()
+    assert gc.get_threshold() == before and gc.get_freeze_count() == frozen_before
+    gcguard.leave()                                 # unbalanced leave is harmless
+    assert gc.get_threshold() == before

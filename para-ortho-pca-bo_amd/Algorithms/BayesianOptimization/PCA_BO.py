@@ -163,8 +163,8 @@ class PCA_BO(AbstractBayesianOptimizer):
     # ---------------------------------------------------------------------------------------------
     def __call__(self, problem: Union[Callable, object], dim: Optional[int] = -1,
                  bounds: Optional[np.ndarray] = None, **kwargs) -> None:
-        self._start(problem, dim, bounds, **kwargs)
         try:
+            self._start(problem, dim, bounds, **kwargs)      # inside the try: whatever it switched on is switched off again
             for _ in range(self.budget - self.n_DoE):
                 if self.number_of_function_evaluations >= self.budget:
                     break

@@ -7,13 +7,20 @@
 A "step" is one BO iteration (rank-weighted PCA -> GP re-conditioning -> 512 raw samples + 10-restart
 L-BFGS-B over log-EI -> inverse map -> objective) of the configuration BASELINE.json quotes the metric
 on: configs[1] = PCA_BO on BBOB f15, d=40, budget 450, n_DoE 120 (330 BO iterations, n grows 120 -> 449).
-Each rank (one process per GPU) advances its OWN copy of that run (instance 0, seed 15400 per
-ExperimentRunner.py:146), so the work per GPU is identical and fixed as N grows (weak scaling in the strict sense; the
-runs of a real experiment differ by up to +-15 % in cost, see tests/gpu_instance_spread.py).  Runs are independent,
-there is no data-path collective; best-so-far values are gathered over RCCL after the timed region and must agree.  Data: synthetic (in-repo BBOB f15 restatement, pinned by the
-reference's own known answers).
 
-Output: ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+The cost of an iteration grows with n (2.3 ms at n=120, ~3.6 ms at n=449), so the K timed steps are SPREAD EVENLY OVER
+THE WHOLE RUN: iteration indices floor((i + 1/2) * 330 / K); the iterations in between are advanced untimed (a whole
+run costs about a second).  Each timed step is bracketed by a device synchronisation, the job by barriers; the time
+of a rank is the sum of its K step times, the job's time the maximum over ranks.  With K >= 330 every iteration of the
+run is timed (and further runs of the rank's list follow, their DoE and context set-up untimed).
+
+N > 1: the job is the run list {f15, d=40, instances 0..N-1} - one run per GPU, fixed work per GPU (weak scaling) -
+partitioned with the product's own `pcabo.sharding.assign_runs`; no data-path collective; the best-so-far values are
+gathered once after the timed region (RCCL; the backend actually used is recorded in the line).
+
+Output: ONE JSON line on rank 0 with `roofline` (dominant kernel), `roofline_kchol` (K(X,X) + Cholesky, north_star's
+named step), `cpu_baseline` (N = 1 only) and, with --batch B, the aggregate rate of B runs advancing together.
+Data: synthetic (in-repo BBOB f15 restatement, pinned by the reference's own known answers).
 """
 from __future__ import annotations
 
@@ -32,57 +39,50 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from pcabo import distributed as D  # noqa: E402
+from pcabo import sharding  # noqa: E402
 from pcabo.bbob import BBOBProblem  # noqa: E402
 
 FID, DIM, BUDGET, NDOE = 15, 40, 450, 120
+ITERS = BUDGET - NDOE
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 FP64_PEAK_TFLOPS = 78.6        # MI355X FP64 vector = matrix peak (spec)
 
 
-class RunChain:
-    """Consecutive BO iterations; when a run reaches its budget the next instance starts (DoE included)."""
+def spread(k: int, total: int = ITERS):
+    """k iteration indices spread evenly over [0, total) (all of them when k >= total)."""
+    if k >= total:
+        return list(range(total))
+    return sorted({int((i + 0.5) * total / k) for i in range(k)})
 
-    def __init__(self, device: int, first_instance: int, stride: int):
+
+class Run:
+    """One PCA_BO run of the list, advanced iteration by iteration."""
+
+    def __init__(self, device: int, run):
         from Algorithms import PCA_BO
-        self._cls, self.device = PCA_BO, device
-        self.instance, self.stride = first_instance, stride
-        self.opt = None
-        self.problem = None
-        self.best = []
-        self.iterations = 0
-        self.phase_seconds = {}
-        self.before_close = None      # callback(optimizer) while its device context is still open
+        fid, dim, inst = run
+        st = sharding.run_settings(run)
+        self.run, self.problem = run, BBOBProblem(fid, inst, dim)
+        self.opt = PCA_BO(budget=st["budget"], n_DoE=st["n_doe"], var_threshold=0.95,
+                          acquisition_function="expected_improvement", random_seed=st["seed"], maximization=False,
+                          verbose=False, device=device, DoE_parameters={"criterion": "center", "iterations": 1000})
+        self.opt._start(self.problem)             # seeding + DoE (n_DoE objective calls) + device context: set-up
+        self.iteration = 0
 
-    def _open(self):
-        self.problem = BBOBProblem(FID, self.instance, DIM)
-        seed = 1000 * FID + 10 * DIM + self.instance
-        self.opt = self._cls(budget=BUDGET, n_DoE=NDOE, var_threshold=0.95, acquisition_function="expected_improvement",
-                             random_seed=seed, maximization=False, verbose=False, device=self.device,
-                             DoE_parameters={"criterion": "center", "iterations": 1000})
-        self.opt._start(self.problem)
-
-    def _close(self):
-        if self.opt is not None:
-            if self.before_close is not None:
-                self.before_close(self.opt)
-            self.best.append(float(self.opt.current_best))
-            for key, val in list(self.opt.total_times.items()) + [("optimize_acqf/" + k, v) for k, v in self.opt.phase_breakdown.items()]:
-                self.phase_seconds[key] = self.phase_seconds.get(key, 0.0) + val
-            self.phase_seconds["lbfgsb_rounds"] = self.phase_seconds.get("lbfgsb_rounds", 0) + int(sum(int(i[:, 1].max()) for i in self.opt.lbfgsb_info))
-            self.opt._finish()
-            self.opt = None
+    @property
+    def n(self):
+        return len(self.opt.f_evals)
 
     def step(self):
-        if self.opt is None:
-            self._open()
         self.opt._bo_iteration(self.problem)
-        self.iterations += 1
-        if self.opt.number_of_function_evaluations >= self.opt.budget:
-            self._close()
-            self.instance += self.stride
+        self.iteration += 1
 
-    def finish(self):
-        self._close()
+    def close(self):
+        out = {"best": float(self.opt.current_best), "total_times": dict(self.opt.total_times),
+               "phase": dict(self.opt.phase_breakdown),
+               "rounds": int(sum(int(i[:, 1].max()) for i in self.opt.lbfgsb_info))}
+        self.opt._finish()
+        return out
 
 
 def cpu_baseline(states, threads: int):
@@ -117,13 +117,62 @@ def _has(mod: str) -> bool:
     return importlib.util.find_spec(mod) is not None
 
 
+def profiled_pass(device: int, timed_at):
+    """Second pass over the same run: the iterations in `timed_at` run with HIP-event profiling on the context's stream
+    (one plain launch per L-BFGS-B evaluation), everything in between advances unprofiled."""
+    r = Run(device, (FID, DIM, 0))
+    ctx = r.opt.device_context
+    ctx.reset_profile()
+    at = set(timed_at)
+    ns = []
+    for it in range(ITERS):
+        if it in at:
+            ns.append(r.n)
+            ctx.set_profiling(True)
+            r.step()
+            ctx.set_profiling(False)
+            if it == max(at):
+                break
+        else:
+            r.step()
+    prof = ctx.profile()
+    r.close()
+    return prof, ns
+
+
+def nearest_pmc(n_mean: float):
+    """PMC traffic of the acquisition kernel at the shape of the committed table that is closest to the mean n of the
+    timed steps (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied)."""
+    for rel in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", rel, "pmc_traffic.json")
+        try:
+            pmc = json.load(open(path))
+        except Exception:   # noqa: BLE001
+            continue
+        rows = []
+        for key, v in pmc.items():
+            if isinstance(v, dict) and "traffic_bytes" in v and key.startswith("n"):
+                n = int(key[1:].split("_")[0])
+                k = int(key.split("_")[1][1:])
+                q = int(key.split("_")[2][1:])
+                alg = 4.0 * n * (n + 1.0) + 8.0 * n * k + 8.0 * n + 8.0 * q * k + 8.0 * q * (1 + k)
+                rows.append({"n": n, "k": k, "q": q, "traffic_bytes": v["traffic_bytes"], "algorithmic_bytes": alg,
+                             "ratio": v["traffic_bytes"] / alg})
+        if rows:
+            best = min(rows, key=lambda r: abs(r["n"] - n_mean))
+            return best, rows, f"profiles/{rel}/pmc_traffic.json"
+    return None, [], None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=BUDGET - NDOE)
+    ap.add_argument("--steps", type=int, default=ITERS)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("PCABO_BENCH_BATCH", "0")),
+                    help="also measure B runs advancing together (batched contexts; configs[2]: 30 runs on one GPU)")
     args = ap.parse_args()
 
     rank, local_rank, size = D.init()
@@ -137,82 +186,116 @@ def main():
     torch.cuda.set_device(device)
     torch.set_num_threads(4)
 
-    # ---- warmup: W iterations of a throw-away run (different instance) -------------------------------
+    # ---- the job: one run of configs[1] per GPU, handed out by the product's own partitioner ---------------------
+    runs = sharding.enumerate_runs([FID], [DIM], size)
+    my_runs = sharding.assign_runs(runs, size)[rank]
+
+    # ---- warmup: W iterations of a throw-away run (another instance) ---------------------------------------------
     if args.warmup > 0:
-        w = RunChain(device, first_instance=29, stride=0)
+        w = Run(device, (FID, DIM, 29))
         for _ in range(args.warmup):
             w.step()
-        w.finish()
+        w.close()
 
-    # ---- timed region: exactly K BO iterations per rank -----------------------------------------------
-    chain = RunChain(device, first_instance=0, stride=0)      # the same run on every rank: identical work per GPU
-    chain._open()                                   # DoE of the first run (120 objective calls) is set-up
-    states = []
-    sample_at = {int(v) for v in np.linspace(0, max(0, min(args.steps, BUDGET - NDOE) - 1), 6)}
+    # ---- timed region: exactly K BO iterations per rank, spread over the rank's run(s) ---------------------------
+    timed_at = spread(min(args.steps, ITERS))
+    at = set(timed_at)
+    todo = args.steps
+    elapsed_local, n_seen, states, closed = 0.0, [], [], []
+    sample_at = {timed_at[int(i)] for i in np.linspace(0, len(timed_at) - 1, min(12, len(timed_at)))}   # CPU-baseline states
+    run_idx = 0
     D.barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if rank == 0 and not args.no_cpu_baseline and i in sample_at and chain.opt is not None and chain.instance == 0:
-            states.append((np.vstack(chain.opt.x_evals), np.array(chain.opt.f_evals)))   # cheap host copies
-        chain.step()
+    t_job = time.perf_counter()
+    while todo > 0:
+        if run_idx < len(my_runs):
+            run = my_runs[run_idx]
+        else:                                                   # K > 330: further instances, disjoint between ranks
+            run = (FID, DIM, my_runs[0][2] + size * run_idx)
+        r = Run(device, run)
+        for it in range(ITERS):
+            if it in at and todo > 0:
+                if rank == 0 and run_idx == 0 and it in sample_at and not args.no_cpu_baseline:
+                    states.append((np.vstack(r.opt.x_evals), np.array(r.opt.f_evals)))     # untimed host copies
+                n_seen.append(r.n)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                r.step()
+                torch.cuda.synchronize()
+                elapsed_local += time.perf_counter() - t0
+                todo -= 1
+                if todo == 0:
+                    break
+            else:
+                r.step()
+        closed.append(r.close())
+        run_idx += 1
     torch.cuda.synchronize()
     D.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = D.max_over_ranks(elapsed)
-    chain.finish()
-    timing = dict(chain.phase_seconds)
-    last_best = chain.best[-1] if chain.best else float("nan")
+    job_wall = time.perf_counter() - t_job
+    elapsed = D.max_over_ranks(elapsed_local)
     total_steps = D.sum_over_ranks(args.steps)
-    gathered = D.gather_best([float(last_best)])    # the one collective of the design (RCCL when size > 1)
+    gathered = D.gather_best([closed[0]["best"]])    # the one collective of the design (RCCL when size > 1)
 
-    # ---- roofline: second, profiled pass (HIP events on the context's stream), same workload ------------
-    roof, extra = None, {}
+    timing = {}
+    for c in closed:
+        for key, val in list(c["total_times"].items()) + [("optimize_acqf/" + k, v) for k, v in c["phase"].items()]:
+            timing[key] = timing.get(key, 0.0) + val
+        timing["lbfgsb_rounds"] = timing.get("lbfgsb_rounds", 0) + c["rounds"]
+
+    # ---- roofline: second, profiled pass over the SAME iterations (HIP events on the context's stream) -----------
+    roof, kchol, extra = None, None, {}
     if rank == 0 and not args.no_roofline:
-        prof_steps = min(args.steps, BUDGET - NDOE)
-        pc = RunChain(device, first_instance=0, stride=0)
-        pc._open()
-        ctx = pc.opt.device_context
-        ctx.set_profiling(True)
-        ctx.reset_profile()
-        grabbed = {}
-        pc.before_close = lambda opt: grabbed.update(opt.device_context.profile())   # the run closes at its budget
-        for _ in range(prof_steps):
-            pc.step()
-            if pc.opt is None:
-                break
-        pc.finish()
-        prof = grabbed
-        if prof:
-            a = prof["acq_partial"]
-            dur = a["ms"] * 1e-3 / max(1, a["launches"])
-            byt = a["bytes"] / max(1, a["launches"])
-            traffic = None
-            try:    # PMC pass of profiles/r01 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 correction applied)
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
-                traffic = pmc["n250_k33_q10"]["traffic_bytes"]
-            except Exception:   # noqa: BLE001
-                pass
-            roof = {"kernel": "k_acq_fast / k_acq_fused (acquisition value+gradient, one launch per L-BFGS-B round)", "bound": "hbm", "achieved": byt / dur / 1e9, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": byt / dur / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                    "traffic_note": "fabric-side bytes per launch at n=250,k=33,q=10 from the PMC pass in profiles/r01 "
-                                    "(2*FETCH_SIZE+WRITE_SIZE); table for n=120/250/449 in profiles/r01/pmc_traffic.json",
+        prof, ns = profiled_pass(device, timed_at)
+        n_mean = float(np.mean(ns))
+        a = prof["acq_partial"]
+        if a["launches"]:
+            dur = a["ms"] * 1e-3 / a["launches"]
+            byt = a["bytes"] / a["launches"]
+            near, table, src = nearest_pmc(n_mean)
+            roof = {"kernel": "k_acq_fast<SLAB,NB> (acquisition value+gradient, one launch per L-BFGS-B round)",
+                    "bound": "hbm", "achieved": byt / dur / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": byt / dur / 1e9 / HBM_PEAK_GBS,
+                    "traffic": near["traffic_bytes"] if near else None,
+                    "traffic_shape": {k: near[k] for k in ("n", "k", "q", "algorithmic_bytes", "ratio")} if near else None,
+                    "traffic_table": table, "traffic_source": src,
                     "avg_launch_us": dur * 1e6, "launches": a["launches"], "algorithmic_bytes_per_launch": byt,
                     "achieved_tflops": a["flops"] / (a["ms"] * 1e-3) / 1e12,
-                    "note": f"second, profiled pass over {prof_steps} BO iterations of the same run (n=120..{120 + prof_steps - 1}), "
-                            "HIP events on the context's stream around every launch; latency-bound kernel, "
-                            "R and ZnT stay L2 / Infinity-Cache resident"}
-            for name in ("wpca", "gram", "cholesky", "root_inverse_alpha"):
-                g = prof[name]
-                if g["launches"]:
-                    extra[name] = {"avg_us": g["ms"] * 1e3 / g["launches"], "calls": g["launches"],
-                                   "GBs": g["bytes"] / (g["ms"] * 1e-3) / 1e9 if g["ms"] else None,
-                                   "TFLOPs": g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] else None}
+                    "n_mean": n_mean,
+                    "note": f"profiled pass over the same {len(ns)} BO iterations as the timed region (n = {ns[0]}..{ns[-1]}, "
+                            f"mean {n_mean:.0f}); HIP events on the context's stream around every launch; `traffic` is the PMC "
+                            "figure at the committed shape closest to that mean n, next to that shape's algorithmic bytes; "
+                            "latency-bound kernel, R and ZnT stay L2 / Infinity-Cache resident"}
+        for name in ("wpca", "gram", "cholesky", "root_inverse_alpha", "acq_large_batches"):
+            g = prof[name]
+            if g["launches"]:
+                extra[name] = {"avg_us": g["ms"] * 1e3 / g["launches"], "calls": g["launches"],
+                               "GBs": g["bytes"] / (g["ms"] * 1e-3) / 1e9 if g["ms"] else None,
+                               "TFLOPs": g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] else None}
+        g, c = prof["gram"], prof["cholesky"]
+        if g["launches"] and c["launches"] and (g["ms"] + c["ms"]) > 0:
+            sec = (g["ms"] + c["ms"]) * 1e-3
+            tf = (g["flops"] + c["flops"]) / sec / 1e12
+            kchol = {"kernels": "k_zstats + k_znorm + k_gram; k_chol_panel_w + k_chol_update per 64-wide panel",
+                     "bound": "mfma", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": tf / FP64_PEAK_TFLOPS, "hbm_GBs": (g["bytes"] + c["bytes"]) / sec / 1e9,
+                     "hbm_frac": (g["bytes"] + c["bytes"]) / sec / 1e9 / HBM_PEAK_GBS,
+                     "avg_us_per_iteration": sec * 1e6 / g["launches"], "iterations": g["launches"], "batch": 1,
+                     "note": "single run: 47 MFLOP / 5 MB per iteration at n=450 - latency-bound (a dependency chain of "
+                             "n pivots); the batched path (--batch) puts many runs' factorisations side by side"}
+
+    batch = None
+    if rank == 0 and args.batch > 1:
+        try:
+            from pcabo import batchrun
+            batch = batchrun.bench_block(device, args.batch, FID, DIM)
+        except Exception as e:   # noqa: BLE001
+            batch = {"error": f"{type(e).__name__}: {e}"}
 
     cpu = None
     if rank == 0 and size == 1 and not args.no_cpu_baseline and states:      # N = 1 only (contract)
         # the oracle's tiny fp64 tensors run fastest single-threaded on this host (measured 0.246 s/iteration at 1
-        # thread vs 0.465 s at 16, tests/cpu_oracle_threads.py), so the baseline gets its best setting
+        # thread vs 0.465 s at 16, tools/cpu_oracle_threads.py), so the baseline gets its best setting
         cpu = cpu_baseline(states, threads=1)
 
     if rank == 0:
@@ -222,13 +305,17 @@ def main():
             "value": value, "unit": "BO iterations/s", "n_gpus": size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[1]: PCA_BO on BBOB f15 d=40, budget=450, n_DoE=120, EI, var_threshold=0.95, "
-                                   "one run per GPU (every rank the same run: instance 0, seed 15400), steps = consecutive BO iterations",
+            "config": {"workload": "configs[1]: PCA_BO on BBOB f15 d=40, budget=450, n_DoE=120, EI, var_threshold=0.95; "
+                                   "one run per GPU (run list f15/d40/instances 0..N-1 partitioned by pcabo.sharding), "
+                                   "timed steps spread evenly over the 330 BO iterations of the run",
                        "num_restarts": 10, "raw_samples": 512, "batch_limit": 5, "maxiter": 200,
                        "parallelism": f"run-parallel x{size}"},
-            "roofline": roof, "cpu_baseline": cpu,
+            "n_range": [int(min(n_seen)), int(max(n_seen))], "n_mean": float(np.mean(n_seen)),
+            "timed_iterations": len(n_seen), "timed_seconds": elapsed, "job_wall_seconds": job_wall,
+            "backend": D.backend_name(),
+            "roofline": roof, "roofline_kchol": kchol, "cpu_baseline": cpu, "batched": batch,
             "kernels": extra, "host_phase_seconds": timing, "best_f": gathered,
-            "ranks_agree": all(g == gathered[0] for g in gathered),     # same run on every GPU -> same result
+            "runs": [list(r) for r in runs],
             "speedup_vs_cpu_baseline": (value / size / cpu["value"]) if cpu else None,
         }
         print(json.dumps(line), flush=True)

@@ -58,6 +58,15 @@ int pcabo_ctx_destroy(pcabo_ctx* ctx);
 int pcabo_set_pointer_mode(pcabo_ctx* ctx, int mode);
 int pcabo_last_error(pcabo_ctx* ctx, char* buf, int buflen);
 
+/* Per-context switches.
+ * PCABO_OPT_RESIDENT (default 1): pcabo_optimize_acqf may serve all evaluations of a call from ONE resident launch of
+ *   the acquisition kernel (query points through a mailbox); 0 = one launch per evaluation.  Same arithmetic, same bits.
+ * PCABO_OPT_BESTF_F32 (default 1): best_f is rounded to float32 before use, as botorch does when the reference hands it
+ *   a Python float (`torch.as_tensor(best_f)`, PCA_BO.py:199-203); 0 keeps all 64 bits (what botorch does when the
+ *   objective returned a numpy float64 scalar). */
+enum { PCABO_OPT_RESIDENT = 0, PCABO_OPT_BESTF_F32 = 1 };
+int pcabo_set_option(pcabo_ctx* ctx, int option, int value);
+
 /* Rows A-C (+D,J): rank-weighted PCA of the evaluated points.
  * Replaces PCA_BO._calculate_weights + _transform_points_to_reduced_space
  * (Algorithms/BayesianOptimization/PCA_BO.py:316-408), i.e. numpy + sklearn PCA().fit/transform.

@@ -341,7 +341,11 @@ def log_ei_helper(u: torch.Tensor) -> torch.Tensor:
 
 
 def round_best_f(best_f: float) -> float:
-    return float(np.float32(best_f)) if BEST_F_FLOAT32 else float(best_f)
+    """What `torch.as_tensor(best_f)` holds inside botorch's acquisition: float32 for a Python float / int, all 64 bits
+    for a numpy float64 scalar (executed for real: torch is present)."""
+    if not BEST_F_FLOAT32:
+        return float(best_f)
+    return float(torch.as_tensor(best_f).to(torch.float64))
 
 
 class Acquisition:

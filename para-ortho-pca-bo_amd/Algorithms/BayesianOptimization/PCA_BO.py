@@ -205,6 +205,7 @@ class PCA_BO(AbstractBayesianOptimizer):
                                "torch_state": torch.get_rng_state(), "best_f": self.current_best})
         self._transform_points_to_reduced_space()
         self._initialize_model(**kwargs)
+        self.__ctx.match_best_f_dtype(self.current_best)      # float32 like torch.as_tensor(python float), or all 64 bits
         self.acquisition_function = self.acquisition_function_class(
             model=self.__ctx, best_f=self.current_best, maximize=self.maximization)
         new_z = self.optimize_acqf_and_get_observation()

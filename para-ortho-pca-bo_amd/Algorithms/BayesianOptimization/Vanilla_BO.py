@@ -94,6 +94,7 @@ class Vanilla_BO(AbstractBayesianOptimizer):
             self.trace.append({"n": len(self.f_evals), "numpy_state": np.random.get_state(),
                                "torch_state": torch.get_rng_state(), "best_f": self.current_best})
         self._initialise_model(**kwargs)
+        self.__ctx.match_best_f_dtype(self.current_best)      # float32 like torch.as_tensor(python float), or all 64 bits
         self.acquisition_function = self.acquisition_function_class(
             model=self.__ctx, best_f=self.current_best, maximize=self.maximization)
         new_x = self.optimize_acqf_and_get_observation()

@@ -33,7 +33,7 @@
 
 #define PSTRIDE (2 + 2 * PCABO_MAXD)   // doubles per (query, slab) partial record
 
-// Phase stamps for tests/gpu_acq_phases.py (diagnostic build only: `make timing` -> libpcabo_timing.so).
+// Phase stamps for tools/gpu_acq_phases.py (diagnostic build only: `make timing` -> libpcabo_timing.so).
 #ifdef PCABO_ACQ_TIMING
 __device__ unsigned long long g_acq_stamps[16];
 #define STAMP(i) do { if (blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && threadIdx.x == 0) g_acq_stamps[i] = wall_clock64(); } while (0)

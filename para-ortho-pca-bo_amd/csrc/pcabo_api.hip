@@ -20,9 +20,9 @@
 #include <dirent.h>
 #include <fcntl.h>
 #include <signal.h>
+#include <stdint.h>
 #include <cerrno>
 #include <unistd.h>
-#include <csetjmp>
 #include <emmintrin.h>
 
 #define PCABO_ABI_VERSION 1
@@ -110,6 +110,8 @@ struct pcabo_ctx {
   MailPair *hMail = nullptr, *dMail = nullptr;   // mailbox of the resident acquisition kernel (pinned host copy, device copy)
   bool mail_bar = false;                 // the host writes dMail itself through the PCIe BAR (no relay group, no hMail)
   MailPair* dPairs = nullptr;            // its partial records as (value, tag) pairs: 32 queries x 32 slabs
+  bool opt_resident = true;             // PCABO_OPT_RESIDENT: may pcabo_optimize_acqf use the resident acquisition kernel
+  bool bestf_f32 = true;                // PCABO_OPT_BESTF_F32: best_f rounded like torch.as_tensor(python float)
   int srv_penalty = 0;                   // > 0: the next calls use plain launches (the GPU looked shared, see pcabo_optimize_acqf)
   unsigned long long seq = 0;
   OptHelper helper;
@@ -214,34 +216,42 @@ static hipError_t wait_event(hipEvent_t ev) {
 // With a large PCIe BAR the CPU can address device memory.  The host then stores the round's (value, tag) pairs into the
 // DEVICE mailbox itself (16-byte stores, write-combined, one sfence) and the relay work-group that used to fetch them
 // from pinned host memory over PCIe has nothing to do: 5.5 -> 4.6 us per round trip in profiles/tools/bar_mailbox_rtt.hip.
-// Used when the device reports a large BAR AND a probe store is seen by the device (PCABO_MAIL_BAR=0/1 overrides).
+// Used when the device reports a large BAR, the process maps the mailbox read-write (/proc/self/maps - no store is tried
+// otherwise, no fault is caught) AND a probe store is read back from the device (PCABO_MAIL_BAR=0 switches it off).
 static inline void put_mail_pair(MailPair* dst, double v, unsigned long long seq) {
   unsigned long long vb; memcpy(&vb, &v, 8);
   const __m128i x = _mm_set_epi64x((long long)(seq ^ mail_mix(vb)), (long long)vb);
   _mm_store_si128(reinterpret_cast<__m128i*>(dst), x);        // value and tag leave in one store
 }
-static sigjmp_buf g_probe_jmp;
-static void probe_fault(int) { siglongjmp(g_probe_jmp, 1); }
+// Can the CPU store to [p, p+len)?  Answered from /proc/self/maps: on a large-BAR system the runtime maps device
+// allocations into the process read-write; without host access the range is reserved without write permission.  No
+// store is attempted unless the mapping says it is allowed, so nothing can fault and no signal handler is touched.
+static bool host_mapping_writable(const void* p, size_t len) {
+  FILE* f = fopen("/proc/self/maps", "r");
+  if (!f) return false;
+  const unsigned long long a = (unsigned long long)(uintptr_t)p, b = a + len;
+  char line[512];
+  bool ok = false;
+  while (fgets(line, sizeof(line), f)) {
+    unsigned long long lo = 0, hi = 0;
+    char perms[8] = {0};
+    if (sscanf(line, "%llx-%llx %7s", &lo, &hi, perms) != 3) continue;
+    if (a >= lo && b <= hi) { ok = perms[0] == 'r' && perms[1] == 'w'; break; }
+  }
+  fclose(f);
+  return ok;
+}
 static bool mail_bar_usable(pcabo_ctx* ctx) {
   const char* e = getenv("PCABO_MAIL_BAR");
   if (e && atoi(e) == 0) return false;
   int large = 0;
   if (hipDeviceGetAttribute(&large, hipDeviceAttributeIsLargeBar, ctx->device) != hipSuccess) { (void)hipGetLastError(); large = 0; }
-  if (!large && !(e && atoi(e) == 1)) return false;
-  static std::mutex mu;                                        // the probe swaps process-wide signal handlers for a moment
-  std::lock_guard<std::mutex> lk(mu);
+  if (!large) return false;
+  if (!host_mapping_writable(ctx->dMail, PCABO_MAIL_PAIRS * sizeof(MailPair))) return false;
+  // the mapping is writable: verify that a store through it is what the device sees (read back with a copy)
   MailPair* probe = ctx->dMail + (PCABO_MAIL_PAIRS - 1);
-  struct sigaction old_segv, old_bus, sa;
-  memset(&sa, 0, sizeof(sa)); sa.sa_handler = probe_fault; sigemptyset(&sa.sa_mask);
-  sigaction(SIGSEGV, &sa, &old_segv); sigaction(SIGBUS, &sa, &old_bus);
-  bool ok = false;
-  if (sigsetjmp(g_probe_jmp, 1) == 0) {
-    put_mail_pair(probe, 42.5, 0x1234ull);
-    _mm_sfence();
-    ok = true;
-  }
-  sigaction(SIGSEGV, &old_segv, nullptr); sigaction(SIGBUS, &old_bus, nullptr);
-  if (!ok) return false;
+  put_mail_pair(probe, 42.5, 0x1234ull);
+  _mm_sfence();
   MailPair back{0.0, 0};
   if (hipMemcpy(&back, probe, sizeof(back), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return false; }
   unsigned long long vb; const double v = 42.5; memcpy(&vb, &v, 8);
@@ -356,7 +366,8 @@ int pcabo_ctx_create(int device, int max_n, int max_d, int max_q, pcabo_ctx** ou
   HIPCHK(hipMemsetAsync(ctx->dR, 0, N * N * sizeof(double), ctx->stream));   // the blocks above the diagonal stay zero for good
   HIPCHK(hipHostMalloc((void**)&ctx->hm, sizeof(HostMirror), hipHostMallocDefault));
   memset((void*)ctx->hm, 0, sizeof(HostMirror));
-  HIPCHK(hipHostMalloc((void**)&ctx->hXq, Q * d * sizeof(double), hipHostMallocDefault));
+  // (at least one QueryArgs block: small batches are handed to the kernel by value from here)
+  HIPCHK(hipHostMalloc((void**)&ctx->hXq, std::max<size_t>(Q * d, PCABO_QA_MAX) * sizeof(double), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&ctx->hVal, Q * sizeof(double), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&ctx->hGrad, Q * d * sizeof(double), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&ctx->hSmall, (d * d + 8 * d + 64) * sizeof(double), hipHostMallocDefault));
@@ -411,6 +422,15 @@ int pcabo_set_pointer_mode(pcabo_ctx* ctx, int mode) {
   if (!ctx || (mode != PCABO_PTR_HOST && mode != PCABO_PTR_DEVICE)) return PCABO_ERR_ARG;
   ctx->ptr_mode = mode;
   return PCABO_OK;
+}
+
+int pcabo_set_option(pcabo_ctx* ctx, int option, int value) {
+  if (!ctx) return PCABO_ERR_ARG;
+  switch (option) {
+    case PCABO_OPT_RESIDENT: ctx->opt_resident = value != 0; return PCABO_OK;
+    case PCABO_OPT_BESTF_F32: ctx->bestf_f32 = value != 0; return PCABO_OK;
+    default: return set_err(ctx, PCABO_ERR_ARG, "pcabo_set_option: unknown option %s%d", "", option);
+  }
 }
 
 int pcabo_last_error(pcabo_ctx* ctx, char* buf, int buflen) {
@@ -696,7 +716,8 @@ int pcabo_acq_bounds(pcabo_ctx* ctx, double* bounds) {
 
 static AcqParams make_params(pcabo_ctx* ctx, double best_f, int maximize, int acq, int want_grad) {
   AcqParams p;
-  p.best_f = (double)(float)best_f;     // torch.as_tensor(python float) keeps float32 (see oracle)
+  // torch.as_tensor(python float) gives a float32 tensor; a numpy float64 scalar keeps its 64 bits (PCABO_OPT_BESTF_F32)
+  p.best_f = ctx->bestf_f32 ? (double)(float)best_f : best_f;
   p.y_mean = 0.0; p.y_std = 1.0;
   p.inv_ls = 1.0 / ctx->lengthscale;
   p.maximize = maximize ? 1 : 0;
@@ -954,7 +975,7 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
     int rc;
     if (round_no == 1 && (ctx->alone_age++ & 7) == 0) ctx->alone = presence_alone(ctx->device);
     if (round_no == 1 && ctx->srv_penalty > 0) --ctx->srv_penalty;
-    else if (round_no == 1 && ctx->alone && !ctx->prof && acq_server_possible(nq, ctx->n, k, ctx->NP)) {
+    else if (round_no == 1 && ctx->opt_resident && ctx->alone && !ctx->prof && acq_server_possible(nq, ctx->n, k, ctx->NP)) {
       // the evaluations of this call go to ONE resident launch (see k_acq_fast): no launch and no operand refill per round
       srv_cap = nq;
       launch_acq(ctx->stream, nullptr, nullptr, srv_cap, ctx->n, k, ctx->NP, ctx->ld, ctx->dZnT, ctx->dR, ctx->dAlpha,

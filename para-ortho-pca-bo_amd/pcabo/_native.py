@@ -16,13 +16,14 @@ ABI_VERSION = 1
 KERNEL_MATERN52, KERNEL_RBF = 0, 1
 ACQ_LOG_EI, ACQ_PI = 0, 1
 PTR_HOST, PTR_DEVICE = 0, 1
+OPT_RESIDENT, OPT_BESTF_F32 = 0, 1
 PROFILE_GROUPS = ("wpca", "gram", "cholesky", "root_inverse_alpha", "acq_partial", "acq_large_batches")
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "lib", "libpcabo.so")
 
 EXPORTS = [
     "pcabo_abi_version", "pcabo_device_count", "pcabo_ctx_create", "pcabo_ctx_destroy",
-    "pcabo_set_pointer_mode", "pcabo_last_error", "pcabo_wpca", "pcabo_gp_condition", "pcabo_gp_condition_begin",
+    "pcabo_set_pointer_mode", "pcabo_set_option", "pcabo_last_error", "pcabo_wpca", "pcabo_gp_condition", "pcabo_gp_condition_begin",
     "pcabo_gp_condition_end", "pcabo_gp_condition_end_eval", "pcabo_wpca_gp_condition_begin", "pcabo_wpca_results",
     "pcabo_acq_bounds",
     "pcabo_acq_eval", "pcabo_logei", "pcabo_optimize_acqf", "pcabo_inverse_map", "pcabo_get_gp_state",
@@ -56,6 +57,7 @@ def _load() -> C.CDLL:
     lib.pcabo_ctx_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     lib.pcabo_ctx_destroy.argtypes = [vp]
     lib.pcabo_set_pointer_mode.argtypes = [vp, C.c_int]
+    lib.pcabo_set_option.argtypes = [vp, C.c_int, C.c_int]
     lib.pcabo_last_error.argtypes = [vp, C.c_char_p, C.c_int]
     lib.pcabo_wpca.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp,
                                vp, vp, vp, vp, ip, vp]
@@ -128,6 +130,17 @@ class Context:
     def _chk(self, rc: int) -> None:
         if rc != 0:
             raise PcaboError(rc, self._err())
+
+    def set_option(self, option: int, value: int) -> None:
+        self._chk(LIB.pcabo_set_option(self._h, int(option), int(value)))
+
+    def match_best_f_dtype(self, best_f) -> None:
+        """botorch stores `torch.as_tensor(best_f)`: float32 for a Python float (or int), float64 for a numpy float64
+        scalar (what a callable objective may return).  Tell the library which of the two the caller's value is."""
+        f32 = 0 if isinstance(best_f, np.floating) and best_f.dtype == np.float64 else 1
+        if getattr(self, "_bestf_f32", 1) != f32:
+            self.set_option(OPT_BESTF_F32, f32)
+            self._bestf_f32 = f32
 
     def close(self) -> None:
         if getattr(self, "_h", None):

@@ -5,7 +5,6 @@ from __future__ import annotations
 
 import datetime
 import os
-import warnings
 from typing import List, Sequence
 
 import torch
@@ -25,23 +24,28 @@ def init(backend: str = None) -> tuple:
             # PCABO_DIST_BACKEND=gloo: rehearsal on a box with fewer GPUs than ranks (ranks then share a device)
             backend = os.environ.get("PCABO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
-            # RCCL first; if it cannot come up on this node (IPC/driver trouble) the few scalar collectives of this
-            # package (barrier, max, sum, final gather - none of them on the data path) run over gloo instead.
-            try:
-                torch.cuda.set_device(local_rank)
-                dist.init_process_group(backend="nccl", rank=rank, world_size=size,
-                                        timeout=datetime.timedelta(seconds=180))
-                t = torch.zeros(1, dtype=torch.float64, device=torch.device("cuda", local_rank))
-                dist.all_reduce(t)
-                torch.cuda.synchronize()
-            except Exception as e:  # noqa: BLE001
-                warnings.warn(f"RCCL initialisation failed ({type(e).__name__}: {e}); falling back to gloo", RuntimeWarning)
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                dist.init_process_group(backend="gloo", rank=rank, world_size=size)
+            # RCCL or nothing: a rank that quietly went on over gloo while its peers sit in RCCL hangs the job, and a
+            # scaling line must not be able to claim RCCL without having used it.  A rehearsal on a box with fewer GPUs
+            # than ranks asks for gloo explicitly (PCABO_DIST_BACKEND=gloo).
+            if torch.cuda.device_count() <= local_rank:
+                raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible); "
+                                 "set PCABO_DIST_BACKEND=gloo to rehearse with ranks sharing a device")
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", rank=rank, world_size=size,
+                                    timeout=datetime.timedelta(seconds=180))
+            t = torch.ones(1, dtype=torch.float64, device=torch.device("cuda", local_rank))
+            dist.all_reduce(t)
+            torch.cuda.synchronize()
+            if int(t.item()) != size:
+                raise SystemExit(f"rank {rank}: RCCL all-reduce saw {t.item()} ranks instead of {size}")
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=size)
     return rank, local_rank, size
+
+
+def backend_name() -> str:
+    """Backend the collectives of this process run on ("nccl" = RCCL over xGMI, "gloo", or "none" for a single rank)."""
+    return dist.get_backend() if dist.is_initialized() else "none"
 
 
 def _dev():

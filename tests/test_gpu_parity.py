@@ -321,7 +321,7 @@ def _replay_with_oracle(opt, problem_factory, dim, lb=-5.0, ub=5.0, oracle_cls=O
         if rec.trace.retried != bool(tr.get("retried", False)):
             # tolerated only in the collapsed regime the reference itself runs into (earlier out-of-box candidates
             # with coordinates ~1e9 sit in the data, the search box is > 1e6 wide, every candidate is penalised):
-            # states then agree to ~1e-13 * 1e9 only and a line search can end differently (tests/gpu_retry_debug.py)
+            # states then agree to ~1e-13 * 1e9 only and a line search can end differently (tools/gpu_retry_debug.py)
             assert np.abs(rec.acq_bounds).max() > 1e6, (it, rec.trace.retried)
             st["collapsed_retry_mismatch"] = st.get("collapsed_retry_mismatch", 0) + 1
             continue
@@ -358,24 +358,25 @@ def _replay_with_oracle(opt, problem_factory, dim, lb=-5.0, ub=5.0, oracle_cls=O
     return st
 
 
-def _check_replay(st, min_iters):
-    """Thresholds sit well above what was measured on MI355X (profiles/r01/parity_stats.txt): end points median
-    1e-16..7e-12, q90 <= 1e-5; chosen x median <= 6e-12, q90 <= 7e-8, max 6e-4; counts equal for 93-95 %."""
+def _check_replay(st, min_iters, frac=0.9):
+    """Thresholds follow what was measured on MI355X (profiles/r01/parity_stats.txt): end points median
+    1e-16..7e-12, q90 <= 1e-5; chosen x median <= 6e-12, q90 <= 7e-8, max 6e-4; counts equal for 93-97 % of the restart
+    groups, end points within 1e-5 for 93-97 % -> `frac` = 0.9 so that a regression shows."""
     q = lambda a, p: float(np.quantile(np.array(a), p))
     assert st["iters"] >= min_iters
     assert max(st["dic"]) < 1e-9                                     # initial conditions essentially identical
     # q90 of the end points moves between 1e-5 and 1e-3 from build to build (it counts restart groups whose line search
     # branched differently; the same run has 31..46 of 400 such restarts depending on rounding in the Cholesky kernels)
     assert q(st["dcand"], 0.5) < 1e-8 and q(st["dcand"], 0.9) < 1e-2
-    assert np.mean(np.array(st["dcand"]) < 1e-5) >= 0.8
+    assert np.mean(np.array(st["dcand"]) < 1e-5) >= frac
     assert q(st["dval"], 0.5) < 1e-10 and q(st["dval"], 0.9) < 1e-6
-    assert np.mean(st["count_equal"]) >= 0.8
+    assert np.mean(st["count_equal"]) >= frac
     if st["dx"]:
         # a single restart left short of its optimum (joint stopping rule) can move the chosen point by ~1e-2:
         # allowed for 1 in 20 iterations (measured: 1 of 40)
         assert q(st["dx"], 0.5) < 1e-7 and np.mean(np.array(st["dx"]) < 1e-2) >= 0.95 and max(st["dx"]) < 0.5
-        assert np.mean(np.array(st["dx"]) < 1e-5) >= 0.8
-        assert q(st["df"], 0.5) < 1e-9 and np.mean(np.array(st["df"]) < 1e-5) >= 0.8
+        assert np.mean(np.array(st["dx"]) < 1e-5) >= frac
+        assert q(st["df"], 0.5) < 1e-9 and np.mean(np.array(st["df"]) < 1e-5) >= frac
     assert st["ties"] <= max(2, st["iters"] // 2)
     assert st["diverged_choice"] <= max(1, st["iters"] // 20)      # best restart in another local optimum: rare
     assert max(st["dsurf"]) < 1e-9               # the surface itself agrees wherever the device ended (measured 6e-15)

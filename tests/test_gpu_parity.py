@@ -358,25 +358,31 @@ def _replay_with_oracle(opt, problem_factory, dim, lb=-5.0, ub=5.0, oracle_cls=O
     return st
 
 
-def _check_replay(st, min_iters, frac=0.9):
+def _check_replay(st, min_iters, frac=0.9, late=False):
     """Thresholds follow what was measured on MI355X (profiles/r01/parity_stats.txt): end points median
     1e-16..7e-12, q90 <= 1e-5; chosen x median <= 6e-12, q90 <= 7e-8, max 6e-4; counts equal for 93-97 % of the restart
-    groups, end points within 1e-5 for 93-97 % -> `frac` = 0.9 so that a regression shows."""
+    groups, end points within 1e-5 for 93-97 % -> `frac` = 0.9 so that a regression shows.
+    late=True: the late phase of the d=40 headline run (n = 130..449, k = 8..20, most points penalised).  There the
+    acquisition optima are flat and a third of the L-BFGS-B runs branch differently on last-bit differences - real scipy
+    driven by the DEVICE's own f/g parts from lbfgsb.cpp just as often (tests/test_gpu_late_phase.py).  Measured (14
+    iterations): counts equal 61 %, end points q50 1.2e-7 / q90 5.8e-4, chosen x q50 6.6e-7 / max 4.9e-4, surface 2.8e-13."""
     q = lambda a, p: float(np.quantile(np.array(a), p))
+    frac_cnt = 0.45 if late else frac
+    frac_pts = 0.5 if late else frac
     assert st["iters"] >= min_iters
     assert max(st["dic"]) < 1e-9                                     # initial conditions essentially identical
     # q90 of the end points moves between 1e-5 and 1e-3 from build to build (it counts restart groups whose line search
     # branched differently; the same run has 31..46 of 400 such restarts depending on rounding in the Cholesky kernels)
-    assert q(st["dcand"], 0.5) < 1e-8 and q(st["dcand"], 0.9) < 1e-2
-    assert np.mean(np.array(st["dcand"]) < 1e-5) >= frac
-    assert q(st["dval"], 0.5) < 1e-10 and q(st["dval"], 0.9) < 1e-6
-    assert np.mean(st["count_equal"]) >= frac
+    assert q(st["dcand"], 0.5) < (1e-5 if late else 1e-8) and q(st["dcand"], 0.9) < 1e-2
+    assert np.mean(np.array(st["dcand"]) < 1e-5) >= frac_pts
+    assert q(st["dval"], 0.5) < 1e-10 and q(st["dval"], 0.9) < (1e-5 if late else 1e-6)
+    assert np.mean(st["count_equal"]) >= frac_cnt
     if st["dx"]:
         # a single restart left short of its optimum (joint stopping rule) can move the chosen point by ~1e-2:
         # allowed for 1 in 20 iterations (measured: 1 of 40)
-        assert q(st["dx"], 0.5) < 1e-7 and np.mean(np.array(st["dx"]) < 1e-2) >= 0.95 and max(st["dx"]) < 0.5
-        assert np.mean(np.array(st["dx"]) < 1e-5) >= frac
-        assert q(st["df"], 0.5) < 1e-9 and np.mean(np.array(st["df"]) < 1e-5) >= frac
+        assert q(st["dx"], 0.5) < (1e-5 if late else 1e-7) and np.mean(np.array(st["dx"]) < 1e-2) >= 0.95 and max(st["dx"]) < 0.5
+        assert np.mean(np.array(st["dx"]) < 1e-5) >= frac_pts
+        assert q(st["df"], 0.5) < 1e-9 and np.mean(np.array(st["df"]) < 1e-5) >= frac_pts
     assert st["ties"] <= max(2, st["iters"] // 2)
     assert st["diverged_choice"] <= max(1, st["iters"] // 20)      # best restart in another local optimum: rare
     assert max(st["dsurf"]) < 1e-9               # the surface itself agrees wherever the device ended (measured 6e-15)

@@ -194,6 +194,48 @@ int pcabo_set_profiling(pcabo_ctx* ctx, int enabled);
 int pcabo_get_profile(pcabo_ctx* ctx, int which, double* ms, int64_t* launches, double* bytes, double* flops);
 int pcabo_reset_profile(pcabo_ctx* ctx);
 
+/* ---- Batched contexts: B independent BO runs advancing in lock-step ---------------------------------------------------
+ * The reference's outer loop is a list of independent runs (Algorithms/Experiment/ExperimentRunner.py:137-183: 30 instances
+ * x functions x dimensions, one optimiser object each).  A batch holds B per-run contexts of equal capacity side by side in
+ * one device slab and advances them together: every phase of rows A-H is ONE launch sequence with blockIdx.z = run (the
+ * work-groups of all runs fill the chip together), the raw-sample scoring is one launch for all runs, and the L-BFGS-B
+ * rounds of all runs are fed to shared acquisition launches (one per gang of runs and round; an active-query table names the
+ * (run, query) pairs of the round).  The kernels and their per-run grids are those of the single context, so every run's
+ * numbers are bit-identical to the same run in a context of its own.
+ * All runs of a call share n and d (same budget / DoE sizes: the runs of one (function, dimension) cell or of several cells
+ * with the same dimension); k and best_f are per run.  Per-run arrays are laid out [B][...] with the strides named below.
+ * status[b] receives the pcabo_status of run b where a call can fail per run; the return value reports argument / HIP errors.
+ * pcabo_batch_ctx(batch, b) is run b's context: the single-context calls above work on it (introspection, the rare retry of
+ * one run), but not pcabo_ctx_destroy. */
+typedef struct pcabo_batch pcabo_batch;
+int pcabo_batch_create(int device, int B, int max_n, int max_d, int max_q, pcabo_batch** out);
+int pcabo_batch_destroy(pcabo_batch* batch);
+int pcabo_batch_last_error(pcabo_batch* batch, char* buf, int buflen);
+pcabo_ctx* pcabo_batch_ctx(pcabo_batch* batch, int b);
+
+/* Rows A-H of all runs as one enqueue (pcabo_wpca_gp_condition_begin for B runs).  X[B][n*d], ranks[B][n], noise[B][n*d] or
+ * NULL, y[B][n].  Returns after the enqueue; pcabo_batch_wpca_results waits for the wPCA part only. */
+int pcabo_batch_wpca_gp_condition_begin(pcabo_batch* batch, const double* X, const int64_t* ranks, const double* noise,
+                                        const double* y, int n, int d, int maximize, double var_threshold,
+                                        int n_components, double lengthscale, double gp_noise, int kernel);
+/* data_mean[B][d], pca_mean[B][d], comps[B][d*d] (the first min(n,d)*d entries of each block), evr[B][d], k[B]; any may be NULL */
+int pcabo_batch_wpca_results(pcabo_batch* batch, double* data_mean, double* pca_mean, double* comps, double* evr, int* k);
+/* Row J for every run: bounds[B][2*max_d], run b's block holds lo[k_b] then hi[k_b]. */
+int pcabo_batch_acq_bounds(pcabo_batch* batch, double* bounds);
+/* Wait for the conditioning of all runs and score q points per run (values only; the raw samples of
+ * gen_batch_initial_conditions), enqueued behind the conditioning.  Xq[B][q*max_d]: run b's block holds a dense q x k_b array;
+ * best_f[B]; val[B][q]; status[B] (PCABO_ERR_NOT_PD for a run whose factorisation failed after the jitter retries). */
+int pcabo_batch_gp_condition_end_eval(pcabo_batch* batch, const double* Xq, int q, const double* best_f, int maximize,
+                                      int acq, double* val, int* status);
+/* Rows M-N for every run (pcabo_optimize_acqf semantics per run).  ics[B][num_restarts*max_d] (dense num_restarts x k_b per
+ * block), bounds[B][2*max_d] as pcabo_batch_acq_bounds gives them, best_f[B]; cand[B][num_restarts*max_d] (dense per block),
+ * vals[B][num_restarts], info[B][4*ngroups] or NULL, failed[B], status[B]. */
+int pcabo_batch_optimize_acqf(pcabo_batch* batch, const double* ics, int num_restarts, int batch_limit,
+                              const double* bounds, int maxiter, const double* best_f, int maximize, int acq,
+                              double* cand, double* vals, int* info, int* failed, int* status);
+/* Row O for every run: z[B][max_d] (k_b entries used) -> x[B][d]. */
+int pcabo_batch_inverse_map(pcabo_batch* batch, const double* z, double* x);
+
 #ifdef __cplusplus
 }
 #endif

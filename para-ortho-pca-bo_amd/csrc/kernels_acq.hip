@@ -166,6 +166,26 @@ __device__ inline void acq_tail(int combine, double* s_v, double* partial, unsig
   }
 }
 
+// Batched launches: which run does this work-group serve, and (table mode) which of its queries?  Offsets every per-run
+// operand; k and best_f of the run come from its own device words.
+#define ACQ_BATCH_PROLOGUE()                                                                                     \
+  unsigned run_ = blockIdx.z;                                                                                    \
+  int qsel_ = -1;                                                                                                \
+  if (ab.table) {                                                                                                \
+    const unsigned e_ = reinterpret_cast<const unsigned*>(qa.x)[blockIdx.y];                                     \
+    run_ = e_ >> 16; qsel_ = (int)(e_ & 0xffffu);                                                                \
+  }                                                                                                              \
+  if (ab.zs) {                                                                                                   \
+    ZnT = zrun(ZnT, ab.zs, run_); R = zrun(R, ab.zs, run_); alpha = zrun(alpha, ab.zs, run_);                    \
+    bounds4 = zrun(bounds4, ab.zs, run_); ystats = zrun(ystats, ab.zs, run_); partial = zrun(partial, ab.zs, run_); \
+    counters = zrun(counters, ab.zs, run_); val = zrun(val, ab.zs, run_); grad = zrun(grad, ab.zs, run_);        \
+    Xq = zrun(Xq, ab.xq_host ? ab.hzs : ab.zs, run_);                                                            \
+    host_val = zrun(host_val, ab.hzs, run_); host_grad = zrun(host_grad, ab.hzs, run_); hm = zrun(hm, ab.hzs, run_); \
+    if (ab.k_dev) k = *zrun(ab.k_dev, ab.zs, run_);                                                              \
+    if (ab.bestf) prm.best_f = *zrun(ab.bestf, ab.zs, run_);                                                     \
+  }                                                                                                              \
+  (void)qsel_;
+
 template <int SLAB>
 __global__ __launch_bounds__(256) void k_acq_fused(
     QueryArgs qa, const double* __restrict__ Xq, int q_total, int n, int k, int NP, int ld,
@@ -173,7 +193,8 @@ __global__ __launch_bounds__(256) void k_acq_fused(
     const double* __restrict__ bounds4, const double* __restrict__ ystats, AcqParams prm, double* partial,
     unsigned int* counters, double* __restrict__ val, double* __restrict__ grad,
     double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq, int combine, int /*qb*/,
-    const MailPair* /*host_mail*/, MailPair* /*dev_mail*/, MailPair* /*part_pairs*/) {
+    const MailPair* /*host_mail*/, MailPair* /*dev_mail*/, MailPair* /*part_pairs*/, AcqBatch ab) {
+  ACQ_BATCH_PROLOGUE()
   const double inv_ls = prm.inv_ls;
   const int kernel = prm.kernel, want_grad = prm.want_grad;
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
@@ -183,7 +204,7 @@ __global__ __launch_bounds__(256) void k_acq_fused(
   double* s_xn = s_dyn + 3 * NP;     // PCABO_MAXD
   double* s_v = s_xn + PCABO_MAXD;   // SLAB
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-  const int s = blockIdx.x, q = blockIdx.y, S = gridDim.x;
+  const int s = blockIdx.x, q = ab.table ? qsel_ : (int)blockIdx.y, S = gridDim.x;
   double* out = partial + ((size_t)q * S + s) * PSTRIDE;
   STAMP(0);
 
@@ -489,7 +510,8 @@ __global__ __launch_bounds__(256) void k_acq_fast(
     const double* __restrict__ bounds4, const double* __restrict__ ystats, AcqParams prm, double* partial,
     unsigned int* counters, double* __restrict__ val, double* __restrict__ grad,
     double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq, int combine, int qb,
-    const MailPair* host_mail, MailPair* dev_mail, MailPair* part_pairs) {
+    const MailPair* host_mail, MailPair* dev_mail, MailPair* part_pairs, AcqBatch ab) {
+  if (!SRV) { ACQ_BATCH_PROLOGUE() }
   constexpr int NP = NB * 64;
   constexpr int CU = 10;                 // components per wave
   constexpr int RW = SLAB / 4;           // slab rows per wave
@@ -555,7 +577,7 @@ __global__ __launch_bounds__(256) void k_acq_fast(
   double b_lo = 0.0, b_hi = 1.0;
   if (server && l < k) { b_lo = bounds4[l]; b_hi = bounds4[PCABO_MAXD + l]; }
   for (;;) {                                                  // rounds (one pass unless resident)
-  int q = blockIdx.y * qb;
+  int q = (!SRV && ab.table) ? (int)(reinterpret_cast<const unsigned*>(qa.x)[blockIdx.y] & 0xffffu) : (int)blockIdx.y * qb;
   double* out = partial + ((size_t)q * S + s) * PSTRIDE;
   if (server) {
     const unsigned long long t0 = wall_clock64();
@@ -735,7 +757,7 @@ __global__ __launch_bounds__(256) void k_acq_fast(
   }
   }  // want_grad
   }   // queries of this group
-  q = blockIdx.y * qb;                  // (combine: qb = 1)
+  q = (!SRV && ab.table) ? (int)(reinterpret_cast<const unsigned*>(qa.x)[blockIdx.y] & 0xffffu) : (int)blockIdx.y * qb;   // (combine: qb = 1)
   out = partial + ((size_t)q * S + s) * PSTRIDE;
   if (!server) {
     acq_tail<SLAB>(combine, s_v, partial, counters, q, S, k, bounds4, ystats, prm, val, grad, host_val, host_grad, hm, cur_seq, tid, w, l);
@@ -849,7 +871,14 @@ __device__ void acq_finish_query(const double* base, int S, int k, int q, const 
 __global__ __launch_bounds__(256) void k_acq_combine(const double* __restrict__ partial, int q_total, int S, int k,
                                                      const double* __restrict__ bounds4,
                                                      const double* __restrict__ ystats, AcqParams p,
-                                                     double* __restrict__ val, double* __restrict__ grad) {
+                                                     double* __restrict__ val, double* __restrict__ grad, AcqBatch ab) {
+  if (ab.zs) {
+    const unsigned run_ = blockIdx.z;
+    partial = zrun(partial, ab.zs, run_); bounds4 = zrun(bounds4, ab.zs, run_); ystats = zrun(ystats, ab.zs, run_);
+    val = zrun(val, ab.zs, run_); grad = zrun(grad, ab.zs, run_);
+    if (ab.k_dev) k = *zrun(ab.k_dev, ab.zs, run_);
+    if (ab.bestf) p.best_f = *zrun(ab.bestf, ab.zs, run_);
+  }
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q < q_total)
     acq_finish_query(partial + (size_t)q * S * PSTRIDE, S, k, q, bounds4, ystats, p, val, grad, nullptr, nullptr,
@@ -879,7 +908,8 @@ void launch_acq(hipStream_t st, const QueryArgs* qa, const double* Xq, int q, in
                 const double* ZnT, const double* R, const double* alpha, const double* bounds4, const double* ystats,
                 AcqParams p, double* partial, unsigned int* counters, double* val,
                 double* grad, double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq,
-                const MailPair* host_mail, MailPair* dev_mail, MailPair* part_pairs) {
+                const MailPair* host_mail, MailPair* dev_mail, MailPair* part_pairs, AcqBatch ab, int B,
+                int table_entries) {
   // 16 rows per work-group while S*q groups fit the 256 CUs (NP <= 384 at q = 10), 32 rows beyond that: measured
   // on MI355X (q=10, with gradient) 16 rows win at n=120/250 (22.2 vs 23.0, 26.9 vs 27.8 us), 32 rows at n=449 (34.4 vs
   // 37.3 us).  PCABO_SLAB32_NP overrides the switch point (tuning only).
@@ -898,9 +928,11 @@ void launch_acq(hipStream_t st, const QueryArgs* qa, const double* Xq, int q, in
   static int qb_large = -1;
   if (qb_large < 0) { const char* e = getenv("PCABO_ACQ_QB"); qb_large = e ? atoi(e) : 8; if (qb_large < 1) qb_large = 1; }
   const int qb = (fast && !combine && q >= 64) ? qb_large : 1;
-  const int gy = (q + qb - 1) / qb;
+  // batched: table mode -> one grid row per active (run, query) entry; otherwise grid.z = run
+  const int gy = ab.table ? table_entries : (q + qb - 1) / qb;
+  const int gz = ab.table ? 1 : B;
 #define ACQ_ARGS qa ? *qa : empty, Xq, q, n, k, NP, ld, ZnT, R, alpha, bounds4, ystats, p, partial, counters, val, grad, \
-                 host_val, host_grad, hm, seq, combine, qb, host_mail, dev_mail, part_pairs
+                 host_val, host_grad, hm, seq, combine, qb, host_mail, dev_mail, part_pairs, ab
   const int FIN_LDS = 6 * PCABO_MAXD + 2;   // finishing group's LDS beyond s_v
 #define ACQ_LDS(SL, NBV) (3 * NBV * 64 + PCABO_MAXD + SL + 2 + (4 * NBV * 64 > FIN_LDS ? 4 * NBV * 64 : FIN_LDS))
 #define ACQ_FAST(SL, NBV)                                                                                      \
@@ -909,7 +941,7 @@ void launch_acq(hipStream_t st, const QueryArgs* qa, const double* Xq, int q, in
       hipLaunchKernelGGL((k_acq_fast<SL, NBV, true>), dim3(S + 1, gy), dim3(256),                              \
                          (size_t)std::max<int>(ACQ_LDS(SL, NBV), FIN_LDS_DOUBLES) * sizeof(double), st, ACQ_ARGS); \
     else                                                                                                       \
-      hipLaunchKernelGGL((k_acq_fast<SL, NBV, false>), dim3(S, gy), dim3(256),                                 \
+      hipLaunchKernelGGL((k_acq_fast<SL, NBV, false>), dim3(S, gy, gz), dim3(256),                             \
                          (size_t)ACQ_LDS(SL, NBV) * sizeof(double), st, ACQ_ARGS);                             \
     break;
   if (fast) {
@@ -923,14 +955,14 @@ void launch_acq(hipStream_t st, const QueryArgs* qa, const double* Xq, int q, in
   } else {
     size_t lds = (size_t)(3 * NP + PCABO_MAXD + 32 + 2 + 6 * PCABO_MAXD + 2) * sizeof(double);
     if (slab == 16)
-      hipLaunchKernelGGL(k_acq_fused<16>, dim3(S, q), dim3(256), lds, st, ACQ_ARGS);
+      hipLaunchKernelGGL(k_acq_fused<16>, dim3(S, ab.table ? gy : q, gz), dim3(256), lds, st, ACQ_ARGS);
     else
-      hipLaunchKernelGGL(k_acq_fused<32>, dim3(S, q), dim3(256), lds, st, ACQ_ARGS);
+      hipLaunchKernelGGL(k_acq_fused<32>, dim3(S, ab.table ? gy : q, gz), dim3(256), lds, st, ACQ_ARGS);
   }
 #undef ACQ_FAST
 #undef ACQ_LDS
 #undef ACQ_ARGS
   if (!combine)
-    hipLaunchKernelGGL(k_acq_combine, dim3((q + 3) / 4), dim3(256), 0, st, partial, q, S, k, bounds4, ystats, p, val,
-                       grad);
+    hipLaunchKernelGGL(k_acq_combine, dim3((q + 3) / 4, 1, gz), dim3(256), 0, st, partial, q, S, k, bounds4, ystats, p, val,
+                       grad, ab);
 }

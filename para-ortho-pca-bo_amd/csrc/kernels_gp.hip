@@ -23,7 +23,8 @@
 __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ AT, const double* __restrict__ nrm, int n,
                                               int KP, int ld, double noise, int kernel, double* __restrict__ K,
                                               const int* __restrict__ k_dev, double* __restrict__ K2,
-                                              int* __restrict__ info_reset) {
+                                              int* __restrict__ info_reset, size_t zs) {
+  ZRUN(AT); ZRUN(nrm); ZRUN(K); ZRUN(k_dev); ZRUN(K2); ZRUN(info_reset);
   const int ti = blockIdx.x, tj = blockIdx.y;
   // K2: the copy the factorisation works on in place; info_reset: its failure flag (saves a copy and a fill launch)
   if (info_reset && ti == 0 && tj == 0 && threadIdx.x == 0) *info_reset = 0;
@@ -197,7 +198,8 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ A, int 
 // Both 64x64 operand tiles are staged in LDS with coalesced loads; fragments are read with a
 // leading dimension of 66 doubles (conflict-free for ds_read_b64).
 __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int p, int nblk, int ld,
-                                                     const double* __restrict__ diag_scratch) {
+                                                     const double* __restrict__ diag_scratch, size_t zs) {
+  ZRUN(A); ZRUN(diag_scratch);
   __shared__ __attribute__((aligned(16))) double s_a[BS * TLD];
   __shared__ __attribute__((aligned(16))) double s_b[BS * TLD];
   if (blockIdx.x == gridDim.x - 1) {                 // one extra group puts panel p's diagonal factor in place (see
@@ -282,7 +284,8 @@ __global__ __launch_bounds__(256) void k_trinv_diag(const double* __restrict__ L
 // registers while the MFMAs of the current step run: the walk is a chain of ~35 short steps for the first block column,
 // and each used to pay a full global-load latency (2 us per step, 62 us per call on average).
 __global__ __launch_bounds__(256) void k_trinv_cols(const double* __restrict__ L, int nblk, int ld,
-                                                    double* R) {
+                                                    double* R, size_t zs) {
+  ZRUN(L); ZRUN(R);
   __shared__ __attribute__((aligned(16))) double s_t[BS * TLD];   // 64x64 operand tile
   __shared__ __attribute__((aligned(16))) double s_xk[BS * 16];   // 64x16 block of X (or S)
   const int tid = threadIdx.x;
@@ -341,7 +344,8 @@ __global__ __launch_bounds__(256) void k_trinv_cols(const double* __restrict__ L
 // ---------------------------------------------------------------------------------------------
 // alpha = K^-1 y_s = R^T (R y_s): two matrix-vector products with the root inverse.
 __global__ __launch_bounds__(256) void k_rmatvec(const double* __restrict__ R, const double* __restrict__ y, int n,
-                                                 int ld, double* __restrict__ t) {
+                                                 int ld, double* __restrict__ t, size_t zs) {
+  ZRUN(R); ZRUN(y); ZRUN(t);
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   for (int rr = 0; rr < 4; ++rr) {
     const int i = blockIdx.x * 16 + w * 4 + rr;
@@ -358,7 +362,8 @@ __global__ __launch_bounds__(256) void k_rmatvec(const double* __restrict__ R, c
 // skipped group-wise).  Fixed summation order: 4 interleaved accumulators per wave, then the 16 waves in order.
 #define RTM_WAVES 16
 __global__ __launch_bounds__(64 * RTM_WAVES) void k_rtmatvec(const double* __restrict__ R, const double* __restrict__ t,
-                                                             int n, int ld, double* __restrict__ out) {
+                                                             int n, int ld, double* __restrict__ out, size_t zs) {
+  ZRUN(R); ZRUN(t); ZRUN(out);
   __shared__ double s_p[RTM_WAVES][64];
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int j0 = blockIdx.x * 64, j = j0 + l;
@@ -383,32 +388,36 @@ __global__ __launch_bounds__(64 * RTM_WAVES) void k_rtmatvec(const double* __res
 
 // ---- launchers --------------------------------------------------------------------------------
 void launch_gram(hipStream_t s, const double* AT, const double* nrm, int n, int NP, int KP, int ld, double noise,
-                 int kernel, double* K, const int* k_dev, double* K2, int* info_reset) {
+                 int kernel, double* K, const int* k_dev, double* K2, int* info_reset, ZB zb) {
   int nb = NP / BS;
-  hipLaunchKernelGGL(k_gram, dim3(nb, nb), dim3(256), 0, s, AT, nrm, n, KP, ld, noise, kernel, K, k_dev, K2, info_reset);
+  hipLaunchKernelGGL(k_gram, dim3(nb, nb, zb.B), dim3(256), 0, s, AT, nrm, n, KP, ld, noise, kernel, K, k_dev, K2, info_reset,
+                     zb.zs);
 }
 void launch_add_jitter(hipStream_t s, double* K, int n, int ld, double jitter) {
   hipLaunchKernelGGL(k_add_jitter, dim3((n + 255) / 256), dim3(256), 0, s, K, n, ld, jitter);
 }
-void launch_cholesky(hipStream_t s, double* L, int NP, int ld, int* info, double* diag_scratch) {
+void launch_cholesky(hipStream_t s, double* L, int NP, int ld, int* info, double* diag_scratch, ZB zb) {
   const int nblk = NP / BS;
   static const bool lanes4 = getenv("PCABO_GP_FOUR_LANE_ROWS") != nullptr;      // A/B: the earlier panel / inverse kernels
   for (int p = 0; p < nblk; ++p) {
-    if (lanes4) hipLaunchKernelGGL(k_chol_panel, dim3(nblk - p), dim3(256), 0, s, L, p, ld, info, diag_scratch);
-    else launch_chol_panel_w(s, L, p, nblk - p, ld, info, diag_scratch);
+    if (lanes4 && zb.B == 1) hipLaunchKernelGGL(k_chol_panel, dim3(nblk - p), dim3(256), 0, s, L, p, ld, info, diag_scratch);
+    else launch_chol_panel_w(s, L, p, nblk - p, ld, info, diag_scratch, zb);
     int m = nblk - p - 1;
-    if (m > 0) hipLaunchKernelGGL(k_chol_update, dim3(m * (m + 1) / 2 + 1), dim3(256), 0, s, L, p, nblk, ld, diag_scratch);
+    if (m > 0)
+      hipLaunchKernelGGL(k_chol_update, dim3(m * (m + 1) / 2 + 1, 1, zb.B), dim3(256), 0, s, L, p, nblk, ld, diag_scratch,
+                         zb.zs);
   }
 }
-void launch_trinv(hipStream_t s, const double* L, int NP, int ld, double* R) {
+void launch_trinv(hipStream_t s, const double* L, int NP, int ld, double* R, ZB zb) {
   const int nblk = NP / BS;
   // (blocks above the diagonal are never written by anything: they keep the zeros of pcabo_ctx_create)
   static const bool lanes4 = getenv("PCABO_GP_FOUR_LANE_ROWS") != nullptr;
-  if (lanes4) hipLaunchKernelGGL(k_trinv_diag, dim3(nblk), dim3(256), 0, s, L, ld, R);
-  else launch_trinv_diag_w(s, L, nblk, ld, R);
-  hipLaunchKernelGGL(k_trinv_cols, dim3(NP / 16), dim3(256), 0, s, L, nblk, ld, R);
+  if (lanes4 && zb.B == 1) hipLaunchKernelGGL(k_trinv_diag, dim3(nblk), dim3(256), 0, s, L, ld, R);
+  else launch_trinv_diag_w(s, L, nblk, ld, R, zb);
+  hipLaunchKernelGGL(k_trinv_cols, dim3(NP / 16, 1, zb.B), dim3(256), 0, s, L, nblk, ld, R, zb.zs);
 }
-void launch_alpha(hipStream_t s, const double* R, const double* ys, int n, int NP, int ld, double* tmp, double* alpha) {
-  hipLaunchKernelGGL(k_rmatvec, dim3(NP / 16), dim3(256), 0, s, R, ys, n, ld, tmp);
-  hipLaunchKernelGGL(k_rtmatvec, dim3(NP / 64), dim3(64 * RTM_WAVES), 0, s, R, tmp, n, ld, alpha);
+void launch_alpha(hipStream_t s, const double* R, const double* ys, int n, int NP, int ld, double* tmp, double* alpha,
+                  ZB zb) {
+  hipLaunchKernelGGL(k_rmatvec, dim3(NP / 16, 1, zb.B), dim3(256), 0, s, R, ys, n, ld, tmp, zb.zs);
+  hipLaunchKernelGGL(k_rtmatvec, dim3(NP / 64, 1, zb.B), dim3(64 * RTM_WAVES), 0, s, R, tmp, n, ld, alpha, zb.zs);
 }

@@ -118,7 +118,8 @@ __device__ inline void panel_solve_rows(double (&ar)[BS], const double* s_d, con
 }
 
 __global__ __launch_bounds__(128) void k_chol_panel_w(double* __restrict__ A, int p, int ld, int* __restrict__ info,
-                                                      double* __restrict__ diag_scratch) {
+                                                      double* __restrict__ diag_scratch, size_t zs) {
+  ZRUN(A); ZRUN(info); ZRUN(diag_scratch);
   __shared__ double s_d[BS * WLD];
   __shared__ double s_a[BS * WLD];
   __shared__ double s_rs[BS];
@@ -207,7 +208,9 @@ struct InvChunk<BS - 1, CH, P> {
   }
 };
 
-__global__ __launch_bounds__(64) void k_trinv_diag_w(const double* __restrict__ L, int ld, double* __restrict__ R) {
+__global__ __launch_bounds__(64) void k_trinv_diag_w(const double* __restrict__ L, int ld, double* __restrict__ R,
+                                                     size_t zs) {
+  ZRUN(L); ZRUN(R);
   __shared__ __attribute__((aligned(16))) double s_lt[BS * BS];    // s_lt[m][r] = L[r][m]
   __shared__ double s_rd[BS];
   const int c = threadIdx.x, b = blockIdx.x;
@@ -232,9 +235,9 @@ __global__ __launch_bounds__(64) void k_trinv_diag_w(const double* __restrict__ 
 }
 
 
-void launch_chol_panel_w(hipStream_t s, double* L, int p, int nblocks, int ld, int* info, double* diag_scratch) {
-  hipLaunchKernelGGL(k_chol_panel_w, dim3(nblocks), dim3(128), 0, s, L, p, ld, info, diag_scratch);
+void launch_chol_panel_w(hipStream_t s, double* L, int p, int nblocks, int ld, int* info, double* diag_scratch, ZB zb) {
+  hipLaunchKernelGGL(k_chol_panel_w, dim3(nblocks, 1, zb.B), dim3(128), 0, s, L, p, ld, info, diag_scratch, zb.zs);
 }
-void launch_trinv_diag_w(hipStream_t s, const double* L, int nblk, int ld, double* R) {
-  hipLaunchKernelGGL(k_trinv_diag_w, dim3(nblk), dim3(64), 0, s, L, ld, R);
+void launch_trinv_diag_w(hipStream_t s, const double* L, int nblk, int ld, double* R, ZB zb) {
+  hipLaunchKernelGGL(k_trinv_diag_w, dim3(nblk, 1, zb.B), dim3(64), 0, s, L, ld, R, zb.zs);
 }

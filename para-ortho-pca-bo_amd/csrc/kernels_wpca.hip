@@ -44,7 +44,8 @@ __global__ void k_rank(const double* __restrict__ f, int n, int maximize, long l
 __global__ __launch_bounds__(WP_THREADS) void k_wpca_prep(
     const double* __restrict__ X, const long long* __restrict__ ranks, const double* __restrict__ noise,
     int n, int d, int DP, double* __restrict__ weights, double* __restrict__ data_mean,
-    double* __restrict__ pca_mean, double* __restrict__ Wc) {
+    double* __restrict__ pca_mean, double* __restrict__ Wc, size_t zs) {
+  ZRUN(X); ZRUN(ranks); ZRUN(noise); ZRUN(weights); ZRUN(data_mean); ZRUN(pca_mean); ZRUN(Wc);
   __shared__ double s_red[WP_THREADS];
   __shared__ double s_col[PCABO_MAXD];
   const int tid = threadIdx.x;
@@ -157,7 +158,8 @@ __global__ __launch_bounds__(WP_THREADS) void k_wpca_prep(
 // v_mfma_f64_16x16x4_f64: lane l supplies A[i=l&15][k=l>>4] and B[k=l>>4][j=l&15]; D holds
 // rows (l>>4)+4r, column l&15.
 __global__ __launch_bounds__(256) void k_cov(const double* __restrict__ Wc, int n4, int DP, double inv_nm1,
-                                             double* __restrict__ C) {
+                                             double* __restrict__ C, size_t zs) {
+  ZRUN(Wc); ZRUN(C);
   __shared__ double s_acc[4][4][64];
   const int ti = blockIdx.x, tj = blockIdx.y;
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -202,7 +204,9 @@ struct PcaSelect {        // arguments of the selection step that ends the kerne
 __global__ __launch_bounds__(JAC_THREADS) void k_jacobi(const double* __restrict__ C, int d, int DP,
                                                         const double* __restrict__ V0, double* __restrict__ Gout,
                                                         double* __restrict__ lam, int* __restrict__ sweeps_out,
-                                                        PcaSelect sel) {
+                                                        PcaSelect sel, size_t zs, size_t hzs) {
+  ZRUN(C); ZRUN(V0); ZRUN(Gout); ZRUN(lam); ZRUN(sweeps_out); ZRUN(sel.comps); ZRUN(sel.evr); ZRUN(sel.k_dev);
+  sel.hm = zrun(sel.hm, hzs, blockIdx.z);
   extern __shared__ __attribute__((aligned(16))) double s_g[];   // d columns of length d, column-major, stride LD
   __shared__ double s_lam[PCABO_MAXD], s_sgn[PCABO_MAXD];
   __shared__ int s_order[PCABO_MAXD];
@@ -423,7 +427,9 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi(const double* __restrict
 // Eight points per work-group; Z is n x k row-major, k read from device memory.
 __global__ __launch_bounds__(256) void k_project(const double* __restrict__ X, const double* __restrict__ data_mean,
                                                  const double* __restrict__ pca_mean, const double* __restrict__ comps,
-                                                 const int* __restrict__ k_dev, int n, int d, double* __restrict__ Z) {
+                                                 const int* __restrict__ k_dev, int n, int d, double* __restrict__ Z,
+                                                 size_t zs) {
+  ZRUN(X); ZRUN(data_mean); ZRUN(pca_mean); ZRUN(comps); ZRUN(k_dev); ZRUN(Z);
   __shared__ double s_x[8][PCABO_MAXD];
   __shared__ double s_m[PCABO_MAXD];
   const int k = *k_dev;
@@ -451,7 +457,10 @@ __global__ __launch_bounds__(WP_THREADS) void k_zstats(const double* __restrict_
                                                        int n, int k, const double* __restrict__ user_nb,
                                                        double* __restrict__ bounds4, double* __restrict__ zn_mean,
                                                        double* __restrict__ ystats, double* __restrict__ ys,
-                                                       HostMirror* hm, const int* __restrict__ k_dev) {
+                                                       HostMirror* hm, const int* __restrict__ k_dev, size_t zs,
+                                                       size_t hzs) {
+  ZRUN(Z); ZRUN(y); ZRUN(user_nb); ZRUN(bounds4); ZRUN(zn_mean); ZRUN(ystats); ZRUN(ys); ZRUN(k_dev);
+  hm = zrun(hm, hzs, blockIdx.z);
   if (k_dev) k = *k_dev;          // enqueued behind the wPCA: the reduced dimension is not on the host yet
   __shared__ double s_red[WP_THREADS];
   __shared__ double s_min[WP_THREADS];
@@ -505,7 +514,8 @@ __global__ __launch_bounds__(WP_THREADS) void k_zstats(const double* __restrict_
 __global__ __launch_bounds__(256) void k_znorm(const double* __restrict__ Z, int n, int k, int NP, int KP, int ld,
                                                const double* __restrict__ bounds4, const double* __restrict__ zn_mean,
                                                double inv_ls, double* __restrict__ ZnT, double* __restrict__ AT,
-                                               double* __restrict__ nrm, const int* __restrict__ k_dev) {
+                                               double* __restrict__ nrm, const int* __restrict__ k_dev, size_t zs) {
+  ZRUN(Z); ZRUN(bounds4); ZRUN(zn_mean); ZRUN(ZnT); ZRUN(AT); ZRUN(nrm); ZRUN(k_dev);
   if (k_dev) { k = *k_dev; KP = (k + 3) & ~3; }
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= NP) return;
@@ -528,7 +538,9 @@ __global__ __launch_bounds__(256) void k_znorm(const double* __restrict__ Z, int
 __global__ __launch_bounds__(128) void k_inverse_map(const double* __restrict__ z, const double* __restrict__ comps,
                                                      const double* __restrict__ data_mean,
                                                      const double* __restrict__ pca_mean, int k, int d,
-                                                     double* __restrict__ x) {
+                                                     double* __restrict__ x, const int* __restrict__ k_dev, size_t zs) {
+  ZRUN(z); ZRUN(comps); ZRUN(data_mean); ZRUN(pca_mean); ZRUN(x); ZRUN(k_dev);
+  if (k_dev) k = *k_dev;
   const int j = threadIdx.x;
   if (j >= d) return;
   double s = 0.0;
@@ -541,16 +553,17 @@ void launch_rank(hipStream_t s, const double* f, int n, int maximize, long long*
   hipLaunchKernelGGL(k_rank, dim3((n + 255) / 256), dim3(256), 0, s, f, n, maximize, ranks);
 }
 void launch_wpca_prep(hipStream_t s, const double* X, const long long* ranks, const double* noise, int n, int d,
-                      int DP, double* weights, double* data_mean, double* pca_mean, double* Wc) {
-  hipLaunchKernelGGL(k_wpca_prep, dim3(1), dim3(WP_THREADS), 0, s, X, ranks, noise, n, d, DP, weights, data_mean,
-                     pca_mean, Wc);
+                      int DP, double* weights, double* data_mean, double* pca_mean, double* Wc, ZB zb) {
+  hipLaunchKernelGGL(k_wpca_prep, dim3(1, 1, zb.B), dim3(WP_THREADS), 0, s, X, ranks, noise, n, d, DP, weights, data_mean,
+                     pca_mean, Wc, zb.zs);
 }
-void launch_cov(hipStream_t s, const double* Wc, int n, int DP, double* C) {
+void launch_cov(hipStream_t s, const double* Wc, int n, int DP, double* C, ZB zb) {
   int n4 = (n + 3) & ~3;
-  hipLaunchKernelGGL(k_cov, dim3(DP / 16, DP / 16), dim3(256), 0, s, Wc, n4, DP, 1.0 / (double)(n - 1), C);
+  hipLaunchKernelGGL(k_cov, dim3(DP / 16, DP / 16, zb.B), dim3(256), 0, s, Wc, n4, DP, 1.0 / (double)(n - 1), C, zb.zs);
 }
 void launch_jacobi(hipStream_t s, const double* C, int d, int DP, const double* V0, double* G, double* lam, int* sweeps,
-                   int n, double var_threshold, int n_components, double* comps, double* evr, int* k_dev, HostMirror* hm) {
+                   int n, double var_threshold, int n_components, double* comps, double* evr, int* k_dev, HostMirror* hm,
+                   ZB zb) {
   size_t lds = ((size_t)d * (d | 1) + 2) * sizeof(double);
   if (V0 && d <= 64) lds += (size_t)2 * d * (d | 1) * sizeof(double);      // LDS copies of C and V0 for the warm start
   static bool attr_set = false;
@@ -566,23 +579,24 @@ void launch_jacobi(hipStream_t s, const double* C, int d, int DP, const double* 
   threads = (threads + 63) & ~63;
   if (threads < d) threads = (d + 63) & ~63;          // the selection step at the end uses one thread per component
   PcaSelect sel{n, var_threshold, n_components, comps, evr, k_dev, hm};
-  hipLaunchKernelGGL(k_jacobi, dim3(1), dim3(threads), lds, s, C, d, DP, V0, G, lam, sweeps, sel);
+  hipLaunchKernelGGL(k_jacobi, dim3(1, 1, zb.B), dim3(threads), lds, s, C, d, DP, V0, G, lam, sweeps, sel, zb.zs, zb.hzs);
 }
 void launch_project(hipStream_t s, const double* X, const double* data_mean, const double* pca_mean,
-                    const double* comps, const int* k_dev, int n, int d, double* Z) {
-  hipLaunchKernelGGL(k_project, dim3((n + 7) / 8), dim3(256), 0, s, X, data_mean, pca_mean, comps, k_dev, n, d, Z);
+                    const double* comps, const int* k_dev, int n, int d, double* Z, ZB zb) {
+  hipLaunchKernelGGL(k_project, dim3((n + 7) / 8, 1, zb.B), dim3(256), 0, s, X, data_mean, pca_mean, comps, k_dev, n, d, Z,
+                     zb.zs);
 }
 void launch_zstats(hipStream_t s, const double* Z, const double* y, int n, int k, const double* user_norm_bounds,
-                   double* bounds4, double* zn_mean, double* ystats, double* ys, HostMirror* hm, const int* k_dev) {
-  hipLaunchKernelGGL(k_zstats, dim3(1), dim3(WP_THREADS), 0, s, Z, y, n, k, user_norm_bounds, bounds4, zn_mean,
-                     ystats, ys, hm, k_dev);
+                   double* bounds4, double* zn_mean, double* ystats, double* ys, HostMirror* hm, const int* k_dev, ZB zb) {
+  hipLaunchKernelGGL(k_zstats, dim3(1, 1, zb.B), dim3(WP_THREADS), 0, s, Z, y, n, k, user_norm_bounds, bounds4, zn_mean,
+                     ystats, ys, hm, k_dev, zb.zs, zb.hzs);
 }
 void launch_znorm(hipStream_t s, const double* Z, int n, int k, int NP, int KP, int ld, const double* bounds4,
-                  const double* zn_mean, double inv_ls, double* ZnT, double* AT, double* nrm, const int* k_dev) {
-  hipLaunchKernelGGL(k_znorm, dim3((NP + 255) / 256), dim3(256), 0, s, Z, n, k, NP, KP, ld, bounds4, zn_mean, inv_ls,
-                     ZnT, AT, nrm, k_dev);
+                  const double* zn_mean, double inv_ls, double* ZnT, double* AT, double* nrm, const int* k_dev, ZB zb) {
+  hipLaunchKernelGGL(k_znorm, dim3((NP + 255) / 256, 1, zb.B), dim3(256), 0, s, Z, n, k, NP, KP, ld, bounds4, zn_mean, inv_ls,
+                     ZnT, AT, nrm, k_dev, zb.zs);
 }
 void launch_inverse_map(hipStream_t s, const double* z, const double* comps, const double* data_mean,
-                        const double* pca_mean, int k, int d, double* x) {
-  hipLaunchKernelGGL(k_inverse_map, dim3(1), dim3(128), 0, s, z, comps, data_mean, pca_mean, k, d, x);
+                        const double* pca_mean, int k, int d, double* x, const int* k_dev, ZB zb) {
+  hipLaunchKernelGGL(k_inverse_map, dim3(1, 1, zb.B), dim3(128), 0, s, z, comps, data_mean, pca_mean, k, d, x, k_dev, zb.zs);
 }

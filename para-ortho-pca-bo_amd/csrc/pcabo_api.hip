@@ -104,9 +104,13 @@ struct pcabo_ctx {
   double *dXq = nullptr, *dPartial = nullptr, *dVal = nullptr, *dGrad = nullptr, *dZq = nullptr, *dXout = nullptr;
   unsigned int* dCounters = nullptr;     // per-query tickets of the in-launch combine
   int cnt_S = 0; bool cnt_dirty = true;  // slab-group count the tickets are consistent with / a launch may have died
+  double* dBestF = nullptr;              // best_f of this run for the batched acquisition launches (set by the batch)
+  char *dRegion = nullptr, *hRegion = nullptr;   // the two allocations everything above / below is carved from
+  size_t region_bytes = 0, hregion_bytes = 0;
+  bool in_batch = false; int batch_index = 0;
   // pinned host
   HostMirror* hm = nullptr;
-  double *hXq = nullptr, *hVal = nullptr, *hGrad = nullptr, *hSmall = nullptr;
+  double *hXq = nullptr, *hVal = nullptr, *hGrad = nullptr, *hSmall = nullptr, *hBestF = nullptr;
   MailPair *hMail = nullptr, *dMail = nullptr;   // mailbox of the resident acquisition kernel (pinned host copy, device copy)
   bool mail_bar = false;                 // the host writes dMail itself through the PCIe BAR (no relay group, no hMail)
   MailPair* dPairs = nullptr;            // its partial records as (value, tag) pairs: 32 queries x 32 slabs
@@ -315,15 +319,70 @@ int pcabo_device_count(void) {
   return n;
 }
 
-int pcabo_ctx_create(int device, int max_n, int max_d, int max_q, pcabo_ctx** out) {
-  if (!out) return PCABO_ERR_ARG;
-  *out = nullptr;
-  if (max_n < 2 || max_d < 1 || max_d > PCABO_MAXD || max_q < 1 || max_q >= PCABO_CNT_DONE) return PCABO_ERR_ARG;
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return PCABO_ERR_HIP;
-  pcabo_ctx* ctx = new (std::nothrow) pcabo_ctx();
-  if (!ctx) return PCABO_ERR_HIP;
-  *out = ctx;                       // handed back even on failure so the caller can read the message
+}  // extern "C" (helpers with C++ linkage follow)
+
+// ---- memory of a context --------------------------------------------------------------------------------------------
+// All device buffers of a context are carved out of ONE allocation (its "region"), all pinned host buffers out of another.
+// A stand-alone context owns both.  The contexts of a batch (pcabo_batch_create) live side by side in one device slab and
+// one pinned slab with the SAME layout, so that buffer X of run b sits at (X of run 0) + b * region_bytes: the batched
+// launches address a run's operands as `pointer + blockIdx.z * stride` with a single stride for every buffer.
+struct Carver {
+  char* base; size_t off = 0;
+  template <typename T> T* take(size_t count) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += count * sizeof(T);
+    return p;
+  }
+};
+static size_t carve_device(pcabo_ctx* ctx, char* base) {
+  Carver c{base};
+  const size_t N = ctx->NPcap, D = ctx->DPcap, n = ctx->max_n, d = ctx->max_d, Q = ctx->max_q;
+  ctx->dX = c.take<double>(n * d);        ctx->dNoise = c.take<double>(n * d);
+  ctx->dF = c.take<double>(n);            ctx->dWeights = c.take<double>(n);
+  ctx->dWc = c.take<double>((n + 4) * D); ctx->dRanks = c.take<long long>(n);
+  ctx->dPcaOut = c.take<double>(3 * d + d * d);
+  ctx->dDataMean = ctx->dPcaOut; ctx->dPcaMean = ctx->dPcaOut + d; ctx->dEvr = ctx->dPcaOut + 2 * d;
+  ctx->dComps = ctx->dPcaOut + 3 * d;
+  ctx->dIn = c.take<double>(n * (2 * d + 2));
+  ctx->dC = c.take<double>(D * D);        ctx->dGbuf[0] = c.take<double>(d * d); ctx->dGbuf[1] = c.take<double>(d * d);
+  ctx->dG = ctx->dGbuf[0];
+  ctx->dLam = c.take<double>(d);          ctx->dZ = c.take<double>(n * d);
+  ctx->dK = c.take<int>(1);               ctx->dSweeps = c.take<int>(1);         ctx->dInfo = c.take<int>(1);
+  ctx->dY = c.take<double>(n);            ctx->dYs = c.take<double>(N);
+  ctx->dYstats = c.take<double>(2);       ctx->dBounds4 = c.take<double>(4 * PCABO_MAXD);
+  ctx->dZnMean = c.take<double>(PCABO_MAXD); ctx->dUserNB = c.take<double>(2 * PCABO_MAXD);
+  ctx->dZnT = c.take<double>((size_t)ctx->KPcap * N); ctx->dAT = c.take<double>((size_t)ctx->KPcap * N);
+  ctx->dNrm = c.take<double>(N);
+  ctx->dGram = c.take<double>(N * N);     ctx->dL = c.take<double>(N * N);       ctx->dR = c.take<double>(N * N);
+  ctx->dTmp = c.take<double>(N);          ctx->dAlpha = c.take<double>(N);
+  ctx->dDiag = c.take<double>((size_t)PCABO_BS * PCABO_BS);
+  ctx->dXq = c.take<double>(Q * d + 8);   // (+ the run's best_f behind the query block in batched scoring)
+  ctx->dPartial = c.take<double>(Q * (size_t)ctx->Scap * (2 + 2 * PCABO_MAXD));
+  ctx->dVal = c.take<double>(Q);          ctx->dGrad = c.take<double>(Q * d);
+  ctx->dZq = c.take<double>(d);           ctx->dXout = c.take<double>(d);
+  ctx->dBestF = c.take<double>(2);
+  ctx->dCounters = c.take<unsigned int>(PCABO_CNT_DONE + 1);
+  return (c.off + 4095) & ~(size_t)4095;
+}
+static size_t carve_host(pcabo_ctx* ctx, char* base) {
+  Carver c{base};
+  const size_t n = ctx->max_n, d = ctx->max_d, Q = ctx->max_q;
+  ctx->hm = c.take<HostMirror>(1);
+  // (hXq: at least one QueryArgs block - small batches are handed to the kernel by value from here)
+  ctx->hXq = c.take<double>(std::max<size_t>(Q * d, PCABO_QA_MAX) + 8);
+  ctx->hVal = c.take<double>(Q);
+  ctx->hGrad = c.take<double>(Q * d);
+  ctx->hSmall = c.take<double>(d * d + 8 * d + 64);
+  ctx->hIn = c.take<double>(n * (2 * d + 2));
+  ctx->hBestF = c.take<double>(2);
+  return (c.off + 4095) & ~(size_t)4095;
+}
+
+// Fill in a context over (optionally) somebody else's memory and stream: `dreg` / `hreg` / `stream` non-null = a member
+// of a batch (no resident-mode buffers, nothing owned).
+static int ctx_setup(pcabo_ctx* ctx, int device, int max_n, int max_d, int max_q, char* dreg, char* hreg,
+                     hipStream_t stream) {
   ctx->device = device;
   ctx->max_n = max_n; ctx->max_d = max_d; ctx->max_q = max_q;
   ctx->NPcap = round_up(max_n, PCABO_BS);
@@ -331,62 +390,43 @@ int pcabo_ctx_create(int device, int max_n, int max_d, int max_q, pcabo_ctx** ou
   ctx->DPcap = round_up(max_d, 16);
   ctx->KPcap = round_up(max_d, 4);
   ctx->Scap = ctx->NPcap / PCABO_SLAB;
+  ctx->in_batch = dreg != nullptr;
   HIPCHK(hipSetDevice(device));
-  HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  if (stream) ctx->stream = stream;
+  else HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   presence_register(ctx->device); ctx->registered = true;
   HIPCHK(hipEventCreateWithFlags(&ctx->evBounds, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&ctx->evPca, hipEventDisableTiming));
-  const size_t N = ctx->NPcap, D = ctx->DPcap, n = max_n, d = max_d, Q = max_q;
-  HIPCHK(dalloc(&ctx->dX, n * d));       HIPCHK(dalloc(&ctx->dNoise, n * d));
-  HIPCHK(dalloc(&ctx->dF, n));           HIPCHK(dalloc(&ctx->dWeights, n));
-  HIPCHK(dalloc(&ctx->dWc, (n + 4) * D)); HIPCHK(dalloc(&ctx->dRanks, n));
-  HIPCHK(dalloc(&ctx->dPcaOut, 3 * d + d * d));
-  ctx->dDataMean = ctx->dPcaOut; ctx->dPcaMean = ctx->dPcaOut + d; ctx->dEvr = ctx->dPcaOut + 2 * d;
-  ctx->dComps = ctx->dPcaOut + 3 * d;
-  HIPCHK(dalloc(&ctx->dIn, n * (2 * d + 2)));
-  HIPCHK(dalloc(&ctx->dC, D * D));       HIPCHK(dalloc(&ctx->dGbuf[0], d * d));  HIPCHK(dalloc(&ctx->dGbuf[1], d * d));
-  ctx->dG = ctx->dGbuf[0];
-  HIPCHK(dalloc(&ctx->dLam, d));         HIPCHK(dalloc(&ctx->dZ, n * d));
-  HIPCHK(dalloc(&ctx->dK, 1));           HIPCHK(dalloc(&ctx->dSweeps, 1));   HIPCHK(dalloc(&ctx->dInfo, 1));
-  HIPCHK(dalloc(&ctx->dY, n));           HIPCHK(dalloc(&ctx->dYs, N));
-  HIPCHK(dalloc(&ctx->dYstats, 2));      HIPCHK(dalloc(&ctx->dBounds4, 4 * PCABO_MAXD));
-  HIPCHK(dalloc(&ctx->dZnMean, PCABO_MAXD)); HIPCHK(dalloc(&ctx->dUserNB, 2 * PCABO_MAXD));
-  HIPCHK(dalloc(&ctx->dZnT, (size_t)ctx->KPcap * N)); HIPCHK(dalloc(&ctx->dAT, (size_t)ctx->KPcap * N));
-  HIPCHK(dalloc(&ctx->dNrm, N));
-  HIPCHK(dalloc(&ctx->dGram, N * N));    HIPCHK(dalloc(&ctx->dL, N * N));    HIPCHK(dalloc(&ctx->dR, N * N));
-  HIPCHK(dalloc(&ctx->dTmp, N));         HIPCHK(dalloc(&ctx->dAlpha, N));
-  HIPCHK(dalloc(&ctx->dDiag, (size_t)PCABO_BS * PCABO_BS));
-  HIPCHK(dalloc(&ctx->dXq, Q * d));
-  HIPCHK(dalloc(&ctx->dPartial, Q * (size_t)ctx->Scap * (2 + 2 * PCABO_MAXD)));
-  HIPCHK(dalloc(&ctx->dVal, Q));         HIPCHK(dalloc(&ctx->dGrad, Q * d));
-  HIPCHK(dalloc(&ctx->dZq, d));          HIPCHK(dalloc(&ctx->dXout, d));
-  HIPCHK(dalloc(&ctx->dCounters, PCABO_CNT_DONE + 1));
-  HIPCHK(hipMemsetAsync(ctx->dCounters, 0, (PCABO_CNT_DONE + 1) * sizeof(unsigned int), ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->dYs, 0, N * sizeof(double), ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->dR, 0, N * N * sizeof(double), ctx->stream));   // the blocks above the diagonal stay zero for good
-  HIPCHK(hipHostMalloc((void**)&ctx->hm, sizeof(HostMirror), hipHostMallocDefault));
-  memset((void*)ctx->hm, 0, sizeof(HostMirror));
-  // (at least one QueryArgs block: small batches are handed to the kernel by value from here)
-  HIPCHK(hipHostMalloc((void**)&ctx->hXq, std::max<size_t>(Q * d, PCABO_QA_MAX) * sizeof(double), hipHostMallocDefault));
-  HIPCHK(hipHostMalloc((void**)&ctx->hVal, Q * sizeof(double), hipHostMallocDefault));
-  HIPCHK(hipHostMalloc((void**)&ctx->hGrad, Q * d * sizeof(double), hipHostMallocDefault));
-  HIPCHK(hipHostMalloc((void**)&ctx->hSmall, (d * d + 8 * d + 64) * sizeof(double), hipHostMallocDefault));
-  HIPCHK(hipHostMalloc((void**)&ctx->hIn, n * (2 * d + 2) * sizeof(double), hipHostMallocDefault));
-  HIPCHK(hipHostMalloc((void**)&ctx->hMail, PCABO_MAIL_PAIRS * sizeof(MailPair), hipHostMallocMapped | hipHostMallocCoherent));
-  memset(ctx->hMail, 0, PCABO_MAIL_PAIRS * sizeof(MailPair));
-  if (hipExtMallocWithFlags((void**)&ctx->dMail, PCABO_MAIL_PAIRS * sizeof(MailPair), hipDeviceMallocFinegrained) != hipSuccess) {
-    (void)hipGetLastError();
-    HIPCHK(dalloc(&ctx->dMail, PCABO_MAIL_PAIRS));
+  ctx->region_bytes = carve_device(ctx, nullptr);
+  ctx->hregion_bytes = carve_host(ctx, nullptr);
+  if (dreg) {
+    ctx->dRegion = dreg; ctx->hRegion = hreg;        // zeroed by the batch
+  } else {
+    HIPCHK(hipMalloc((void**)&ctx->dRegion, ctx->region_bytes));
+    HIPCHK(hipHostMalloc((void**)&ctx->hRegion, ctx->hregion_bytes, hipHostMallocDefault));
+    memset(ctx->hRegion, 0, ctx->hregion_bytes);
   }
-  HIPCHK(hipMemsetAsync(ctx->dMail, 0, PCABO_MAIL_PAIRS * sizeof(MailPair), ctx->stream));
-  {
+  carve_device(ctx, ctx->dRegion);
+  carve_host(ctx, ctx->hRegion);
+  if (!dreg) {
+    // zero: the per-query tickets, the padded tail of y_s, and R (its blocks above the diagonal stay zero for good)
+    HIPCHK(hipMemsetAsync(ctx->dRegion, 0, ctx->region_bytes, ctx->stream));
+    HIPCHK(hipHostMalloc((void**)&ctx->hMail, PCABO_MAIL_PAIRS * sizeof(MailPair), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(ctx->hMail, 0, PCABO_MAIL_PAIRS * sizeof(MailPair));
+    if (hipExtMallocWithFlags((void**)&ctx->dMail, PCABO_MAIL_PAIRS * sizeof(MailPair), hipDeviceMallocFinegrained) != hipSuccess) {
+      (void)hipGetLastError();
+      HIPCHK(dalloc(&ctx->dMail, PCABO_MAIL_PAIRS));
+    }
+    HIPCHK(hipMemsetAsync(ctx->dMail, 0, PCABO_MAIL_PAIRS * sizeof(MailPair), ctx->stream));
     const size_t np = (size_t)PCABO_INLAUNCH_MAXQ * 32 * (2 + 2 * PCABO_MAXD);
     HIPCHK(dalloc(&ctx->dPairs, np));
     HIPCHK(hipMemsetAsync(ctx->dPairs, 0, np * sizeof(MailPair), ctx->stream));   // on OUR stream: a memset on the
     // null stream is not ordered with the non-blocking streams the resident kernels run on
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->mail_bar = mail_bar_usable(ctx);
+  } else {
+    ctx->opt_resident = false;           // the resident kernel wants most of the chip for one run: not inside a batch
   }
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  ctx->mail_bar = mail_bar_usable(ctx);
   // Sequence numbers double as mailbox tags.  Memory handed out by the allocator may come from a context that was
   // destroyed earlier in this process, so every context numbers from its own base: a stale tag can never match.
   {
@@ -396,24 +436,46 @@ int pcabo_ctx_create(int device, int max_n, int max_d, int max_q, pcabo_ctx** ou
   return PCABO_OK;
 }
 
-int pcabo_ctx_destroy(pcabo_ctx* ctx) {
-  if (!ctx) return PCABO_ERR_ARG;
+static void ctx_teardown(pcabo_ctx* ctx) {
   (void)hipSetDevice(ctx->device);        // tear-down: nothing useful to do with an error from here on
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (auto& p : ctx->pairs) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-  void* dev[] = {ctx->dX, ctx->dNoise, ctx->dF, ctx->dWeights, ctx->dWc, ctx->dRanks, ctx->dPcaOut, ctx->dIn,
-                 ctx->dC, ctx->dGbuf[0], ctx->dGbuf[1], ctx->dLam, ctx->dZ, ctx->dK, ctx->dSweeps, ctx->dInfo,
-                 ctx->dY, ctx->dYs, ctx->dYstats, ctx->dBounds4, ctx->dZnMean, ctx->dUserNB, ctx->dZnT, ctx->dAT,
-                 ctx->dNrm, ctx->dGram, ctx->dL, ctx->dR, ctx->dTmp, ctx->dAlpha, ctx->dDiag, ctx->dXq, ctx->dPartial, ctx->dVal,
-                 ctx->dGrad, ctx->dZq, ctx->dXout, ctx->dCounters, ctx->dMail, ctx->dPairs};
-  for (void* p : dev) if (p) (void)hipFree(p);
-  void* host[] = {(void*)ctx->hm, ctx->hXq, ctx->hVal, ctx->hGrad, ctx->hSmall, ctx->hIn, (void*)ctx->hMail};
-  for (void* p : host) if (p) (void)hipHostFree(p);
+  if (!ctx->in_batch) {
+    if (ctx->dRegion) (void)hipFree(ctx->dRegion);
+    if (ctx->hRegion) (void)hipHostFree(ctx->hRegion);
+    if (ctx->dMail) (void)hipFree(ctx->dMail);
+    if (ctx->dPairs) (void)hipFree(ctx->dPairs);
+    if (ctx->hMail) (void)hipHostFree((void*)ctx->hMail);
+  }
   if (ctx->evBounds) (void)hipEventDestroy(ctx->evBounds);
   if (ctx->evPca) (void)hipEventDestroy(ctx->evPca);
-  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  if (ctx->stream && !ctx->in_batch) (void)hipStreamDestroy(ctx->stream);
   ctx->helper.shutdown();
   if (ctx->registered) presence_unregister(ctx->device);
+}
+
+static bool ctx_sizes_ok(int max_n, int max_d, int max_q) {
+  return max_n >= 2 && max_d >= 1 && max_d <= PCABO_MAXD && max_q >= 1 && max_q < PCABO_CNT_DONE;
+}
+
+extern "C" {
+
+int pcabo_ctx_create(int device, int max_n, int max_d, int max_q, pcabo_ctx** out) {
+  if (!out) return PCABO_ERR_ARG;
+  *out = nullptr;
+  if (!ctx_sizes_ok(max_n, max_d, max_q)) return PCABO_ERR_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return PCABO_ERR_HIP;
+  pcabo_ctx* ctx = new (std::nothrow) pcabo_ctx();
+  if (!ctx) return PCABO_ERR_HIP;
+  *out = ctx;                       // handed back even on failure so the caller can read the message
+  return ctx_setup(ctx, device, max_n, max_d, max_q, nullptr, nullptr, nullptr);
+}
+
+int pcabo_ctx_destroy(pcabo_ctx* ctx) {
+  if (!ctx) return PCABO_ERR_ARG;
+  if (ctx->in_batch) return set_err(ctx, PCABO_ERR_ARG, "pcabo_ctx_destroy: the context belongs to a batch (pcabo_batch_destroy frees it)%s", "");
+  ctx_teardown(ctx);
   delete ctx;
   return PCABO_OK;
 }
@@ -427,7 +489,7 @@ int pcabo_set_pointer_mode(pcabo_ctx* ctx, int mode) {
 int pcabo_set_option(pcabo_ctx* ctx, int option, int value) {
   if (!ctx) return PCABO_ERR_ARG;
   switch (option) {
-    case PCABO_OPT_RESIDENT: ctx->opt_resident = value != 0; return PCABO_OK;
+    case PCABO_OPT_RESIDENT: ctx->opt_resident = value != 0 && !ctx->in_batch; return PCABO_OK;   // (never inside a batch)
     case PCABO_OPT_BESTF_F32: ctx->bestf_f32 = value != 0; return PCABO_OK;
     default: return set_err(ctx, PCABO_ERR_ARG, "pcabo_set_option: unknown option %s%d", "", option);
   }
@@ -1291,6 +1353,581 @@ int pcabo_reset_profile(pcabo_ctx* ctx) {
   if (!ctx) return PCABO_ERR_ARG;
   prof_resolve(ctx);
   for (int i = 0; i < PROF_GROUPS; ++i) { ctx->prof_ms[i] = 0.0; ctx->prof_launches[i] = 0; ctx->prof_bytes[i] = 0.0; ctx->prof_flops[i] = 0.0; }
+  return PCABO_OK;
+}
+
+
+// =====================================================================================================================
+// Batched contexts (declared in include/pcabo.h): B runs advancing in lock-step.
+// =====================================================================================================================
+}  // extern "C"
+
+// One restart group of one run: scipy's L-BFGS-B state machine plus the memoisation of scipy's ScalarFunction (same
+// logic as in pcabo_optimize_acqf, which keeps its own copy for the resident-kernel path).
+struct RestartGroup {
+  Lbfgsb opt;
+  int q0 = 0, nq = 0, k = 0, maxiter = 200;
+  std::vector<double> x, g, lo, hi, xc, gc, vc;
+  double fval = 0.0, fc = 0.0;
+  bool have_cache = false, active = true;
+  int niter = 0, nfev = 0;
+  void init(const double* ics, const double* bounds, int q0_, int nq_, int k_, int maxiter_) {
+    q0 = q0_; nq = nq_; k = k_; maxiter = maxiter_;
+    const int nv = nq * k;
+    x.resize(nv); g.assign(nv, 0.0); lo.resize(nv); hi.resize(nv);
+    for (int j = 0; j < nq; ++j)
+      for (int c = 0; c < k; ++c) {
+        const double l = bounds[c], h = bounds[k + c], v = ics[(size_t)(q0 + j) * k + c];
+        lo[j * k + c] = l; hi[j * k + c] = h;
+        x[j * k + c] = v < l ? l : (v > h ? h : v);              // columnwise_clamp / np.clip
+      }
+    opt.init(nv, 10, lo.data(), hi.data(), 1e7, 1e-5, 20);
+  }
+  void advance() {                    // until the group needs f, g at x (or stops)
+    while (active) {
+      const int task = opt.step(x.data(), &fval, g.data());
+      if (task == LBFGSB_FG) {
+        if (have_cache && memcmp(x.data(), xc.data(), x.size() * sizeof(double)) == 0) { fval = fc; g = gc; continue; }
+        return;
+      }
+      if (task == LBFGSB_NEW_X) {
+        niter += 1;
+        if (niter >= maxiter) opt.stop(LBFGSB_STOP_ITER);
+        else if (nfev > 15000) opt.stop(LBFGSB_STOP_FUN);
+        continue;
+      }
+      active = false;
+    }
+  }
+  bool absorb(const double* hVal, const double* hGrad) {      // false: NaN in the gradient
+    double fs = 0.0;
+    bool nan = false;
+    for (int j = 0; j < nq; ++j) fs += hVal[q0 + j];
+    for (int t = 0; t < nq * k; ++t) {
+      const double gv = -hGrad[(size_t)q0 * k + t];
+      if (gv != gv) nan = true;
+      g[t] = gv;
+    }
+    if (nan) return false;
+    fval = -fs;
+    nfev += 1;
+    xc = x; gc = g; fc = fval; have_cache = true;
+    vc.assign(hVal + q0, hVal + q0 + nq);
+    return true;
+  }
+};
+
+// Worker pool of a batch: persistent threads, one "gang" of runs each; sleeping between calls, woken per call.
+struct GangPool {
+  std::vector<std::thread> th;
+  std::mutex mu;
+  std::condition_variable cv, cv_done;
+  std::function<void(int)> fn;
+  unsigned epoch = 0;
+  int pending = 0;
+  bool quit = false;
+  void start(int n) {
+    for (int i = 0; i < n; ++i)
+      th.emplace_back([this, i] {
+        unsigned seen = 0;
+        for (;;) {
+          std::function<void(int)> f;
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return quit || epoch != seen; });
+            if (quit) return;
+            seen = epoch;
+            f = fn;
+          }
+          f(i);
+          { std::lock_guard<std::mutex> lk(mu); if (--pending == 0) cv_done.notify_all(); }
+        }
+      });
+  }
+  void run(std::function<void(int)> f) {                   // every worker runs f(worker index); returns when all are done
+    std::unique_lock<std::mutex> lk(mu);
+    fn = std::move(f);
+    pending = (int)th.size();
+    ++epoch;
+    cv.notify_all();
+    cv_done.wait(lk, [&] { return pending == 0; });
+  }
+  void shutdown() {
+    { std::lock_guard<std::mutex> lk(mu); quit = true; }
+    cv.notify_all();
+    for (auto& t : th) if (t.joinable()) t.join();
+    th.clear();
+  }
+};
+
+struct pcabo_batch {
+  int device = 0, B = 0, max_n = 0, max_d = 0, max_q = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t evPca = nullptr, evBounds = nullptr;
+  char *dSlab = nullptr, *hSlab = nullptr;
+  size_t zs = 0, hzs = 0;
+  std::vector<pcabo_ctx*> ctx;
+  int n = 0, d = 0, NP = 0;
+  bool wpca_uncollected = false, gp_pending = false, have_gp = false;
+  double lengthscale = 0.0, noise = 0.0;
+  int kernel = 0;
+  int gcur = 0, vprev_d = 0;             // eigenvector ping-pong of ALL runs (they advance together)
+  int cnt_S = 0; bool cnt_dirty = true;
+  int G = 0;                             // gangs = worker threads of the L-BFGS-B phase
+  std::vector<hipStream_t> gstream;
+  GangPool pool;
+  std::atomic<unsigned long long> seq{0};
+  char err[512] = {0};
+};
+
+static int bset_err(pcabo_batch* b, int code, const char* fmt, const char* a = "", int v = 0) {
+  if (b) snprintf(b->err, sizeof(b->err), fmt, a, v);
+  return code;
+}
+#define BHIPCHK(call)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess) return bset_err(batch, PCABO_ERR_HIP, "HIP error: %s (line %d)", hipGetErrorString(e_), __LINE__); \
+  } while (0)
+
+static ZB batch_zb(const pcabo_batch* b) { ZB z; z.B = b->B; z.zs = b->zs; z.hzs = b->hzs; return z; }
+
+static void batch_free(pcabo_batch* batch) {
+  (void)hipSetDevice(batch->device);
+  batch->pool.shutdown();
+  if (batch->stream) (void)hipStreamSynchronize(batch->stream);
+  for (pcabo_ctx* c : batch->ctx) if (c) { ctx_teardown(c); delete c; }
+  for (hipStream_t s : batch->gstream) if (s) (void)hipStreamDestroy(s);
+  if (batch->evPca) (void)hipEventDestroy(batch->evPca);
+  if (batch->evBounds) (void)hipEventDestroy(batch->evBounds);
+  if (batch->dSlab) (void)hipFree(batch->dSlab);
+  if (batch->hSlab) (void)hipHostFree(batch->hSlab);
+  if (batch->stream) (void)hipStreamDestroy(batch->stream);
+  delete batch;
+}
+
+extern "C" {
+
+int pcabo_batch_create(int device, int B, int max_n, int max_d, int max_q, pcabo_batch** out) {
+  if (!out) return PCABO_ERR_ARG;
+  *out = nullptr;
+  if (B < 1 || B > 4096 || !ctx_sizes_ok(max_n, max_d, max_q)) return PCABO_ERR_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return PCABO_ERR_HIP;
+  pcabo_batch* batch = new (std::nothrow) pcabo_batch();
+  if (!batch) return PCABO_ERR_HIP;
+  *out = batch;                      // handed back even on failure so the caller can read the message (and must destroy it)
+  batch->device = device; batch->B = B; batch->max_n = max_n; batch->max_d = max_d; batch->max_q = max_q;
+  BHIPCHK(hipSetDevice(device));
+  BHIPCHK(hipStreamCreateWithFlags(&batch->stream, hipStreamNonBlocking));
+  BHIPCHK(hipEventCreateWithFlags(&batch->evPca, hipEventDisableTiming));
+  BHIPCHK(hipEventCreateWithFlags(&batch->evBounds, hipEventDisableTiming));
+  {
+    pcabo_ctx probe;                 // layout only
+    probe.max_n = max_n; probe.max_d = max_d; probe.max_q = max_q;
+    probe.NPcap = round_up(max_n, PCABO_BS); probe.DPcap = round_up(max_d, 16); probe.KPcap = round_up(max_d, 4);
+    probe.Scap = probe.NPcap / PCABO_SLAB;
+    batch->zs = carve_device(&probe, nullptr);
+    batch->hzs = carve_host(&probe, nullptr);
+  }
+  BHIPCHK(hipMalloc((void**)&batch->dSlab, batch->zs * (size_t)B));
+  BHIPCHK(hipHostMalloc((void**)&batch->hSlab, batch->hzs * (size_t)B, hipHostMallocDefault));
+  memset(batch->hSlab, 0, batch->hzs * (size_t)B);
+  BHIPCHK(hipMemsetAsync(batch->dSlab, 0, batch->zs * (size_t)B, batch->stream));
+  BHIPCHK(hipStreamSynchronize(batch->stream));
+  batch->ctx.assign(B, nullptr);
+  for (int b = 0; b < B; ++b) {
+    pcabo_ctx* c = new (std::nothrow) pcabo_ctx();
+    if (!c) return bset_err(batch, PCABO_ERR_HIP, "out of memory%s", "");
+    batch->ctx[b] = c;
+    int rc = ctx_setup(c, device, max_n, max_d, max_q, batch->dSlab + batch->zs * (size_t)b,
+                       batch->hSlab + batch->hzs * (size_t)b, batch->stream);
+    c->batch_index = b;
+    if (rc != PCABO_OK) return bset_err(batch, rc, "context %s%d of the batch could not be set up", "", b);
+    if (c->region_bytes != batch->zs || c->hregion_bytes != batch->hzs)
+      return bset_err(batch, PCABO_ERR_ARG, "internal: layout mismatch%s", "");
+  }
+  // worker threads of the L-BFGS-B phase: one gang of runs per thread, a HIP stream per gang
+  int T = (int)std::thread::hardware_concurrency() - 2;
+  if (const char* e = getenv("PCABO_BATCH_THREADS")) T = atoi(e);
+  T = std::max(1, std::min(T, std::min(B, 32)));
+  batch->G = T;
+  batch->gstream.assign(T, nullptr);
+  for (int g = 0; g < T; ++g) BHIPCHK(hipStreamCreateWithFlags(&batch->gstream[g], hipStreamNonBlocking));
+  batch->pool.start(T);
+  batch->seq.store(((unsigned long long)(getpid() & 0xffff) << 44) + (1ull << 43));
+  return PCABO_OK;
+}
+
+int pcabo_batch_destroy(pcabo_batch* batch) {
+  if (!batch) return PCABO_ERR_ARG;
+  batch_free(batch);
+  return PCABO_OK;
+}
+
+int pcabo_batch_last_error(pcabo_batch* batch, char* buf, int buflen) {
+  if (!batch || !buf || buflen <= 0) return PCABO_ERR_ARG;
+  snprintf(buf, buflen, "%s", batch->err);
+  return PCABO_OK;
+}
+
+pcabo_ctx* pcabo_batch_ctx(pcabo_batch* batch, int b) {
+  if (!batch || b < 0 || b >= batch->B) return nullptr;
+  return batch->ctx[b];
+}
+
+int pcabo_batch_wpca_gp_condition_begin(pcabo_batch* batch, const double* X, const int64_t* ranks, const double* noise,
+                                        const double* y, int n, int d, int maximize, double var_threshold,
+                                        int n_components, double lengthscale, double gp_noise, int kernel) {
+  (void)maximize;                    // ranks are given: nothing on the device depends on the direction
+  if (!batch) return PCABO_ERR_ARG;
+  pcabo_ctx* c0 = batch->ctx[0];
+  if (!X || !ranks || !y || n < 2 || n > batch->max_n || d < 1 || d > batch->max_d || !gp_args_ok(c0, n, lengthscale, gp_noise, kernel))
+    return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_wpca_gp_condition_begin: bad argument or size beyond the batch's capacity%s", "");
+  if (batch->gp_pending) return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_wpca_gp_condition_begin: a conditioning is in flight%s", "");
+  BHIPCHK(hipSetDevice(batch->device));
+  hipStream_t s = batch->stream;
+  const int B = batch->B;
+  const size_t nd = (size_t)n * d;
+  // pack [X | noise | ranks | y] of every run into its pinned block; ONE strided copy carries all runs
+  const size_t off_noise = nd, off_r = noise ? 2 * nd : nd, off_y = off_r + n, total = off_y + n;
+  for (int b = 0; b < B; ++b) {
+    double* h = batch->ctx[b]->hIn;
+    memcpy(h, X + (size_t)b * nd, nd * sizeof(double));
+    if (noise) memcpy(h + off_noise, noise + (size_t)b * nd, nd * sizeof(double));
+    memcpy(h + off_r, ranks + (size_t)b * n, (size_t)n * 8);
+    memcpy(h + off_y, y + (size_t)b * n, (size_t)n * sizeof(double));
+  }
+  BHIPCHK(hipMemcpy2DAsync(c0->dIn, batch->zs, c0->hIn, batch->hzs, total * sizeof(double), B, hipMemcpyHostToDevice, s));
+  const double* inX = c0->dIn;
+  const double* inNoise = noise ? c0->dIn + off_noise : nullptr;
+  const long long* inRanks = reinterpret_cast<const long long*>(c0->dIn + off_r);
+  const double* inY = c0->dIn + off_y;
+  const ZB zb = batch_zb(batch);
+  const int DP = round_up(d, 16);
+  // rows A-C
+  launch_wpca_prep(s, inX, inRanks, inNoise, n, d, DP, c0->dWeights, c0->dDataMean, c0->dPcaMean, c0->dWc, zb);
+  launch_cov(s, c0->dWc, n, DP, c0->dC, zb);
+  const double* v0 = (batch->vprev_d == d) ? c0->dGbuf[batch->gcur] : nullptr;
+  batch->gcur ^= 1;
+  launch_jacobi(s, c0->dC, d, DP, v0, c0->dGbuf[batch->gcur], c0->dLam, c0->dSweeps, n, var_threshold, n_components,
+                c0->dComps, c0->dEvr, c0->dK, c0->hm, zb);
+  batch->vprev_d = d;
+  launch_project(s, inX, c0->dDataMean, c0->dPcaMean, c0->dComps, c0->dK, n, d, c0->dZ, zb);
+  const int rcount = n < d ? n : d;
+  BHIPCHK(hipMemcpy2DAsync(c0->hSmall, batch->hzs, c0->dPcaOut, batch->zs,
+                           ((size_t)3 * batch->max_d + (size_t)rcount * d) * sizeof(double), B, hipMemcpyDeviceToHost, s));
+  BHIPCHK(hipEventRecord(batch->evPca, s));
+  // rows D-H, queued behind the projection (k is read on the device)
+  const int NP = round_up(n, PCABO_BS);
+  if (acq_slabs(NP) != batch->cnt_S || batch->cnt_dirty) {
+    BHIPCHK(hipMemset2DAsync(c0->dCounters, batch->zs, 0, (PCABO_CNT_DONE + 1) * sizeof(unsigned int), B, s));
+    batch->cnt_S = acq_slabs(NP); batch->cnt_dirty = false;
+  }
+  launch_zstats(s, c0->dZ, inY, n, -1, nullptr, c0->dBounds4, c0->dZnMean, c0->dYstats, c0->dYs, c0->hm, c0->dK, zb);
+  BHIPCHK(hipEventRecord(batch->evBounds, s));
+  launch_znorm(s, c0->dZ, n, -1, NP, 0, c0->ld, c0->dBounds4, c0->dZnMean, 1.0 / lengthscale, c0->dZnT, c0->dAT, c0->dNrm,
+               c0->dK, zb);
+  launch_gram(s, c0->dAT, c0->dNrm, n, NP, 0, c0->ld, gp_noise, kernel, c0->dGram, c0->dK, c0->dL, c0->dInfo, zb);
+  launch_cholesky(s, c0->dL, NP, c0->ld, c0->dInfo, c0->dDiag, zb);
+  launch_trinv(s, c0->dL, NP, c0->ld, c0->dR, zb);
+  launch_alpha(s, c0->dR, c0->dYs, n, NP, c0->ld, c0->dTmp, c0->dAlpha, zb);
+  BHIPCHK(hipMemcpy2DAsync((void*)&c0->hm->chol_info, batch->hzs, c0->dInfo, batch->zs, sizeof(int), B, hipMemcpyDeviceToHost, s));
+  BHIPCHK(hipGetLastError());
+  batch->n = n; batch->d = d; batch->NP = NP;
+  batch->lengthscale = lengthscale; batch->noise = gp_noise; batch->kernel = kernel;
+  batch->wpca_uncollected = true; batch->gp_pending = true; batch->have_gp = false;
+  for (int b = 0; b < B; ++b) {          // the per-run contexts see the same state (single-context calls keep working)
+    pcabo_ctx* c = batch->ctx[b];
+    c->n = n; c->d = d; c->NP = NP; c->lengthscale = lengthscale; c->noise = gp_noise; c->kernel = kernel;
+    c->have_gp = false; c->have_wpca = false; c->gp_pending = false; c->wpca_uncollected = false;
+    c->gcur = batch->gcur; c->dG = c->dGbuf[c->gcur]; c->vprev_d = d;
+    c->cnt_S = batch->cnt_S; c->cnt_dirty = false;
+  }
+  return PCABO_OK;
+}
+
+int pcabo_batch_wpca_results(pcabo_batch* batch, double* data_mean, double* pca_mean, double* comps, double* evr, int* k) {
+  if (!batch) return PCABO_ERR_ARG;
+  if (!batch->wpca_uncollected && batch->n == 0) return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_wpca_results: nothing enqueued%s", "");
+  BHIPCHK(hipSetDevice(batch->device));
+  BHIPCHK(wait_event(batch->evPca));
+  BHIPCHK(hipGetLastError());
+  const int n = batch->n, d = batch->d, rcount = n < d ? n : d;
+  const size_t D = batch->max_d;
+  for (int b = 0; b < batch->B; ++b) {
+    pcabo_ctx* c = batch->ctx[b];
+    const double* h = c->hSmall;
+    if (data_mean) memcpy(data_mean + (size_t)b * d, h, (size_t)d * sizeof(double));
+    if (pca_mean) memcpy(pca_mean + (size_t)b * d, h + D, (size_t)d * sizeof(double));
+    if (evr) memcpy(evr + (size_t)b * d, h + 2 * D, (size_t)rcount * sizeof(double));
+    if (comps) memcpy(comps + (size_t)b * d * d, h + 3 * D, (size_t)rcount * d * sizeof(double));
+    c->k = c->hm->k; c->KP = round_up(c->k, 4); c->have_wpca = true;
+    if (k) k[b] = c->k;
+  }
+  batch->wpca_uncollected = false;
+  return PCABO_OK;
+}
+
+int pcabo_batch_acq_bounds(pcabo_batch* batch, double* bounds) {
+  if (!batch || !bounds) return PCABO_ERR_ARG;
+  if (batch->wpca_uncollected) { int rc = pcabo_batch_wpca_results(batch, nullptr, nullptr, nullptr, nullptr, nullptr); if (rc != PCABO_OK) return rc; }
+  if (batch->gp_pending) {
+    BHIPCHK(hipSetDevice(batch->device));
+    BHIPCHK(wait_event(batch->evBounds));
+  } else if (!batch->have_gp) {
+    return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_acq_bounds: no conditioning enqueued%s", "");
+  }
+  for (int b = 0; b < batch->B; ++b) {
+    const pcabo_ctx* c = batch->ctx[b];
+    double* o = bounds + (size_t)b * 2 * batch->max_d;
+    for (int j = 0; j < c->k; ++j) { o[j] = c->hm->acq_lo[j]; o[c->k + j] = c->hm->acq_hi[j]; }
+  }
+  return PCABO_OK;
+}
+
+static int batch_max_k(const pcabo_batch* batch) {
+  int km = 1;
+  for (const pcabo_ctx* c : batch->ctx) km = std::max(km, c->k);
+  return km;
+}
+
+static AcqBatch batch_ab(const pcabo_batch* batch, int table, int xq_host) {
+  AcqBatch ab;
+  ab.zs = batch->zs; ab.hzs = batch->hzs; ab.k_dev = batch->ctx[0]->dK; ab.bestf = batch->ctx[0]->dBestF;
+  ab.table = table; ab.xq_host = xq_host;
+  return ab;
+}
+
+// best_f of every run -> its device word (rounded per run like the single-context calls do)
+static int batch_put_best_f(pcabo_batch* batch, const double* best_f) {
+  pcabo_ctx* c0 = batch->ctx[0];
+  for (int b = 0; b < batch->B; ++b) {
+    pcabo_ctx* c = batch->ctx[b];
+    c->hBestF[0] = c->bestf_f32 ? (double)(float)best_f[b] : best_f[b];
+  }
+  BHIPCHK(hipMemcpy2DAsync(c0->dBestF, batch->zs, c0->hBestF, batch->hzs, sizeof(double), batch->B, hipMemcpyHostToDevice, batch->stream));
+  return PCABO_OK;
+}
+
+int pcabo_batch_gp_condition_end_eval(pcabo_batch* batch, const double* Xq, int q, const double* best_f, int maximize,
+                                      int acq, double* val, int* status) {
+  if (!batch) return PCABO_ERR_ARG;
+  if (!Xq || !best_f || !val || q < 1 || q > batch->max_q || (acq != PCABO_ACQ_LOG_EI && acq != PCABO_ACQ_PI))
+    return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_gp_condition_end_eval: bad argument%s", "");
+  if (!batch->gp_pending) return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_gp_condition_end_eval: no conditioning in flight%s", "");
+  if (batch->wpca_uncollected) { int rc = pcabo_batch_wpca_results(batch, nullptr, nullptr, nullptr, nullptr, nullptr); if (rc != PCABO_OK) return rc; }
+  BHIPCHK(hipSetDevice(batch->device));
+  hipStream_t s = batch->stream;
+  const int B = batch->B, kmax = batch_max_k(batch);
+  pcabo_ctx* c0 = batch->ctx[0];
+  for (int b = 0; b < B; ++b)
+    memcpy(batch->ctx[b]->hXq, Xq + (size_t)b * q * batch->max_d, (size_t)q * batch->ctx[b]->k * sizeof(double));
+  BHIPCHK(hipMemcpy2DAsync(c0->dXq, batch->zs, c0->hXq, batch->hzs, (size_t)q * kmax * sizeof(double), B, hipMemcpyHostToDevice, s));
+  int rc = batch_put_best_f(batch, best_f);
+  if (rc != PCABO_OK) return rc;
+  AcqParams p = make_params(c0, 0.0, maximize, acq, 0);
+  p.inv_ls = 1.0 / batch->lengthscale; p.kernel = batch->kernel;
+  launch_acq(s, nullptr, c0->dXq, q, batch->n, kmax, batch->NP, c0->ld, c0->dZnT, c0->dR, c0->dAlpha, c0->dBounds4, c0->dYstats,
+             p, c0->dPartial, c0->dCounters, c0->dVal, c0->dGrad, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr,
+             batch_ab(batch, 0, 0), B, 0);
+  BHIPCHK(hipMemcpy2DAsync(c0->hVal, batch->hzs, c0->dVal, batch->zs, (size_t)q * sizeof(double), B, hipMemcpyDeviceToHost, s));
+  BHIPCHK(wait_stream(s));
+  BHIPCHK(hipGetLastError());
+  batch->gp_pending = false; batch->have_gp = true;
+  int worst = PCABO_OK;
+  for (int b = 0; b < B; ++b) {
+    pcabo_ctx* c = batch->ctx[b];
+    int st = PCABO_OK;
+    if (c->hm->chol_info != 0) {
+      // rare: this run's K needed jitter (psd_safe_cholesky: 1e-8, 1e-7, 1e-6) - redo it alone, then score again
+      double jitter = 0.0;
+      st = PCABO_ERR_NOT_PD;
+      for (int attempt = 0; attempt < 3; ++attempt) {
+        jitter = attempt == 0 ? 1e-8 : jitter * 10.0;
+        int r2 = launch_factorisation(c, jitter);
+        if (r2 != PCABO_OK) { st = r2; break; }
+        if (wait_stream(c->stream) != hipSuccess) { st = PCABO_ERR_HIP; break; }
+        if (c->hm->chol_info == 0) { st = PCABO_OK; break; }
+      }
+      if (st == PCABO_OK) {
+        c->have_gp = true;
+        st = pcabo_acq_eval(c, Xq + (size_t)b * q * batch->max_d, q, best_f[b], maximize, acq, c->hVal, nullptr);
+      } else {
+        set_err(c, st, "K + s2 I not positive definite after jitter retries (pivot %s%d)", "", c->hm->chol_info);
+      }
+    }
+    c->have_gp = st == PCABO_OK;
+    if (st == PCABO_OK) memcpy(val + (size_t)b * q, c->hVal, (size_t)q * sizeof(double));
+    if (status) status[b] = st;
+    if (st != PCABO_OK) worst = st;
+  }
+  if (worst != PCABO_OK && !status) return bset_err(batch, worst, "a run of the batch failed in the conditioning (status array not given)%s", "");
+  return PCABO_OK;
+}
+
+int pcabo_batch_optimize_acqf(pcabo_batch* batch, const double* ics, int num_restarts, int batch_limit,
+                              const double* bounds, int maxiter, const double* best_f, int maximize, int acq,
+                              double* cand, double* vals, int* info, int* failed, int* status) {
+  if (!batch) return PCABO_ERR_ARG;
+  if (!ics || !bounds || !best_f || !cand || !vals || num_restarts < 1 || batch_limit < 1 ||
+      num_restarts > PCABO_INLAUNCH_MAXQ || (acq != PCABO_ACQ_LOG_EI && acq != PCABO_ACQ_PI))
+    return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_optimize_acqf: bad argument (num_restarts <= 32)%s", "");
+  if (!batch->have_gp) return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_optimize_acqf: no conditioned GP%s", "");
+  BHIPCHK(hipSetDevice(batch->device));
+  const int B = batch->B, MD = batch->max_d, kmax = batch_max_k(batch), G = batch->G;
+  const int ngroups = (num_restarts + batch_limit - 1) / batch_limit;
+  int rc = batch_put_best_f(batch, best_f);
+  if (rc != PCABO_OK) return rc;
+  BHIPCHK(hipStreamSynchronize(batch->stream));
+  pcabo_ctx* c0 = batch->ctx[0];
+  AcqParams pg = make_params(c0, 0.0, maximize, acq, 1);
+  pg.inv_ls = 1.0 / batch->lengthscale; pg.kernel = batch->kernel;
+  AcqParams pv = pg; pv.want_grad = 0;
+  std::vector<std::vector<RestartGroup>> groups(B);
+  std::vector<int> run_status(B, PCABO_OK);
+  for (int b = 0; b < B; ++b) {
+    const pcabo_ctx* c = batch->ctx[b];
+    groups[b].resize(c->have_gp ? ngroups : 0);
+    if (!c->have_gp) { run_status[b] = PCABO_ERR_NOT_PD; continue; }
+    for (int gi = 0; gi < ngroups; ++gi) {
+      const int q0 = gi * batch_limit, nq = std::min(batch_limit, num_restarts - q0);
+      groups[b][gi].init(ics + (size_t)b * num_restarts * MD, bounds + (size_t)b * 2 * MD, q0, nq, c->k, maxiter);
+    }
+  }
+  std::atomic<int> hip_failed{0};
+  const int table_cap = PCABO_QA_MAX * 2;          // 32-bit entries in the QueryArgs slot
+  if (((B + G - 1) / G) * num_restarts > table_cap)
+    return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_optimize_acqf: too many runs per worker thread for one launch table (%s%d entries)", "", table_cap);
+  // One gang = the runs b with b % G == g, driven by worker g on its own stream: advance the gang's restart groups,
+  // hand every pending (run, query) to ONE launch, wait for the per-query sequence words, feed the results back.
+  auto gang = [&](int g) {
+    if (hipSetDevice(batch->device) != hipSuccess) { hip_failed.store(1); return; }
+    hipStream_t st = batch->gstream[g];
+    std::vector<int> mine;
+    for (int b = g; b < B; b += G) if (run_status[b] == PCABO_OK) mine.push_back(b);
+    QueryArgs tab;
+    unsigned* ent = reinterpret_cast<unsigned*>(tab.x);
+    struct Pending { int b, gi; };
+    std::vector<Pending> pend;
+    auto launch_and_wait = [&](int nent, const AcqParams& p, unsigned long long seq) -> bool {
+      launch_acq(st, &tab, c0->hXq, PCABO_INLAUNCH_MAXQ, batch->n, kmax, batch->NP, c0->ld, c0->dZnT, c0->dR, c0->dAlpha,
+                 c0->dBounds4, c0->dYstats, p, c0->dPartial, c0->dCounters, c0->dVal, c0->dGrad, c0->hVal, c0->hGrad, c0->hm,
+                 seq, nullptr, nullptr, nullptr, batch_ab(batch, 1, 1), B, nent);
+      if (hipGetLastError() != hipSuccess) return false;
+      const auto t0 = std::chrono::steady_clock::now();
+      unsigned long spins = 0;
+      for (int e = 0; e < nent; ++e) {
+        const pcabo_ctx* c = batch->ctx[ent[e] >> 16];
+        const int q = (int)(ent[e] & 0xffffu);
+        while (__atomic_load_n(&c->hm->qflag[q], __ATOMIC_ACQUIRE) != seq) {
+          if ((++spins & 0xFFFF) == 0 &&
+              std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 20.0) return false;
+        }
+      }
+      return true;
+    };
+    for (;;) {
+      pend.clear();
+      int nent = 0;
+      for (int b : mine) {
+        if (run_status[b] != PCABO_OK) continue;
+        pcabo_ctx* c = batch->ctx[b];
+        for (int gi = 0; gi < ngroups; ++gi) {
+          RestartGroup& rg = groups[b][gi];
+          if (!rg.active) continue;
+          rg.advance();
+          if (!rg.active) continue;
+          if (nent + rg.nq > table_cap) continue;            // (cannot happen: <= 32 queries per run, gangs are small)
+          memcpy(c->hXq + (size_t)rg.q0 * c->k, rg.x.data(), (size_t)rg.nq * c->k * sizeof(double));
+          for (int j = 0; j < rg.nq; ++j) ent[nent++] = ((unsigned)b << 16) | (unsigned)(rg.q0 + j);
+          pend.push_back({b, gi});
+        }
+      }
+      if (nent == 0) break;
+      const unsigned long long seq = batch->seq.fetch_add(1) + 1;
+      if (!launch_and_wait(nent, pg, seq)) { hip_failed.store(1); return; }
+      for (const Pending& pe : pend) {
+        pcabo_ctx* c = batch->ctx[pe.b];
+        if (!groups[pe.b][pe.gi].absorb(c->hVal, c->hGrad)) {
+          run_status[pe.b] = PCABO_ERR_NAN;
+          set_err(c, PCABO_ERR_NAN, "NaN in acquisition gradient%s", "");
+        }
+      }
+    }
+    // end points, values there (botorch evaluates once more at the clamped end points; normally that is the last point
+    // the run evaluated - same kernel arithmetic, same bits - otherwise one value-only launch for the gang's leftovers)
+    int nent = 0;
+    std::vector<int> redo;
+    for (int b : mine) {
+      if (run_status[b] != PCABO_OK) continue;
+      pcabo_ctx* c = batch->ctx[b];
+      const int k = c->k;
+      double* cb = cand + (size_t)b * num_restarts * MD;
+      bool reuse = true;
+      for (int gi = 0; gi < ngroups; ++gi) {
+        RestartGroup& rg = groups[b][gi];
+        for (int t = 0; t < rg.nq * k; ++t) {
+          double v = rg.x[t];
+          v = v < rg.lo[t] ? rg.lo[t] : (v > rg.hi[t] ? rg.hi[t] : v);
+          cb[(size_t)rg.q0 * k + t] = v;
+        }
+        reuse = reuse && rg.have_cache && (int)rg.vc.size() == rg.nq &&
+                memcmp(cb + (size_t)rg.q0 * k, rg.xc.data(), (size_t)rg.nq * k * sizeof(double)) == 0;
+      }
+      if (reuse) {
+        for (int gi = 0; gi < ngroups; ++gi)
+          for (int j = 0; j < groups[b][gi].nq; ++j) vals[(size_t)b * num_restarts + groups[b][gi].q0 + j] = groups[b][gi].vc[j];
+      } else {
+        memcpy(c->hXq, cb, (size_t)num_restarts * k * sizeof(double));
+        for (int j = 0; j < num_restarts; ++j) ent[nent++] = ((unsigned)b << 16) | (unsigned)j;
+        redo.push_back(b);
+      }
+    }
+    if (nent > 0) {
+      const unsigned long long seq = batch->seq.fetch_add(1) + 1;
+      if (!launch_and_wait(nent, pv, seq)) { hip_failed.store(1); return; }
+      for (int b : redo)
+        for (int j = 0; j < num_restarts; ++j) vals[(size_t)b * num_restarts + j] = batch->ctx[b]->hVal[j];
+    }
+  };
+  batch->pool.run(gang);
+  if (hip_failed.load()) {
+    batch->cnt_dirty = true;
+    (void)hipDeviceSynchronize();
+    return bset_err(batch, PCABO_ERR_HIP, "an acquisition launch of the batch failed or did not answer%s", "");
+  }
+  for (int b = 0; b < B; ++b) {
+    int any_failed = 0;
+    for (int gi = 0; gi < (int)groups[b].size(); ++gi) {
+      const RestartGroup& rg = groups[b][gi];
+      const int wf = rg.opt.warnflag();
+      if (info) {
+        int* o = info + ((size_t)b * ngroups + gi) * 4;
+        o[0] = rg.niter; o[1] = rg.nfev; o[2] = wf; o[3] = rg.opt.task();
+      }
+      if (wf == 2) any_failed = 1;
+    }
+    if (failed) failed[b] = any_failed;
+    if (status) status[b] = run_status[b];
+  }
+  return PCABO_OK;
+}
+
+int pcabo_batch_inverse_map(pcabo_batch* batch, const double* z, double* x) {
+  if (!batch || !z || !x) return PCABO_ERR_ARG;
+  if (batch->n == 0 || batch->wpca_uncollected) return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_inverse_map: no weighted PCA collected%s", "");
+  BHIPCHK(hipSetDevice(batch->device));
+  hipStream_t s = batch->stream;
+  pcabo_ctx* c0 = batch->ctx[0];
+  const int B = batch->B, MD = batch->max_d, d = batch->d;
+  for (int b = 0; b < B; ++b) memcpy(batch->ctx[b]->hXq, z + (size_t)b * MD, (size_t)batch->ctx[b]->k * sizeof(double));
+  BHIPCHK(hipMemcpy2DAsync(c0->dZq, batch->zs, c0->hXq, batch->hzs, (size_t)MD * sizeof(double), B, hipMemcpyHostToDevice, s));
+  launch_inverse_map(s, c0->dZq, c0->dComps, c0->dDataMean, c0->dPcaMean, 0, d, c0->dXout, c0->dK, batch_zb(batch));
+  BHIPCHK(hipMemcpy2DAsync(c0->hSmall, batch->hzs, c0->dXout, batch->zs, (size_t)d * sizeof(double), B, hipMemcpyDeviceToHost, s));
+  BHIPCHK(wait_stream(s));
+  BHIPCHK(hipGetLastError());
+  for (int b = 0; b < B; ++b) memcpy(x + (size_t)b * d, batch->ctx[b]->hSmall, (size_t)d * sizeof(double));
   return PCABO_OK;
 }
 

@@ -59,6 +59,17 @@ struct AcqParams {
   int want_grad;
 };
 
+// Batched acquisition launches (all zero / null for a single context).  Runs are addressed as in zrun(); per run the
+// reduced dimension and best_f come from device memory (they differ between the runs of a batch).
+struct AcqBatch {
+  size_t zs = 0, hzs = 0;          // strides of the device region / the pinned host region
+  const int* k_dev = nullptr;      // run 0's dK      (null: the k argument)
+  const double* bestf = nullptr;   // run 0's dBestF  (null: prm.best_f)
+  int table = 0;                   // 1: blockIdx.y indexes the active-query table that travels in the QueryArgs slot
+                                   //    (32-bit entries: run << 16 | query of that run); 0: run = blockIdx.z
+  int xq_host = 0;                 // 1: Xq is a pinned HOST pointer (stride hzs), read by the kernel over PCIe
+};
+
 // Small results the host needs after a device phase; lives in pinned host memory.
 struct HostMirror {
   int k;                 // reduced dimension chosen by the wPCA
@@ -107,6 +118,14 @@ __device__ inline unsigned long long mail_seq(pcabo_u4 v) {
   return pair_tag(v) ^ mail_mix(((unsigned long long)v.y << 32) | v.x);
 }
 
+// Batched launches (pcabo_batch_*): blockIdx.z = run.  The contexts of a batch share one layout, so run b's copy of any
+// device buffer sits b * zs bytes behind run 0's (b * hzs for the pinned host mirror).  zs = 0 / gridDim.z = 1 otherwise.
+template <typename T>
+__device__ inline T* zrun(T* p, size_t stride, unsigned run) {
+  return p ? reinterpret_cast<T*>((uintptr_t)p + (size_t)run * stride) : p;
+}
+#define ZRUN(p) p = zrun(p, zs, blockIdx.z)
+
 // Wave-wide sum without LDS traffic.  `__shfl_xor` compiles to ds_bpermute_b32 (two per double, each followed by an
 // lgkmcnt wait: ~100 cycles of dependent latency per step); in a kernel whose whole budget is ~15 us the reductions
 // were the largest single item.  DPP steps stay inside the VALU: quad_perm x2, row_half_mirror, row_mirror leave the
@@ -134,35 +153,41 @@ __device__ inline double wave_sum(double v) {         // uniform result: sum ove
 #endif
 
 void launch_rank(hipStream_t s, const double* f, int n, int maximize, long long* ranks);
+// B > 1: batched launch over the B contexts of a batch (blockIdx.z = run, buffer strides zs / hzs bytes, see zrun)
+struct ZB { int B = 1; size_t zs = 0, hzs = 0; };
 void launch_wpca_prep(hipStream_t s, const double* X, const long long* ranks, const double* noise, int n, int d,
-                      int DP, double* weights, double* data_mean, double* pca_mean, double* Wc);
-void launch_cov(hipStream_t s, const double* Wc, int n, int DP, double* C);
+                      int DP, double* weights, double* data_mean, double* pca_mean, double* Wc, ZB zb = ZB());
+void launch_cov(hipStream_t s, const double* Wc, int n, int DP, double* C, ZB zb = ZB());
 // eigen-decomposition + selection (components sorted by variance, evr, k, sign rule) in one launch
 void launch_jacobi(hipStream_t s, const double* C, int d, int DP, const double* V0, double* G, double* lam, int* sweeps,
-                   int n, double var_threshold, int n_components, double* comps, double* evr, int* k_dev, HostMirror* hm);
+                   int n, double var_threshold, int n_components, double* comps, double* evr, int* k_dev, HostMirror* hm,
+                   ZB zb = ZB());
 void launch_project(hipStream_t s, const double* X, const double* data_mean, const double* pca_mean,
-                    const double* comps, const int* k_dev, int n, int d, double* Z);
+                    const double* comps, const int* k_dev, int n, int d, double* Z, ZB zb = ZB());
 void launch_zstats(hipStream_t s, const double* Z, const double* y, int n, int k, const double* user_norm_bounds,
                    double* bounds4 /*norm_lo,norm_hi,acq_lo,acq_hi each MAXD*/, double* zn_mean, double* ystats,
-                   double* ys, HostMirror* hm, const int* k_dev = nullptr);
+                   double* ys, HostMirror* hm, const int* k_dev = nullptr, ZB zb = ZB());
 void launch_znorm(hipStream_t s, const double* Z, int n, int k, int NP, int KP, int ld, const double* bounds4,
                   const double* zn_mean, double inv_ls, double* ZnT, double* AT, double* nrm,
-                  const int* k_dev = nullptr);   // k_dev != NULL: k (and KP) are read on the device, the arguments ignored
+                  const int* k_dev = nullptr, ZB zb = ZB());   // k_dev != NULL: k (and KP) are read on the device, the arguments ignored
 void launch_gram(hipStream_t s, const double* AT, const double* nrm, int n, int NP, int KP, int ld, double noise,
-                 int kernel, double* K, const int* k_dev = nullptr, double* K2 = nullptr, int* info_reset = nullptr);
+                 int kernel, double* K, const int* k_dev = nullptr, double* K2 = nullptr, int* info_reset = nullptr,
+                 ZB zb = ZB());
 void launch_add_jitter(hipStream_t s, double* K, int n, int ld, double jitter);
-void launch_cholesky(hipStream_t s, double* L, int NP, int ld, int* info, double* diag_scratch);
-void launch_trinv(hipStream_t s, const double* L, int NP, int ld, double* R);
-void launch_chol_panel_w(hipStream_t s, double* L, int p, int nblocks, int ld, int* info, double* diag_scratch);
-void launch_trinv_diag_w(hipStream_t s, const double* L, int nblk, int ld, double* R);
-void launch_alpha(hipStream_t s, const double* R, const double* ys, int n, int NP, int ld, double* tmp, double* alpha);
+void launch_cholesky(hipStream_t s, double* L, int NP, int ld, int* info, double* diag_scratch, ZB zb = ZB());
+void launch_trinv(hipStream_t s, const double* L, int NP, int ld, double* R, ZB zb = ZB());
+void launch_chol_panel_w(hipStream_t s, double* L, int p, int nblocks, int ld, int* info, double* diag_scratch, ZB zb = ZB());
+void launch_trinv_diag_w(hipStream_t s, const double* L, int nblk, int ld, double* R, ZB zb = ZB());
+void launch_alpha(hipStream_t s, const double* R, const double* ys, int n, int NP, int ld, double* tmp, double* alpha,
+                  ZB zb = ZB());
 void launch_acq(hipStream_t s, const QueryArgs* qa, const double* Xq, int q, int n, int k, int NP, int ld,
                 const double* ZnT, const double* R, const double* alpha, const double* bounds4, const double* ystats,
                 AcqParams p, double* partial, unsigned int* counters, double* val,
                 double* grad, double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq,
-                const MailPair* host_mail = nullptr, MailPair* dev_mail = nullptr, MailPair* part_pairs = nullptr);
+                const MailPair* host_mail = nullptr, MailPair* dev_mail = nullptr, MailPair* part_pairs = nullptr,
+                AcqBatch ab = AcqBatch(), int B = 1, int table_entries = 0);
 // resident mode available for this shape? (fast path + every group of the grid co-resident)
 bool acq_server_possible(int q, int n, int k, int NP);
 int acq_slabs(int NP);
 void launch_inverse_map(hipStream_t s, const double* z, const double* comps, const double* data_mean,
-                        const double* pca_mean, int k, int d, double* x);
+                        const double* pca_mean, int k, int d, double* x, const int* k_dev = nullptr, ZB zb = ZB());

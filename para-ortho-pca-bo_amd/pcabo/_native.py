@@ -28,6 +28,9 @@ EXPORTS = [
     "pcabo_acq_bounds",
     "pcabo_acq_eval", "pcabo_logei", "pcabo_optimize_acqf", "pcabo_inverse_map", "pcabo_get_gp_state",
     "pcabo_get_gram", "pcabo_lbfgsb_minimize", "pcabo_sobol_scramble", "pcabo_set_profiling", "pcabo_get_profile", "pcabo_reset_profile",
+    "pcabo_batch_create", "pcabo_batch_destroy", "pcabo_batch_last_error", "pcabo_batch_ctx",
+    "pcabo_batch_wpca_gp_condition_begin", "pcabo_batch_wpca_results", "pcabo_batch_acq_bounds",
+    "pcabo_batch_gp_condition_end_eval", "pcabo_batch_optimize_acqf", "pcabo_batch_inverse_map",
 ]
 
 
@@ -80,8 +83,20 @@ def _load() -> C.CDLL:
     lib.pcabo_set_profiling.argtypes = [vp, C.c_int]
     lib.pcabo_get_profile.argtypes = [vp, C.c_int, dp, C.POINTER(C.c_int64), dp, dp]
     lib.pcabo_reset_profile.argtypes = [vp]
+    lib.pcabo_batch_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.pcabo_batch_destroy.argtypes = [vp]
+    lib.pcabo_batch_last_error.argtypes = [vp, C.c_char_p, C.c_int]
+    lib.pcabo_batch_ctx.argtypes = [vp, C.c_int]
+    lib.pcabo_batch_wpca_gp_condition_begin.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
+                                                        C.c_double, C.c_double, C.c_int]
+    lib.pcabo_batch_wpca_results.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.pcabo_batch_acq_bounds.argtypes = [vp, vp]
+    lib.pcabo_batch_gp_condition_end_eval.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp]
+    lib.pcabo_batch_optimize_acqf.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+    lib.pcabo_batch_inverse_map.argtypes = [vp, vp, vp]
     for name in EXPORTS:
         getattr(lib, name).restype = C.c_int
+    lib.pcabo_batch_ctx.restype = vp
     return lib
 
 
@@ -297,6 +312,133 @@ class Context:
             self._chk(LIB.pcabo_get_profile(self._h, i, C.byref(ms), C.byref(cnt), C.byref(by), C.byref(fl)))
             out[name] = {"ms": ms.value, "launches": cnt.value, "bytes": by.value, "flops": fl.value}
         return out
+
+
+class _BorrowedContext(Context):
+    """Run b's context inside a Batch: every single-context call works on it; the batch owns and frees it."""
+
+    def __init__(self, handle, max_n, max_d, max_q, device):   # noqa: D401 - no pcabo_ctx_create here
+        self._h = C.c_void_p(handle)
+        self.max_n, self.max_d, self.max_q, self.device = max_n, max_d, max_q, device
+        self.n = self.d = self.k = 0
+
+    def close(self) -> None:
+        self._h = C.c_void_p()
+
+
+class Batch:
+    """B per-run contexts advancing in lock-step (pcabo_batch_* of include/pcabo.h): one launch sequence for the
+    rows A-H of all runs, one scoring launch, shared acquisition launches for the L-BFGS-B rounds of all runs."""
+
+    def __init__(self, B: int, max_n: int, max_d: int, max_q: int = 512, device: int = 0):
+        self._h = C.c_void_p()
+        rc = LIB.pcabo_batch_create(int(device), int(B), int(max_n), int(max_d), int(max_q), C.byref(self._h))
+        if rc != 0:
+            msg = self._err() if self._h else "no usable HIP device (the HIP path has no CPU fallback)"
+            if self._h:
+                LIB.pcabo_batch_destroy(self._h)
+                self._h = C.c_void_p()
+            raise PcaboError(rc, msg)
+        self.B, self.max_n, self.max_d, self.max_q, self.device = B, max_n, max_d, max_q, device
+        self.n = self.d = 0
+        self.k = np.zeros(B, dtype=np.int32)
+        self.ctx = [_BorrowedContext(LIB.pcabo_batch_ctx(self._h, b), max_n, max_d, max_q, device) for b in range(B)]
+
+    def _err(self) -> str:
+        buf = C.create_string_buffer(512)
+        LIB.pcabo_batch_last_error(self._h, buf, 512)
+        return buf.value.decode(errors="replace")
+
+    def _chk(self, rc: int) -> None:
+        if rc != 0:
+            raise PcaboError(rc, self._err())
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            for c in self.ctx:
+                c.close()
+            LIB.pcabo_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def wpca_gp_condition_begin(self, X, ranks, noise, y, maximize=False, var_threshold=0.95, n_components=0,
+                                lengthscale=0.6931471805599453, gp_noise=0.006737946999085467, kernel=KERNEL_MATERN52):
+        """X[B,n,d], ranks[B,n] (int64), noise[B,n,d] or None, y[B,n]: enqueue rows A-H of every run."""
+        X = _f64(X)
+        B, n, d = X.shape
+        assert B == self.B
+        ranks = np.ascontiguousarray(ranks, dtype=np.int64).reshape(B, n)
+        nz = None if noise is None else _f64(noise, (B, n, d))
+        y = _f64(y, (B, n))
+        self._chk(LIB.pcabo_batch_wpca_gp_condition_begin(self._h, _ptr(X), _ptr(ranks), _ptr(nz), _ptr(y), n, d,
+                                                          int(bool(maximize)), float(var_threshold), int(n_components),
+                                                          float(lengthscale), float(gp_noise), int(kernel)))
+        self.n, self.d = n, d
+
+    def wpca_results(self):
+        B, n, d = self.B, self.n, self.d
+        rc_ = min(n, d)
+        dm, pm, comps, evr = np.empty((B, d)), np.empty((B, d)), np.empty((B, d, d)), np.empty((B, d))
+        k = np.zeros(B, dtype=np.int32)
+        self._chk(LIB.pcabo_batch_wpca_results(self._h, _ptr(dm), _ptr(pm), _ptr(comps), _ptr(evr), _ptr(k)))
+        self.k = k
+        for b, c in enumerate(self.ctx):
+            c.n, c.d, c.k = n, d, int(k[b])
+        return [{"data_mean": dm[b], "pca_mean": pm[b], "components": comps[b].reshape(-1)[: rc_ * d].reshape(rc_, d),
+                 "evr": evr[b, :rc_], "k": int(k[b]), "Z": None} for b in range(B)]
+
+    def acq_bounds(self):
+        buf = np.zeros((self.B, 2 * self.max_d))
+        self._chk(LIB.pcabo_batch_acq_bounds(self._h, _ptr(buf)))
+        return [buf[b, : 2 * int(self.k[b])].reshape(2, int(self.k[b])).copy() for b in range(self.B)]
+
+    def gp_wait_eval(self, Xq_list, best_f, maximize=False, acq=ACQ_LOG_EI):
+        """Xq_list[b]: q x k_b points of run b.  Returns (values[B, q], status[B])."""
+        q = Xq_list[0].shape[0]
+        buf = np.zeros((self.B, q * self.max_d))
+        for b, xq in enumerate(Xq_list):
+            buf[b, : xq.size] = np.ascontiguousarray(xq, dtype=np.float64).ravel()
+        bf = _f64(best_f, (self.B,))
+        val = np.empty((self.B, q))
+        status = np.zeros(self.B, dtype=np.int32)
+        self._chk(LIB.pcabo_batch_gp_condition_end_eval(self._h, _ptr(buf), q, _ptr(bf), int(bool(maximize)), int(acq),
+                                                        _ptr(val), _ptr(status)))
+        return val, status
+
+    def optimize_acqf(self, ics_list, bounds_list, best_f, maximize=False, acq=ACQ_LOG_EI, batch_limit=5, maxiter=200):
+        """ics_list[b]: num_restarts x k_b; bounds_list[b]: 2 x k_b.  Returns per run (cand, vals, info, failed) + status."""
+        B, MD = self.B, self.max_d
+        nr = ics_list[0].shape[0]
+        ng = (nr + batch_limit - 1) // batch_limit
+        ics, bnd = np.zeros((B, nr * MD)), np.zeros((B, 2 * MD))
+        for b in range(B):
+            ics[b, : ics_list[b].size] = np.ascontiguousarray(ics_list[b], dtype=np.float64).ravel()
+            bnd[b, : bounds_list[b].size] = np.ascontiguousarray(bounds_list[b], dtype=np.float64).ravel()
+        bf = _f64(best_f, (B,))
+        cand, vals = np.zeros((B, nr * MD)), np.zeros((B, nr))
+        info = np.zeros((B, ng, 4), dtype=np.int32)
+        failed, status = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
+        self._chk(LIB.pcabo_batch_optimize_acqf(self._h, _ptr(ics), nr, int(batch_limit), _ptr(bnd), int(maxiter), _ptr(bf),
+                                                int(bool(maximize)), int(acq), _ptr(cand), _ptr(vals), _ptr(info),
+                                                _ptr(failed), _ptr(status)))
+        out = []
+        for b in range(B):
+            k = int(self.k[b])
+            out.append((cand[b, : nr * k].reshape(nr, k).copy(), vals[b].copy(), info[b].copy(), bool(failed[b])))
+        return out, status
+
+    def inverse_map(self, z_list):
+        z = np.zeros((self.B, self.max_d))
+        for b, zb in enumerate(z_list):
+            z[b, : zb.size] = np.asarray(zb, dtype=np.float64).ravel()
+        x = np.empty((self.B, self.d))
+        self._chk(LIB.pcabo_batch_inverse_map(self._h, _ptr(z), _ptr(x)))
+        return x
 
 
 def sobol_scramble(state: np.ndarray, ltm: np.ndarray) -> None:

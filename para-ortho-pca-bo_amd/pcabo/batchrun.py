@@ -1,0 +1,225 @@
+"""B independent PCA_BO runs advancing in lock-step on one GPU (the batched multi-run driver).
+
+The reference's outer loop is a list of independent runs - 30 instances per (function, dimension) cell, each with its
+own optimiser object and seed (/root/reference/Algorithms/Experiment/ExperimentRunner.py:137-183).  One run alone is
+latency-bound on a GPU: its matrices are a few MB and every phase is a short dependency chain.  Here the runs of a
+cell (same dimension, budget and DoE size, hence the same n at every iteration) advance TOGETHER through
+`pcabo._native.Batch`: one launch sequence conditions the GPs of all runs (blockIdx.z = run), one launch scores all raw
+samples, and the L-BFGS-B rounds of all runs share acquisition launches.
+
+Every run is the reference's run: the loop below is `PCA_BO.__call__` (PCA_BO.py:140-310) per run, with the numpy
+and torch GLOBAL generators of the reference replaced by one `RandomState` / `torch.Generator` per run seeded like the
+reference seeds its globals (AbstractAlgorithm.py:310-328) - the same streams, so a run here takes, bit for bit, the
+path the same run takes alone in `Algorithms.PCA_BO` (tests/test_gpu_batch.py).
+"""
+from __future__ import annotations
+
+import warnings
+from time import perf_counter
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _native
+from . import initializers as _init
+from .lhs import lhs_center
+
+LENGTHSCALE = 0.6931471805599453     # softplus(0)
+NOISE = 0.006737946999085467         # exp(-5)
+OOB_PENALTY = 1000
+
+
+class BatchedPCABO:
+    """`problems[b]`: ioh-like objects (`.bounds.lb/.ub`, `.meta_data.n_variables`, callable) of ONE dimension;
+    `seeds[b]`: the run's seed (ExperimentRunner.py:146).  After `run()`: `x_evals[b]`, `f_evals[b]`, `current_best[b]`,
+    `current_best_index[b]`, `timing` (seconds per phase, summed over iterations)."""
+
+    def __init__(self, problems: Sequence, seeds: Sequence[int], budget: int, n_DoE: int, n_components: int = 0,
+                 var_threshold: float = 0.95, acquisition_function: str = "expected_improvement",
+                 maximization: bool = False, device: int = 0, num_restarts: int = 10, raw_samples: int = 512,
+                 record_trace: bool = False):
+        self.problems, self.seeds = list(problems), [int(s) for s in seeds]
+        self.B = len(self.problems)
+        assert self.B == len(self.seeds) and self.B >= 1
+        self.dimension = int(self.problems[0].meta_data.n_variables)
+        assert all(int(p.meta_data.n_variables) == self.dimension for p in self.problems), "one dimension per batch"
+        self.budget, self.n_DoE = int(budget), int(n_DoE) if n_DoE else self.dimension
+        self.n_components, self.var_threshold, self.maximization = int(n_components), float(var_threshold), bool(maximization)
+        name = {"EI": "expected_improvement", "PI": "probability_of_improvement"}.get(acquisition_function, acquisition_function)
+        if name not in ("expected_improvement", "probability_of_improvement"):
+            raise ValueError("Oddly defined name")
+        self.acq_code = _native.ACQ_LOG_EI if name == "expected_improvement" else _native.ACQ_PI
+        self.num_restarts, self.raw_samples, self.device = int(num_restarts), int(raw_samples), int(device)
+        self.bounds = [np.column_stack([np.asarray(p.bounds.lb, dtype=float), np.asarray(p.bounds.ub, dtype=float)])
+                       for p in self.problems]
+        self.x_evals: List[List[np.ndarray]] = [[] for _ in range(self.B)]
+        self.f_evals: List[List[float]] = [[] for _ in range(self.B)]
+        self.current_best = [None] * self.B
+        self.current_best_index = [0] * self.B
+        self.k_prev = [0] * self.B
+        self.lbfgsb_info = []
+        self.retries = 0
+        self.timing = {"pca": 0.0, "wait_score": 0.0, "init_pick": 0.0, "lbfgsb": 0.0, "tail": 0.0, "host_prep": 0.0}
+        self.record_trace, self.trace = bool(record_trace), []
+        self._batch: Optional[_native.Batch] = None
+        self._rs = self._tg = None
+        self._X = None
+
+    # ---- seeding + DoE (AbstractAlgorithm.py:310-328, AbstractBayesianOptimizer.py:142-176) --------------------------
+    def start(self) -> None:
+        B, d = self.B, self.dimension
+        self._rs = [np.random.RandomState(s) for s in self.seeds]
+        self._tg = [torch.Generator().manual_seed(s) for s in self.seeds]
+        self._X = np.empty((B, self.budget, d))
+        for b in range(B):
+            unit = lhs_center(d, self.n_DoE, self._rs[b])
+            span = self.bounds[b][:, 1] - self.bounds[b][:, 0]
+            for point in span * unit + self.bounds[b][:, 0]:
+                self.x_evals[b].append(point)
+                self.f_evals[b].append(self.problems[b](point))
+            self._assign_new_best(b)
+            self._X[b, : self.n_DoE] = np.vstack(self.x_evals[b])
+        self._batch = _native.Batch(B, max_n=self.budget, max_d=d, max_q=max(self.raw_samples, 16), device=self.device)
+
+    def _assign_new_best(self, b: int) -> None:
+        f = self.f_evals[b]
+        self.current_best[b] = max(f) if self.maximization else min(f)
+        self.current_best_index[b] = f.index(self.current_best[b], self.current_best_index[b])
+
+    @property
+    def n(self) -> int:
+        return len(self.f_evals[0])
+
+    # ---- one lock-step BO iteration (PCA_BO.py:178-298 for every run) ------------------------------------------------
+    def iteration(self) -> None:
+        B, d, n, bt = self.B, self.dimension, self.n, self._batch
+        t0 = perf_counter()
+        F = np.array(self.f_evals, dtype=np.float64)                                   # B x n
+        ranks = np.empty((B, n), dtype=np.int64)
+        noise = np.empty((B, n, d))
+        for b in range(B):
+            # per run, on a 1-D array exactly as the reference does it (PCA_BO.py:330-333): the penalty value repeats, and
+            # how numpy's unstable sort orders ties must be what the run sees alone
+            fb = np.array(self.f_evals[b])
+            ranks[b] = np.argsort(np.argsort(-fb if self.maximization else fb)) + 1
+            noise[b] = self._rs[b].normal(0, 1e-8, size=(n, d))                       # PCA_BO.py:376, the run's own stream
+        t1 = perf_counter()
+        bt.wpca_gp_condition_begin(self._X[:, :n], ranks, noise, F, maximize=self.maximization,
+                                   var_threshold=self.var_threshold, n_components=self.n_components,
+                                   lengthscale=LENGTHSCALE, gp_noise=NOISE)
+        # while the device runs the eigen-decompositions: the scrambled Sobol engines, with last iteration's k
+        engines, saved = [None] * B, [None] * B
+        for b in range(B):
+            if self.k_prev[b]:
+                saved[b] = self._tg[b].get_state()
+                engines[b] = _init.scrambled_sobol_engine(self.k_prev[b], self._tg[b])
+        res = bt.wpca_results()
+        for b in range(B):
+            if engines[b] is not None and res[b]["k"] != self.k_prev[b]:
+                self._tg[b].set_state(saved[b])                                        # wrong guess: as if never drawn
+                engines[b] = None
+            if engines[b] is None:
+                engines[b] = _init.scrambled_sobol_engine(res[b]["k"], self._tg[b])
+            self.k_prev[b] = res[b]["k"]
+        t2 = perf_counter()
+        bounds = bt.acq_bounds()
+        raw = [_init.draw_sobol(bounds[b], self.raw_samples, engines[b]) for b in range(B)]
+        best_f = [self.current_best[b] for b in range(B)]
+        for b in range(B):
+            bt.ctx[b].match_best_f_dtype(best_f[b])
+        t3 = perf_counter()
+        vals, status = bt.gp_wait_eval(raw, best_f, self.maximization, self.acq_code)
+        if np.any(status != 0):
+            raise _native.PcaboError(int(status[status != 0][0]), f"GP conditioning failed for runs {np.nonzero(status)[0].tolist()}")
+        t4 = perf_counter()
+        pick = _init.initialize_q_batch if self.acq_code == _native.ACQ_LOG_EI else _init.initialize_q_batch_nonneg
+        idx = [pick(vals[b], self.num_restarts, generator=self._tg[b]) for b in range(B)]
+        ics = [raw[b][idx[b]] for b in range(B)]
+        t5 = perf_counter()
+        outs, status = bt.optimize_acqf(ics, bounds, best_f, self.maximization, self.acq_code, batch_limit=5, maxiter=200)
+        if np.any(status != 0):
+            raise _native.PcaboError(int(status[status != 0][0]), f"acquisition optimisation failed for runs {np.nonzero(status)[0].tolist()}")
+        t6 = perf_counter()
+        z_new, infos = [], []
+        for b in range(B):
+            cand, v, info, failed = outs[b]
+            retried = False
+            if failed:       # botorch: OptimizationWarning -> one retry with freshly drawn initial conditions (this run alone)
+                warnings.warn("Optimization failed in `gen_candidates_scipy`; trying again with a new set of "
+                              "initial conditions.", RuntimeWarning)
+                self.retries += 1
+                retried = True
+                c = bt.ctx[b]
+                raw_b = _init.draw_sobol(bounds[b], self.raw_samples, _init.scrambled_sobol_engine(int(bt.k[b]), self._tg[b]))
+                vals_b = c.acq_eval(raw_b, best_f[b], self.maximization, self.acq_code, grad=False)
+                ics_b = raw_b[pick(vals_b, self.num_restarts, generator=self._tg[b])]
+                cand, v, info, failed = c.optimize_acqf(ics_b, bounds[b], best_f[b], self.maximization, self.acq_code,
+                                                        batch_limit=5, maxiter=200)
+                ics[b] = ics_b
+            best = int(np.argmax(v))
+            z_new.append(cand[best])
+            infos.append(info)
+            if self.record_trace:
+                self.trace.append({"b": b, "n": n, "k": int(bt.k[b]), "ic_idx": np.asarray(idx[b]).copy(), "ics": ics[b].copy(),
+                                   "cands": cand.copy(), "vals": v.copy(), "info": info.copy(), "chosen": best,
+                                   "retried": retried})
+        self.lbfgsb_info.append(infos)
+        X_new = bt.inverse_map(z_new)
+        for b in range(B):
+            new_x = X_new[b].copy()
+            outside = not np.all(new_x >= self.bounds[b][:, 0]) or not np.all(new_x <= self.bounds[b][:, 1])
+            # out-of-box candidates are not evaluated; they cost budget and a fixed penalty (PCA_BO.py:260-263)
+            new_f = (-OOB_PENALTY if self.maximization else OOB_PENALTY) if outside else self.problems[b](new_x)
+            self.x_evals[b].append(new_x)
+            self.f_evals[b].append(new_f)
+            self._X[b, n] = new_x
+            self._assign_new_best(b)
+        t7 = perf_counter()
+        tm = self.timing
+        tm["host_prep"] += t1 - t0
+        tm["pca"] += t2 - t1
+        tm["wait_score"] += t4 - t2
+        tm["init_pick"] += t5 - t4
+        tm["lbfgsb"] += t6 - t5
+        tm["tail"] += t7 - t6
+
+    def finish(self) -> None:
+        if self._batch is not None:
+            self._batch.close()
+            self._batch = None
+
+    def run(self) -> None:
+        try:
+            self.start()
+            while self.n < self.budget:
+                self.iteration()
+        finally:
+            self.finish()
+
+
+def bench_block(device: int, B: int, fid: int, dim: int, budget_factor: int = 10, doe_factor: float = 3.0) -> dict:
+    """Aggregate BO iterations / second of B runs (instances 0..B-1 of one BBOB function and dimension, seeds per
+    ExperimentRunner.py:146) advancing together on one GPU; DoE and set-up untimed."""
+    from .bbob import BBOBProblem
+    budget, n_doe = budget_factor * dim + 50, int(doe_factor * dim)
+    probs = [BBOBProblem(fid, i, dim) for i in range(B)]
+    seeds = [1000 * fid + 10 * dim + i for i in range(B)]
+    r = BatchedPCABO(probs, seeds, budget, n_doe, device=device)
+    r.start()
+    torch.cuda.synchronize()
+    t0 = perf_counter()
+    try:
+        while r.n < budget:
+            r.iteration()
+        torch.cuda.synchronize()
+        dt = perf_counter() - t0
+    finally:
+        r.finish()
+    iters = B * (budget - n_doe)
+    return {"runs": B, "function": fid, "dimension": dim, "budget": budget, "n_DoE": n_doe,
+            "aggregate_bo_iterations_per_s": iters / dt, "seconds": dt, "bo_iterations": iters,
+            "ms_per_lockstep_iteration": 1e3 * dt / (budget - n_doe), "host_phase_seconds": dict(r.timing),
+            "retries": r.retries, "best_f": [float(v) for v in r.current_best],
+            "note": "B runs of configs[1]'s cell advancing in lock-step through pcabo_batch_* (one launch sequence for rows "
+                    "A-H of all runs, shared acquisition launches for the L-BFGS-B rounds); one Python host thread"}

@@ -20,8 +20,10 @@ _MAXBIT = 30
 _POW_LOW = torch.pow(2, torch.arange(0, _MAXBIT))
 
 
-def scrambled_sobol_engine(k: int) -> torch.quasirandom.SobolEngine:
+def scrambled_sobol_engine(k: int, generator=None) -> torch.quasirandom.SobolEngine:
     """Bit-identical to `SobolEngine(k, scramble=True, seed=None)`, ~3x faster to construct.
+    `generator`: a `torch.Generator` standing in for torch's global CPU generator (same stream for the same seed) - used
+    where several runs share one process (pcabo.batchrun); None = the global generator, as botorch.
 
     The two `torch.randint` draws are exactly the ones torch makes (same consumption of the global CPU
     generator, same order) and `draw` stays torch's; only the matrix scramble (torch's
@@ -29,9 +31,9 @@ def scrambled_sobol_engine(k: int) -> torch.quasirandom.SobolEngine:
     `pcabo_sobol_scramble`.  Pinned against the real engine in tests/test_abi_and_host.py."""
     from . import _native
     eng = torch.quasirandom.SobolEngine(k, scramble=False)
-    shift_ints = torch.randint(2, (k, _MAXBIT))
+    shift_ints = torch.randint(2, (k, _MAXBIT), generator=generator)
     eng.shift = torch.mv(shift_ints, _POW_LOW)
-    ltm = torch.randint(2, (k, _MAXBIT, _MAXBIT)).tril()
+    ltm = torch.randint(2, (k, _MAXBIT, _MAXBIT), generator=generator).tril()
     state = eng.sobolstate.numpy()                                  # (k, 30) int64, shares memory with the engine
     _native.sobol_scramble(state, ltm.numpy())
     eng.quasi = eng.shift.clone(memory_format=torch.contiguous_format)
@@ -53,7 +55,7 @@ def draw_sobol(bounds: np.ndarray, n: int, engine=None) -> np.ndarray:
 
 
 @torch.inference_mode()
-def initialize_q_batch(acq_vals: np.ndarray, n: int, eta: float = INIT_ETA) -> np.ndarray:
+def initialize_q_batch(acq_vals: np.ndarray, n: int, eta: float = INIT_ETA, generator=None) -> np.ndarray:
     """Boltzmann sampling of n restart indices (without replacement) + forced arg-max."""
     v = torch.from_numpy(np.ascontiguousarray(acq_vals, dtype=np.float64))
     n_samples = v.shape[0]
@@ -65,20 +67,21 @@ def initialize_q_batch(acq_vals: np.ndarray, n: int, eta: float = INIT_ETA) -> n
     if bool(torch.any(std == 0)):
         warnings.warn("All acquisition values for raw samples points are the same. "
                       "Choosing initial conditions at random.", RuntimeWarning)
-        return torch.randperm(n=n_samples)[:n].numpy()
+        return torch.randperm(n=n_samples, generator=generator)[:n].numpy()
     max_idx = torch.max(v, dim=0)[1]
     eta_z = eta * ((v - v.mean(dim=0)) / std)
     weights = torch.exp(eta_z)
     while bool(torch.isinf(weights).any()):
         eta_z = eta_z * 0.5
         weights = torch.exp(eta_z)
-    idcs = torch.multinomial(weights, n)
+    idcs = torch.multinomial(weights, n, generator=generator)
     if max_idx not in idcs:
         idcs[-1] = max_idx
     return idcs.numpy()
 
 
-def initialize_q_batch_nonneg(acq_vals: np.ndarray, n: int, eta: float = 1.0, alpha: float = 1e-4) -> np.ndarray:
+def initialize_q_batch_nonneg(acq_vals: np.ndarray, n: int, eta: float = 1.0, alpha: float = 1e-4,
+                              generator=None) -> np.ndarray:
     """Variant botorch uses for non-negative acquisitions (probability of improvement)."""
     v = torch.from_numpy(np.ascontiguousarray(acq_vals, dtype=np.float64))
     n_samples = v.shape[0]
@@ -88,12 +91,12 @@ def initialize_q_batch_nonneg(acq_vals: np.ndarray, n: int, eta: float = 1.0, al
     if bool(max_val <= 0):
         warnings.warn("All acquisition values for raw sampled points are nonpositive, so initial conditions "
                       "are being selected randomly.", RuntimeWarning)
-        return torch.randperm(n=n_samples)[:n].numpy()
+        return torch.randperm(n=n_samples, generator=generator)[:n].numpy()
     pos = v > 0
     num_pos = int(pos.sum())
     if num_pos < n:
         remaining = (~pos).nonzero(as_tuple=False).view(-1)
-        rand = torch.randperm(remaining.shape[0])
+        rand = torch.randperm(remaining.shape[0], generator=generator)
         pos[remaining[rand[: n - num_pos]]] = 1
         return pos.nonzero(as_tuple=False).view(-1).numpy()
     alpha_pos = v >= alpha * max_val
@@ -102,7 +105,7 @@ def initialize_q_batch_nonneg(acq_vals: np.ndarray, n: int, eta: float = 1.0, al
         alpha_pos = v >= alpha * max_val
     alpha_pos_idcs = torch.arange(len(v))[alpha_pos]
     weights = torch.exp(eta * (v[alpha_pos] / max_val - 1))
-    idcs = alpha_pos_idcs[torch.multinomial(weights, n)]
+    idcs = alpha_pos_idcs[torch.multinomial(weights, n, generator=generator)]
     if max_idx not in idcs:
         idcs[-1] = max_idx
     return idcs.numpy()

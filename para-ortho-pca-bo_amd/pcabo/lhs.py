@@ -14,11 +14,14 @@ import numpy as np
 __all__ = ["lhs_center"]
 
 
-def lhs_center(dim: int, samples: int) -> np.ndarray:
+def lhs_center(dim: int, samples: int, rng=None) -> np.ndarray:
+    """`rng`: a `np.random.RandomState` standing in for the legacy global generator (same stream for the same seed) -
+    used where several runs share one process (pcabo.batchrun); None = the global generator, as the reference."""
+    rng = np.random if rng is None else rng
     cut = np.linspace(0, 1, samples + 1)
-    np.random.rand(samples, dim)              # pyDOE draws this and then ignores it for "center"
+    rng.rand(samples, dim)                    # pyDOE draws this and then ignores it for "center"
     centres = (cut[:samples] + cut[1:samples + 1]) / 2
     h = np.empty((samples, dim))
     for j in range(dim):
-        h[:, j] = np.random.permutation(centres)
+        h[:, j] = rng.permutation(centres)
     return h

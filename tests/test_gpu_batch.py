@@ -1,0 +1,86 @@
+"""Batched contexts: B runs advancing in lock-step through pcabo_batch_* must each take, bit for bit,
+the path the same run takes alone in `Algorithms.PCA_BO` (same kernels, same per-run grids; per-run RandomState /
+torch.Generator seeded like the reference's global generators)."""
+import numpy as np
+import pytest
+import torch
+
+from pcabo.bbob import BBOBProblem
+
+pytestmark = pytest.mark.gpu
+
+
+def _single(fid, inst, dim, budget, n_doe, seed):
+    from Algorithms import PCA_BO
+    opt = PCA_BO(budget=budget, n_DoE=n_doe, random_seed=seed, maximization=False)
+    opt(BBOBProblem(fid, inst, dim))
+    return np.vstack(opt.x_evals), np.array(opt.f_evals), opt.current_best, opt.current_best_index
+
+
+def _batched(fid, insts, dim, budget, n_doe, seeds, monkeypatch=None, threads=None):
+    from pcabo.batchrun import BatchedPCABO
+    r = BatchedPCABO([BBOBProblem(fid, i, dim) for i in insts], seeds, budget, n_doe)
+    r.run()
+    return r
+
+
+@pytest.mark.parametrize("dim,budget,n_doe,B", [(10, 70, 30, 5), (40, 200, 120, 3)])
+def test_batched_runs_equal_single_runs_bit_for_bit(native, dim, budget, n_doe, B):
+    torch.set_num_threads(4)
+    insts = list(range(B))
+    seeds = [15000 + 10 * dim + i for i in insts]
+    r = _batched(15, insts, dim, budget, n_doe, seeds)
+    for b, i in enumerate(insts):
+        X, f, best, bi = _single(15, i, dim, budget, n_doe, seeds[b])
+        assert np.array_equal(np.vstack(r.x_evals[b]), X), (dim, b)
+        assert np.array_equal(np.array(r.f_evals[b]), f), (dim, b)
+        assert r.current_best[b] == best and r.current_best_index[b] == bi
+
+
+def test_batch_state_matches_single_context_calls(native):
+    """One lock-step conditioning of 4 runs (different data, same n and d): every run's GP state, search box, scores and
+    one optimize call equal what a stand-alone context computes from the same inputs, bit for bit."""
+    rng = np.random.default_rng(21)
+    B, n, d, q = 4, 150, 12, 512
+    X = rng.uniform(-5, 5, (B, n, d))
+    y = rng.normal(size=(B, n)) * 50 + 300
+    ranks = np.argsort(np.argsort(y, axis=1), axis=1) + 1
+    noise = rng.normal(0, 1e-8, (B, n, d))
+    bt = native.Batch(B, max_n=200, max_d=d, max_q=q)
+    bt.wpca_gp_condition_begin(X, ranks, noise, y)
+    res = bt.wpca_results()
+    boxes = bt.acq_bounds()
+    raw = [boxes[b][0] + (boxes[b][1] - boxes[b][0]) * rng.uniform(size=(q, res[b]["k"])) for b in range(B)]
+    best = [float(y[b].min()) for b in range(B)]
+    vals, status = bt.gp_wait_eval(raw, best)
+    assert not status.any()
+    ics = [raw[b][:10] for b in range(B)]
+    outs, status = bt.optimize_acqf(ics, boxes, best)
+    assert not status.any()
+    z = [outs[b][0][int(np.argmax(outs[b][1]))] for b in range(B)]
+    xs = bt.inverse_map(z)
+    assert len({r["k"] for r in res}) >= 1
+    for b in range(B):
+        c = native.Context(max_n=200, max_d=d, max_q=q)
+        c.set_option(native.OPT_RESIDENT, 0)
+        r1 = c.wpca_gp_condition(X[b], y[b], ranks=ranks[b], noise=noise[b])
+        assert r1["k"] == res[b]["k"]
+        for key in ("data_mean", "pca_mean", "components", "evr"):
+            assert np.array_equal(r1[key], res[b][key]), (b, key)
+        assert np.array_equal(c.acq_bounds(), boxes[b])
+        v1 = c.gp_wait_eval(raw[b], best[b])
+        assert np.array_equal(v1, vals[b]), b
+        st1, stb = c.gp_state(), bt.ctx[b].gp_state()
+        for key in ("L", "R", "alpha", "norm_bounds"):
+            assert np.array_equal(st1[key], stb[key]), (b, key)
+        assert np.array_equal(c.gram(), bt.ctx[b].gram())
+        cand, v, info, failed = c.optimize_acqf(ics[b], boxes[b], best[b])
+        assert np.array_equal(cand, outs[b][0]) and np.array_equal(v, outs[b][1]) and np.array_equal(info, outs[b][2])
+        assert failed == outs[b][3]
+        assert np.array_equal(c.inverse_map(z[b]), xs[b])
+        # the single-context calls also work on a batch's member
+        v2, g2 = bt.ctx[b].acq_eval(ics[b], best[b])
+        v3, g3 = c.acq_eval(ics[b], best[b])
+        assert np.array_equal(v2, v3) and np.array_equal(g2, g3)
+        c.close()
+    bt.close()

@@ -1,0 +1,13 @@
+"""Aggregate rate of B runs advancing in lock-step (pcabo.batchrun) - diagnostic.  usage: gpu_batch_clock.py B [dim] [fid]"""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "para-ortho-pca-bo_amd"))
+import torch
+from pcabo import batchrun
+torch.set_num_threads(4)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+dim = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+fid = int(sys.argv[3]) if len(sys.argv) > 3 else 15
+out = batchrun.bench_block(0, B, fid, dim)
+out.pop("best_f")
+print(json.dumps(out))

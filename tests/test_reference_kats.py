@@ -63,7 +63,7 @@ def test_problem_interface_and_fopt():
     assert p(x) == pytest.approx(p.raw(x) + p.f_opt)
     assert p.raw(p.optimum.x) == pytest.approx(0.0, abs=1e-9)
     with pytest.raises(NotImplementedError):
-        BBOBProblem(16, 0, 5)
+        BBOBProblem(14, 0, 5)
 
 
 def test_f20_on_reference_rows():

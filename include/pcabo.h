@@ -63,8 +63,12 @@ int pcabo_last_error(pcabo_ctx* ctx, char* buf, int buflen);
  *   the acquisition kernel (query points through a mailbox); 0 = one launch per evaluation.  Same arithmetic, same bits.
  * PCABO_OPT_BESTF_F32 (default 1): best_f is rounded to float32 before use, as botorch does when the reference hands it
  *   a Python float (`torch.as_tensor(best_f)`, PCA_BO.py:199-203); 0 keeps all 64 bits (what botorch does when the
- *   objective returned a numpy float64 scalar). */
-enum { PCABO_OPT_RESIDENT = 0, PCABO_OPT_BESTF_F32 = 1 };
+ *   objective returned a numpy float64 scalar).
+ * PCABO_OPT_GROUP_ACQ (default 0; 1 for the contexts of a batch): value+gradient evaluations of up to 32 points run through the
+ *   throughput kernel (one work-group per restart group of <= 5 points and 64-row slab) instead of the per-query
+ *   latency kernels; implies one launch per evaluation.  Same formulas, another summation order (~1e-15 relative), so a
+ *   run is bit-reproducible within a mode, not across modes. */
+enum { PCABO_OPT_RESIDENT = 0, PCABO_OPT_BESTF_F32 = 1, PCABO_OPT_GROUP_ACQ = 2 };
 int pcabo_set_option(pcabo_ctx* ctx, int option, int value);
 
 /* Rows A-C (+D,J): rank-weighted PCA of the evaluated points.

@@ -119,6 +119,12 @@ class PCA_BO(AbstractBayesianOptimizer):
         self.__saved_torch_threads = None
         # gc_freeze: keep the interpreter's cyclic collector away from the loop (0.3-0.45 ms per iteration otherwise,
         # see pcabo/gcguard.py)
+        # acq_kernel: "latency" (default: per-query kernels, resident across the evaluations of an optimize call - the
+        # fastest for ONE run) or "group" (the throughput kernel the batched driver uses; a run then takes, bit for bit,
+        # the path it takes inside a batch - pcabo.batchrun)
+        self.__acq_kernel = str(kwargs.pop("acq_kernel", "latency"))
+        if self.__acq_kernel not in ("latency", "group"):
+            raise ValueError("acq_kernel must be 'latency' or 'group'")
         self.__gc_freeze = bool(kwargs.pop("gc_freeze", _gcguard.enabled_by_default()))
         self.__gc_entered = False
         super().__init__(budget, n_DoE, **kwargs)
@@ -189,6 +195,8 @@ class PCA_BO(AbstractBayesianOptimizer):
             self._pbar.update(self.n_DoE)
         self.__ctx = _native.Context(max_n=self.budget, max_d=self.dimension,
                                      max_q=max(self.__torch_config["RAW_SAMPLES"], 16), device=self.__device)
+        if self.__acq_kernel == "group":
+            self.__ctx.set_option(_native.OPT_GROUP_ACQ, 1)
         self.__X_buf, self.__X_rows = None, 0
         if self.__prefetch is None:
             from pcabo.bbob import BBOBProblem

@@ -885,6 +885,290 @@ __global__ __launch_bounds__(256) void k_acq_combine(const double* __restrict__ 
                      threadIdx.x & 63);
 }
 
+// =====================================================================================================================
+// Throughput variant for batched runs: one work-group per (restart group, 64-row slab of R).
+// k_acq_fast / k_acq_fused above are built for the latency of ONE run: a work-group per (16-row slab, query), each
+// recomputing the kernel vector - ~290 groups of ~10 us for the 10 queries of a run at n = 449, which is the right
+// trade for a single run and 100x the necessary CU-time when thirty runs share the chip.  Here a work-group serves the
+// (up to) GQ = 5 queries of one joint L-BFGS-B problem together:
+//   ks      thread per column j: one pass over ZnT[:, j] serves all 5 queries (ks and the radial factor stay in LDS / registers)
+//   v       v_q[i] = sum_j R[i][j] ks_q[j] for the slab's 64 rows: R tiles (64 x 32) go through LDS and are read back
+//           row-wise, so a LANE OWNS A ROW - no cross-lane reduction; the four waves split the columns of a tile
+//   w       w_q[j] = sum_{i in slab} R[i][j] v_q[i]: thread per column, coalesced straight from global - no reduction either
+//   grad    gs_q[c] = sum_j w_q[j] cf_q[j] (xn_q[c] - zn[c][j]) (+ the alpha part restricted to the slab's rows): wave per
+//           component, lanes over j, DPP wave sums
+// R is read once per pass for 5 queries (two passes: the second needs all of v), ZnT twice.  Slab partials are combined
+// by the last work-group to arrive at the queries' tickets, as above; it finishes its 5 queries side by side (scalar
+// chains on different waves, the gradient sums one thread per (query, component)).
+// The table in the QueryArgs slot names the groups of the launch: 32-bit entries run << 16 | first query << 8 | count.
+// Arithmetic differs from the kernels above in summation order only (~1e-15 relative): it is selected per context /
+// batch (PCABO_OPT_GROUP_ACQ), never mixed within a run.
+#define GQ 5
+#define GT_LD 33            // LDS leading dimension of the 64 x 32 tile (odd: row-wise reads conflict-free)
+template <int NT>           // NT = ceil(NP / 256): columns per thread in the thread-per-column phases
+__global__ __launch_bounds__(256) void k_acq_group(
+    QueryArgs qa, const double* __restrict__ Xq, int n, int k, int NP, int ld,
+    const double* __restrict__ ZnT, const double* __restrict__ R, const double* __restrict__ alpha,
+    const double* __restrict__ bounds4, const double* __restrict__ ystats, AcqParams prm, double* partial,
+    unsigned int* counters, double* __restrict__ val, double* __restrict__ grad, double* host_val, double* host_grad,
+    HostMirror* hm, unsigned long long seq, AcqBatch ab) {
+  const unsigned ent = reinterpret_cast<const unsigned*>(qa.x)[blockIdx.y];
+  const unsigned run_ = ent >> 16;
+  const int q0 = (int)((ent >> 8) & 0xffu), nq = (int)(ent & 0xffu);
+  if (ab.zs) {
+    ZnT = zrun(ZnT, ab.zs, run_); R = zrun(R, ab.zs, run_); alpha = zrun(alpha, ab.zs, run_);
+    bounds4 = zrun(bounds4, ab.zs, run_); ystats = zrun(ystats, ab.zs, run_); partial = zrun(partial, ab.zs, run_);
+    counters = zrun(counters, ab.zs, run_); val = zrun(val, ab.zs, run_); grad = zrun(grad, ab.zs, run_);
+    Xq = zrun(Xq, ab.xq_host ? ab.hzs : ab.zs, run_);
+    host_val = zrun(host_val, ab.hzs, run_); host_grad = zrun(host_grad, ab.hzs, run_); hm = zrun(hm, ab.hzs, run_);
+    if (ab.k_dev) k = *zrun(ab.k_dev, ab.zs, run_);
+    if (ab.bestf) prm.best_f = *zrun(ab.bestf, ab.zs, run_);
+  }
+  const int tid = threadIdx.x, l = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int s = blockIdx.x, S = gridDim.x;
+  const int r0 = 64 * s, ncol = 64 * (s + 1);       // the slab's rows; columns >= ncol hold zeros in these rows
+  const int KS = (k + 1) & ~1;                        // stride of a query's coordinates in LDS
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+  double* s_ks = s_dyn;                               // [GQ][NP]  kernel vectors, later t_sigma = w * cf
+  double* s_tile = s_ks + GQ * NP;                    // [64][GT_LD]
+  double* s_v = s_tile + 64 * GT_LD + 1;              // [64][8]   v of the slab's rows (queries contiguous)
+  double* s_part = s_v + 64 * 8;                      // [4][GQ][64] per-wave partial row sums
+  double* s_xn = s_part + 4 * GQ * 64;                // [GQ][KS]
+  double* s_tm = s_xn + GQ * PCABO_MAXD;              // [GQ][64]  alpha_j cf_q[j] for the slab's own rows
+  double* s_coef = s_tm + GQ * 64;                    // [GQ][2]
+  int* s_flag = reinterpret_cast<int*>(s_coef + 2 * GQ);   // [GQ + 1]
+  const double inv_ls = prm.inv_ls;
+  const int kernel = prm.kernel;
+
+  // ---- normalised query points (queries beyond nq repeat the first: computed, never published) -----------------
+  for (int idx = tid; idx < GQ * k; idx += 256) {
+    const int q = idx / k, c = idx - q * k;
+    const int qq = q < nq ? q : 0;
+    const double lo = bounds4[c], hi = bounds4[PCABO_MAXD + c];
+    s_xn[q * KS + c] = (Xq[(size_t)(q0 + qq) * k + c] - lo) / (hi - lo);
+  }
+  __syncthreads();
+  // ---- ks and the radial derivative factor, all queries per pass over ZnT -----------------------------------------
+  double cfr[NT][GQ];
+  const double s5 = 2.23606797749979;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int j = tid + 256 * t;
+    double sq[GQ];
+#pragma unroll
+    for (int q = 0; q < GQ; ++q) sq[q] = 0.0;
+    if (j < n) {
+      for (int c = 0; c < k; ++c) {
+        const double z = ZnT[(size_t)c * ld + j];
+#pragma unroll
+        for (int q = 0; q < GQ; ++q) { const double d = s_xn[q * KS + c] - z; sq[q] += d * d; }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < GQ; ++q) {
+      double ks = 0.0, cf = 0.0;
+      if (j < n) {
+        const double sqq = sq[q] * (inv_ls * inv_ls);
+        if (kernel == 1) {
+          ks = exp(-0.5 * sqq);
+          cf = -ks * inv_ls * inv_ls;
+        } else {
+          const double dist = sqrt(fmax(sqq, 1e-30));
+          const double e = exp(-s5 * dist);
+          ks = ((s5 * dist + 1.0) + (5.0 / 3.0) * (dist * dist)) * e;
+          cf = -(5.0 / 3.0) * (1.0 + s5 * dist) * e * inv_ls * inv_ls;
+        }
+      }
+      if (j < NP) s_ks[q * NP + j] = ks;
+      cfr[t][q] = cf;
+    }
+  }
+  __syncthreads();
+  // ---- v for the slab's rows: tiles of 64 rows x 32 columns through LDS, a lane owns a row ----------------------
+  {
+    double acc[GQ];
+#pragma unroll
+    for (int q = 0; q < GQ; ++q) acc[q] = 0.0;
+    const int ntile = ncol / 32;
+    double nx[8];
+    const double* Rs = R + (size_t)r0 * ld;
+    auto fetch = [&](int J2) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int idx = tid + 256 * u; nx[u] = Rs[(size_t)(idx >> 5) * ld + J2 * 32 + (idx & 31)]; }
+    };
+    fetch(0);
+    for (int J2 = 0; J2 < ntile; ++J2) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int idx = tid + 256 * u; s_tile[(idx >> 5) * GT_LD + (idx & 31)] = nx[u]; }
+      __syncthreads();
+      if (J2 + 1 < ntile) fetch(J2 + 1);
+      const double* trow = s_tile + l * GT_LD + 8 * w;
+      const double* kcol = s_ks + J2 * 32 + 8 * w;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const double rv = trow[jj];
+#pragma unroll
+        for (int q = 0; q < GQ; ++q) acc[q] += rv * kcol[q * NP + jj];
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < GQ; ++q) s_part[(w * GQ + q) * 64 + l] = acc[q];
+  }
+  __syncthreads();
+  for (int idx = tid; idx < GQ * 64; idx += 256) {
+    const int q = idx >> 6, m = idx & 63;
+    s_v[m * 8 + q] = ((s_part[(0 * GQ + q) * 64 + m] + s_part[(1 * GQ + q) * 64 + m]) + s_part[(2 * GQ + q) * 64 + m]) +
+                     s_part[(3 * GQ + q) * 64 + m];
+  }
+  __syncthreads();
+  // ---- slab contributions to |v|^2 and mu_s = alpha . ks: wave q (wave 0 also the fifth query) -------------------
+  for (int q = w; q < nq; q += 4) {
+    const int i = r0 + l;
+    const double vi = s_v[l * 8 + q];
+    double vv = vi * vi;
+    double mu = i < n ? alpha[i] * s_ks[q * NP + i] : 0.0;
+    vv = wave_sum(vv);
+    mu = wave_sum(mu);
+    if (l == 0) {
+      double* out = partial + ((size_t)(q0 + q) * S + s) * PSTRIDE;
+      st_wt(out + 0, vv); st_wt(out + 1, mu);
+    }
+  }
+  if (prm.want_grad) {
+    // ---- w (slab part), thread per column: w_q[j] = sum_m R[r0 + m][j] v_q[m] --------------------------------------
+    double wacc[NT][GQ];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q = 0; q < GQ; ++q) wacc[t][q] = 0.0;
+    for (int m0 = 0; m0 < 64; m0 += 8) {
+      double rr[8][NT];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int j = tid + 256 * t;
+          rr[u][t] = j < ncol ? R[(size_t)(r0 + m0 + u) * ld + j] : 0.0;
+        }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        double vq[GQ];
+#pragma unroll
+        for (int q = 0; q < GQ; ++q) vq[q] = s_v[(m0 + u) * 8 + q];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int q = 0; q < GQ; ++q) wacc[t][q] += rr[u][t] * vq[q];
+      }
+    }
+    __syncthreads();                      // every wave has read the ks it needed (mu above): s_ks becomes t_sigma
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int j = tid + 256 * t;
+      if (j < NP) {
+        const bool mine = j >= r0 && j < r0 + 64;
+        const double aj = (mine && j < n) ? alpha[j] : 0.0;
+#pragma unroll
+        for (int q = 0; q < GQ; ++q) {
+          s_ks[q * NP + j] = wacc[t][q] * cfr[t][q];
+          if (mine) s_tm[q * 64 + (j - r0)] = aj * cfr[t][q];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- contraction with (xn_c - zn_jc): wave per component, lanes over points -----------------------------------
+    const int jmax = n < ncol ? n : ncol;
+    for (int c = w; c < k; c += 4) {
+      const double* zrow = ZnT + (size_t)c * ld;
+      double gs[GQ], gm[GQ], xc[GQ];
+#pragma unroll
+      for (int q = 0; q < GQ; ++q) { gs[q] = 0.0; gm[q] = 0.0; xc[q] = s_xn[q * KS + c]; }
+      for (int j = l; j < jmax; j += 64) {
+        const double z = zrow[j];
+#pragma unroll
+        for (int q = 0; q < GQ; ++q) gs[q] += s_ks[q * NP + j] * (xc[q] - z);
+      }
+      if (r0 + l < n) {
+        const double z = zrow[r0 + l];
+#pragma unroll
+        for (int q = 0; q < GQ; ++q) gm[q] += s_tm[q * 64 + l] * (xc[q] - z);
+      }
+#pragma unroll
+      for (int q = 0; q < GQ; ++q) {
+        const double a = wave_sum(gs[q]), b2 = wave_sum(gm[q]);
+        if (l == 0 && q < nq) {
+          double* out = partial + ((size_t)(q0 + q) * S + s) * PSTRIDE;
+          st_wt(out + 2 + c, a); st_wt(out + 2 + PCABO_MAXD + c, b2);
+        }
+      }
+    }
+  }
+  // ---- tickets: the last slab group of a query finishes it ---------------------------------------------------------
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    int any = 0;
+    for (int q = 0; q < nq; ++q) {
+      const unsigned int t = __hip_atomic_fetch_add(&counters[q0 + q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = (t % (unsigned int)S) == (unsigned int)(S - 1);
+      s_flag[q] = last;
+      any |= last;
+    }
+    if (any) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    s_flag[GQ] = any;
+  }
+  __syncthreads();
+  if (!s_flag[GQ]) return;
+  // scalar chains side by side: wave q (wave 0 also the fifth)
+  for (int q = w; q < nq; q += 4)
+    if (s_flag[q])
+      acq_finish_scalar(partial + (size_t)(q0 + q) * S * PSTRIDE, S, q0 + q, ystats, prm, val, host_val, s_coef + 2 * q, l);
+  __syncthreads();
+  if (prm.want_grad) {
+    for (int idx = tid; idx < nq * k; idx += 256) {          // one thread per (query, component): slabs in order
+      const int q = idx / k, c = idx - q * k;
+      if (!s_flag[q]) continue;
+      const double* base = partial + (size_t)(q0 + q) * S * PSTRIDE;
+      double gs = 0.0, gm = 0.0;
+      for (int sl = 0; sl < S; ++sl) { gs += base[(size_t)sl * PSTRIDE + 2 + c]; gm += base[(size_t)sl * PSTRIDE + 2 + PCABO_MAXD + c]; }
+      const double g = __fma_rn(s_coef[2 * q], gm, s_coef[2 * q + 1] * gs) / (bounds4[PCABO_MAXD + c] - bounds4[c]);
+      grad[(size_t)(q0 + q) * k + c] = g;
+      if (host_grad) host_grad[(size_t)(q0 + q) * k + c] = g;
+    }
+  }
+  // publish: every thread's host writes are out before the sequence words follow
+  __threadfence_system();
+  __syncthreads();
+  if (hm && tid < nq && s_flag[tid])
+    __hip_atomic_store(const_cast<unsigned long long*>(&hm->qflag[q0 + tid]), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+bool acq_group_possible(int NP, int k) { return NP <= 1280 && k <= PCABO_MAXD; }
+
+void launch_acq_group(hipStream_t st, const QueryArgs* tab, int entries, const double* Xq, int n, int k, int NP, int ld,
+                      const double* ZnT, const double* R, const double* alpha, const double* bounds4, const double* ystats,
+                      AcqParams p, double* partial, unsigned int* counters, double* val, double* grad, double* host_val,
+                      double* host_grad, HostMirror* hm, unsigned long long seq, AcqBatch ab) {
+  const size_t lds = ((size_t)GQ * NP + 64 * GT_LD + 1 + 64 * 8 + 4 * GQ * 64 + GQ * PCABO_MAXD + GQ * 64 + 2 * GQ + 8) * sizeof(double);
+  const dim3 grid(NP / 64, entries), block(256);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)k_acq_group<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    attr_set = true;
+  }
+#define GROUP_ARGS *tab, Xq, n, k, NP, ld, ZnT, R, alpha, bounds4, ystats, p, partial, counters, val, grad, host_val, host_grad, \
+                   hm, seq, ab
+  if (NP <= 256) hipLaunchKernelGGL(k_acq_group<1>, grid, block, lds, st, GROUP_ARGS);
+  else if (NP <= 512) hipLaunchKernelGGL(k_acq_group<2>, grid, block, lds, st, GROUP_ARGS);
+  else hipLaunchKernelGGL(k_acq_group<5>, grid, block, lds, st, GROUP_ARGS);
+#undef GROUP_ARGS
+}
+
 // Resident mode needs every group of the grid on the chip at the same time (groups wait for one another through the
 // mailbox and the tickets): one group per CU is always possible for these kernels, so S q <= number of CUs is enough.
 bool acq_server_possible(int q, int n, int k, int NP) {

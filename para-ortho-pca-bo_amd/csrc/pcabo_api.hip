@@ -115,6 +115,7 @@ struct pcabo_ctx {
   bool mail_bar = false;                 // the host writes dMail itself through the PCIe BAR (no relay group, no hMail)
   MailPair* dPairs = nullptr;            // its partial records as (value, tag) pairs: 32 queries x 32 slabs
   bool opt_resident = true;             // PCABO_OPT_RESIDENT: may pcabo_optimize_acqf use the resident acquisition kernel
+  bool opt_group_acq = false;           // PCABO_OPT_GROUP_ACQ: gradient evaluations through k_acq_group (throughput variant)
   bool bestf_f32 = true;                // PCABO_OPT_BESTF_F32: best_f rounded like torch.as_tensor(python float)
   int srv_penalty = 0;                   // > 0: the next calls use plain launches (the GPU looked shared, see pcabo_optimize_acqf)
   unsigned long long seq = 0;
@@ -491,6 +492,7 @@ int pcabo_set_option(pcabo_ctx* ctx, int option, int value) {
   switch (option) {
     case PCABO_OPT_RESIDENT: ctx->opt_resident = value != 0 && !ctx->in_batch; return PCABO_OK;   // (never inside a batch)
     case PCABO_OPT_BESTF_F32: ctx->bestf_f32 = value != 0; return PCABO_OK;
+    case PCABO_OPT_GROUP_ACQ: ctx->opt_group_acq = value != 0; return PCABO_OK;
     default: return set_err(ctx, PCABO_ERR_ARG, "pcabo_set_option: unknown option %s%d", "", option);
   }
 }
@@ -835,6 +837,45 @@ static int eval_staged(pcabo_ctx* ctx, int nq, AcqParams& p) {
   return PCABO_OK;
 }
 
+// The same for restart groups through the throughput kernel (PCABO_OPT_GROUP_ACQ): group g = the gn[g] <= 5 points staged
+// at query slots g0[g].. of ctx->hXq, which the kernel reads in place (pinned memory); one work-group per (group, 64-row slab).
+static int eval_staged_groups(pcabo_ctx* ctx, const int* g0, const int* gn, int ng, AcqParams& p) {
+  hipStream_t s = ctx->stream;
+  const unsigned long long seq = ++ctx->seq;
+  QueryArgs tab;
+  unsigned* ent = reinterpret_cast<unsigned*>(tab.x);
+  for (int g = 0; g < ng; ++g) ent[g] = ((unsigned)g0[g] << 8) | (unsigned)gn[g];
+  {
+    int nq = 0;
+    for (int g = 0; g < ng; ++g) nq += gn[g];
+    ProfScope ps(ctx, 4, acq_bytes(ctx->n, ctx->k, nq, p.want_grad), acq_flops(ctx->n, ctx->k, nq, p.want_grad));
+    launch_acq_group(s, &tab, ng, ctx->hXq, ctx->n, ctx->k, ctx->NP, ctx->ld, ctx->dZnT, ctx->dR, ctx->dAlpha, ctx->dBounds4,
+                     ctx->dYstats, p, ctx->dPartial, ctx->dCounters + PCABO_GROUP_CNT_OFFSET, ctx->dVal, ctx->dGrad, ctx->hVal,
+                     ctx->hGrad, ctx->hm, seq, AcqBatch());
+  }
+  HIPCHK(hipGetLastError());
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned long spins = 0;
+  for (int g = 0; g < ng; ++g)
+    for (int j = 0; j < gn[g]; ++j) {
+      while (__atomic_load_n(&ctx->hm->qflag[g0[g] + j], __ATOMIC_ACQUIRE) != seq) {
+        if ((++spins & 0xFFFF) == 0) {
+          if (hipStreamQuery(s) == hipSuccess) {
+            if (__atomic_load_n(&ctx->hm->qflag[g0[g] + j], __ATOMIC_ACQUIRE) == seq) break;
+            HIPCHK(hipGetLastError());
+            return set_err(ctx, PCABO_ERR_TIMEOUT, "acquisition kernel finished without publishing its results%s", "");
+          }
+          if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 20.0)
+            return set_err(ctx, PCABO_ERR_TIMEOUT, "device did not publish acquisition results%s", "");
+        }
+      }
+    }
+  return PCABO_OK;
+}
+static bool group_mode(const pcabo_ctx* ctx, int q, int want_grad) {
+  return ctx->opt_group_acq && want_grad && q <= PCABO_INLAUNCH_MAXQ && acq_group_possible(ctx->NP, ctx->k);
+}
+
 int pcabo_acq_eval(pcabo_ctx* ctx, const double* Xq, int q, double best_f, int maximize, int acq, double* val,
                    double* grad) {
   if (!ctx) return PCABO_ERR_ARG;
@@ -851,7 +892,14 @@ int pcabo_acq_eval(pcabo_ctx* ctx, const double* Xq, int q, double best_f, int m
     HIPCHK(hipStreamSynchronize(s));
   }
   AcqParams p = make_params(ctx, best_f, maximize, acq, grad ? 1 : 0);
-  int rc = eval_staged(ctx, q, p);
+  int rc;
+  if (group_mode(ctx, q, grad != nullptr) && ctx->ptr_mode == PCABO_PTR_HOST) {
+    int g0[(PCABO_INLAUNCH_MAXQ + PCABO_GROUP_Q - 1) / PCABO_GROUP_Q], gn[(PCABO_INLAUNCH_MAXQ + PCABO_GROUP_Q - 1) / PCABO_GROUP_Q], ng = 0;
+    for (int a = 0; a < q; a += PCABO_GROUP_Q) { g0[ng] = a; gn[ng] = std::min(PCABO_GROUP_Q, q - a); ++ng; }
+    rc = eval_staged_groups(ctx, g0, gn, ng, p);
+  } else {
+    rc = eval_staged(ctx, q, p);
+  }
   if (rc != PCABO_OK) return rc;
   if (ctx->ptr_mode == PCABO_PTR_HOST) {
     memcpy(val, ctx->hVal, (size_t)q * sizeof(double));
@@ -1037,7 +1085,7 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
     int rc;
     if (round_no == 1 && (ctx->alone_age++ & 7) == 0) ctx->alone = presence_alone(ctx->device);
     if (round_no == 1 && ctx->srv_penalty > 0) --ctx->srv_penalty;
-    else if (round_no == 1 && ctx->opt_resident && ctx->alone && !ctx->prof && acq_server_possible(nq, ctx->n, k, ctx->NP)) {
+    else if (round_no == 1 && ctx->opt_resident && !ctx->opt_group_acq && ctx->alone && !ctx->prof && acq_server_possible(nq, ctx->n, k, ctx->NP)) {
       // the evaluations of this call go to ONE resident launch (see k_acq_fast): no launch and no operand refill per round
       srv_cap = nq;
       launch_acq(ctx->stream, nullptr, nullptr, srv_cap, ctx->n, k, ctx->NP, ctx->ld, ctx->dZnT, ctx->dR, ctx->dAlpha,
@@ -1139,6 +1187,10 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
         // one after the other, whole calls at a time; plain launches interleave much better, so use them for a while.
         ctx->srv_penalty = 40;
       }
+    } else if (group_mode(ctx, nq, 1) && batch_limit <= PCABO_GROUP_Q && ngroups <= 8) {
+      int g0[8], gn[8], ng = 0;
+      for (int gi = 0; gi < ngroups; ++gi) if (qoff[gi] >= 0) { g0[ng] = qoff[gi]; gn[ng] = gsize[gi]; ++ng; }
+      rc = eval_staged_groups(ctx, g0, gn, ng, p);
     } else {
       rc = eval_staged(ctx, nq, p);
     }
@@ -1473,6 +1525,7 @@ struct pcabo_batch {
   int kernel = 0;
   int gcur = 0, vprev_d = 0;             // eigenvector ping-pong of ALL runs (they advance together)
   int cnt_S = 0; bool cnt_dirty = true;
+  bool group_acq = true;                 // L-BFGS-B rounds through k_acq_group (PCABO_BATCH_ACQ=slab: the per-query kernels)
   int G = 0;                             // gangs = worker threads of the L-BFGS-B phase
   std::vector<hipStream_t> gstream;
   GangPool pool;
@@ -1555,6 +1608,8 @@ int pcabo_batch_create(int device, int B, int max_n, int max_d, int max_q, pcabo
   batch->gstream.assign(T, nullptr);
   for (int g = 0; g < T; ++g) BHIPCHK(hipStreamCreateWithFlags(&batch->gstream[g], hipStreamNonBlocking));
   batch->pool.start(T);
+  if (const char* e = getenv("PCABO_BATCH_ACQ")) batch->group_acq = strcmp(e, "slab") != 0;
+  for (pcabo_ctx* c : batch->ctx) c->opt_group_acq = batch->group_acq;      // a run's single-context calls match its batch
   batch->seq.store(((unsigned long long)(getpid() & 0xffff) << 44) + (1ull << 43));
   return PCABO_OK;
 }
@@ -1810,6 +1865,27 @@ int pcabo_batch_optimize_acqf(pcabo_batch* batch, const double* ics, int num_res
     unsigned* ent = reinterpret_cast<unsigned*>(tab.x);
     struct Pending { int b, gi; };
     std::vector<Pending> pend;
+    const bool use_group = batch->group_acq && batch_limit <= PCABO_GROUP_Q && acq_group_possible(batch->NP, kmax);
+    // group kernel: one table entry per restart group (run << 16 | first query << 8 | count), its own ticket words
+    auto launch_groups_and_wait = [&](int nent, const AcqParams& p, unsigned long long seq) -> bool {
+      AcqBatch ab = batch_ab(batch, 1, 1);
+      launch_acq_group(st, &tab, nent, c0->hXq, batch->n, kmax, batch->NP, c0->ld, c0->dZnT, c0->dR, c0->dAlpha, c0->dBounds4,
+                       c0->dYstats, p, c0->dPartial, c0->dCounters + PCABO_GROUP_CNT_OFFSET, c0->dVal, c0->dGrad, c0->hVal,
+                       c0->hGrad, c0->hm, seq, ab);
+      if (hipGetLastError() != hipSuccess) return false;
+      const auto t0 = std::chrono::steady_clock::now();
+      unsigned long spins = 0;
+      for (int e = 0; e < nent; ++e) {
+        const pcabo_ctx* c = batch->ctx[ent[e] >> 16];
+        const int q0 = (int)((ent[e] >> 8) & 0xffu), nqe = (int)(ent[e] & 0xffu);
+        for (int j = 0; j < nqe; ++j)
+          while (__atomic_load_n(&c->hm->qflag[q0 + j], __ATOMIC_ACQUIRE) != seq) {
+            if ((++spins & 0xFFFF) == 0 &&
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 20.0) return false;
+          }
+      }
+      return true;
+    };
     auto launch_and_wait = [&](int nent, const AcqParams& p, unsigned long long seq) -> bool {
       launch_acq(st, &tab, c0->hXq, PCABO_INLAUNCH_MAXQ, batch->n, kmax, batch->NP, c0->ld, c0->dZnT, c0->dR, c0->dAlpha,
                  c0->dBounds4, c0->dYstats, p, c0->dPartial, c0->dCounters, c0->dVal, c0->dGrad, c0->hVal, c0->hGrad, c0->hm,
@@ -1840,13 +1916,14 @@ int pcabo_batch_optimize_acqf(pcabo_batch* batch, const double* ics, int num_res
           if (!rg.active) continue;
           if (nent + rg.nq > table_cap) continue;            // (cannot happen: <= 32 queries per run, gangs are small)
           memcpy(c->hXq + (size_t)rg.q0 * c->k, rg.x.data(), (size_t)rg.nq * c->k * sizeof(double));
-          for (int j = 0; j < rg.nq; ++j) ent[nent++] = ((unsigned)b << 16) | (unsigned)(rg.q0 + j);
+          if (use_group) ent[nent++] = ((unsigned)b << 16) | ((unsigned)rg.q0 << 8) | (unsigned)rg.nq;
+          else for (int j = 0; j < rg.nq; ++j) ent[nent++] = ((unsigned)b << 16) | (unsigned)(rg.q0 + j);
           pend.push_back({b, gi});
         }
       }
       if (nent == 0) break;
       const unsigned long long seq = batch->seq.fetch_add(1) + 1;
-      if (!launch_and_wait(nent, pg, seq)) { hip_failed.store(1); return; }
+      if (!(use_group ? launch_groups_and_wait(nent, pg, seq) : launch_and_wait(nent, pg, seq))) { hip_failed.store(1); return; }
       for (const Pending& pe : pend) {
         pcabo_ctx* c = batch->ctx[pe.b];
         if (!groups[pe.b][pe.gi].absorb(c->hVal, c->hGrad)) {

@@ -186,6 +186,15 @@ void launch_acq(hipStream_t s, const QueryArgs* qa, const double* Xq, int q, int
                 double* grad, double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq,
                 const MailPair* host_mail = nullptr, MailPair* dev_mail = nullptr, MailPair* part_pairs = nullptr,
                 AcqBatch ab = AcqBatch(), int B = 1, int table_entries = 0);
+// throughput variant: one work-group per (restart group of <= 5 queries, 64-row slab); `tab` holds `entries` 32-bit words
+// run << 16 | first query << 8 | count (see k_acq_group)
+#define PCABO_GROUP_Q 5
+#define PCABO_GROUP_CNT_OFFSET 8192      // its tickets live in the upper half of the counter array (other slab count)
+bool acq_group_possible(int NP, int k);
+void launch_acq_group(hipStream_t st, const QueryArgs* tab, int entries, const double* Xq, int n, int k, int NP, int ld,
+                      const double* ZnT, const double* R, const double* alpha, const double* bounds4, const double* ystats,
+                      AcqParams p, double* partial, unsigned int* counters, double* val, double* grad, double* host_val,
+                      double* host_grad, HostMirror* hm, unsigned long long seq, AcqBatch ab);
 // resident mode available for this shape? (fast path + every group of the grid co-resident)
 bool acq_server_possible(int q, int n, int k, int NP);
 int acq_slabs(int NP);

@@ -16,7 +16,7 @@ ABI_VERSION = 1
 KERNEL_MATERN52, KERNEL_RBF = 0, 1
 ACQ_LOG_EI, ACQ_PI = 0, 1
 PTR_HOST, PTR_DEVICE = 0, 1
-OPT_RESIDENT, OPT_BESTF_F32 = 0, 1
+OPT_RESIDENT, OPT_BESTF_F32, OPT_GROUP_ACQ = 0, 1, 2
 PROFILE_GROUPS = ("wpca", "gram", "cholesky", "root_inverse_alpha", "acq_partial", "acq_large_batches")
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "lib", "libpcabo.so")

@@ -10,9 +10,9 @@ from pcabo.bbob import BBOBProblem
 pytestmark = pytest.mark.gpu
 
 
-def _single(fid, inst, dim, budget, n_doe, seed):
+def _single(fid, inst, dim, budget, n_doe, seed, acq_kernel="latency"):
     from Algorithms import PCA_BO
-    opt = PCA_BO(budget=budget, n_DoE=n_doe, random_seed=seed, maximization=False)
+    opt = PCA_BO(budget=budget, n_DoE=n_doe, random_seed=seed, maximization=False, acq_kernel=acq_kernel)
     opt(BBOBProblem(fid, inst, dim))
     return np.vstack(opt.x_evals), np.array(opt.f_evals), opt.current_best, opt.current_best_index
 
@@ -24,14 +24,19 @@ def _batched(fid, insts, dim, budget, n_doe, seeds, monkeypatch=None, threads=No
     return r
 
 
+@pytest.mark.parametrize("mode", ["group", "slab"])
 @pytest.mark.parametrize("dim,budget,n_doe,B", [(10, 70, 30, 5), (40, 200, 120, 3)])
-def test_batched_runs_equal_single_runs_bit_for_bit(native, dim, budget, n_doe, B):
+def test_batched_runs_equal_single_runs_bit_for_bit(native, monkeypatch, dim, budget, n_doe, B, mode):
+    """mode "group": the batch's default - L-BFGS-B rounds through the throughput kernel k_acq_group; the single run takes
+    the same kernel (acq_kernel="group").  mode "slab": the per-query kernels on both sides (the single run's default,
+    resident kernel included: same arithmetic as one launch per evaluation)."""
     torch.set_num_threads(4)
+    monkeypatch.setenv("PCABO_BATCH_ACQ", mode)
     insts = list(range(B))
     seeds = [15000 + 10 * dim + i for i in insts]
     r = _batched(15, insts, dim, budget, n_doe, seeds)
     for b, i in enumerate(insts):
-        X, f, best, bi = _single(15, i, dim, budget, n_doe, seeds[b])
+        X, f, best, bi = _single(15, i, dim, budget, n_doe, seeds[b], "group" if mode == "group" else "latency")
         assert np.array_equal(np.vstack(r.x_evals[b]), X), (dim, b)
         assert np.array_equal(np.array(r.f_evals[b]), f), (dim, b)
         assert r.current_best[b] == best and r.current_best_index[b] == bi
@@ -62,7 +67,7 @@ def test_batch_state_matches_single_context_calls(native):
     assert len({r["k"] for r in res}) >= 1
     for b in range(B):
         c = native.Context(max_n=200, max_d=d, max_q=q)
-        c.set_option(native.OPT_RESIDENT, 0)
+        c.set_option(native.OPT_GROUP_ACQ, 1)             # the batch's default kernel for value+gradient evaluations
         r1 = c.wpca_gp_condition(X[b], y[b], ranks=ranks[b], noise=noise[b])
         assert r1["k"] == res[b]["k"]
         for key in ("data_mean", "pca_mean", "components", "evr"):

@@ -97,6 +97,15 @@ def _check_state(native, ctx, rec, tr, stats):
     s["val"] = float((np.abs(v - ov) / np.maximum(1.0, np.abs(ov))).max())
     s["grad"] = _rel(g, og)
     assert s["val"] < 1e-8 and s["grad"] < 1e-6, s
+    # the throughput kernel of the batched driver (k_acq_group: 5 queries per work-group, 64-row slabs) on the same points
+    ctx.set_option(native.OPT_GROUP_ACQ, 1)
+    vg, gg = ctx.acq_eval(Xs, rec.best_f, False)
+    v7, g7 = ctx.acq_eval(Xs[:7], rec.best_f, False)            # a full group and one of two points
+    ctx.set_option(native.OPT_GROUP_ACQ, 0)
+    s["val_group"] = float((np.abs(vg - ov) / np.maximum(1.0, np.abs(ov))).max())
+    s["grad_group"] = _rel(gg, og)
+    assert s["val_group"] < 1e-8 and s["grad_group"] < 1e-6, s
+    assert np.array_equal(v7, vg[:7]) and np.array_equal(g7, gg[:7])       # a point's numbers do not depend on its group
     # value-only path and single queries: the same arithmetic
     assert np.array_equal(ctx.acq_eval(Xs, rec.best_f, False, grad=False), v)
     v1, g1 = ctx.acq_eval(Xs[3:4], rec.best_f, False)

@@ -237,6 +237,10 @@ int pcabo_batch_gp_condition_end_eval(pcabo_batch* batch, const double* Xq, int 
 int pcabo_batch_optimize_acqf(pcabo_batch* batch, const double* ics, int num_restarts, int batch_limit,
                               const double* bounds, int maxiter, const double* best_f, int maximize, int acq,
                               double* cand, double* vals, int* info, int* failed, int* status);
+/* Device time of the phases of the last pcabo_batch_wpca_gp_condition_begin (HIP events on the batch's stream; call once
+ * that conditioning has been waited for): ms[0] rows A-C, ms[1] Normalize + Gram, ms[2] Cholesky, ms[3] root inverse + alpha. */
+int pcabo_batch_set_profiling(pcabo_batch* batch, int enabled);
+int pcabo_batch_get_profile(pcabo_batch* batch, double* ms);
 /* Row O for every run: z[B][max_d] (k_b entries used) -> x[B][d]. */
 int pcabo_batch_inverse_map(pcabo_batch* batch, const double* z, double* x);
 

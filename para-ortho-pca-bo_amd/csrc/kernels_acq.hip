@@ -904,7 +904,7 @@ __global__ __launch_bounds__(256) void k_acq_combine(const double* __restrict__ 
 // Arithmetic differs from the kernels above in summation order only (~1e-15 relative): it is selected per context /
 // batch (PCABO_OPT_GROUP_ACQ), never mixed within a run.
 #define GQ 5
-#define GT_LD 33            // LDS leading dimension of the 64 x 32 tile (odd: row-wise reads conflict-free)
+#define GT_LD 17            // LDS leading dimension of a wave's 64 x 16 tile (odd: row-wise reads conflict-free)
 template <int NT>           // NT = ceil(NP / 256): columns per thread in the thread-per-column phases
 __global__ __launch_bounds__(256) void k_acq_group(
     QueryArgs qa, const double* __restrict__ Xq, int n, int k, int NP, int ld,
@@ -931,13 +931,13 @@ __global__ __launch_bounds__(256) void k_acq_group(
   const int KS = (k + 1) & ~1;                        // stride of a query's coordinates in LDS
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
   double* s_ks = s_dyn;                               // [GQ][NP]  kernel vectors, later t_sigma = w * cf
-  double* s_tile = s_ks + GQ * NP;                    // [64][GT_LD]
-  double* s_v = s_tile + 64 * GT_LD + 1;              // [64][8]   v of the slab's rows (queries contiguous)
-  double* s_part = s_v + 64 * 8;                      // [4][GQ][64] per-wave partial row sums
-  double* s_xn = s_part + 4 * GQ * 64;                // [GQ][KS]
-  double* s_tm = s_xn + GQ * PCABO_MAXD;              // [GQ][64]  alpha_j cf_q[j] for the slab's own rows
+  double* s_tile = s_ks + GQ * NP;                    // [4 waves][64][GT_LD] wave-private transposing tiles (64 rows x 16 columns)
+  double* s_v = s_tile + 4 * 64 * GT_LD;              // [64][8]   v of the slab's rows (queries contiguous)
+  double* s_tm = s_v + 64 * 8;                        // [GQ][64]  alpha_j cf_q[j] for the slab's own rows
   double* s_coef = s_tm + GQ * 64;                    // [GQ][2]
   int* s_flag = reinterpret_cast<int*>(s_coef + 2 * GQ);   // [GQ + 1]
+  double* s_xn = s_coef + 2 * GQ + 4;                 // [GQ][KS]
+  double* s_part = s_tile;                            // [4][GQ][64] per-wave partial row sums: each wave inside its own tile
   const double inv_ls = prm.inv_ls;
   const int kernel = prm.kernel;
 
@@ -959,10 +959,18 @@ __global__ __launch_bounds__(256) void k_acq_group(
 #pragma unroll
     for (int q = 0; q < GQ; ++q) sq[q] = 0.0;
     if (j < n) {
-      for (int c = 0; c < k; ++c) {
-        const double z = ZnT[(size_t)c * ld + j];
+      constexpr int CB = NT <= 2 ? 12 : 8;            // components whose loads are in flight per trip (a trip = one L2 round trip)
+      for (int c0 = 0; c0 < k; c0 += CB) {
+        double z[CB];
 #pragma unroll
-        for (int q = 0; q < GQ; ++q) { const double d = s_xn[q * KS + c] - z; sq[q] += d * d; }
+        for (int u = 0; u < CB; ++u) z[u] = (c0 + u < k) ? ZnT[(size_t)(c0 + u) * ld + j] : 0.0;
+#pragma unroll
+        for (int u = 0; u < CB; ++u) {
+          if (c0 + u < k) {                           // uniform
+#pragma unroll
+            for (int q = 0; q < GQ; ++q) { const double d = s_xn[q * KS + c0 + u] - z[u]; sq[q] += d * d; }
+          }
+        }
       }
     }
 #pragma unroll
@@ -985,42 +993,61 @@ __global__ __launch_bounds__(256) void k_acq_group(
     }
   }
   __syncthreads();
-  // ---- v for the slab's rows: tiles of 64 rows x 32 columns through LDS, a lane owns a row ----------------------
+  // ---- v for the slab's rows.  Wave w owns columns 16 w .. 16 w + 15 of every 64-column block: it loads its 64 x 16
+  // piece coalesced (lanes along the columns), turns it in its PRIVATE LDS tile and reads it back with a lane per row -
+  // no work-group barrier in the loop, two pieces in flight ahead of the one being consumed --------------------------
   {
     double acc[GQ];
 #pragma unroll
     for (int q = 0; q < GQ; ++q) acc[q] = 0.0;
-    const int ntile = ncol / 32;
-    double nx[8];
-    const double* Rs = R + (size_t)r0 * ld;
-    auto fetch = [&](int J2) {
+    const int nblk = s + 1;
+    const double* Rs = R + (size_t)r0 * ld + 16 * w + (l & 15);
+    double* tw = s_tile + w * 64 * GT_LD;
+    auto fetch = [&](int J, double (&dst)[16]) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { const int idx = tid + 256 * u; nx[u] = Rs[(size_t)(idx >> 5) * ld + J2 * 32 + (idx & 31)]; }
+      for (int u = 0; u < 16; ++u) dst[u] = Rs[(size_t)(4 * u + (l >> 4)) * ld + 64 * J];
     };
-    fetch(0);
-    for (int J2 = 0; J2 < ntile; ++J2) {
+    auto put = [&](const double (&src)[16]) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { const int idx = tid + 256 * u; s_tile[(idx >> 5) * GT_LD + (idx & 31)] = nx[u]; }
-      __syncthreads();
-      if (J2 + 1 < ntile) fetch(J2 + 1);
-      const double* trow = s_tile + l * GT_LD + 8 * w;
-      const double* kcol = s_ks + J2 * 32 + 8 * w;
+      for (int u = 0; u < 16; ++u) tw[(4 * u + (l >> 4)) * GT_LD + (l & 15)] = src[u];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto use = [&](int J) {
+      const double* trow = tw + l * GT_LD;
+      const double* kcol = s_ks + 64 * J + 16 * w;
 #pragma unroll
-      for (int jj = 0; jj < 8; ++jj) {
+      for (int jj = 0; jj < 16; ++jj) {
         const double rv = trow[jj];
 #pragma unroll
         for (int q = 0; q < GQ; ++q) acc[q] += rv * kcol[q * NP + jj];
       }
-      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    double bufA[16], bufB[16];
+    fetch(0, bufA);
+    if (nblk > 1) fetch(1, bufB);
+    for (int J = 0; J < nblk; J += 2) {
+      put(bufA);
+      if (J + 2 < nblk) fetch(J + 2, bufA);
+      use(J);
+      if (J + 1 < nblk) {
+        put(bufB);
+        if (J + 3 < nblk) fetch(J + 3, bufB);
+        use(J + 1);
+      }
     }
 #pragma unroll
-    for (int q = 0; q < GQ; ++q) s_part[(w * GQ + q) * 64 + l] = acc[q];
+    for (int q = 0; q < GQ; ++q) s_part[w * 64 * GT_LD + q * 64 + l] = acc[q];
   }
   __syncthreads();
   for (int idx = tid; idx < GQ * 64; idx += 256) {
     const int q = idx >> 6, m = idx & 63;
-    s_v[m * 8 + q] = ((s_part[(0 * GQ + q) * 64 + m] + s_part[(1 * GQ + q) * 64 + m]) + s_part[(2 * GQ + q) * 64 + m]) +
-                     s_part[(3 * GQ + q) * 64 + m];
+    const double* pp = s_part + q * 64 + m;
+    s_v[m * 8 + q] = ((pp[0] + pp[64 * GT_LD]) + pp[2 * 64 * GT_LD]) + pp[3 * 64 * GT_LD];
   }
   __syncthreads();
   // ---- slab contributions to |v|^2 and mu_s = alpha . ks: wave q (wave 0 also the fifth query) -------------------
@@ -1043,17 +1070,18 @@ __global__ __launch_bounds__(256) void k_acq_group(
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int q = 0; q < GQ; ++q) wacc[t][q] = 0.0;
-    for (int m0 = 0; m0 < 64; m0 += 8) {
-      double rr[8][NT];
+    constexpr int RU = NT <= 2 ? 16 : 8;      // rows per trip: RU * NT loads in flight
+    for (int m0 = 0; m0 < 64; m0 += RU) {
+      double rr[RU][NT];
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < RU; ++u)
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const int j = tid + 256 * t;
           rr[u][t] = j < ncol ? R[(size_t)(r0 + m0 + u) * ld + j] : 0.0;
         }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < RU; ++u) {
         double vq[GQ];
 #pragma unroll
         for (int q = 0; q < GQ; ++q) vq[q] = s_v[(m0 + u) * 8 + q];
@@ -1078,22 +1106,38 @@ __global__ __launch_bounds__(256) void k_acq_group(
       }
     }
     __syncthreads();
-    // ---- contraction with (xn_c - zn_jc): wave per component, lanes over points -----------------------------------
+    // ---- contraction with (xn_c - zn_jc): wave per component, lanes over points.  The lane's share of t_sigma lives in
+    // registers; the ZnT row of the NEXT component is loaded before the wave sums of the current one ------------------
+    constexpr int NBL = 4 * NT;                        // 64-column blocks per lane
     const int jmax = n < ncol ? n : ncol;
-    for (int c = w; c < k; c += 4) {
+    double ts[GQ][NBL], tmq[GQ];
+#pragma unroll
+    for (int b = 0; b < NBL; ++b) {
+      const int j = l + 64 * b;
+#pragma unroll
+      for (int q = 0; q < GQ; ++q) ts[q][b] = j < jmax ? s_ks[q * NP + j] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < GQ; ++q) tmq[q] = (r0 + l < n) ? s_tm[q * 64 + l] : 0.0;
+    double zc[NBL], zn_[NBL];
+    auto load_row = [&](int c, double (&dst)[NBL]) {
       const double* zrow = ZnT + (size_t)c * ld;
-      double gs[GQ], gm[GQ], xc[GQ];
 #pragma unroll
-      for (int q = 0; q < GQ; ++q) { gs[q] = 0.0; gm[q] = 0.0; xc[q] = s_xn[q * KS + c]; }
-      for (int j = l; j < jmax; j += 64) {
-        const double z = zrow[j];
+      for (int b = 0; b < NBL; ++b) dst[b] = (64 * b < jmax) ? zrow[l + 64 * b] : 0.0;     // (columns >= n hold zeros in ZnT)
+    };
+    if (w < k) load_row(w, zc);
+    for (int c = w; c < k; c += 4) {
+      if (c + 4 < k) load_row(c + 4, zn_);
+      double gs[GQ], gm[GQ];
+      const int bm = r0 >> 6;                          // the 64-column block that holds the slab's own rows (= lane's row r0 + l)
 #pragma unroll
-        for (int q = 0; q < GQ; ++q) gs[q] += s_ks[q * NP + j] * (xc[q] - z);
-      }
-      if (r0 + l < n) {
-        const double z = zrow[r0 + l];
+      for (int q = 0; q < GQ; ++q) {
+        const double xq = s_xn[q * KS + c];
+        double a = 0.0, zm = 0.0;
 #pragma unroll
-        for (int q = 0; q < GQ; ++q) gm[q] += s_tm[q * 64 + l] * (xc[q] - z);
+        for (int b = 0; b < NBL; ++b) { a += ts[q][b] * (xq - zc[b]); if (b == bm) zm = zc[b]; }
+        gs[q] = a;
+        gm[q] = tmq[q] * (xq - zm);
       }
 #pragma unroll
       for (int q = 0; q < GQ; ++q) {
@@ -1103,6 +1147,8 @@ __global__ __launch_bounds__(256) void k_acq_group(
           st_wt(out + 2 + c, a); st_wt(out + 2 + PCABO_MAXD + c, b2);
         }
       }
+#pragma unroll
+      for (int b = 0; b < NBL; ++b) zc[b] = zn_[b];
     }
   }
   // ---- tickets: the last slab group of a query finishes it ---------------------------------------------------------
@@ -1154,7 +1200,7 @@ void launch_acq_group(hipStream_t st, const QueryArgs* tab, int entries, const d
                       const double* ZnT, const double* R, const double* alpha, const double* bounds4, const double* ystats,
                       AcqParams p, double* partial, unsigned int* counters, double* val, double* grad, double* host_val,
                       double* host_grad, HostMirror* hm, unsigned long long seq, AcqBatch ab) {
-  const size_t lds = ((size_t)GQ * NP + 64 * GT_LD + 1 + 64 * 8 + 4 * GQ * 64 + GQ * PCABO_MAXD + GQ * 64 + 2 * GQ + 8) * sizeof(double);
+  const size_t lds = ((size_t)GQ * NP + 4 * 64 * GT_LD + 64 * 8 + GQ * 64 + 2 * GQ + 4 + GQ * (((size_t)k + 1) & ~(size_t)1) + 8) * sizeof(double);
   const dim3 grid(NP / 64, entries), block(256);
   static bool attr_set = false;
   if (!attr_set) {

@@ -1469,7 +1469,8 @@ struct RestartGroup {
   }
 };
 
-// Worker pool of a batch: persistent threads, one "gang" of runs each; sleeping between calls, woken per call.
+// Worker pool of a batch: the calling thread is worker 0, n - 1 persistent threads are workers 1..n-1 (sleeping between
+// calls, woken per call).  With one worker nothing leaves the calling thread (PCABO_BATCH_THREADS=1: profiler runs).
 struct GangPool {
   std::vector<std::thread> th;
   std::mutex mu;
@@ -1479,7 +1480,7 @@ struct GangPool {
   int pending = 0;
   bool quit = false;
   void start(int n) {
-    for (int i = 0; i < n; ++i)
+    for (int i = 1; i < n; ++i)
       th.emplace_back([this, i] {
         unsigned seen = 0;
         for (;;) {
@@ -1497,11 +1498,15 @@ struct GangPool {
       });
   }
   void run(std::function<void(int)> f) {                   // every worker runs f(worker index); returns when all are done
-    std::unique_lock<std::mutex> lk(mu);
-    fn = std::move(f);
-    pending = (int)th.size();
-    ++epoch;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      fn = f;
+      pending = (int)th.size();
+      ++epoch;
+    }
     cv.notify_all();
+    f(0);
+    std::unique_lock<std::mutex> lk(mu);
     cv_done.wait(lk, [&] { return pending == 0; });
   }
   void shutdown() {
@@ -1512,6 +1517,7 @@ struct GangPool {
   }
 };
 
+#define PCABO_BATCH_MAXSPLIT 4
 struct pcabo_batch {
   int device = 0, B = 0, max_n = 0, max_d = 0, max_q = 0;
   hipStream_t stream = nullptr;
@@ -1525,6 +1531,8 @@ struct pcabo_batch {
   int kernel = 0;
   int gcur = 0, vprev_d = 0;             // eigenvector ping-pong of ALL runs (they advance together)
   int cnt_S = 0; bool cnt_dirty = true;
+  bool prof = false; hipEvent_t pev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // phase marks of the last conditioning
+  int split = 1;                         // halves per gang that take turns (PCABO_BATCH_SPLIT)
   bool group_acq = true;                 // L-BFGS-B rounds through k_acq_group (PCABO_BATCH_ACQ=slab: the per-query kernels)
   int G = 0;                             // gangs = worker threads of the L-BFGS-B phase
   std::vector<hipStream_t> gstream;
@@ -1553,6 +1561,7 @@ static void batch_free(pcabo_batch* batch) {
   for (hipStream_t s : batch->gstream) if (s) (void)hipStreamDestroy(s);
   if (batch->evPca) (void)hipEventDestroy(batch->evPca);
   if (batch->evBounds) (void)hipEventDestroy(batch->evBounds);
+  for (hipEvent_t e : batch->pev) if (e) (void)hipEventDestroy(e);
   if (batch->dSlab) (void)hipFree(batch->dSlab);
   if (batch->hSlab) (void)hipHostFree(batch->hSlab);
   if (batch->stream) (void)hipStreamDestroy(batch->stream);
@@ -1601,12 +1610,15 @@ int pcabo_batch_create(int device, int B, int max_n, int max_d, int max_q, pcabo
       return bset_err(batch, PCABO_ERR_ARG, "internal: layout mismatch%s", "");
   }
   // worker threads of the L-BFGS-B phase: one gang of runs per thread, a HIP stream per gang
-  int T = (int)std::thread::hardware_concurrency() - 2;
+  // (hardware_concurrency reports the host, not this process's share of it: a GPU of a shared node comes with ~16 cores,
+  // and every worker spins while it waits - 8 by default)
+  int T = std::min(8, (int)std::thread::hardware_concurrency() - 2);
   if (const char* e = getenv("PCABO_BATCH_THREADS")) T = atoi(e);
   T = std::max(1, std::min(T, std::min(B, 32)));
   batch->G = T;
-  batch->gstream.assign(T, nullptr);
-  for (int g = 0; g < T; ++g) BHIPCHK(hipStreamCreateWithFlags(&batch->gstream[g], hipStreamNonBlocking));
+  if (const char* e = getenv("PCABO_BATCH_SPLIT")) batch->split = std::max(1, std::min(atoi(e), PCABO_BATCH_MAXSPLIT));
+  batch->gstream.assign((size_t)T * PCABO_BATCH_MAXSPLIT, nullptr);
+  for (size_t g = 0; g < batch->gstream.size(); ++g) BHIPCHK(hipStreamCreateWithFlags(&batch->gstream[g], hipStreamNonBlocking));
   batch->pool.start(T);
   if (const char* e = getenv("PCABO_BATCH_ACQ")) batch->group_acq = strcmp(e, "slab") != 0;
   for (pcabo_ctx* c : batch->ctx) c->opt_group_acq = batch->group_acq;      // a run's single-context calls match its batch
@@ -1617,6 +1629,23 @@ int pcabo_batch_create(int device, int B, int max_n, int max_d, int max_q, pcabo
 int pcabo_batch_destroy(pcabo_batch* batch) {
   if (!batch) return PCABO_ERR_ARG;
   batch_free(batch);
+  return PCABO_OK;
+}
+
+// Device time of the phases of the LAST pcabo_batch_wpca_gp_condition_begin (HIP events on the batch's stream; call after
+// the conditioning has been waited for): ms[0] rows A-C (wPCA), ms[1] Normalize + Gram, ms[2] Cholesky, ms[3] root inverse + alpha.
+int pcabo_batch_set_profiling(pcabo_batch* batch, int enabled) {
+  if (!batch) return PCABO_ERR_ARG;
+  BHIPCHK(hipSetDevice(batch->device));
+  if (enabled && !batch->pev[0]) for (auto& e : batch->pev) BHIPCHK(hipEventCreate(&e));
+  batch->prof = enabled != 0;
+  return PCABO_OK;
+}
+int pcabo_batch_get_profile(pcabo_batch* batch, double* ms) {
+  if (!batch || !ms || !batch->prof) return PCABO_ERR_ARG;
+  BHIPCHK(hipSetDevice(batch->device));
+  BHIPCHK(hipEventSynchronize(batch->pev[4]));
+  for (int i = 0; i < 4; ++i) { float t = 0.f; BHIPCHK(hipEventElapsedTime(&t, batch->pev[i], batch->pev[i + 1])); ms[i] = t; }
   return PCABO_OK;
 }
 
@@ -1660,6 +1689,8 @@ int pcabo_batch_wpca_gp_condition_begin(pcabo_batch* batch, const double* X, con
   const double* inY = c0->dIn + off_y;
   const ZB zb = batch_zb(batch);
   const int DP = round_up(d, 16);
+  auto mark = [&](int i) { if (batch->prof) (void)hipEventRecord(batch->pev[i], s); };
+  mark(0);
   // rows A-C
   launch_wpca_prep(s, inX, inRanks, inNoise, n, d, DP, c0->dWeights, c0->dDataMean, c0->dPcaMean, c0->dWc, zb);
   launch_cov(s, c0->dWc, n, DP, c0->dC, zb);
@@ -1679,14 +1710,18 @@ int pcabo_batch_wpca_gp_condition_begin(pcabo_batch* batch, const double* X, con
     BHIPCHK(hipMemset2DAsync(c0->dCounters, batch->zs, 0, (PCABO_CNT_DONE + 1) * sizeof(unsigned int), B, s));
     batch->cnt_S = acq_slabs(NP); batch->cnt_dirty = false;
   }
+  mark(1);
   launch_zstats(s, c0->dZ, inY, n, -1, nullptr, c0->dBounds4, c0->dZnMean, c0->dYstats, c0->dYs, c0->hm, c0->dK, zb);
   BHIPCHK(hipEventRecord(batch->evBounds, s));
   launch_znorm(s, c0->dZ, n, -1, NP, 0, c0->ld, c0->dBounds4, c0->dZnMean, 1.0 / lengthscale, c0->dZnT, c0->dAT, c0->dNrm,
                c0->dK, zb);
   launch_gram(s, c0->dAT, c0->dNrm, n, NP, 0, c0->ld, gp_noise, kernel, c0->dGram, c0->dK, c0->dL, c0->dInfo, zb);
+  mark(2);
   launch_cholesky(s, c0->dL, NP, c0->ld, c0->dInfo, c0->dDiag, zb);
+  mark(3);
   launch_trinv(s, c0->dL, NP, c0->ld, c0->dR, zb);
   launch_alpha(s, c0->dR, c0->dYs, n, NP, c0->ld, c0->dTmp, c0->dAlpha, zb);
+  mark(4);
   BHIPCHK(hipMemcpy2DAsync((void*)&c0->hm->chol_info, batch->hzs, c0->dInfo, batch->zs, sizeof(int), B, hipMemcpyDeviceToHost, s));
   BHIPCHK(hipGetLastError());
   batch->n = n; batch->d = d; batch->NP = NP;
@@ -1858,34 +1893,108 @@ int pcabo_batch_optimize_acqf(pcabo_batch* batch, const double* ics, int num_res
   // hand every pending (run, query) to ONE launch, wait for the per-query sequence words, feed the results back.
   auto gang = [&](int g) {
     if (hipSetDevice(batch->device) != hipSuccess) { hip_failed.store(1); return; }
-    hipStream_t st = batch->gstream[g];
     std::vector<int> mine;
     for (int b = g; b < B; b += G) if (run_status[b] == PCABO_OK) mine.push_back(b);
-    QueryArgs tab;
-    unsigned* ent = reinterpret_cast<unsigned*>(tab.x);
     struct Pending { int b, gi; };
-    std::vector<Pending> pend;
     const bool use_group = batch->group_acq && batch_limit <= PCABO_GROUP_Q && acq_group_possible(batch->NP, kmax);
-    // group kernel: one table entry per restart group (run << 16 | first query << 8 | count), its own ticket words
-    auto launch_groups_and_wait = [&](int nent, const AcqParams& p, unsigned long long seq) -> bool {
-      AcqBatch ab = batch_ab(batch, 1, 1);
-      launch_acq_group(st, &tab, nent, c0->hXq, batch->n, kmax, batch->NP, c0->ld, c0->dZnT, c0->dR, c0->dAlpha, c0->dBounds4,
-                       c0->dYstats, p, c0->dPartial, c0->dCounters + PCABO_GROUP_CNT_OFFSET, c0->dVal, c0->dGrad, c0->hVal,
-                       c0->hGrad, c0->hm, seq, ab);
-      if (hipGetLastError() != hipSuccess) return false;
-      const auto t0 = std::chrono::steady_clock::now();
-      unsigned long spins = 0;
-      for (int e = 0; e < nent; ++e) {
-        const pcabo_ctx* c = batch->ctx[ent[e] >> 16];
-        const int q0 = (int)((ent[e] >> 8) & 0xffu), nqe = (int)(ent[e] & 0xffu);
-        for (int j = 0; j < nqe; ++j)
-          while (__atomic_load_n(&c->hm->qflag[q0 + j], __ATOMIC_ACQUIRE) != seq) {
-            if ((++spins & 0xFFFF) == 0 &&
-                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 20.0) return false;
-          }
+    // The gang's runs are split into `H` halves that take turns: while the kernel of one half is in flight, the host
+    // steps the L-BFGS-B state machines of the other and launches it (its own stream) - a round of a half costs
+    // max(kernel latency, host steps of the other halves) instead of their sum.
+    struct Half {
+      std::vector<int> runs; QueryArgs tab; int nent = 0; std::vector<Pending> pend; unsigned long long seq = 0;
+      bool inflight = false, done = false; hipStream_t st = nullptr;
+    };
+    const int H = std::max(1, std::min(batch->split, (int)mine.size()));
+    std::vector<Half> halves(H);
+    for (size_t i = 0; i < mine.size(); ++i) halves[i % H].runs.push_back(mine[i]);
+    // (streams are handed to hardware queues in creation order: consecutive indices for the gangs, so that gangs that run at
+    // the same time do not share a queue - kernels in one queue run one after the other)
+    for (int h = 0; h < H; ++h) halves[h].st = batch->gstream[(size_t)h * G + g];
+    auto flags_ready = [&](const Half& hf) -> bool {
+      const unsigned* e2 = reinterpret_cast<const unsigned*>(hf.tab.x);
+      for (int e = 0; e < hf.nent; ++e) {
+        const pcabo_ctx* c = batch->ctx[e2[e] >> 16];
+        if (use_group) {
+          const int q0 = (int)((e2[e] >> 8) & 0xffu), nqe = (int)(e2[e] & 0xffu);
+          for (int j = 0; j < nqe; ++j) if (__atomic_load_n(&c->hm->qflag[q0 + j], __ATOMIC_ACQUIRE) != hf.seq) return false;
+        } else if (__atomic_load_n(&c->hm->qflag[e2[e] & 0xffffu], __ATOMIC_ACQUIRE) != hf.seq) return false;
       }
       return true;
     };
+    int remaining = H;
+    auto t_last = std::chrono::steady_clock::now();
+    unsigned long idle = 0;
+    static const bool btrace = getenv("PCABO_BATCH_TRACE") != nullptr;
+    double tr_step = 0.0, tr_launch = 0.0, tr_total = 0.0; long tr_launches = 0, tr_entries = 0;
+    auto nowd = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tr_t0 = btrace ? nowd() : 0.0;
+    while (remaining > 0) {
+      bool progressed = false;
+      for (Half& hf : halves) {
+        if (hf.done) continue;
+        if (hf.inflight) {
+          if (!flags_ready(hf)) continue;
+          for (const Pending& pe : hf.pend) {
+            pcabo_ctx* c = batch->ctx[pe.b];
+            if (!groups[pe.b][pe.gi].absorb(c->hVal, c->hGrad)) {
+              run_status[pe.b] = PCABO_ERR_NAN;
+              set_err(c, PCABO_ERR_NAN, "NaN in acquisition gradient%s", "");
+            }
+          }
+          hf.inflight = false;
+          progressed = true;
+        }
+        unsigned* he = reinterpret_cast<unsigned*>(hf.tab.x);
+        hf.pend.clear();
+        hf.nent = 0;
+        const double tr_a = btrace ? nowd() : 0.0;
+        for (int b : hf.runs) {
+          if (run_status[b] != PCABO_OK) continue;
+          pcabo_ctx* c = batch->ctx[b];
+          for (int gi = 0; gi < ngroups; ++gi) {
+            RestartGroup& rg = groups[b][gi];
+            if (!rg.active) continue;
+            rg.advance();
+            if (!rg.active) continue;
+            memcpy(c->hXq + (size_t)rg.q0 * c->k, rg.x.data(), (size_t)rg.nq * c->k * sizeof(double));
+            if (use_group) he[hf.nent++] = ((unsigned)b << 16) | ((unsigned)rg.q0 << 8) | (unsigned)rg.nq;
+            else for (int j = 0; j < rg.nq; ++j) he[hf.nent++] = ((unsigned)b << 16) | (unsigned)(rg.q0 + j);
+            hf.pend.push_back({b, gi});
+          }
+        }
+        progressed = true;
+        const double tr_b = btrace ? nowd() : 0.0;
+        tr_step += tr_b - tr_a;
+        if (hf.nent == 0) { hf.done = true; --remaining; continue; }
+        hf.seq = batch->seq.fetch_add(1) + 1;
+        if (use_group) {
+          launch_acq_group(hf.st, &hf.tab, hf.nent, c0->hXq, batch->n, kmax, batch->NP, c0->ld, c0->dZnT, c0->dR, c0->dAlpha,
+                           c0->dBounds4, c0->dYstats, pg, c0->dPartial, c0->dCounters + PCABO_GROUP_CNT_OFFSET, c0->dVal,
+                           c0->dGrad, c0->hVal, c0->hGrad, c0->hm, hf.seq, batch_ab(batch, 1, 1));
+        } else {
+          launch_acq(hf.st, &hf.tab, c0->hXq, PCABO_INLAUNCH_MAXQ, batch->n, kmax, batch->NP, c0->ld, c0->dZnT, c0->dR,
+                     c0->dAlpha, c0->dBounds4, c0->dYstats, pg, c0->dPartial, c0->dCounters, c0->dVal, c0->dGrad, c0->hVal,
+                     c0->hGrad, c0->hm, hf.seq, nullptr, nullptr, nullptr, batch_ab(batch, 1, 1), B, hf.nent);
+        }
+        if (hipGetLastError() != hipSuccess) { hip_failed.store(1); return; }
+        hf.inflight = true;
+        if (btrace) { tr_launch += nowd() - tr_b; ++tr_launches; tr_entries += hf.nent; }
+      }
+      if (progressed) { t_last = std::chrono::steady_clock::now(); idle = 0; }
+      else if ((++idle & 0xFFFF) == 0 &&
+               std::chrono::duration<double>(std::chrono::steady_clock::now() - t_last).count() > 20.0) {
+        hip_failed.store(1); return;                         // a launch did not publish its results
+      }
+    }
+    if (btrace) {
+      tr_total = nowd() - tr_t0;
+      fprintf(stderr, "[pcabo batch] gang %d: %zu runs, %ld launches (%.1f entries each), host steps %.2f ms, launch calls %.2f ms, "
+              "waiting %.2f ms of %.2f ms\n", g, mine.size(), tr_launches, tr_launches ? (double)tr_entries / tr_launches : 0.0,
+              1e3 * tr_step, 1e3 * tr_launch, 1e3 * (tr_total - tr_step - tr_launch), 1e3 * tr_total);
+    }
+    hipStream_t st = halves[0].st;
+    QueryArgs& tab = halves[0].tab;
+    unsigned* ent = reinterpret_cast<unsigned*>(tab.x);
     auto launch_and_wait = [&](int nent, const AcqParams& p, unsigned long long seq) -> bool {
       launch_acq(st, &tab, c0->hXq, PCABO_INLAUNCH_MAXQ, batch->n, kmax, batch->NP, c0->ld, c0->dZnT, c0->dR, c0->dAlpha,
                  c0->dBounds4, c0->dYstats, p, c0->dPartial, c0->dCounters, c0->dVal, c0->dGrad, c0->hVal, c0->hGrad, c0->hm,
@@ -1903,35 +2012,6 @@ int pcabo_batch_optimize_acqf(pcabo_batch* batch, const double* ics, int num_res
       }
       return true;
     };
-    for (;;) {
-      pend.clear();
-      int nent = 0;
-      for (int b : mine) {
-        if (run_status[b] != PCABO_OK) continue;
-        pcabo_ctx* c = batch->ctx[b];
-        for (int gi = 0; gi < ngroups; ++gi) {
-          RestartGroup& rg = groups[b][gi];
-          if (!rg.active) continue;
-          rg.advance();
-          if (!rg.active) continue;
-          if (nent + rg.nq > table_cap) continue;            // (cannot happen: <= 32 queries per run, gangs are small)
-          memcpy(c->hXq + (size_t)rg.q0 * c->k, rg.x.data(), (size_t)rg.nq * c->k * sizeof(double));
-          if (use_group) ent[nent++] = ((unsigned)b << 16) | ((unsigned)rg.q0 << 8) | (unsigned)rg.nq;
-          else for (int j = 0; j < rg.nq; ++j) ent[nent++] = ((unsigned)b << 16) | (unsigned)(rg.q0 + j);
-          pend.push_back({b, gi});
-        }
-      }
-      if (nent == 0) break;
-      const unsigned long long seq = batch->seq.fetch_add(1) + 1;
-      if (!(use_group ? launch_groups_and_wait(nent, pg, seq) : launch_and_wait(nent, pg, seq))) { hip_failed.store(1); return; }
-      for (const Pending& pe : pend) {
-        pcabo_ctx* c = batch->ctx[pe.b];
-        if (!groups[pe.b][pe.gi].absorb(c->hVal, c->hGrad)) {
-          run_status[pe.b] = PCABO_ERR_NAN;
-          set_err(c, PCABO_ERR_NAN, "NaN in acquisition gradient%s", "");
-        }
-      }
-    }
     // end points, values there (botorch evaluates once more at the clamped end points; normally that is the last point
     // the run evaluated - same kernel arithmetic, same bits - otherwise one value-only launch for the gang's leftovers)
     int nent = 0;

@@ -19,6 +19,11 @@ PTR_HOST, PTR_DEVICE = 0, 1
 OPT_RESIDENT, OPT_BESTF_F32, OPT_GROUP_ACQ = 0, 1, 2
 PROFILE_GROUPS = ("wpca", "gram", "cholesky", "root_inverse_alpha", "acq_partial", "acq_large_batches")
 
+# Independent runs drive the GPU from several host threads on separate HIP streams (the gangs of a Batch, one context
+# per thread): the runtime's default of 4 hardware queues per process makes streams share queues, and kernels that share
+# a queue run one after the other.  Read by the HIP runtime when it initialises; an explicit setting wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "lib", "libpcabo.so")
 
 EXPORTS = [
@@ -31,6 +36,7 @@ EXPORTS = [
     "pcabo_batch_create", "pcabo_batch_destroy", "pcabo_batch_last_error", "pcabo_batch_ctx",
     "pcabo_batch_wpca_gp_condition_begin", "pcabo_batch_wpca_results", "pcabo_batch_acq_bounds",
     "pcabo_batch_gp_condition_end_eval", "pcabo_batch_optimize_acqf", "pcabo_batch_inverse_map",
+    "pcabo_batch_set_profiling", "pcabo_batch_get_profile",
 ]
 
 
@@ -94,6 +100,8 @@ def _load() -> C.CDLL:
     lib.pcabo_batch_gp_condition_end_eval.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp]
     lib.pcabo_batch_optimize_acqf.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
     lib.pcabo_batch_inverse_map.argtypes = [vp, vp, vp]
+    lib.pcabo_batch_set_profiling.argtypes = [vp, C.c_int]
+    lib.pcabo_batch_get_profile.argtypes = [vp, vp]
     for name in EXPORTS:
         getattr(lib, name).restype = C.c_int
     lib.pcabo_batch_ctx.restype = vp
@@ -431,6 +439,15 @@ class Batch:
             k = int(self.k[b])
             out.append((cand[b, : nr * k].reshape(nr, k).copy(), vals[b].copy(), info[b].copy(), bool(failed[b])))
         return out, status
+
+    def set_profiling(self, on: bool) -> None:
+        self._chk(LIB.pcabo_batch_set_profiling(self._h, int(bool(on))))
+
+    def condition_profile(self) -> dict:
+        """Device milliseconds of the last conditioning's phases (after it has been waited for)."""
+        ms = np.zeros(4)
+        self._chk(LIB.pcabo_batch_get_profile(self._h, _ptr(ms)))
+        return dict(zip(("wpca", "gram", "cholesky", "root_inverse_alpha"), ms.tolist()))
 
     def inverse_map(self, z_list):
         z = np.zeros((self.B, self.max_d))

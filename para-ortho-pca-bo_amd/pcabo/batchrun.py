@@ -38,7 +38,7 @@ class BatchedPCABO:
     def __init__(self, problems: Sequence, seeds: Sequence[int], budget: int, n_DoE: int, n_components: int = 0,
                  var_threshold: float = 0.95, acquisition_function: str = "expected_improvement",
                  maximization: bool = False, device: int = 0, num_restarts: int = 10, raw_samples: int = 512,
-                 record_trace: bool = False):
+                 record_trace: bool = False, host_threads: int = 0):
         self.problems, self.seeds = list(problems), [int(s) for s in seeds]
         self.B = len(self.problems)
         assert self.B == len(self.seeds) and self.B >= 1
@@ -65,6 +65,10 @@ class BatchedPCABO:
         self._batch: Optional[_native.Batch] = None
         self._rs = self._tg = None
         self._X = None
+        # the runs' noise draws (numpy releases the interpreter lock while it generates) are spread over a few threads;
+        # every run has its own generator, so the order in which the threads get to the runs does not matter
+        self._pool = None
+        self._host_threads = int(host_threads) if host_threads else min(8, self.B)
 
     # ---- seeding + DoE (AbstractAlgorithm.py:310-328, AbstractBayesianOptimizer.py:142-176) --------------------------
     def start(self) -> None:
@@ -81,6 +85,15 @@ class BatchedPCABO:
             self._assign_new_best(b)
             self._X[b, : self.n_DoE] = np.vstack(self.x_evals[b])
         self._batch = _native.Batch(B, max_n=self.budget, max_d=d, max_q=max(self.raw_samples, 16), device=self.device)
+        if self._host_threads > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=self._host_threads)
+
+    def _each(self, fn):
+        """fn(b) for every run, on the host threads."""
+        if self._pool is None:
+            return [fn(b) for b in range(self.B)]
+        return list(self._pool.map(fn, range(self.B)))
 
     def _assign_new_best(self, b: int) -> None:
         f = self.f_evals[b]
@@ -98,33 +111,42 @@ class BatchedPCABO:
         F = np.array(self.f_evals, dtype=np.float64)                                   # B x n
         ranks = np.empty((B, n), dtype=np.int64)
         noise = np.empty((B, n, d))
-        for b in range(B):
+
+        def prep(b):
             # per run, on a 1-D array exactly as the reference does it (PCA_BO.py:330-333): the penalty value repeats, and
             # how numpy's unstable sort orders ties must be what the run sees alone
             fb = np.array(self.f_evals[b])
             ranks[b] = np.argsort(np.argsort(-fb if self.maximization else fb)) + 1
             noise[b] = self._rs[b].normal(0, 1e-8, size=(n, d))                       # PCA_BO.py:376, the run's own stream
+        self._each(prep)
         t1 = perf_counter()
         bt.wpca_gp_condition_begin(self._X[:, :n], ranks, noise, F, maximize=self.maximization,
                                    var_threshold=self.var_threshold, n_components=self.n_components,
                                    lengthscale=LENGTHSCALE, gp_noise=NOISE)
         # while the device runs the eigen-decompositions: the scrambled Sobol engines, with last iteration's k
         engines, saved = [None] * B, [None] * B
-        for b in range(B):
+
+        def guess(b):
             if self.k_prev[b]:
                 saved[b] = self._tg[b].get_state()
                 engines[b] = _init.scrambled_sobol_engine(self.k_prev[b], self._tg[b])
+        for b in range(B):                # (torch's small ops do not gain from the host threads: measured slower)
+            guess(b)
         res = bt.wpca_results()
-        for b in range(B):
+        t2 = perf_counter()
+        bounds = bt.acq_bounds()
+        raw = [None] * B
+
+        def draw(b):
             if engines[b] is not None and res[b]["k"] != self.k_prev[b]:
                 self._tg[b].set_state(saved[b])                                        # wrong guess: as if never drawn
                 engines[b] = None
             if engines[b] is None:
                 engines[b] = _init.scrambled_sobol_engine(res[b]["k"], self._tg[b])
             self.k_prev[b] = res[b]["k"]
-        t2 = perf_counter()
-        bounds = bt.acq_bounds()
-        raw = [_init.draw_sobol(bounds[b], self.raw_samples, engines[b]) for b in range(B)]
+            raw[b] = _init.draw_sobol(bounds[b], self.raw_samples, engines[b])
+        for b in range(B):
+            draw(b)
         best_f = [self.current_best[b] for b in range(B)]
         for b in range(B):
             bt.ctx[b].match_best_f_dtype(best_f[b])
@@ -185,6 +207,9 @@ class BatchedPCABO:
         tm["tail"] += t7 - t6
 
     def finish(self) -> None:
+        if self._pool is not None:
+            self._pool.shutdown()
+            self._pool = None
         if self._batch is not None:
             self._batch.close()
             self._batch = None

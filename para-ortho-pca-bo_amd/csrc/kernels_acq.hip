@@ -1215,6 +1215,153 @@ void launch_acq_group(hipStream_t st, const QueryArgs* tab, int entries, const d
 #undef GROUP_ARGS
 }
 
+// =====================================================================================================================
+// Large value-only batches (the 512 raw samples of gen_batch_initial_conditions) as a GEMM:
+//   KS[q][j] = k(x_q, z_j)                      k_score_ks:   thread per training point, 16 queries per work-group
+//   V = R KS^T  (n x q),  |v_q|^2 = column norms  k_score_gemm: 64 x 64 output tiles on v_mfma_f64_16x16x4, operand
+//                                                tiles through LDS (leading dimension 66: conflict-free), the next tiles
+//                                                travelling in registers while the MFMAs of the current ones run
+// Only the column norms leave the kernel (V itself is never stored): per (query, 64-row block) one partial record, the
+// same records k_acq_combine sums for the slab kernels.  mu_s = alpha . ks is formed where ks is, in k_score_ks.
+// 0.10 GFLOP per run at n = 450: one work-group per (row block, 64 queries) instead of one per (16-row slab, 8 queries).
+#define SC_QB 16
+__global__ __launch_bounds__(256) void k_score_ks(const double* __restrict__ Xq, int q_total, int n, int k, int NP, int ld,
+                                                  const double* __restrict__ ZnT, const double* __restrict__ alpha,
+                                                  const double* __restrict__ bounds4, AcqParams prm,
+                                                  double* __restrict__ KS, double* __restrict__ partial, int S, AcqBatch ab) {
+  if (ab.zs) {
+    const unsigned run_ = blockIdx.z;
+    Xq = zrun(Xq, ab.zs, run_); ZnT = zrun(ZnT, ab.zs, run_); alpha = zrun(alpha, ab.zs, run_);
+    bounds4 = zrun(bounds4, ab.zs, run_); KS = zrun(KS, ab.zs, run_); partial = zrun(partial, ab.zs, run_);
+    if (ab.k_dev) k = *zrun(ab.k_dev, ab.zs, run_);
+  }
+  __shared__ double s_xn[SC_QB][PCABO_MAXD];
+  __shared__ double s_mu[4][SC_QB];
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+  const int j = blockIdx.x * 256 + tid, q0 = blockIdx.y * SC_QB;
+  for (int idx = tid; idx < SC_QB * k; idx += 256) {
+    const int q = idx / k, c = idx - q * k;
+    const int qq = q0 + q < q_total ? q0 + q : q_total - 1;
+    const double lo = bounds4[c], hi = bounds4[PCABO_MAXD + c];
+    s_xn[q][c] = (Xq[(size_t)qq * k + c] - lo) / (hi - lo);
+  }
+  __syncthreads();
+  double sq[SC_QB];
+#pragma unroll
+  for (int q = 0; q < SC_QB; ++q) sq[q] = 0.0;
+  if (j < n) {
+    for (int c0 = 0; c0 < k; c0 += 8) {
+      double z[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) z[u] = (c0 + u < k) ? ZnT[(size_t)(c0 + u) * ld + j] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (c0 + u < k) {
+#pragma unroll
+          for (int q = 0; q < SC_QB; ++q) { const double d = s_xn[q][c0 + u] - z[u]; sq[q] += d * d; }
+        }
+    }
+  }
+  const double inv_ls = prm.inv_ls, s5 = 2.23606797749979;
+  const double aj = j < n ? alpha[j] : 0.0;
+#pragma unroll
+  for (int q = 0; q < SC_QB; ++q) {
+    double ks = 0.0;
+    if (j < n) {
+      const double sqq = sq[q] * (inv_ls * inv_ls);
+      if (prm.kernel == 1) ks = exp(-0.5 * sqq);
+      else {
+        const double dist = sqrt(fmax(sqq, 1e-30));
+        ks = ((s5 * dist + 1.0) + (5.0 / 3.0) * (dist * dist)) * exp(-s5 * dist);
+      }
+    }
+    if (j < NP && q0 + q < q_total) KS[(size_t)(q0 + q) * ld + j] = ks;
+    const double m = wave_sum(aj * ks);
+    if (l == 0) s_mu[w][q] = m;
+  }
+  __syncthreads();
+  // mu_s part of this block of 256 points -> slot 1 of the query's record number blockIdx.x (the GEMM zeroes the others')
+  if (tid < SC_QB && q0 + tid < q_total)
+    partial[((size_t)(q0 + tid) * S + blockIdx.x) * PSTRIDE + 1] = ((s_mu[0][tid] + s_mu[1][tid]) + s_mu[2][tid]) + s_mu[3][tid];
+}
+
+__global__ __launch_bounds__(256) void k_score_gemm(const double* __restrict__ R, const double* __restrict__ KS,
+                                                    int q_total, int NP, int ld, int njb, double* __restrict__ partial,
+                                                    size_t zs) {
+  ZRUN(R); ZRUN(KS); ZRUN(partial);
+  __shared__ __attribute__((aligned(16))) double s_a[64 * PCABO_TLD];
+  __shared__ __attribute__((aligned(16))) double s_b[64 * PCABO_TLD];
+  __shared__ double s_red[4][64];
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+  const int I = blockIdx.x, qb = blockIdx.y, S = gridDim.x;
+  const double* Rrow = R + (size_t)(I * 64) * ld;
+  const double* Krow = KS + (size_t)(qb * 64) * ld;
+  double pa[16], pb[16];
+  auto fetch = [&](int J) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int idx = tid + 256 * u, r = idx >> 6, c = idx & 63;
+      pa[u] = Rrow[(size_t)r * ld + J * 64 + c];
+      pb[u] = (qb * 64 + r < q_total) ? Krow[(size_t)r * ld + J * 64 + c] : 0.0;
+    }
+  };
+  auto put = [&]() {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int idx = tid + 256 * u, r = idx >> 6, c = idx & 63;
+      s_a[r * PCABO_TLD + c] = pa[u];
+      s_b[r * PCABO_TLD + c] = pb[u];
+    }
+  };
+  double4_t acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  fetch(0);
+  for (int J = 0; J <= I; ++J) {              // R is lower triangular: column blocks beyond the diagonal hold zeros
+    __syncthreads();                          // the previous step's MFMAs have read the LDS tiles
+    put();
+    if (J < I) fetch(J + 1);
+    __syncthreads();
+    for (int kk = 0; kk < 64; kk += 4) {
+      const double a = s_a[(16 * w + (l & 15)) * PCABO_TLD + kk + (l >> 4)];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const double b = s_b[(16 * t + (l & 15)) * PCABO_TLD + kk + (l >> 4)];
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  // column norms of this 64-row block: acc[t][r] = V[16 w + (l >> 4) + 4 r][16 t + (l & 15)]
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    double v = ((acc[t][0] * acc[t][0] + acc[t][1] * acc[t][1]) + acc[t][2] * acc[t][2]) + acc[t][3] * acc[t][3];
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (l < 16) s_red[w][16 * t + l] = v;
+  }
+  __syncthreads();
+  if (tid < 64 && qb * 64 + tid < q_total) {
+    double* rec = partial + ((size_t)(qb * 64 + tid) * S + I) * PSTRIDE;
+    rec[0] = ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid];
+    if (I >= njb) rec[1] = 0.0;               // (records 0 .. njb-1 got their mu_s part from k_score_ks)
+  }
+}
+
+bool score_gemm_possible(int q) { return q >= 64; }
+
+// Value-only scoring of q >= 64 points: KS, then V = R KS^T on MFMA, then the scalar chain per query (k_acq_combine).
+void launch_score(hipStream_t st, const double* Xq, int q, int n, int k, int NP, int ld, const double* ZnT, const double* R,
+                  const double* alpha, const double* bounds4, const double* ystats, AcqParams p, double* KS, double* partial,
+                  double* val, AcqBatch ab, int B) {
+  const int S = NP / 64, njb = (NP + 255) / 256;
+  hipLaunchKernelGGL(k_score_ks, dim3(njb, (q + SC_QB - 1) / SC_QB, B), dim3(256), 0, st, Xq, q, n, k, NP, ld, ZnT, alpha, bounds4,
+                     p, KS, partial, S, ab);
+  hipLaunchKernelGGL(k_score_gemm, dim3(S, (q + 63) / 64, B), dim3(256), 0, st, R, KS, q, NP, ld, njb, partial, ab.zs);
+  p.want_grad = 0;
+  hipLaunchKernelGGL(k_acq_combine, dim3((q + 3) / 4, 1, B), dim3(256), 0, st, partial, q, S, k, bounds4, ystats, p, val,
+                     (double*)nullptr, ab);
+}
+
 // Resident mode needs every group of the grid on the chip at the same time (groups wait for one another through the
 // mailbox and the tickets): one group per CU is always possible for these kernels, so S q <= number of CUs is enough.
 bool acq_server_possible(int q, int n, int k, int NP) {

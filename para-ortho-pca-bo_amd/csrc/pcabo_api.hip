@@ -104,6 +104,7 @@ struct pcabo_ctx {
   double *dXq = nullptr, *dPartial = nullptr, *dVal = nullptr, *dGrad = nullptr, *dZq = nullptr, *dXout = nullptr;
   unsigned int* dCounters = nullptr;     // per-query tickets of the in-launch combine
   int cnt_S = 0; bool cnt_dirty = true;  // slab-group count the tickets are consistent with / a launch may have died
+  double* dKS = nullptr;                 // q x ld kernel vectors of the GEMM scoring path
   double* dBestF = nullptr;              // best_f of this run for the batched acquisition launches (set by the batch)
   char *dRegion = nullptr, *hRegion = nullptr;   // the two allocations everything above / below is carved from
   size_t region_bytes = 0, hregion_bytes = 0;
@@ -363,6 +364,7 @@ static size_t carve_device(pcabo_ctx* ctx, char* base) {
   ctx->dVal = c.take<double>(Q);          ctx->dGrad = c.take<double>(Q * d);
   ctx->dZq = c.take<double>(d);           ctx->dXout = c.take<double>(d);
   ctx->dBestF = c.take<double>(2);
+  ctx->dKS = c.take<double>(Q * N);        // kernel vectors of a large value-only batch (GEMM scoring)
   ctx->dCounters = c.take<unsigned int>(PCABO_CNT_DONE + 1);
   return (c.off + 4095) & ~(size_t)4095;
 }
@@ -806,7 +808,17 @@ static int eval_staged(pcabo_ctx* ctx, int nq, AcqParams& p) {
     xdev = ctx->dXq;
   }
   const bool small = nq <= PCABO_INLAUNCH_MAXQ;   // in-launch combine + host flag; larger batches: two launches + copy
-  {
+  static const bool gemm_env = !(getenv("PCABO_SCORE_GEMM") && atoi(getenv("PCABO_SCORE_GEMM")) == 0);
+  if (!small && !p.want_grad && gemm_env && score_gemm_possible(nq)) {
+    // value-only scoring of a large batch (the raw samples): V = R KS^T on MFMA
+    if (!xdev) {
+      HIPCHK(hipMemcpyAsync(ctx->dXq, ctx->hXq, (size_t)nq * k * sizeof(double), hipMemcpyHostToDevice, s));
+      xdev = ctx->dXq;
+    }
+    ProfScope ps(ctx, 5, acq_bytes(ctx->n, k, nq, 0), acq_flops(ctx->n, k, nq, 0));
+    launch_score(s, xdev, nq, ctx->n, k, ctx->NP, ctx->ld, ctx->dZnT, ctx->dR, ctx->dAlpha, ctx->dBounds4, ctx->dYstats, p,
+                 ctx->dKS, ctx->dPartial, ctx->dVal);
+  } else {
     ProfScope ps(ctx, small ? 4 : 5, acq_bytes(ctx->n, k, nq, p.want_grad), acq_flops(ctx->n, k, nq, p.want_grad));
     launch_acq(s, qa, xdev, nq, ctx->n, k, ctx->NP, ctx->ld, ctx->dZnT, ctx->dR, ctx->dAlpha, ctx->dBounds4, ctx->dYstats,
                p, ctx->dPartial, ctx->dCounters, ctx->dVal, ctx->dGrad, small ? ctx->hVal : nullptr,
@@ -1818,9 +1830,14 @@ int pcabo_batch_gp_condition_end_eval(pcabo_batch* batch, const double* Xq, int 
   if (rc != PCABO_OK) return rc;
   AcqParams p = make_params(c0, 0.0, maximize, acq, 0);
   p.inv_ls = 1.0 / batch->lengthscale; p.kernel = batch->kernel;
-  launch_acq(s, nullptr, c0->dXq, q, batch->n, kmax, batch->NP, c0->ld, c0->dZnT, c0->dR, c0->dAlpha, c0->dBounds4, c0->dYstats,
-             p, c0->dPartial, c0->dCounters, c0->dVal, c0->dGrad, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr,
-             batch_ab(batch, 0, 0), B, 0);
+  static const bool gemm_env = !(getenv("PCABO_SCORE_GEMM") && atoi(getenv("PCABO_SCORE_GEMM")) == 0);
+  if (gemm_env && score_gemm_possible(q))
+    launch_score(s, c0->dXq, q, batch->n, kmax, batch->NP, c0->ld, c0->dZnT, c0->dR, c0->dAlpha, c0->dBounds4, c0->dYstats, p,
+                 c0->dKS, c0->dPartial, c0->dVal, batch_ab(batch, 0, 0), B);
+  else
+    launch_acq(s, nullptr, c0->dXq, q, batch->n, kmax, batch->NP, c0->ld, c0->dZnT, c0->dR, c0->dAlpha, c0->dBounds4, c0->dYstats,
+               p, c0->dPartial, c0->dCounters, c0->dVal, c0->dGrad, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr,
+               batch_ab(batch, 0, 0), B, 0);
   BHIPCHK(hipMemcpy2DAsync(c0->hVal, batch->hzs, c0->dVal, batch->zs, (size_t)q * sizeof(double), B, hipMemcpyDeviceToHost, s));
   BHIPCHK(wait_stream(s));
   BHIPCHK(hipGetLastError());

@@ -195,6 +195,11 @@ void launch_acq_group(hipStream_t st, const QueryArgs* tab, int entries, const d
                       const double* ZnT, const double* R, const double* alpha, const double* bounds4, const double* ystats,
                       AcqParams p, double* partial, unsigned int* counters, double* val, double* grad, double* host_val,
                       double* host_grad, HostMirror* hm, unsigned long long seq, AcqBatch ab);
+// value-only scoring of a large batch as a GEMM (KS, then V = R KS^T on MFMA, then the scalar chain); KS: q x ld scratch
+bool score_gemm_possible(int q);
+void launch_score(hipStream_t st, const double* Xq, int q, int n, int k, int NP, int ld, const double* ZnT, const double* R,
+                  const double* alpha, const double* bounds4, const double* ystats, AcqParams p, double* KS, double* partial,
+                  double* val, AcqBatch ab = AcqBatch(), int B = 1);
 // resident mode available for this shape? (fast path + every group of the grid co-resident)
 bool acq_server_possible(int q, int n, int k, int NP);
 int acq_slabs(int NP);

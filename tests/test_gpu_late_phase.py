@@ -117,7 +117,9 @@ def _check_state(native, ctx, rec, tr, stats):
     vb, gb = ctx.acq_eval(rec.trace.raw_X[:96], rec.best_f, False)                 # large batch WITH gradient
     ov96, og96 = acq.value_and_grad(rec.trace.raw_X[:96])
     s["grad_large"] = _rel(gb, og96)
-    assert np.array_equal(vb, vr[:96]) and s["grad_large"] < 1e-6, s
+    # (value-only batches of >= 64 points run as a GEMM on MFMA, batches with gradient through the slab kernels: same
+    # numbers up to summation order)
+    assert np.abs(vb - vr[:96]).max() <= 1e-11 * max(1.0, np.abs(vb).max()) and s["grad_large"] < 1e-6, s
     assert np.array_equal(gb[:12], g[20:32])                   # both finishing paths sum in the same order
     # ---- finite differences of the device value against the device gradient --------------------------------------
     h = 1e-6

@@ -795,7 +795,7 @@ static AcqParams make_params(pcabo_ctx* ctx, double best_f, int maximize, int ac
 
 // One evaluation of the acquisition at the nq points staged in ctx->hXq (pinned): a single fused launch
 // whose results land in ctx->hVal / ctx->hGrad; the host spins on the sequence flag.
-static int eval_staged(pcabo_ctx* ctx, int nq, AcqParams& p) {
+static int eval_staged(pcabo_ctx* ctx, int nq, AcqParams& p, bool allow_gemm = true) {
   hipStream_t s = ctx->stream;
   const int k = ctx->k;
   const unsigned long long seq = ++ctx->seq;
@@ -809,7 +809,7 @@ static int eval_staged(pcabo_ctx* ctx, int nq, AcqParams& p) {
   }
   const bool small = nq <= PCABO_INLAUNCH_MAXQ;   // in-launch combine + host flag; larger batches: two launches + copy
   static const bool gemm_env = !(getenv("PCABO_SCORE_GEMM") && atoi(getenv("PCABO_SCORE_GEMM")) == 0);
-  if (!small && !p.want_grad && gemm_env && score_gemm_possible(nq)) {
+  if (!small && !p.want_grad && gemm_env && allow_gemm && score_gemm_possible(nq)) {
     // value-only scoring of a large batch (the raw samples): V = R KS^T on MFMA
     if (!xdev) {
       HIPCHK(hipMemcpyAsync(ctx->dXq, ctx->hXq, (size_t)nq * k * sizeof(double), hipMemcpyHostToDevice, s));
@@ -1251,7 +1251,9 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
       for (int j = 0; j < gsize[gi]; ++j) vals[gstart[gi] + j] = vc[gi][j];
   } else {
     AcqParams pv = make_params(ctx, best_f, maximize, acq, 0);
-    int rc = eval_staged(ctx, num_restarts, pv);
+    // (through the slab kernels whatever the number of restarts: the values of a restart must not depend on how many
+    // restarts share the call)
+    int rc = eval_staged(ctx, num_restarts, pv, false);
     if (rc != PCABO_OK) return rc;
     for (int j = 0; j < num_restarts; ++j) vals[j] = ctx->hVal[j];
   }

@@ -113,7 +113,8 @@ def test_acquisition_value_and_gradient(ctx, records, native):
             assert (np.abs(v - ov) / scale).max() < 1e-8, kind
             assert np.abs(g - og).max() < 1e-7 * max(1.0, np.abs(og).max()), kind
             v2 = ctx.acq_eval(X, rec.best_f, False, code, grad=False)
-            assert np.array_equal(v, v2)                        # value-only path is the same arithmetic
+            # value-only batches of >= 64 points run as a GEMM on MFMA: same numbers up to summation order
+            assert np.abs(v - v2).max() <= 1e-11 * max(1.0, np.abs(v).max())
 
 
 def test_acquisition_all_512_raw_samples(ctx, records):

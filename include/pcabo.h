@@ -244,6 +244,19 @@ int pcabo_batch_get_profile(pcabo_batch* batch, double* ms);
 /* Row O for every run: z[B][max_d] (k_b entries used) -> x[B][d]. */
 int pcabo_batch_inverse_map(pcabo_batch* batch, const double* z, double* x);
 
+/* ---- BBOB f15-f24 objectives on the device, for runs that advance in lock-step ---------------------------------------
+ * The reference evaluates `problem(x)` on the host, one candidate per BO iteration (PCA_BO.py:263; the problems come from
+ * ioh, ExperimentRunner.py:90).  With B runs in lock-step their B candidates are evaluated in one launch.
+ * tables[B][pcabo_bbob_table_doubles(d)]: per run [x_opt(d) | R(d*d) | M(d*d) | aux], generated on the host by the seeded
+ * legacy generators (pcabo/bbob.py builds them; layout in pcabo/bbob_device.py).  fid[B] in 15..24.
+ * pcabo_bbob_eval: X[B][d] candidates -> raw[B] (value WITHOUT f_opt; `penalty` for a candidate outside [lb, ub]^d, which is
+ * not evaluated: PCA_BO.py:248-263) and oob[B] (may be NULL). */
+typedef struct pcabo_objective pcabo_objective;
+int pcabo_bbob_table_doubles(int d);
+int pcabo_bbob_create(int device, int B, int d, const int* fid, const double* tables, pcabo_objective** out);
+int pcabo_bbob_destroy(pcabo_objective* obj);
+int pcabo_bbob_eval(pcabo_objective* obj, const double* X, double lb, double ub, double penalty, double* raw, int* oob);
+
 #ifdef __cplusplus
 }
 #endif

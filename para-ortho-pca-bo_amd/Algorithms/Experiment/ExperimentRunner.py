@@ -58,7 +58,7 @@ class ExperimentRunner:
                  budget_factor: int = 10, doe_factor: float = 3.0, root_dir: str = os.getcwd(),
                  experiment_name: str = "experiment", acquisition_function: str = "expected_improvement",
                  pca_components: Optional[int] = None, var_threshold: float = 0.95, verbose: bool = False,
-                 progress: bool = True):
+                 progress: bool = True, batched: int = 0):
         self.algorithms = algorithms
         self.dimensions = dimensions
         self.problem_ids = problem_ids
@@ -72,6 +72,10 @@ class ExperimentRunner:
         self.var_threshold = var_threshold
         self.verbose = verbose
         self.progress = progress and tqdm is not None
+        # batched > 1 (not in the reference): the PCA_BO runs of this rank that share a dimension advance in lock-step,
+        # `batched` at a time, through pcabo.batchrun (one launch sequence for all of them per phase).  Same runs, same
+        # files: a run's rows are written once its batch has finished.  Needs the in-repo BBOB problems (no ioh logger).
+        self.batched = int(batched)
 
         self.triggers = [ALWAYS]
         self.logger_properties = [RAWYBEST]
@@ -129,6 +133,34 @@ class ExperimentRunner:
         for pid, dim, inst in mine:
             yield LoggedProblem(BBOBProblem(pid, inst, dim), logger)
 
+    def _run_pca_batched(self, logger, ebar) -> None:
+        """This rank's PCA_BO runs, `self.batched` runs of one dimension at a time in lock-step (pcabo.batchrun)."""
+        from pcabo.batchrun import BatchedPCABO
+        from pcabo.bbob import BBOBProblem
+        from pcabo.iohlog import LoggedProblem
+        mine = self._my_runs()
+        for dim in sorted({r[1] for r in mine}, key=self.dimensions.index):
+            cell = [r for r in mine if r[1] == dim]
+            for i in range(0, len(cell), self.batched):
+                chunk = cell[i:i + self.batched]
+                probs = [BBOBProblem(pid, inst, dim) for pid, _, inst in chunk]
+                budget, n_doe = self.budget_factor * dim + 50, int(self.doe_factor * dim)
+                seeds = [1000 * pid + 10 * dim + inst for pid, _, inst in chunk]
+                runner = BatchedPCABO(probs, seeds, budget, n_doe, n_components=self.pca_components or 0,
+                                      var_threshold=self.var_threshold, acquisition_function=self.acquisition_function,
+                                      device=self.device)
+                start_time = time()
+                runner.run()
+                elapsed = (time() - start_time) / len(chunk)          # a run's share of its batch
+                for b, (pid, _, inst) in enumerate(chunk):
+                    replay = LoggedProblem(BBOBProblem(pid, inst, dim), logger)     # the run's rows, in its own order
+                    for _, x in probs[b].log:
+                        replay(x)
+                    logger.set_run_attribute("time", elapsed)
+                    self.results.append({"algorithm": "pca", "problem_id": pid, "dim": dim, "instance": inst,
+                                         "best": runner.current_best[b], "time": elapsed, "iterations": budget - n_doe})
+                    ebar.update(1)
+
     # ---- the experiment --------------------------------------------------------------------------------------------
     def run_experiment(self) -> None:
         total_runs = len(self.algorithms) * len(self.problem_ids) * len(self.dimensions) * self.num_runs
@@ -159,6 +191,10 @@ class ExperimentRunner:
                     logger.add_run_attribute(f"{time_profile}_time", 0.0)
                 logger.add_run_attribute("time", 0.0)
 
+                if algorithm == "pca" and self.batched > 1 and not HAVE_IOH:
+                    self._run_pca_batched(logger, ebar)
+                    logger.close()
+                    continue
                 for problem in self._problems(logger):
                     dim = problem.meta_data.n_variables
                     problem_id = problem.meta_data.problem_id

@@ -903,6 +903,11 @@ __global__ __launch_bounds__(256) void k_acq_combine(const double* __restrict__ 
 // The table in the QueryArgs slot names the groups of the launch: 32-bit entries run << 16 | first query << 8 | count.
 // Arithmetic differs from the kernels above in summation order only (~1e-15 relative): it is selected per context /
 // batch (PCABO_OPT_GROUP_ACQ), never mixed within a run.
+#ifdef PCABO_ACQ_TIMING
+#define GSTAMP(i) do { if (blockIdx.x == gridDim.x - 1 && blockIdx.y == 0 && threadIdx.x == 0) g_acq_stamps[i] = wall_clock64(); } while (0)
+#else
+#define GSTAMP(i)
+#endif
 #define GQ 5
 #define GT_LD 17            // LDS leading dimension of a wave's 64 x 16 tile (odd: row-wise reads conflict-free)
 template <int NT>           // NT = ceil(NP / 256): columns per thread in the thread-per-column phases
@@ -942,6 +947,7 @@ __global__ __launch_bounds__(256) void k_acq_group(
   const int kernel = prm.kernel;
 
   // ---- normalised query points (queries beyond nq repeat the first: computed, never published) -----------------
+  GSTAMP(0);
   for (int idx = tid; idx < GQ * k; idx += 256) {
     const int q = idx / k, c = idx - q * k;
     const int qq = q < nq ? q : 0;
@@ -949,6 +955,7 @@ __global__ __launch_bounds__(256) void k_acq_group(
     s_xn[q * KS + c] = (Xq[(size_t)(q0 + qq) * k + c] - lo) / (hi - lo);
   }
   __syncthreads();
+  GSTAMP(1);
   // ---- ks and the radial derivative factor, all queries per pass over ZnT -----------------------------------------
   double cfr[NT][GQ];
   const double s5 = 2.23606797749979;
@@ -993,6 +1000,7 @@ __global__ __launch_bounds__(256) void k_acq_group(
     }
   }
   __syncthreads();
+  GSTAMP(2);
   // ---- v for the slab's rows.  Wave w owns columns 16 w .. 16 w + 15 of every 64-column block: it loads its 64 x 16
   // piece coalesced (lanes along the columns), turns it in its PRIVATE LDS tile and reads it back with a lane per row -
   // no work-group barrier in the loop, two pieces in flight ahead of the one being consumed --------------------------
@@ -1050,6 +1058,7 @@ __global__ __launch_bounds__(256) void k_acq_group(
     s_v[m * 8 + q] = ((pp[0] + pp[64 * GT_LD]) + pp[2 * 64 * GT_LD]) + pp[3 * 64 * GT_LD];
   }
   __syncthreads();
+  GSTAMP(3);
   // ---- slab contributions to |v|^2 and mu_s = alpha . ks: wave q (wave 0 also the fifth query) -------------------
   for (int q = w; q < nq; q += 4) {
     const int i = r0 + l;
@@ -1091,6 +1100,7 @@ __global__ __launch_bounds__(256) void k_acq_group(
           for (int q = 0; q < GQ; ++q) wacc[t][q] += rr[u][t] * vq[q];
       }
     }
+    GSTAMP(4);
     __syncthreads();                      // every wave has read the ks it needed (mu above): s_ks becomes t_sigma
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -1106,6 +1116,7 @@ __global__ __launch_bounds__(256) void k_acq_group(
       }
     }
     __syncthreads();
+    GSTAMP(5);
     // ---- contraction with (xn_c - zn_jc): wave per component, lanes over points.  The lane's share of t_sigma lives in
     // registers; the ZnT row of the NEXT component is loaded before the wave sums of the current one ------------------
     constexpr int NBL = 4 * NT;                        // 64-column blocks per lane
@@ -1154,6 +1165,7 @@ __global__ __launch_bounds__(256) void k_acq_group(
   // ---- tickets: the last slab group of a query finishes it ---------------------------------------------------------
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  GSTAMP(6);
   if (tid == 0) {
     int any = 0;
     for (int q = 0; q < nq; ++q) {
@@ -1170,6 +1182,10 @@ __global__ __launch_bounds__(256) void k_acq_group(
   }
   __syncthreads();
   if (!s_flag[GQ]) return;
+  if (threadIdx.x == 0) { GSTAMP(7); }
+#ifdef PCABO_ACQ_TIMING
+  if (threadIdx.x == 0 && blockIdx.y == 0) g_acq_stamps[7] = wall_clock64();
+#endif
   // scalar chains side by side: wave q (wave 0 also the fifth)
   for (int q = w; q < nq; q += 4)
     if (s_flag[q])
@@ -1187,11 +1203,17 @@ __global__ __launch_bounds__(256) void k_acq_group(
       if (host_grad) host_grad[(size_t)(q0 + q) * k + c] = g;
     }
   }
+#ifdef PCABO_ACQ_TIMING
+  if (threadIdx.x == 0 && blockIdx.y == 0) g_acq_stamps[8] = wall_clock64();
+#endif
   // publish: every thread's host writes are out before the sequence words follow
   __threadfence_system();
   __syncthreads();
   if (hm && tid < nq && s_flag[tid])
     __hip_atomic_store(const_cast<unsigned long long*>(&hm->qflag[q0 + tid]), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#ifdef PCABO_ACQ_TIMING
+  if (threadIdx.x == 0 && blockIdx.y == 0) g_acq_stamps[9] = wall_clock64();
+#endif
 }
 
 bool acq_group_possible(int NP, int k) { return NP <= 1280 && k <= PCABO_MAXD; }

@@ -37,6 +37,7 @@ EXPORTS = [
     "pcabo_batch_wpca_gp_condition_begin", "pcabo_batch_wpca_results", "pcabo_batch_acq_bounds",
     "pcabo_batch_gp_condition_end_eval", "pcabo_batch_optimize_acqf", "pcabo_batch_inverse_map",
     "pcabo_batch_set_profiling", "pcabo_batch_get_profile",
+    "pcabo_bbob_table_doubles", "pcabo_bbob_create", "pcabo_bbob_destroy", "pcabo_bbob_eval",
 ]
 
 

@@ -38,7 +38,7 @@ class BatchedPCABO:
     def __init__(self, problems: Sequence, seeds: Sequence[int], budget: int, n_DoE: int, n_components: int = 0,
                  var_threshold: float = 0.95, acquisition_function: str = "expected_improvement",
                  maximization: bool = False, device: int = 0, num_restarts: int = 10, raw_samples: int = 512,
-                 record_trace: bool = False, host_threads: int = 0):
+                 record_trace: bool = False, host_threads: int = 0, device_objective: bool = False):
         self.problems, self.seeds = list(problems), [int(s) for s in seeds]
         self.B = len(self.problems)
         assert self.B == len(self.seeds) and self.B >= 1
@@ -67,6 +67,9 @@ class BatchedPCABO:
         self._X = None
         # the runs' noise draws (numpy releases the interpreter lock while it generates) are spread over a few threads;
         # every run has its own generator, so the order in which the threads get to the runs does not matter
+        # device_objective: the B candidates of an iteration are evaluated in one launch (pcabo.bbob_device; in-repo BBOB
+        # problems only).  Off by default: the host evaluation keeps a run bit-identical to the same run alone.
+        self._device_objective, self._dev_obj = bool(device_objective), None
         self._pool = None
         self._host_threads = int(host_threads) if host_threads else min(8, self.B)
 
@@ -85,6 +88,9 @@ class BatchedPCABO:
             self._assign_new_best(b)
             self._X[b, : self.n_DoE] = np.vstack(self.x_evals[b])
         self._batch = _native.Batch(B, max_n=self.budget, max_d=d, max_q=max(self.raw_samples, 16), device=self.device)
+        if self._device_objective:
+            from .bbob_device import DeviceObjectives
+            self._dev_obj = DeviceObjectives(self.problems, device=self.device, penalty=OOB_PENALTY)
         if self._host_threads > 1:
             from concurrent.futures import ThreadPoolExecutor
             self._pool = ThreadPoolExecutor(max_workers=self._host_threads)
@@ -188,8 +194,23 @@ class BatchedPCABO:
                                    "retried": retried})
         self.lbfgsb_info.append(infos)
         X_new = bt.inverse_map(z_new)
+        f_dev = None
+        if self._dev_obj is not None and not self.maximization:
+            f_dev, raw_dev, oob_dev = self._dev_obj.evaluate(X_new)
         for b in range(B):
             new_x = X_new[b].copy()
+            if f_dev is not None:
+                new_f = float(f_dev[b])
+                if not oob_dev[b]:               # keep the problem's own record (what the Analyzer rows are written from)
+                    p = self.problems[b]
+                    p.evaluations += 1
+                    p.best_raw = min(p.best_raw, float(raw_dev[b]))
+                    p.log.append((float(raw_dev[b]), new_x.copy()))
+                self.x_evals[b].append(new_x)
+                self.f_evals[b].append(new_f)
+                self._X[b, n] = new_x
+                self._assign_new_best(b)
+                continue
             outside = not np.all(new_x >= self.bounds[b][:, 0]) or not np.all(new_x <= self.bounds[b][:, 1])
             # out-of-box candidates are not evaluated; they cost budget and a fixed penalty (PCA_BO.py:260-263)
             new_f = (-OOB_PENALTY if self.maximization else OOB_PENALTY) if outside else self.problems[b](new_x)
@@ -210,6 +231,9 @@ class BatchedPCABO:
         if self._pool is not None:
             self._pool.shutdown()
             self._pool = None
+        if self._dev_obj is not None:
+            self._dev_obj.close()
+            self._dev_obj = None
         if self._batch is not None:
             self._batch.close()
             self._batch = None

@@ -54,3 +54,51 @@ def test_partition_is_balanced_and_deterministic():
     assert sharding.run_settings((15, 40, 7)) == {"budget": 450, "n_doe": 120, "seed": 15407}
     with pytest.raises(ValueError):
         sharding.assign_runs(runs, 0)
+
+
+def _runner_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from pcabo import distributed as D
+    D.init(backend="gloo")
+    import importlib
+    er_mod = importlib.import_module("Algorithms.Experiment.ExperimentRunner")
+    er = er_mod.ExperimentRunner(algorithms=["pca"], dimensions=[20, 40], problem_ids=list(range(15, 25)), num_runs=30,
+                                 root_dir="/tmp", experiment_name="x", progress=False)
+    mine = er._my_runs()
+    counts = D.gather_best([float(len(mine)), float(sum(sharding.run_cost(r) for r in mine))])
+    backend = D.backend_name()
+    D.finalize()
+    q.put((rank, mine, counts, er._folder("pca"), backend))
+
+
+def test_sharded_experiment_runner_run_lists_two_ranks_gloo():
+    """BASELINE.json configs[3] (30 runs x f15-f24 x d in {20, 40}) through the runner's own partition on 2 ranks: every
+    run on exactly one rank, suite order kept inside a rank, balanced cost, rank-suffixed folders, backend recorded."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_runner_worker, args=(r, 2, 29613, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, m0, c0, f0, b0), (r1, m1, c1, f1, b1) = res
+    all_runs = sharding.enumerate_runs(range(15, 25), [20, 40], 30)
+    assert sorted(m0 + m1) == sorted(all_runs) and set(m0).isdisjoint(m1)
+    assert m0 == [r for r in all_runs if r in set(m0)]                      # suite order inside the rank
+    assert c0 == c1 and c0[0][0] + c0[1][0] == 600.0
+    assert max(c0[0][1], c0[1][1]) / min(c0[0][1], c0[1][1]) < 1.02
+    assert (f0, f1) == ("pca-x-rank0", "pca-x-rank1") and b0 == b1 == "gloo"
+
+
+def test_nccl_request_without_gpu_exits_instead_of_falling_back(monkeypatch):
+    """A rank that cannot use RCCL must stop (non-zero exit), not continue over gloo on its own."""
+    import torch
+    from pcabo import distributed as D
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without GPUs")
+    monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("LOCAL_RANK", "0"); monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit):
+        D.init(backend="nccl")

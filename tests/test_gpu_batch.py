@@ -89,3 +89,73 @@ def test_batch_state_matches_single_context_calls(native):
         assert np.array_equal(v2, v3) and np.array_equal(g2, g3)
         c.close()
     bt.close()
+
+
+def test_device_objectives_match_the_host_restatements(native):
+    """BBOB f15-f24 on the device (csrc/kernels_bbob.hip) against pcabo.bbob on the same points, all ten functions at
+    d = 5 / 20 / 40, instances 0..2: values to 1e-11 relative (other summation order), the out-of-box rule exactly."""
+    from pcabo.bbob import FUNCTIONS
+    from pcabo.bbob_device import DeviceObjectives
+    rng = np.random.default_rng(8)
+    for d in (5, 20, 40):
+        probs = [BBOBProblem(fid, inst, d) for fid in sorted(FUNCTIONS) for inst in range(3)]
+        dev = DeviceObjectives(probs)
+        for rep in range(4):
+            X = rng.uniform(-5, 5, (len(probs), d))
+            if rep == 1:
+                X[::4, 0] = 5.0 + 1e-9                      # just outside: penalised, not evaluated
+            if rep == 2:
+                X = np.stack([p.optimum.x + 1e-3 * rng.normal(size=d) for p in probs]).clip(-5, 5)
+            f, raw, oob = dev.evaluate(X)
+            for b, p in enumerate(probs):
+                outside = bool(np.any(X[b] < -5.0) or np.any(X[b] > 5.0))
+                assert bool(oob[b]) == outside
+                if outside:
+                    assert f[b] == 1000.0
+                else:
+                    want = p.raw(X[b])
+                    assert abs(raw[b] - want) <= 1e-11 * max(1.0, abs(want)), (p.meta_data.problem_id, d, raw[b], want)
+                    assert abs(f[b] - (want + p.f_opt)) <= 1e-11 * max(1.0, abs(want + p.f_opt))
+        dev.close()
+
+
+def test_batched_run_with_device_objectives(native):
+    """The whole lock-step loop with the objectives on the device: f15/f16/f17 (BASELINE.json configs[2]) at d = 10, one
+    batch.  Against the same batch with host objectives: same DoE, same first BO candidates; trajectories may part later
+    where a 1e-13 difference in f flips a rank (chaos), so the check is on the first iterations."""
+    from pcabo.batchrun import BatchedPCABO
+    runs = [(fid, inst) for fid in (15, 16, 17) for inst in (0, 1)]
+    out = []
+    for dev in (False, True):
+        r = BatchedPCABO([BBOBProblem(f, i, 10) for f, i in runs], [1000 * f + 100 + i for f, i in runs], 45, 30,
+                         device_objective=dev)
+        r.run()
+        out.append(r)
+    for b in range(len(runs)):
+        xa, xb = np.vstack(out[0].x_evals[b]), np.vstack(out[1].x_evals[b])
+        assert np.array_equal(xa[:31], xb[:31])                       # DoE + first candidate: same inputs, same device path
+        fa, fb = np.array(out[0].f_evals[b]), np.array(out[1].f_evals[b])
+        assert np.abs(fa[:31] - fb[:31]).max() <= 1e-10 * max(1.0, np.abs(fa[:31]).max())
+        assert len(out[1].problems[b].log) == out[1].problems[b].evaluations
+
+
+def test_experiment_runner_batched_writes_the_same_files(native, tmp_path, monkeypatch):
+    """ExperimentRunner(batched=B): the PCA_BO runs of a dimension advance in lock-step; with the per-query kernels on both
+    sides the files must equal those of the run-by-run runner byte for byte (apart from the wall-time attributes)."""
+    import os
+    from Algorithms import ExperimentRunner
+    from pcabo import iohlog
+    monkeypatch.setenv("PCABO_BATCH_ACQ", "slab")
+    outs = []
+    for batched in (0, 4):
+        root = tmp_path / f"b{batched}"
+        er = ExperimentRunner(algorithms=["pca"], dimensions=[5], problem_ids=[15, 20], num_runs=3, budget_factor=5,
+                              doe_factor=2.0, root_dir=str(root), experiment_name="experiment", progress=False, batched=batched)
+        er.run_experiment()
+        assert len(er.results) == 6
+        outs.append((root, sorted((r["problem_id"], r["instance"], r["best"]) for r in er.results)))
+    assert outs[0][1] == outs[1][1]
+    for fid, name in ((15, "RastriginRotated"), (20, "Schwefel")):
+        rel = os.path.join("pca-experiment", f"data_f{fid}_{name}", f"IOHprofiler_f{fid}_DIM5.dat")
+        a, b = open(os.path.join(outs[0][0], rel)).read(), open(os.path.join(outs[1][0], rel)).read()
+        assert a == b

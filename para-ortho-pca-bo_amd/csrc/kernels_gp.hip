@@ -74,10 +74,9 @@ __global__ void k_add_jitter(double* __restrict__ K, int n, int ld, double jitte
 }
 
 // ---------------------------------------------------------------------------------------------
-// Blocked right-looking Cholesky, panel width 64.
-// k_chol_panel, block b of the grid: every work-group factors the 64x64 diagonal block in LDS
-// (redundantly - cheaper than a second launch), block 0 stores it, block b > 0 solves its 64x64
-// off-diagonal block X L_dd^T = A_bd.
+// Blocked right-looking Cholesky, panel width 64: per panel k_chol_panel_w (kernels_gpw.hip: two waves per 64 x 64
+// block, a matrix row per lane) factors the diagonal block and solves the off-diagonal blocks, k_chol_update below
+// applies the trailing update on MFMA.
 __device__ inline void load_tile(const double* __restrict__ src, int ld, double* s_t) {
   for (int idx = threadIdx.x; idx < BS * BS; idx += 256) {
     int r = idx >> 6, c = idx & 63;
@@ -85,115 +84,11 @@ __device__ inline void load_tile(const double* __restrict__ src, int ld, double*
   }
 }
 
-// Factor the 64x64 SPD block held in s_d (lower triangle used) in place into its Cholesky factor (upper part
-// zeroed).  256 threads; thread (ri = tid>>2, part = tid&3) owns the row elements c = part + 4u in registers.
-// Right-looking with DELAYED scaling: at step j column j is final, its owner lanes capture it (fin) and publish
-// it through a double-buffered LDS column (one barrier per step); every row then subtracts (a_ij / a_jj) a_cj
-// from its not-yet-final columns.  Updates are unconditional (columns <= j are never read again; rows <= j use
-// a zero factor), columns final for every lane are pruned at compile time, and L = fin / sqrt(a_jj) is applied
-// once at the end.  Returns through *bad_pivot the 1-based index of the first non-positive pivot (0 = none).
-__device__ inline void chol64_inplace(double* s_d, double (*s_col)[BS], int* bad_pivot) {
-  const int tid = threadIdx.x;
-  const int ri = tid >> 2, part = tid & 3;
-  double a[16], fin[16];
-#pragma unroll
-  for (int u = 0; u < 16; ++u) { a[u] = s_d[ri * TLD + part + 4 * u]; fin[u] = a[u]; }
-  int bad = 0;
-#pragma unroll
-  for (int j = 0; j < BS; ++j) {
-    if (part == (j & 3)) { fin[j >> 2] = a[j >> 2]; s_col[j & 1][ri] = a[j >> 2]; }
-    __syncthreads();
-    double piv = s_col[j & 1][j];
-    if (!(piv > 0.0)) { if (bad == 0) bad = j + 1; piv = 1.0; }
-    const double f = (ri > j) ? s_col[j & 1][ri] * fast_rcp(piv) : 0.0;
-#pragma unroll
-    for (int u = j >> 2; u < 16; ++u) {
-      a[u] -= f * s_col[j & 1][part + 4 * u];
-      asm volatile("" : "+v"(a[u]));         // evaluate now: hipcc otherwise defers these FMAs and spills their inputs
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int u = 0; u < 16; ++u)
-    if (part + 4 * u == ri) s_col[0][ri] = fin[u];     // pivots (static register index: a runtime one would spill)
-  __syncthreads();
-#pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    const int c = part + 4 * u;
-    const double pv = s_col[0][c];
-    const double rs = fast_rsq(pv > 0.0 ? pv : 1.0);
-    double v;
-    if (c < ri) v = fin[u] * rs;
-    else if (c == ri) v = (pv > 0.0 ? pv : 1.0) * rs;     // sqrt(pv)
-    else v = 0.0;
-    s_d[ri * TLD + c] = v;
-  }
-  *bad_pivot = bad;
-  __syncthreads();
-}
-
-// Solve X L^T = B for a 64x64 block B (global, leading dimension ld) with the factor L in s_d; rows in
-// registers, column by column: x_c = b_c / L[c][c] is broadcast inside the 4-lane row group by a shuffle, then
-// b_m -= x_c L[m][c] (unconditional for columns certainly beyond c; the boundary group is predicated).
-__device__ inline void trsm64_right_lt(const double* s_d, const double* s_rdiag, double* Bt, int ld) {
-  const int tid = threadIdx.x;
-  const int ri = tid >> 2, part = tid & 3;
-  double bb[16];
-#pragma unroll
-  for (int u = 0; u < 16; ++u) bb[u] = Bt[(size_t)ri * ld + part + 4 * u];
-#pragma unroll
-  for (int c = 0; c < BS; ++c) {
-    const double own = bb[c >> 2] * s_rdiag[c];
-    double xc;                                   // broadcast inside the quad by DPP (quad_perm [m,m,m,m]), no LDS
-    switch (c & 3) {
-      case 0: xc = dpp_get<0x00, 0xf>(own); break;
-      case 1: xc = dpp_get<0x55, 0xf>(own); break;
-      case 2: xc = dpp_get<0xAA, 0xf>(own); break;
-      default: xc = dpp_get<0xFF, 0xf>(own); break;
-    }
-    if (part == (c & 3)) bb[c >> 2] = xc;
-    if (part > (c & 3)) bb[c >> 2] -= xc * s_d[(part + 4 * (c >> 2)) * TLD + c];
-#pragma unroll
-    for (int u = (c >> 2) + 1; u < 16; ++u) {
-      bb[u] -= xc * s_d[(part + 4 * u) * TLD + c];
-      asm volatile("" : "+v"(bb[u]));
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < 16; ++u) Bt[(size_t)ri * ld + part + 4 * u] = bb[u];
-}
-
-// Block 0 must not store the factor over the diagonal block inside this launch: the other groups read that block as
-// INPUT at their start, and nothing orders their start before block 0's end (on a GPU shared with other processes a
-// group can start tens of microseconds late - seen as a spurious "not positive definite").  With more than one group
-// the factor goes to `diag_scratch`; the trailing-update launch that follows copies it into place (it does not touch
-// the diagonal block otherwise).
-__global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ A, int p, int ld, int* __restrict__ info,
-                                                    double* __restrict__ diag_scratch) {
-  __shared__ __attribute__((aligned(16))) double s_d[BS * TLD];
-  __shared__ __attribute__((aligned(16))) double s_col[2][BS];
-  const int tid = threadIdx.x;
-  const int b = blockIdx.x;
-  double* Add = A + (size_t)(p * BS) * ld + p * BS;
-  load_tile(Add, ld, s_d);
-  __syncthreads();
-  int bad = 0;
-  chol64_inplace(s_d, s_col, &bad);
-  if (bad && b == 0 && tid == 0) atomicCAS(info, 0, p * BS + bad);
-  if (b == 0) {
-    const bool direct = gridDim.x == 1;              // last panel: nobody else reads the block
-    for (int idx = tid; idx < BS * BS; idx += 256) {
-      int r = idx >> 6, c = idx & 63;
-      if (direct) Add[(size_t)r * ld + c] = s_d[r * TLD + c];
-      else diag_scratch[idx] = s_d[r * TLD + c];
-    }
-    return;
-  }
-  if (tid < BS) s_col[1][tid] = fast_rcp(s_d[tid * TLD + tid]);
-  __syncthreads();
-  trsm64_right_lt(s_d, s_col[1], A + (size_t)((p + b) * BS) * ld + p * BS, ld);
-}
-
+// The panel kernel does not store the factored diagonal block over its input inside its own launch: the other groups of
+// that launch read the block as INPUT at their start, and nothing orders their start before block 0's end (on a GPU
+// shared with other processes a group can start tens of microseconds late - seen as a spurious "not positive
+// definite").  With more than one group the factor goes to `diag_scratch`; one extra group of this kernel copies it
+// into place (it does not touch the diagonal block otherwise).
 // Trailing update A[I][J] -= L[I][p] L[J][p]^T for p < J <= I on f64 MFMA.
 // Both 64x64 operand tiles are staged in LDS with coalesced loads; fragments are read with a
 // leading dimension of 66 doubles (conflict-free for ds_read_b64).
@@ -203,7 +98,7 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int
   __shared__ __attribute__((aligned(16))) double s_a[BS * TLD];
   __shared__ __attribute__((aligned(16))) double s_b[BS * TLD];
   if (blockIdx.x == gridDim.x - 1) {                 // one extra group puts panel p's diagonal factor in place (see
-    double* Add = A + (size_t)(p * BS) * ld + p * BS;  // k_chol_panel): off the critical path of the tile groups
+    double* Add = A + (size_t)(p * BS) * ld + p * BS;  // the note above): off the critical path of the tile groups
     for (int idx = threadIdx.x; idx < BS * BS; idx += 256) Add[(size_t)(idx >> 6) * ld + (idx & 63)] = diag_scratch[idx];
     return;
   }
@@ -247,33 +142,7 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int
 
 // ---------------------------------------------------------------------------------------------
 // Root inverse R = L^-1 (what gpytorch caches as `covar_cache`, stored here un-transposed).
-// Step 1: invert every 64x64 diagonal block by forward substitution (one thread per column).
-__global__ __launch_bounds__(256) void k_trinv_diag(const double* __restrict__ L, int ld, double* __restrict__ R) {
-  __shared__ __attribute__((aligned(16))) double s_l[BS * TLD];
-  __shared__ __attribute__((aligned(16))) double s_x[BS * TLD];   // s_x[c][r]: column c of the inverse, contiguous in r
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int c = tid >> 2, part = tid & 3;                         // four lanes (same wave) per column
-  load_tile(L + (size_t)(b * BS) * ld + b * BS, ld, s_l);
-  __syncthreads();
-  for (int r = 0; r < BS; ++r) {
-    double s = 0.0;
-    if (r > c)
-      for (int m = c + part; m < r; m += 4) s += s_l[r * TLD + m] * s_x[c * TLD + m];
-    s += dpp_get<0xB1, 0xf>(s);      // quad_perm [1,0,3,2]
-    s += dpp_get<0x4E, 0xf>(s);      // quad_perm [2,3,0,1]
-    if (part == 0) s_x[c * TLD + r] = (r < c) ? 0.0 : (((r == c) ? 1.0 : 0.0) - s) / s_l[r * TLD + r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  }
-  __syncthreads();
-  double* dst = R + (size_t)(b * BS) * ld + b * BS;
-  for (int idx = tid; idx < BS * BS; idx += 256) {
-    int r = idx >> 6, cc = idx & 63;
-    dst[(size_t)r * ld + cc] = s_x[cc * TLD + r];
-  }
-}
-
+// Step 1 (k_trinv_diag_w, kernels_gpw.hip): invert every 64x64 diagonal block, a column of the inverse per lane.
 // Step 2: one work-group per chunk of 16 columns of R.  Going down the block rows I = J+1..nblk-1
 // (J = block holding the chunk; its diagonal block is already done):
 //   S   = - sum_{K=J}^{I-1} L[I][K] X_K          (64x16 accumulators, f64 MFMA)
@@ -398,10 +267,8 @@ void launch_add_jitter(hipStream_t s, double* K, int n, int ld, double jitter) {
 }
 void launch_cholesky(hipStream_t s, double* L, int NP, int ld, int* info, double* diag_scratch, ZB zb) {
   const int nblk = NP / BS;
-  static const bool lanes4 = getenv("PCABO_GP_FOUR_LANE_ROWS") != nullptr;      // A/B: the earlier panel / inverse kernels
   for (int p = 0; p < nblk; ++p) {
-    if (lanes4 && zb.B == 1) hipLaunchKernelGGL(k_chol_panel, dim3(nblk - p), dim3(256), 0, s, L, p, ld, info, diag_scratch);
-    else launch_chol_panel_w(s, L, p, nblk - p, ld, info, diag_scratch, zb);
+    launch_chol_panel_w(s, L, p, nblk - p, ld, info, diag_scratch, zb);
     int m = nblk - p - 1;
     if (m > 0)
       hipLaunchKernelGGL(k_chol_update, dim3(m * (m + 1) / 2 + 1, 1, zb.B), dim3(256), 0, s, L, p, nblk, ld, diag_scratch,
@@ -411,9 +278,7 @@ void launch_cholesky(hipStream_t s, double* L, int NP, int ld, int* info, double
 void launch_trinv(hipStream_t s, const double* L, int NP, int ld, double* R, ZB zb) {
   const int nblk = NP / BS;
   // (blocks above the diagonal are never written by anything: they keep the zeros of pcabo_ctx_create)
-  static const bool lanes4 = getenv("PCABO_GP_FOUR_LANE_ROWS") != nullptr;
-  if (lanes4 && zb.B == 1) hipLaunchKernelGGL(k_trinv_diag, dim3(nblk), dim3(256), 0, s, L, ld, R);
-  else launch_trinv_diag_w(s, L, nblk, ld, R, zb);
+  launch_trinv_diag_w(s, L, nblk, ld, R, zb);
   hipLaunchKernelGGL(k_trinv_cols, dim3(NP / 16, 1, zb.B), dim3(256), 0, s, L, nblk, ld, R, zb.zs);
 }
 void launch_alpha(hipStream_t s, const double* R, const double* ys, int n, int NP, int ld, double* tmp, double* alpha,

@@ -6,8 +6,8 @@
 #define WLD 65   // LDS leading dimension of the transposing tile (row reads and column writes both conflict-free)
 
 // ---- Cholesky panel: two waves per 64x64 block, a matrix ROW per lane ---------------------------------------------
-// The panel step is a chain of 64 dependent pivots; with four lanes per row (k_chol_panel) every link of the chain
-// costs a work-group barrier and two LDS round trips (44-48 us per panel).  Here a lane keeps a whole row in
+// The panel step is a chain of 64 dependent pivots; with four lanes per row (the first version of this kernel) every link
+// of the chain cost a work-group barrier and two LDS round trips (44-48 us per panel).  Here a lane keeps a whole row in
 // registers (static indices after unrolling; after every 16-column sub-panel the array shifts down by 16 so that the
 // loop body is the same for all four sub-panels):
 //   wave 0, lane r: row r of the diagonal block D.  Inside a sub-panel the factor column of a step is broadcast lane
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(128) void k_chol_panel_w(double* __restrict__ A, in
   __syncthreads();
   if (b == 0) {
     if (role == 0) {
-      const bool direct = gridDim.x == 1;            // last panel: nobody else reads the block (see k_chol_panel)
+      const bool direct = gridDim.x == 1;            // last panel: nobody else reads the block (see kernels_gp.hip)
 #pragma unroll 8
       for (int i = 0; i < BS; ++i) {
         if (direct) Add[(size_t)i * ld + r] = s_d[i * WLD + r];

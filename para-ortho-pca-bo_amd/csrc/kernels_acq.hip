@@ -910,6 +910,10 @@ __global__ __launch_bounds__(256) void k_acq_combine(const double* __restrict__ 
 #endif
 #define GQ 5
 #define GT_LD 17            // LDS leading dimension of a wave's 64 x 16 tile (odd: row-wise reads conflict-free)
+// Hand-over of LDS data between the lanes of ONE wave: the LDS pipeline serves a wave's instructions in order, so all
+// that is needed is that the compiler keeps the order and the data have arrived - a wait on the LDS counter.  (A
+// wavefront-scope fence also waits for every global load in flight, which defeats the prefetching below.)
+#define WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 template <int NT>           // NT = ceil(NP / 256): columns per thread in the thread-per-column phases
 __global__ __launch_bounds__(256) void k_acq_group(
     QueryArgs qa, const double* __restrict__ Xq, int n, int k, int NP, int ld,
@@ -956,47 +960,58 @@ __global__ __launch_bounds__(256) void k_acq_group(
   }
   __syncthreads();
   GSTAMP(1);
-  // ---- ks and the radial derivative factor, all queries per pass over ZnT -----------------------------------------
+  // ---- ks and the radial derivative factor, all queries per pass over ZnT.  Only the columns this slab uses (j < ncol:
+  // R's rows of the slab are zero beyond their diagonal block); all columns of a thread advance together so that a
+  // coordinate read from LDS serves every one of them; CB components' loads are in flight per trip -----------------
   double cfr[NT][GQ];
   const double s5 = 2.23606797749979;
+  {
+    const int jlim = n < ncol ? n : ncol;
+    double sq[NT][GQ];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int j = tid + 256 * t;
-    double sq[GQ];
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int q = 0; q < GQ; ++q) sq[q] = 0.0;
-    if (j < n) {
-      constexpr int CB = NT <= 2 ? 12 : 8;            // components whose loads are in flight per trip (a trip = one L2 round trip)
-      for (int c0 = 0; c0 < k; c0 += CB) {
-        double z[CB];
+      for (int q = 0; q < GQ; ++q) sq[t][q] = 0.0;
+    constexpr int CB = NT == 1 ? 40 : (NT == 2 ? 20 : 8);
+    for (int c0 = 0; c0 < k; c0 += CB) {
+      double z[NT][CB];
 #pragma unroll
-        for (int u = 0; u < CB; ++u) z[u] = (c0 + u < k) ? ZnT[(size_t)(c0 + u) * ld + j] : 0.0;
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int u = 0; u < CB; ++u) {
-          if (c0 + u < k) {                           // uniform
+        for (int u = 0; u < CB; ++u) z[t][u] = (c0 + u < k && tid + 256 * t < jlim) ? ZnT[(size_t)(c0 + u) * ld + tid + 256 * t] : 0.0;
 #pragma unroll
-            for (int q = 0; q < GQ; ++q) { const double d = s_xn[q * KS + c0 + u] - z[u]; sq[q] += d * d; }
+      for (int u = 0; u < CB; ++u) {
+        if (c0 + u < k) {                             // uniform
+#pragma unroll
+          for (int q = 0; q < GQ; ++q) {
+            const double xq = s_xn[q * KS + c0 + u];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { const double d = xq - z[t][u]; sq[t][q] += d * d; }
           }
         }
       }
     }
 #pragma unroll
-    for (int q = 0; q < GQ; ++q) {
-      double ks = 0.0, cf = 0.0;
-      if (j < n) {
-        const double sqq = sq[q] * (inv_ls * inv_ls);
-        if (kernel == 1) {
-          ks = exp(-0.5 * sqq);
-          cf = -ks * inv_ls * inv_ls;
-        } else {
-          const double dist = sqrt(fmax(sqq, 1e-30));
-          const double e = exp(-s5 * dist);
-          ks = ((s5 * dist + 1.0) + (5.0 / 3.0) * (dist * dist)) * e;
-          cf = -(5.0 / 3.0) * (1.0 + s5 * dist) * e * inv_ls * inv_ls;
+    for (int t = 0; t < NT; ++t) {
+      const int j = tid + 256 * t;
+#pragma unroll
+      for (int q = 0; q < GQ; ++q) {
+        double ks = 0.0, cf = 0.0;
+        if (j < jlim) {
+          const double sqq = sq[t][q] * (inv_ls * inv_ls);
+          if (kernel == 1) {
+            ks = exp(-0.5 * sqq);
+            cf = -ks * inv_ls * inv_ls;
+          } else {
+            const double dist = sqrt(fmax(sqq, 1e-30));
+            const double e = exp(-s5 * dist);
+            ks = ((s5 * dist + 1.0) + (5.0 / 3.0) * (dist * dist)) * e;
+            cf = -(5.0 / 3.0) * (1.0 + s5 * dist) * e * inv_ls * inv_ls;
+          }
         }
+        if (j < NP) s_ks[q * NP + j] = ks;
+        cfr[t][q] = cf;
       }
-      if (j < NP) s_ks[q * NP + j] = ks;
-      cfr[t][q] = cf;
     }
   }
   __syncthreads();
@@ -1018,9 +1033,7 @@ __global__ __launch_bounds__(256) void k_acq_group(
     auto put = [&](const double (&src)[16]) {
 #pragma unroll
       for (int u = 0; u < 16; ++u) tw[(4 * u + (l >> 4)) * GT_LD + (l & 15)] = src[u];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      WAVE_LDS_SYNC();
     };
     auto use = [&](int J) {
       const double* trow = tw + l * GT_LD;
@@ -1031,9 +1044,7 @@ __global__ __launch_bounds__(256) void k_acq_group(
 #pragma unroll
         for (int q = 0; q < GQ; ++q) acc[q] += rv * kcol[q * NP + jj];
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      WAVE_LDS_SYNC();
     };
     double bufA[16], bufB[16];
     fetch(0, bufA);
@@ -1150,13 +1161,31 @@ __global__ __launch_bounds__(256) void k_acq_group(
         gs[q] = a;
         gm[q] = tmq[q] * (xq - zm);
       }
+      // 2 GQ wave sums per component: the lanes' partials go through the wave's private LDS tile (free since pass 1) and
+      // come back transposed - lane 4 v + h adds 16 of value v's 64 partials, two quad steps finish - instead of 2 GQ
+      // DPP reduction trees (the largest item of the kernel's timeline when they were)
+      {
+        double* red = s_tile + w * 64 * GT_LD;            // [2 GQ][64] <= 64 * GT_LD doubles
 #pragma unroll
-      for (int q = 0; q < GQ; ++q) {
-        const double a = wave_sum(gs[q]), b2 = wave_sum(gm[q]);
-        if (l == 0 && q < nq) {
-          double* out = partial + ((size_t)(q0 + q) * S + s) * PSTRIDE;
-          st_wt(out + 2 + c, a); st_wt(out + 2 + PCABO_MAXD + c, b2);
+        for (int q = 0; q < GQ; ++q) { red[q * 64 + l] = gs[q]; red[(GQ + q) * 64 + l] = gm[q]; }
+        WAVE_LDS_SYNC();
+        const int v = l >> 2, h = l & 3;                  // lanes 0 .. 4 * 2 GQ - 1 = 39 are active
+        double sum = 0.0;
+        if (v < 2 * GQ) {
+          const double* src = red + v * 64 + 16 * h;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) sum += src[i];
         }
+        sum += dpp_get<0xB1, 0xf>(sum);                   // quad_perm [1,0,3,2]
+        sum += dpp_get<0x4E, 0xf>(sum);                   // quad_perm [2,3,0,1]
+        if (h == 0 && v < 2 * GQ) {
+          const int q = v < GQ ? v : v - GQ;
+          if (q < nq) {
+            double* out = partial + ((size_t)(q0 + q) * S + s) * PSTRIDE;
+            st_wt(out + 2 + (v < GQ ? 0 : PCABO_MAXD) + c, sum);
+          }
+        }
+        WAVE_LDS_SYNC();
       }
 #pragma unroll
       for (int b = 0; b < NBL; ++b) zc[b] = zn_[b];
@@ -1186,13 +1215,49 @@ __global__ __launch_bounds__(256) void k_acq_group(
 #ifdef PCABO_ACQ_TIMING
   if (threadIdx.x == 0 && blockIdx.y == 0) g_acq_stamps[7] = wall_clock64();
 #endif
-  // scalar chains side by side: wave q (wave 0 also the fifth)
-  for (int q = w; q < nq; q += 4)
-    if (s_flag[q])
-      acq_finish_scalar(partial + (size_t)(q0 + q) * S * PSTRIDE, S, q0 + q, ystats, prm, val, host_val, s_coef + 2 * q, l);
+  // The partial records come from other XCDs: every read below is a trip to memory, so all of them are issued first -
+  // the gradient sums (one thread per (query, component), slabs in order) and, per query, the |v|^2 / mu_s sums - and
+  // the scalar log-EI chains of ALL queries then run side by side in the lanes of wave 0.
+  double gsum[2] = {0.0, 0.0}, gmsum[2] = {0.0, 0.0};
+  if (prm.want_grad) {
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {                       // nq * k <= 5 * 128 > 256 threads only beyond k = 51
+      const int idx = tid + 256 * rep;
+      if (idx < nq * k) {
+        const int q = idx / k, c = idx - q * k;
+        if (s_flag[q]) {
+          const double* base = partial + (size_t)(q0 + q) * S * PSTRIDE;
+          double gs = 0.0, gm = 0.0;
+          for (int sl = 0; sl < S; ++sl) { gs += base[(size_t)sl * PSTRIDE + 2 + c]; gm += base[(size_t)sl * PSTRIDE + 2 + PCABO_MAXD + c]; }
+          gsum[rep] = gs; gmsum[rep] = gm;
+        }
+      }
+    }
+  }
+  if (w == 0) {
+    double vv = 0.0, mus = 0.0;
+    const int q = l < nq ? l : 0;
+    if (l < nq && s_flag[q]) {
+      const double* base = partial + (size_t)(q0 + q) * S * PSTRIDE;
+      for (int sl = 0; sl < S; ++sl) { vv += base[(size_t)sl * PSTRIDE]; mus += base[(size_t)sl * PSTRIDE + 1]; }
+    }
+    if (l < nq && s_flag[q]) acq_scalar_core(vv, mus, q0 + q, ystats[0], ystats[1], prm, val, host_val, s_coef + 2 * q, 0);
+  }
   __syncthreads();
   if (prm.want_grad) {
-    for (int idx = tid; idx < nq * k; idx += 256) {          // one thread per (query, component): slabs in order
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+      const int idx = tid + 256 * rep;
+      if (idx < nq * k) {
+        const int q = idx / k, c = idx - q * k;
+        if (s_flag[q]) {
+          const double g = __fma_rn(s_coef[2 * q], gmsum[rep], s_coef[2 * q + 1] * gsum[rep]) / (bounds4[PCABO_MAXD + c] - bounds4[c]);
+          grad[(size_t)(q0 + q) * k + c] = g;
+          if (host_grad) host_grad[(size_t)(q0 + q) * k + c] = g;
+        }
+      }
+    }
+    for (int idx = tid + 512; idx < nq * k; idx += 256) {     // k > 102: the rest, straightforwardly
       const int q = idx / k, c = idx - q * k;
       if (!s_flag[q]) continue;
       const double* base = partial + (size_t)(q0 + q) * S * PSTRIDE;

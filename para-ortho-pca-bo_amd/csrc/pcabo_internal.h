@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #define PCABO_BS 64          // tile edge of the Gram / Cholesky / root-inverse kernels
 #define PCABO_SLAB 16        // rows of R handled by one acquisition work-group
@@ -120,9 +121,13 @@ __device__ inline unsigned long long mail_seq(pcabo_u4 v) {
 
 // Batched launches (pcabo_batch_*): blockIdx.z = run.  The contexts of a batch share one layout, so run b's copy of any
 // device buffer sits b * zs bytes behind run 0's (b * hzs for the pinned host mirror).  zs = 0 / gridDim.z = 1 otherwise.
+// (plain pointer arithmetic on the kernel argument, no detour through an integer: the compiler then still knows the
+// result points to GLOBAL memory and emits global_load/global_store; through uintptr_t it falls back to flat_* accesses,
+// which also count on the LDS counter - every LDS wait then waits for the global loads in flight as well)
 template <typename T>
 __device__ inline T* zrun(T* p, size_t stride, unsigned run) {
-  return p ? reinterpret_cast<T*>((uintptr_t)p + (size_t)run * stride) : p;
+  typedef typename std::remove_const<T>::type U;
+  return p ? reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<U*>(p)) + (size_t)run * stride) : p;   // (NULL stays NULL)
 }
 #define ZRUN(p) p = zrun(p, zs, blockIdx.z)
 

@@ -945,8 +945,10 @@ __global__ __launch_bounds__(256) void k_acq_group(
   double* s_tm = s_v + 64 * 8;                        // [GQ][64]  alpha_j cf_q[j] for the slab's own rows
   double* s_coef = s_tm + GQ * 64;                    // [GQ][2]
   int* s_flag = reinterpret_cast<int*>(s_coef + 2 * GQ);   // [GQ + 1]
-  double* s_xn = s_coef + 2 * GQ + 4;                 // [GQ][KS]
+  double* s_vvmu = s_coef + 2 * GQ + 4;               // [GQ][2]  this slab's |v|^2 / mu_s parts until the final burst of stores
+  double* s_xn = s_vvmu + 2 * GQ;                     // [GQ][KS]
   double* s_part = s_tile;                            // [4][GQ][64] per-wave partial row sums: each wave inside its own tile
+  double* s_gout = s_ks;                              // [2 GQ][KS] gradient parts of all components, staged for one burst of stores
   const double inv_ls = prm.inv_ls;
   const int kernel = prm.kernel;
 
@@ -978,7 +980,12 @@ __global__ __launch_bounds__(256) void k_acq_group(
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int u = 0; u < CB; ++u) z[t][u] = (c0 + u < k && tid + 256 * t < jlim) ? ZnT[(size_t)(c0 + u) * ld + tid + 256 * t] : 0.0;
+        for (int u = 0; u < CB; ++u) {
+          // unconditional loads from clamped addresses: a load behind a branch makes the number of loads in flight unknown
+          // to the compiler, and every later wait becomes "wait for all of them"
+          const int cc = c0 + u < k ? c0 + u : k - 1, jj = tid + 256 * t < NP ? tid + 256 * t : NP - 1;
+          z[t][u] = ZnT[(size_t)cc * ld + jj];
+        }
 #pragma unroll
       for (int u = 0; u < CB; ++u) {
         if (c0 + u < k) {                             // uniform
@@ -1078,10 +1085,8 @@ __global__ __launch_bounds__(256) void k_acq_group(
     double mu = i < n ? alpha[i] * s_ks[q * NP + i] : 0.0;
     vv = wave_sum(vv);
     mu = wave_sum(mu);
-    if (l == 0) {
-      double* out = partial + ((size_t)(q0 + q) * S + s) * PSTRIDE;
-      st_wt(out + 0, vv); st_wt(out + 1, mu);
-    }
+    if (l == 0) { s_vvmu[2 * q] = vv; s_vvmu[2 * q + 1] = mu; }     // (stored with the gradient parts at the end: a
+    // write-through store in front of a load keeps that load's wait open until the store has reached memory)
   }
   if (prm.want_grad) {
     // ---- w (slab part), thread per column: w_q[j] = sum_m R[r0 + m][j] v_q[m] --------------------------------------
@@ -1098,7 +1103,8 @@ __global__ __launch_bounds__(256) void k_acq_group(
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const int j = tid + 256 * t;
-          rr[u][t] = j < ncol ? R[(size_t)(r0 + m0 + u) * ld + j] : 0.0;
+          const double rv = R[(size_t)(r0 + m0 + u) * ld + (j < ncol ? j : 0)];      // (unconditional, see the ks phase)
+          rr[u][t] = j < ncol ? rv : 0.0;
         }
 #pragma unroll
       for (int u = 0; u < RU; ++u) {
@@ -1141,15 +1147,18 @@ __global__ __launch_bounds__(256) void k_acq_group(
     }
 #pragma unroll
     for (int q = 0; q < GQ; ++q) tmq[q] = (r0 + l < n) ? s_tm[q * 64 + l] : 0.0;
+    __syncthreads();                                   // t_sigma is in registers everywhere: its LDS array becomes s_gout
+    GSTAMP(10);
     double zc[NBL], zn_[NBL];
     auto load_row = [&](int c, double (&dst)[NBL]) {
       const double* zrow = ZnT + (size_t)c * ld;
 #pragma unroll
-      for (int b = 0; b < NBL; ++b) dst[b] = (64 * b < jmax) ? zrow[l + 64 * b] : 0.0;     // (columns >= n hold zeros in ZnT)
+      for (int b = 0; b < NBL; ++b) dst[b] = zrow[(64 * b < jmax) ? l + 64 * b : l];       // unconditional; blocks beyond jmax meet t_sigma = 0
     };
     if (w < k) load_row(w, zc);
     for (int c = w; c < k; c += 4) {
       if (c + 4 < k) load_row(c + 4, zn_);
+      if (c == w) { GSTAMP(11); }
       double gs[GQ], gm[GQ];
       const int bm = r0 >> 6;                          // the 64-column block that holds the slab's own rows (= lane's row r0 + l)
 #pragma unroll
@@ -1165,32 +1174,43 @@ __global__ __launch_bounds__(256) void k_acq_group(
       // come back transposed - lane 4 v + h adds 16 of value v's 64 partials, two quad steps finish - instead of 2 GQ
       // DPP reduction trees (the largest item of the kernel's timeline when they were)
       {
-        double* red = s_tile + w * 64 * GT_LD;            // [2 GQ][64] <= 64 * GT_LD doubles
+        if (c == w) { asm volatile("" :: "v"(gs[0]), "v"(gs[4]), "v"(gm[4])); GSTAMP(12); }
+        double* red = s_tile + w * 64 * GT_LD;            // [2 GQ][66] <= 64 * GT_LD doubles
 #pragma unroll
-        for (int q = 0; q < GQ; ++q) { red[q * 64 + l] = gs[q]; red[(GQ + q) * 64 + l] = gm[q]; }
+        for (int q = 0; q < GQ; ++q) { red[q * 66 + l] = gs[q]; red[(GQ + q) * 66 + l] = gm[q]; }    // row stride 66: see below
         WAVE_LDS_SYNC();
+        if (c == w) { GSTAMP(13); }
         const int v = l >> 2, h = l & 3;                  // lanes 0 .. 4 * 2 GQ - 1 = 39 are active
         double sum = 0.0;
         if (v < 2 * GQ) {
-          const double* src = red + v * 64 + 16 * h;
+          // lane (v, h) adds partials h, h + 4, ... of value v.  With rows of 64 doubles and 16 contiguous partials per lane
+          // every lane of a read hit one of two LDS banks (a 20-way conflict: 1.2 us per component); rows of 66 doubles and
+          // interleaved partials spread the 40 lanes over 32 banks
+          const double* src = red + v * 66 + h;
+          double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-          for (int i = 0; i < 16; ++i) sum += src[i];
+          for (int i = 0; i < 16; i += 2) { s0 += src[4 * i]; s1 += src[4 * i + 4]; }
+          sum = s0 + s1;
         }
         sum += dpp_get<0xB1, 0xf>(sum);                   // quad_perm [1,0,3,2]
         sum += dpp_get<0x4E, 0xf>(sum);                   // quad_perm [2,3,0,1]
-        if (h == 0 && v < 2 * GQ) {
-          const int q = v < GQ ? v : v - GQ;
-          if (q < nq) {
-            double* out = partial + ((size_t)(q0 + q) * S + s) * PSTRIDE;
-            st_wt(out + 2 + (v < GQ ? 0 : PCABO_MAXD) + c, sum);
-          }
-        }
+        if (h == 0 && v < 2 * GQ) s_gout[v * KS + c] = sum;
         WAVE_LDS_SYNC();
+        if (c == w) { GSTAMP(14); }
+        if (c == w + 4) { GSTAMP(15); }
       }
 #pragma unroll
       for (int b = 0; b < NBL; ++b) zc[b] = zn_[b];
     }
   }
+  // ---- this slab's partial records, all stores in one burst ---------------------------------------------------------
+  __syncthreads();
+  if (tid < 2 * nq) st_wt(partial + ((size_t)(q0 + (tid >> 1)) * S + s) * PSTRIDE + (tid & 1), s_vvmu[tid]);
+  if (prm.want_grad)
+    for (int idx = tid; idx < 2 * GQ * k; idx += 256) {
+      const int v = idx / k, c = idx - v * k, q = v < GQ ? v : v - GQ;
+      if (q < nq) st_wt(partial + ((size_t)(q0 + q) * S + s) * PSTRIDE + 2 + (v < GQ ? 0 : PCABO_MAXD) + c, s_gout[v * KS + c]);
+    }
   // ---- tickets: the last slab group of a query finishes it ---------------------------------------------------------
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -1287,7 +1307,7 @@ void launch_acq_group(hipStream_t st, const QueryArgs* tab, int entries, const d
                       const double* ZnT, const double* R, const double* alpha, const double* bounds4, const double* ystats,
                       AcqParams p, double* partial, unsigned int* counters, double* val, double* grad, double* host_val,
                       double* host_grad, HostMirror* hm, unsigned long long seq, AcqBatch ab) {
-  const size_t lds = ((size_t)GQ * NP + 4 * 64 * GT_LD + 64 * 8 + GQ * 64 + 2 * GQ + 4 + GQ * (((size_t)k + 1) & ~(size_t)1) + 8) * sizeof(double);
+  const size_t lds = ((size_t)GQ * NP + 4 * 64 * GT_LD + 64 * 8 + GQ * 64 + 2 * GQ + 4 + 2 * GQ + GQ * (((size_t)k + 1) & ~(size_t)1) + 8) * sizeof(double);
   const dim3 grid(NP / 64, entries), block(256);
   static bool attr_set = false;
   if (!attr_set) {

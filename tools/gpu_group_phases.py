@@ -21,4 +21,8 @@ for rep in range(3):
     assert N.LIB.pcabo_debug_acq_stamps(st) == 0
     t = [int(v) for v in st[:10]]
     print("rep", rep, " ".join("%s=%.2f" % (names[i], (t[i] - t[0]) / 100.0) for i in range(1, 10)))
+    t2 = [int(v) for v in st[10:16]]
+    if t2[0]:
+        print("   contraction detail (wave 0): ts in regs=%.2f first row arrived=%.2f fmas=%.2f lds written=%.2f comp 0 done=%.2f comp 1 done=%.2f"
+              % tuple((v - t[0]) / 100.0 for v in t2))
 c.close()

@@ -22,7 +22,12 @@ PARITY PIN STATUS
     (Standardize, Matern-5/2 with lengthscale ln 2 and no output scale, noise e^-5, zero mean, log-EI, best_f):
     every BO row of the reference's committed Vanilla_BO runs is a local maximum of this oracle's acquisition
     surface to the 1e-6 the files print, and is NOT one when a constant is changed
-    (tests/test_oracle.py::test_reference_logged_vanilla_candidates_are_optima_of_the_oracle_surface).
+    (tests/test_oracle.py::test_reference_logged_vanilla_candidates_are_optima_of_the_oracle_surface; all 60 committed runs:
+    ::test_all_sixty_reference_vanilla_runs_and_the_remembered_constants, every BO row of them on the device in
+    tests/test_gpu_parity.py).  Sensitivity of the remembered constants, measured there: noise and lengthscale are PINNED
+    (optima move by > 10x / > 0.1); BEST_F_FLOAT32 moves an optimum by < 1e-5 (below the files' 1e-6 print precision: not
+    pinned); LOG_EI_U_EPS_CLAMP only acts for u < -1e6 (never reached: not pinned, no effect); INIT_ETA does not enter a
+    local-optimum check (not pinned; selects which optimum is returned).
   * still **parity unpinned**: the pieces no committed output can pin - row E's bounds in PCA space and rows A-D as
     a chain (the committed pca-experiment files come from an older revision of the reference that clipped
     candidates; their rows are not reproducible from the current code), and the random-restart heuristic of rows
@@ -60,6 +65,7 @@ BATCH_LIMIT = 5                      # PCA_BO.py:613
 MAXITER = 200                        # PCA_BO.py:613
 INIT_ETA = 1.0                       # initialize_q_batch(eta=1.0)
 BEST_F_FLOAT32 = True                # LogExpectedImprovement stores torch.as_tensor(python float) -> float32
+LOG_EI_U_EPS_CLAMP = True            # _log_ei_helper computes w on u clamped at -1e6 (gradient of the unselected arm)
 OOB_PENALTY = 1000.0                 # PCA_BO.py:261
 
 _DT = torch.float64
@@ -334,7 +340,10 @@ def log_ei_helper(u: torch.Tensor) -> torch.Tensor:
     log_ei_upper = (_phi(u_upper) + u_upper * _Phi(u_upper)).log()
     neg_inv_sqrt_eps = -1e6
     u_lower = u.masked_fill(u > bound, bound)
-    w = torch.log(torch.special.erfcx(_NEG_INV_SQRT2 * u_lower) * u_lower.abs()) + _LOG_SQRT_PI_DIV_2
+    # botorch evaluates w on u clamped at -1/sqrt(eps) (`u_eps`): the log1mexp arm is not selected below that, and the
+    # clamp keeps its (unselected) gradient finite - without it autograd returns NaN for u < -1e6
+    u_eps = u_lower.masked_fill(u < neg_inv_sqrt_eps, neg_inv_sqrt_eps) if LOG_EI_U_EPS_CLAMP else u_lower
+    w = torch.log(torch.special.erfcx(_NEG_INV_SQRT2 * u_eps) * u_eps.abs()) + _LOG_SQRT_PI_DIV_2
     log_phi_u = -0.5 * (u.square() + _LOG2PI)
     log_ei_lower = log_phi_u + torch.where(u > neg_inv_sqrt_eps, _log1mexp(w), -2 * u_lower.abs().log())
     return torch.where(u > bound, log_ei_upper, log_ei_lower)

@@ -17,6 +17,8 @@ Outputs tests/golden/ref_kats_dim5.json holding DATA only (inputs + expected out
   * "vanilla_runs": all 75 logged rows (raw_y, x printed to 1e-6) of 12 committed Vanilla_BO runs -> each BO row is the
             candidate the REFERENCE chose given the rows before it: it must be a local maximum of the acquisition
             surface built from those rows (pins Standardize / Matern-5/2 / lengthscale / noise / log-EI / best_f).
+  * ref_vanilla_runs_dim5.json (second file): ALL 60 committed Vanilla_BO runs (f15 and f20, instances 0..29), 75 rows each,
+            same row format as "vanilla_runs" -> the local-optimum check over every BO row the reference logged.
   * "dat_header", "json_keys": the layout of the IOHprofiler 0.3.18 files (column header of a .dat block, key order
             of the .json) -> pins the writer in pcabo/iohlog.py.
 Source files: /root/reference/{pca,vanilla}-experiment/data_f*/IOHprofiler_f*_DIM5.dat and
@@ -45,6 +47,7 @@ def read_runs(path):
 
 def main():
     out = {"doe": [], "f15_doe": [], "f15_best": [], "f15_bo_rows": [], "f20_doe": [], "f20_best": [], "f20_bo_rows": []}
+    all_vanilla = []          # every committed Vanilla_BO run in full -> ref_vanilla_runs_dim5.json (round 2)
     for alg in ("pca", "vanilla"):
         for fid, name in ((15, "RastriginRotated"), (20, "Schwefel")):
             meta = json.load(open(f"{REF}/{alg}-experiment/IOHprofiler_f{fid}_{name}.json"))
@@ -59,6 +62,8 @@ def main():
                                    "x": [r[3:] for r in doe]})
                 out.setdefault("final_best", []).append({"alg": alg, "fid": fid, "instance": inst, "rows": len(run),
                                                          "best": min(r[1] for r in run)})
+                if alg == "vanilla":
+                    all_vanilla.append({"fid": fid, "instance": inst, "rows": [[r[1]] + r[3:] for r in run]})
                 if alg == "vanilla" and inst % 5 == 0:
                     out.setdefault("vanilla_runs", []).append({"fid": fid, "instance": inst,
                                                                "rows": [[r[1]] + r[3:] for r in run]})
@@ -77,6 +82,9 @@ def main():
                 out["json_head"] = {k: meta[k] for k in meta if k != "scenarios"}
     json.dump(out, open(OUT, "w"))
     print(OUT, os.path.getsize(OUT), "bytes;", {k: len(v) for k, v in out.items()})
+    out2 = os.path.join(os.path.dirname(OUT), "ref_vanilla_runs_dim5.json")
+    json.dump({"vanilla_runs": all_vanilla}, open(out2, "w"))
+    print(out2, os.path.getsize(out2), "bytes;", len(all_vanilla), "runs")
 
 
 if __name__ == "__main__":

@@ -138,18 +138,15 @@ def test_log_ei_tail_branches(native):
     # gradient tolerance: d/du log1mexp(w(u)) cancels catastrophically for u << -1 in BoTorch's own
     # formulation (w'(u) = u + sqrt(2/pi)/erfcx(-u/sqrt2) + 1/u ~ 2/u^3); autograd and the analytic form carry the
     # same ~1e-16 u^4 relative noise, so the comparison is loosened where |u| reaches 1e4..1e5.
-    # At best_f = -1e9 (u ~ -1e9, asymptotic branch) torch.where back-propagates 0 * inf = NaN through the
-    # unselected log1p(-exp(w)) arm of log1mexp, so the oracle has no gradient there (botorch would raise on
-    # it); the kernel's analytic derivative -u - 2/u is finite.  Values are compared in every case.
-    for best, gtol in ((float(y.min()), 1e-7), (-50.0, 1e-7), (-1e4, 1e-4), (-1e9, None), (5.0, 1e-7)):
+    # At best_f = -1e9 (u ~ -1e9, asymptotic branch) the oracle's gradient is finite because w is evaluated on u clamped
+    # at -1e6 (botorch's `u_eps`; without the clamp torch.where back-propagates 0 * inf = NaN through the unselected
+    # log1mexp arm); the kernel's analytic derivative there is -u - 2/u.
+    for best, gtol in ((float(y.min()), 1e-7), (-50.0, 1e-7), (-1e4, 1e-4), (-1e9, 1e-7), (5.0, 1e-7)):
         ov, og = O.Acquisition(gp, best, False).value_and_grad(X)
         v, g = c.acq_eval(X, best, False)
         assert (np.abs(v - ov) / np.maximum(1.0, np.abs(ov))).max() < 1e-9, best
-        assert np.isfinite(g).all()
-        if gtol is not None:
-            assert (np.abs(g - og).max() / max(1.0, np.abs(og).max())) < gtol, best
-        else:
-            assert np.isnan(og).all()
+        assert np.isfinite(g).all() and np.isfinite(og).all(), best
+        assert (np.abs(g - og).max() / max(1.0, np.abs(og).max())) < gtol, best
     c.close()
 
 
@@ -686,18 +683,20 @@ def test_vanilla_bo_final_results_distributed_like_the_reference_runs(native):
 
 
 def test_reference_logged_vanilla_candidates_are_optima_of_the_device_surface(native):
-    """The HIP path against the reference's own outputs (no oracle involved): every BO row of the committed
-    Vanilla_BO runs must be a local maximum of the DEVICE log-EI surface conditioned on the rows before it.
-    Starting the device optimiser (C ABI: pcabo_gp_condition + pcabo_optimize_acqf) at the logged candidate must
-    leave it in place (x is printed to 1e-6); with lengthscale 1.0 instead of ln 2 it walks away."""
+    """The HIP path against the reference's own outputs (no oracle involved): every BO row of ALL 60 committed
+    Vanilla_BO runs (f15 and f20, 30 instances, 65 BO rows each = 3900 cases) must be a local maximum of the DEVICE log-EI
+    surface conditioned on the rows before it.  Starting the device optimiser (C ABI: pcabo_gp_condition +
+    pcabo_optimize_acqf) at the logged candidate must leave it in place (x is printed to 1e-6); with lengthscale 1.0
+    instead of ln 2 it walks away."""
     import json, os, math
-    G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_kats_dim5.json")))
+    G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_vanilla_runs_dim5.json")))
+    assert len(G["vanilla_runs"]) == 60
     ident, box = np.vstack([np.zeros(5), np.ones(5)]), np.vstack([np.full(5, -5.0), np.full(5, 5.0)])
     c = native.Context(max_n=80, max_d=5, max_q=16)
 
-    def moves(lengthscale, every):
+    def moves(lengthscale, every, runs):
         dx, dv = [], []
-        for run in G["vanilla_runs"]:
+        for run in runs:
             rows = np.array(run["rows"])
             for t in range(10, 75, every):
                 X, f, xc = rows[:t, 1:], rows[:t, 0], rows[t, 1:]
@@ -710,15 +709,15 @@ def test_reference_logged_vanilla_candidates_are_optima_of_the_device_surface(na
                 dv.append(vals[0] - v0[0])
         return np.array(dx), np.array(dv)
 
-    dx, dv = moves(math.log(2.0), 3)
-    assert len(dx) == 12 * 22
+    dx, dv = moves(math.log(2.0), 1, G["vanilla_runs"])
+    assert len(dx) == 60 * 65
     assert np.median(dx) < 1e-4 and np.quantile(dx, 0.9) < 5e-4, (np.median(dx), np.quantile(dx, 0.9))
     # the reference optimises 5 restarts as ONE problem and stops on the reduction of their sum, so a single restart
-    # may be left ~1e-3 short of its optimum: allowed for <= 2 % of the rows (measured: 2 of 264, gains 8e-4)
+    # may be left ~1e-3 short of its optimum: allowed for <= 2 % of the rows (measured: 2 of 264 in round 1, gains 8e-4)
     far = dx >= 5e-3
-    assert far.mean() <= 0.02 and (dv[far] < 1e-2).all(), (dx[far], dv[far])
+    assert far.mean() <= 0.02 and (dv[far] < 1e-2).all(), (far.mean(), dx[far][:10], dv[far][:10])
     assert np.median(dv) < 1e-8 and np.quantile(dv, 0.9) < 1e-7 and dv.min() > -1e-12
-    dx_wrong, _ = moves(1.0, 13)
+    dx_wrong, _ = moves(1.0, 13, G["vanilla_runs"][::5])
     assert np.median(dx_wrong) > 0.1
     c.close()
 

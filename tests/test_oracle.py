@@ -128,3 +128,60 @@ def test_reference_logged_vanilla_candidates_are_optima_of_the_oracle_surface():
     dx_ls, _ = moves(1.0, O.NOISE, 13)
     dx_noise, _ = moves(O.LENGTHSCALE, 1e-4, 13)
     assert np.median(dx_ls) > 0.1 and np.median(dx_noise) > 10 * np.median(dx)
+
+
+def test_all_sixty_reference_vanilla_runs_and_the_remembered_constants():
+    """The local-optimum pin over ALL 60 committed Vanilla_BO runs (three BO rows of each here; every row on the device in
+    tests/test_gpu_parity.py), and one sensitivity row per constant that comes from memory of the absent packages: does the
+    reference's own data pin it (the logged candidates stop being optima when it is changed), or is it listed as
+    unpinned together with its measured effect?"""
+    import json, os
+    from scipy.optimize import minimize
+    G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_vanilla_runs_dim5.json")))
+    assert len(G["vanilla_runs"]) == 60 and all(len(r["rows"]) == 75 for r in G["vanilla_runs"])
+    ident = np.vstack([np.zeros(5), np.ones(5)])
+
+    def cases(rows_at):
+        for run in G["vanilla_runs"]:
+            rows = np.array(run["rows"])
+            for t in rows_at:
+                yield rows[:t, 1:], rows[:t, 0], rows[t, 1:]
+
+    def moves(rows_at, **gp_kw):
+        dx = []
+        for X, f, xc in cases(rows_at):
+            gp = O.ExactGP(X, f, ident, **gp_kw)
+            acq = O.Acquisition(gp, float(f.min()), False, "expected_improvement")
+
+            def fg(x):
+                v, g = acq.value_and_grad(x.reshape(1, -1))
+                return -float(v[0]), -np.asarray(g).ravel()
+            res = minimize(fg, xc, jac=True, method="L-BFGS-B", bounds=[(-5, 5)] * 5,
+                           options=dict(maxiter=200, ftol=1e7 * np.finfo(float).eps, gtol=1e-5))
+            dx.append(np.abs(res.x - xc).max())
+        return np.array(dx)
+
+    dx = moves((17, 41, 68))
+    assert len(dx) == 180
+    assert np.median(dx) < 1e-4 and np.quantile(dx, 0.9) < 1e-3 and np.mean(dx < 5e-3) >= 0.97, (np.median(dx), np.sort(dx)[-6:])
+    base = moves((41,))
+    # BEST_F_FLOAT32: float32 rounding of best_f moves an optimum by less than the 1e-6 the files print -> NOT pinned by
+    # the reference's data (effect measured here: the two variants' optima agree to < 1e-5)
+    try:
+        O.BEST_F_FLOAT32 = False
+        assert np.abs(moves((41,)) - base).max() < 1e-4
+    finally:
+        O.BEST_F_FLOAT32 = True
+    # LOG_EI_U_EPS_CLAMP: only reached for u < -1e6, never on these surfaces -> not pinned; identical optima
+    try:
+        O.LOG_EI_U_EPS_CLAMP = False
+        assert np.array_equal(moves((41,))[:20], base[:20])
+    finally:
+        O.LOG_EI_U_EPS_CLAMP = True
+    # INIT_ETA (temperature of the Boltzmann pick) does not enter a local-optimum check at all: it selects WHICH optimum a
+    # restart starts near.  Not pinned; its effect is the choice among restarts, covered only in distribution by the
+    # end-to-end check against the reference's final results (tests/test_gpu_parity.py).
+    assert O.INIT_ETA == 1.0
+    # pinned constants, for contrast: the GP noise and the lengthscale DO move the optima far beyond print precision
+    assert np.median(moves((41,), noise=1e-4)[:20]) > 10 * np.median(base[:20])
+    assert np.median(moves((41,), lengthscale=1.0)[:20]) > 0.1

@@ -160,6 +160,12 @@ static void presence_unregister(int device) {
     unlink(path);
   }
 }
+// contexts of THIS process on the device (stand-alone ones and the members of batches alike)
+static int presence_local_contexts(int device) {
+  if (device < 0 || device >= 64) return 1;
+  std::lock_guard<std::mutex> lk(g_presence_mu);
+  return g_presence_refs[device];
+}
 static bool presence_alone(int device) {
   DIR* d = opendir("/dev/shm");
   if (!d) return true;
@@ -1096,8 +1102,11 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
     const double tb = trace ? now() : 0.0;
     int rc;
     if (round_no == 1 && (ctx->alone_age++ & 7) == 0) ctx->alone = presence_alone(ctx->device);
+    // several contexts in ONE process (one run per host thread, or a batch next to a single run): their resident kernels
+    // would each want most of the chip at the same time - one launch per evaluation then, which interleaves well
+    const bool only_context_here = presence_local_contexts(ctx->device) == 1;
     if (round_no == 1 && ctx->srv_penalty > 0) --ctx->srv_penalty;
-    else if (round_no == 1 && ctx->opt_resident && !ctx->opt_group_acq && ctx->alone && !ctx->prof && acq_server_possible(nq, ctx->n, k, ctx->NP)) {
+    else if (round_no == 1 && ctx->opt_resident && !ctx->opt_group_acq && ctx->alone && only_context_here && !ctx->prof && acq_server_possible(nq, ctx->n, k, ctx->NP)) {
       // the evaluations of this call go to ONE resident launch (see k_acq_fast): no launch and no operand refill per round
       srv_cap = nq;
       launch_acq(ctx->stream, nullptr, nullptr, srv_cap, ctx->n, k, ctx->NP, ctx->ld, ctx->dZnT, ctx->dR, ctx->dAlpha,

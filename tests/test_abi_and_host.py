@@ -28,6 +28,24 @@ def test_no_cpu_fallback_without_device(native):
     assert e.value.code == -3
 
 
+def test_batch_and_device_objectives_fail_loudly_without_device(native):
+    """The lock-step batch and the device objectives have no CPU path either."""
+    if native.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(native.PcaboError) as e:
+        native.Batch(2, max_n=32, max_d=4)
+    assert e.value.code == -3
+    from pcabo.bbob import BBOBProblem
+    from pcabo.bbob_device import DeviceObjectives
+    with pytest.raises(native.PcaboError):
+        DeviceObjectives([BBOBProblem(15, 0, 4), BBOBProblem(21, 1, 4)])
+    from pcabo.batchrun import BatchedPCABO
+    r = BatchedPCABO([BBOBProblem(15, 0, 4)], [3], 12, 8)
+    with pytest.raises(native.PcaboError):
+        r.run()                              # DoE runs on the host, the first device call raises
+    assert len(r.f_evals[0]) == 8
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "para-ortho-pca-bo_amd")
     for base, _, files in os.walk(pkg):

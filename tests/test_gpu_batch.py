@@ -159,3 +159,30 @@ def test_experiment_runner_batched_writes_the_same_files(native, tmp_path, monke
         rel = os.path.join("pca-experiment", f"data_f{fid}_{name}", f"IOHprofiler_f{fid}_DIM5.dat")
         a, b = open(os.path.join(outs[0][0], rel)).read(), open(os.path.join(outs[1][0], rel)).read()
         assert a == b
+
+
+def test_runs_on_concurrent_host_threads_in_one_process(native):
+    """BASELINE.json configs[3] "one run per stream": several PCA_BO runs inside ONE process, a host thread and a context
+    (= a HIP stream) each.  The library notices the other contexts and serves every evaluation with a launch of its own
+    (resident kernels of several runs cannot share the chip); each run must reproduce what it produces alone, bit for bit.
+    (numpy's and torch's GLOBAL generators are shared by the threads of a process, so the reference's own classes cannot run
+    concurrently with RNG parity; the runs here use the lock-step driver's per-run generators, one batch of one run each.)"""
+    import threading
+    from pcabo.batchrun import BatchedPCABO
+
+    def one(inst, out):
+        r = BatchedPCABO([BBOBProblem(15, inst, 10)], [15100 + inst], 60, 30)
+        r.run()
+        out[inst] = (np.vstack(r.x_evals[0]), np.array(r.f_evals[0]))
+
+    alone = {}
+    for i in range(3):
+        one(i, alone)
+    together = {}
+    threads = [threading.Thread(target=one, args=(i, together)) for i in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for i in range(3):
+        assert np.array_equal(alone[i][0], together[i][0]) and np.array_equal(alone[i][1], together[i][1]), i

@@ -237,6 +237,10 @@ int pcabo_batch_gp_condition_end_eval(pcabo_batch* batch, const double* Xq, int 
 int pcabo_batch_optimize_acqf(pcabo_batch* batch, const double* ics, int num_restarts, int batch_limit,
                               const double* bounds, int maxiter, const double* best_f, int maximize, int acq,
                               double* cand, double* vals, int* info, int* failed, int* status);
+/* Park / unpark runs: active[B]; a parked run still goes through the lock-step launches of rows A-K but is skipped by
+ * pcabo_batch_optimize_acqf (status PCABO_ERR_ARG).  For runs that failed the way the reference's would (botorch raises on a
+ * NaN acquisition gradient, reached once the reference's unclipped out-of-box candidates have blown up the search box). */
+int pcabo_batch_set_active(pcabo_batch* batch, const int* active);
 /* Device time of the phases of the last pcabo_batch_wpca_gp_condition_begin (HIP events on the batch's stream; call once
  * that conditioning has been waited for): ms[0] rows A-C, ms[1] Normalize + Gram, ms[2] Cholesky, ms[3] root inverse + alpha. */
 int pcabo_batch_set_profiling(pcabo_batch* batch, int enabled);

@@ -92,6 +92,7 @@ class ExperimentRunner:
         local = int(os.environ.get("LOCAL_RANK", "0"))
         self.device = local % ndev if ndev > 0 else local
         self.results = []                      # one dict per finished run (this rank)
+        self.failed_runs = []                  # batched mode: runs that stopped early, with the reason
 
     # ---- run list and its shard -----------------------------------------------------------------------------------
     def _my_runs(self):
@@ -157,8 +158,14 @@ class ExperimentRunner:
                     for _, x in probs[b].log:
                         replay(x)
                     logger.set_run_attribute("time", elapsed)
+                    done = len(runner.f_evals[b]) - n_doe
                     self.results.append({"algorithm": "pca", "problem_id": pid, "dim": dim, "instance": inst,
-                                         "best": runner.current_best[b], "time": elapsed, "iterations": budget - n_doe})
+                                         "best": min(runner.f_evals[b]), "time": elapsed, "iterations": done})
+                    if runner.failed[b] is not None:
+                        # the reference's run ends with an exception here (botorch raises on a NaN acquisition gradient) and
+                        # takes the experiment with it; in a batch the other runs finish and the failure is reported
+                        self.failed_runs.append({"problem_id": pid, "dim": dim, "instance": inst,
+                                                 "n": runner.failed[b][0], "error": runner.failed[b][1]})
                     ebar.update(1)
 
     # ---- the experiment --------------------------------------------------------------------------------------------

@@ -1548,6 +1548,7 @@ struct pcabo_batch {
   char *dSlab = nullptr, *hSlab = nullptr;
   size_t zs = 0, hzs = 0;
   std::vector<pcabo_ctx*> ctx;
+  std::vector<char> active;              // runs that still take part in pcabo_batch_optimize_acqf (pcabo_batch_set_active)
   int n = 0, d = 0, NP = 0;
   bool wpca_uncollected = false, gp_pending = false, have_gp = false;
   double lengthscale = 0.0, noise = 0.0;
@@ -1621,6 +1622,7 @@ int pcabo_batch_create(int device, int B, int max_n, int max_d, int max_q, pcabo
   BHIPCHK(hipMemsetAsync(batch->dSlab, 0, batch->zs * (size_t)B, batch->stream));
   BHIPCHK(hipStreamSynchronize(batch->stream));
   batch->ctx.assign(B, nullptr);
+  batch->active.assign(B, 1);
   for (int b = 0; b < B; ++b) {
     pcabo_ctx* c = new (std::nothrow) pcabo_ctx();
     if (!c) return bset_err(batch, PCABO_ERR_HIP, "out of memory%s", "");
@@ -1669,6 +1671,15 @@ int pcabo_batch_get_profile(pcabo_batch* batch, double* ms) {
   BHIPCHK(hipSetDevice(batch->device));
   BHIPCHK(hipEventSynchronize(batch->pev[4]));
   for (int i = 0; i < 4; ++i) { float t = 0.f; BHIPCHK(hipEventElapsedTime(&t, batch->pev[i], batch->pev[i + 1])); ms[i] = t; }
+  return PCABO_OK;
+}
+
+// A run whose optimisation cannot go on (botorch would raise there: NaN in the acquisition gradient once the reference's
+// unclipped candidates have blown the search box up) is parked by the caller: it stays in the lock-step launches of rows
+// A-K (on whatever finite data the caller keeps feeding it) but no longer takes part in pcabo_batch_optimize_acqf.
+int pcabo_batch_set_active(pcabo_batch* batch, const int* active) {
+  if (!batch || !active) return PCABO_ERR_ARG;
+  for (int b = 0; b < batch->B; ++b) batch->active[b] = active[b] != 0;
   return PCABO_OK;
 }
 
@@ -1906,6 +1917,7 @@ int pcabo_batch_optimize_acqf(pcabo_batch* batch, const double* ics, int num_res
   std::vector<int> run_status(B, PCABO_OK);
   for (int b = 0; b < B; ++b) {
     const pcabo_ctx* c = batch->ctx[b];
+    if (!batch->active[b]) { groups[b].clear(); run_status[b] = PCABO_ERR_ARG; continue; }      // parked by the caller
     groups[b].resize(c->have_gp ? ngroups : 0);
     if (!c->have_gp) { run_status[b] = PCABO_ERR_NOT_PD; continue; }
     for (int gi = 0; gi < ngroups; ++gi) {

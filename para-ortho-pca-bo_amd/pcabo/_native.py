@@ -36,7 +36,7 @@ EXPORTS = [
     "pcabo_batch_create", "pcabo_batch_destroy", "pcabo_batch_last_error", "pcabo_batch_ctx",
     "pcabo_batch_wpca_gp_condition_begin", "pcabo_batch_wpca_results", "pcabo_batch_acq_bounds",
     "pcabo_batch_gp_condition_end_eval", "pcabo_batch_optimize_acqf", "pcabo_batch_inverse_map",
-    "pcabo_batch_set_profiling", "pcabo_batch_get_profile",
+    "pcabo_batch_set_profiling", "pcabo_batch_get_profile", "pcabo_batch_set_active",
     "pcabo_bbob_table_doubles", "pcabo_bbob_create", "pcabo_bbob_destroy", "pcabo_bbob_eval",
 ]
 
@@ -102,6 +102,7 @@ def _load() -> C.CDLL:
     lib.pcabo_batch_optimize_acqf.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
     lib.pcabo_batch_inverse_map.argtypes = [vp, vp, vp]
     lib.pcabo_batch_set_profiling.argtypes = [vp, C.c_int]
+    lib.pcabo_batch_set_active.argtypes = [vp, vp]
     lib.pcabo_batch_get_profile.argtypes = [vp, vp]
     for name in EXPORTS:
         getattr(lib, name).restype = C.c_int
@@ -443,6 +444,11 @@ class Batch:
 
     def set_profiling(self, on: bool) -> None:
         self._chk(LIB.pcabo_batch_set_profiling(self._h, int(bool(on))))
+
+    def set_active(self, active) -> None:
+        """active[b] = False parks run b: it stays in the lock-step launches but is skipped by optimize_acqf."""
+        a = np.ascontiguousarray(active, dtype=np.int32).reshape(self.B)
+        self._chk(LIB.pcabo_batch_set_active(self._h, _ptr(a)))
 
     def condition_profile(self) -> dict:
         """Device milliseconds of the last conditioning's phases (after it has been waited for)."""

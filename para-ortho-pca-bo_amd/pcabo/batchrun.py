@@ -60,6 +60,13 @@ class BatchedPCABO:
         self.k_prev = [0] * self.B
         self.lbfgsb_info = []
         self.retries = 0
+        # failed[b]: None, or (n at failure, message).  The reference's run dies with an exception when botorch meets a NaN
+        # acquisition gradient (reached by the reference's own dynamics: candidates outside the box are penalised but kept,
+        # the PCA search box grows by half each time, coordinates reach 1e30 and beyond).  A single PCA_BO raises there too;
+        # in a batch the run is PARKED instead: its lists stop growing at the failure (x_evals / f_evals hold what it had
+        # reached), the other runs go on, and `run()` reports the failures at the end.
+        self.failed = [None] * self.B
+        self._frozen = [None] * self.B
         self.timing = {"pca": 0.0, "wait_score": 0.0, "init_pick": 0.0, "lbfgsb": 0.0, "tail": 0.0, "host_prep": 0.0}
         self.record_trace, self.trace = bool(record_trace), []
         self._batch: Optional[_native.Batch] = None
@@ -108,20 +115,41 @@ class BatchedPCABO:
 
     @property
     def n(self) -> int:
-        return len(self.f_evals[0])
+        """Evaluated points of the runs that are still advancing (parked runs stopped earlier)."""
+        live = [len(self.f_evals[b]) for b in range(self.B) if self.failed[b] is None]
+        return max(live) if live else self.budget
+
+    def _f_for_device(self, b: int, n: int):
+        """The n objective values run b hands to the device: its own, or - parked - a finite stand-in of the same length
+        (its DoE values repeated; the matching rows of `_X` repeat the DoE points) so that the lock-step launches of the
+        other runs see nothing but finite numbers."""
+        if self.failed[b] is None:
+            return self.f_evals[b]
+        return self._frozen[b][1][:n]
+
+    def _park(self, b: int, n: int, message: str) -> None:
+        self.failed[b] = (n, message)
+        reps = -(-self.budget // self.n_DoE)
+        Xd = np.vstack(self.x_evals[b][: self.n_DoE])
+        fd = np.array(self.f_evals[b][: self.n_DoE], dtype=float)
+        self._frozen[b] = (np.tile(Xd, (reps, 1))[: self.budget], np.tile(fd, reps)[: self.budget])
+        self._X[b] = self._frozen[b][0]
+        self.current_best[b] = float(np.min(fd) if not self.maximization else np.max(fd))
+        self._batch.set_active([self.failed[i] is None for i in range(self.B)])
+        warnings.warn(f"run {b} (seed {self.seeds[b]}) stopped at n = {n}: {message}", RuntimeWarning)
 
     # ---- one lock-step BO iteration (PCA_BO.py:178-298 for every run) ------------------------------------------------
     def iteration(self) -> None:
         B, d, n, bt = self.B, self.dimension, self.n, self._batch
         t0 = perf_counter()
-        F = np.array(self.f_evals, dtype=np.float64)                                   # B x n
+        F = np.array([self._f_for_device(b, n) for b in range(B)], dtype=np.float64)    # B x n
         ranks = np.empty((B, n), dtype=np.int64)
         noise = np.empty((B, n, d))
 
         def prep(b):
             # per run, on a 1-D array exactly as the reference does it (PCA_BO.py:330-333): the penalty value repeats, and
             # how numpy's unstable sort orders ties must be what the run sees alone
-            fb = np.array(self.f_evals[b])
+            fb = F[b].copy()
             ranks[b] = np.argsort(np.argsort(-fb if self.maximization else fb)) + 1
             noise[b] = self._rs[b].normal(0, 1e-8, size=(n, d))                       # PCA_BO.py:376, the run's own stream
         self._each(prep)
@@ -158,20 +186,31 @@ class BatchedPCABO:
             bt.ctx[b].match_best_f_dtype(best_f[b])
         t3 = perf_counter()
         vals, status = bt.gp_wait_eval(raw, best_f, self.maximization, self.acq_code)
-        if np.any(status != 0):
-            raise _native.PcaboError(int(status[status != 0][0]), f"GP conditioning failed for runs {np.nonzero(status)[0].tolist()}")
+        for b in range(B):
+            if self.failed[b] is None and (status[b] != 0 or not np.isfinite(vals[b]).all()):
+                self._park(b, n, "GP conditioning failed (K not positive definite)" if status[b] != 0
+                           else "non-finite acquisition values on the raw samples")
+            if self.failed[b] is not None:
+                vals[b] = np.linspace(0.0, 1.0, vals.shape[1])          # anything finite: the pick below is discarded
         t4 = perf_counter()
         pick = _init.initialize_q_batch if self.acq_code == _native.ACQ_LOG_EI else _init.initialize_q_batch_nonneg
-        idx = [pick(vals[b], self.num_restarts, generator=self._tg[b]) for b in range(B)]
+        idx = [pick(vals[b], self.num_restarts, generator=self._tg[b]) if self.failed[b] is None
+               else np.arange(self.num_restarts) for b in range(B)]
         ics = [raw[b][idx[b]] for b in range(B)]
         t5 = perf_counter()
         outs, status = bt.optimize_acqf(ics, bounds, best_f, self.maximization, self.acq_code, batch_limit=5, maxiter=200)
-        if np.any(status != 0):
-            raise _native.PcaboError(int(status[status != 0][0]), f"acquisition optimisation failed for runs {np.nonzero(status)[0].tolist()}")
+        for b in range(B):
+            if self.failed[b] is None and status[b] != 0:
+                self._park(b, n, "NaN in the acquisition gradient (botorch raises here)" if status[b] == -4
+                           else f"acquisition optimisation failed (status {int(status[b])})")
         t6 = perf_counter()
         z_new, infos = [], []
         for b in range(B):
             cand, v, info, failed = outs[b]
+            if self.failed[b] is not None:
+                z_new.append(np.zeros(int(bt.k[b])))
+                infos.append(info)
+                continue
             retried = False
             if failed:       # botorch: OptimizationWarning -> one retry with freshly drawn initial conditions (this run alone)
                 warnings.warn("Optimization failed in `gen_candidates_scipy`; trying again with a new set of "
@@ -198,6 +237,8 @@ class BatchedPCABO:
         if self._dev_obj is not None and not self.maximization:
             f_dev, raw_dev, oob_dev = self._dev_obj.evaluate(X_new)
         for b in range(B):
+            if self.failed[b] is not None:
+                continue
             new_x = X_new[b].copy()
             if f_dev is not None:
                 new_f = float(f_dev[b])
@@ -239,6 +280,8 @@ class BatchedPCABO:
             self._batch = None
 
     def run(self) -> None:
+        """All iterations of all runs.  Runs that failed on the way are listed in `failed` (the reference's run would
+        have ended with an exception at that point); everything else is complete."""
         try:
             self.start()
             while self.n < self.budget:
@@ -265,10 +308,10 @@ def bench_block(device: int, B: int, fid: int, dim: int, budget_factor: int = 10
         dt = perf_counter() - t0
     finally:
         r.finish()
-    iters = B * (budget - n_doe)
+    iters = sum(len(f) - n_doe for f in r.f_evals)           # (parked runs count what they completed)
     return {"runs": B, "function": fid, "dimension": dim, "budget": budget, "n_DoE": n_doe,
             "aggregate_bo_iterations_per_s": iters / dt, "seconds": dt, "bo_iterations": iters,
             "ms_per_lockstep_iteration": 1e3 * dt / (budget - n_doe), "host_phase_seconds": dict(r.timing),
-            "retries": r.retries, "best_f": [float(v) for v in r.current_best],
+            "retries": r.retries, "failed_runs": sum(f is not None for f in r.failed), "best_f": [float(v) for v in r.current_best],
             "note": "B runs of configs[1]'s cell advancing in lock-step through pcabo_batch_* (one launch sequence for rows "
                     "A-H of all runs, shared acquisition launches for the L-BFGS-B rounds); one Python host thread"}

@@ -186,3 +186,23 @@ def test_runs_on_concurrent_host_threads_in_one_process(native):
         t.join()
     for i in range(3):
         assert np.array_equal(alone[i][0], together[i][0]) and np.array_equal(alone[i][1], together[i][1]), i
+
+
+def test_a_parked_run_does_not_disturb_the_others(native):
+    """A run that cannot go on (the reference's own dynamics can blow its search box up until botorch meets a NaN
+    gradient and raises) is parked: the other runs of the batch must still take, bit for bit, the path they take alone."""
+    from pcabo.batchrun import BatchedPCABO
+    insts = [0, 1, 2]
+    seeds = [15100 + i for i in insts]
+    r = BatchedPCABO([BBOBProblem(15, i, 10) for i in insts], seeds, 60, 30)
+    r.start()
+    for it in range(30):
+        if it == 7:
+            r._park(1, r.n, "parked by the test")
+        r.iteration()
+    r.finish()
+    assert r.failed[1] == (37, "parked by the test") and len(r.f_evals[1]) == 37
+    assert r.failed[0] is None and r.failed[2] is None
+    for b in (0, 2):
+        X, f, best, bi = _single(15, insts[b], 10, 60, 30, seeds[b], "group")
+        assert np.array_equal(np.vstack(r.x_evals[b]), X) and np.array_equal(np.array(r.f_evals[b]), f)

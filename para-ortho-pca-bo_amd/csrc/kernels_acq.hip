@@ -30,6 +30,7 @@
 #include "pcabo_internal.h"
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 
 #define PSTRIDE (2 + 2 * PCABO_MAXD)   // doubles per (query, slab) partial record
 
@@ -1309,11 +1310,10 @@ void launch_acq_group(hipStream_t st, const QueryArgs* tab, int entries, const d
                       double* host_grad, HostMirror* hm, unsigned long long seq, AcqBatch ab) {
   const size_t lds = ((size_t)GQ * NP + 4 * 64 * GT_LD + 64 * 8 + GQ * 64 + 2 * GQ + 4 + 2 * GQ + GQ * (((size_t)k + 1) & ~(size_t)1) + 8) * sizeof(double);
   const dim3 grid(NP / 64, entries), block(256);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag attr_once;       // (launched from the worker threads of a batch)
+  std::call_once(attr_once, [] {
     (void)hipFuncSetAttribute((const void*)k_acq_group<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    attr_set = true;
-  }
+  });
 #define GROUP_ARGS *tab, Xq, n, k, NP, ld, ZnT, R, alpha, bounds4, ystats, p, partial, counters, val, grad, host_val, host_grad, \
                    hm, seq, ab
   if (NP <= 256) hipLaunchKernelGGL(k_acq_group<1>, grid, block, lds, st, GROUP_ARGS);

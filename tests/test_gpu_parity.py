@@ -513,6 +513,17 @@ def test_largest_size_n1050_properties(native):
     assert np.array_equal(v_small, v_big)
     v3, g3 = c.acq_eval(X[:3], best, False)
     assert np.array_equal(g3, g_big[:3]) and np.array_equal(v3, v_big[:3])
+    # the throughput kernel at this size (k_acq_group<5>: 5 columns per thread, 17 slabs) and the GEMM scoring (17 x 17
+    # tiles of R) against the per-query kernels on the same points
+    c.set_option(native.OPT_GROUP_ACQ, 1)
+    v_grp, g_grp = c.acq_eval(X[:23], best, False)
+    c.set_option(native.OPT_GROUP_ACQ, 0)
+    assert np.abs(v_grp - v_big[:23]).max() <= 1e-11 * max(1.0, np.abs(v_big).max())
+    assert np.abs(g_grp - g_big[:23]).max() <= 1e-10 * max(1.0, np.abs(g_big).max())
+    Xs = np.vstack([X, rng.uniform(b[0], b[1], size=(88, k)) * 0.5 + 0.5 * Z[40:128]])
+    v_gemm = c.acq_eval(Xs, best, False, grad=False)                    # 128 points: GEMM path
+    v_slab = np.concatenate([c.acq_eval(Xs[i:i + 32], best, False, grad=False) for i in range(0, 128, 32)])
+    assert np.abs(v_gemm - v_slab).max() <= 1e-11 * max(1.0, np.abs(v_slab).max())
     h = 1e-6
     for j in (0, 17, 88):
         Xp, Xm = X[:8].copy(), X[:8].copy()

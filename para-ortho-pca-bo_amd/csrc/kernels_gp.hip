@@ -74,9 +74,9 @@ __global__ void k_add_jitter(double* __restrict__ K, int n, int ld, double jitte
 }
 
 // ---------------------------------------------------------------------------------------------
-// Blocked right-looking Cholesky, panel width 64: per panel k_chol_panel_w (kernels_gpw.hip: two waves per 64 x 64
-// block, a matrix row per lane) factors the diagonal block and solves the off-diagonal blocks, k_chol_update below
-// applies the trailing update on MFMA.
+// Blocked left-looking Cholesky, panel width 64: per panel k_chol_panel_w (kernels_gpw.hip: two waves per 64 x 64
+// block, a matrix row per lane) factors the diagonal block and solves the off-diagonal blocks, k_chol_lookback below
+// brings a block column up to date on MFMA before it is factored (left-looking).
 __device__ inline void load_tile(const double* __restrict__ src, int ld, double* s_t) {
   for (int idx = threadIdx.x; idx < BS * BS; idx += 256) {
     int r = idx >> 6, c = idx & 63;
@@ -87,57 +87,83 @@ __device__ inline void load_tile(const double* __restrict__ src, int ld, double*
 // The panel kernel does not store the factored diagonal block over its input inside its own launch: the other groups of
 // that launch read the block as INPUT at their start, and nothing orders their start before block 0's end (on a GPU
 // shared with other processes a group can start tens of microseconds late - seen as a spurious "not positive
-// definite").  With more than one group the factor goes to `diag_scratch`; one extra group of this kernel copies it
-// into place (it does not touch the diagonal block otherwise).
-// Trailing update A[I][J] -= L[I][p] L[J][p]^T for p < J <= I on f64 MFMA.
-// Both 64x64 operand tiles are staged in LDS with coalesced loads; fragments are read with a
-// leading dimension of 66 doubles (conflict-free for ds_read_b64).
-__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int p, int nblk, int ld,
-                                                     const double* __restrict__ diag_scratch, size_t zs) {
+// definite").  With more than one group the factor goes to `diag_scratch`; one extra group of the next panel's
+// look-back launch copies it into place (that launch does not touch the diagonal block otherwise).
+// LEFT-LOOKING update on f64 MFMA: before panel J is factored, block row I >= J of block column J receives the
+// contributions of ALL earlier panels at once,  A[I][J] -= sum_{p<J} L[I][p] L[J][p]^T.
+// One work-group per 64x64 tile keeps the tile's accumulators in registers over the J steps (the right-looking form of
+// round 1 re-read and re-wrote every trailing tile once per panel: 128 KB of traffic per 0.5 MFLOP, bound by the
+// L2 / Infinity-Cache bandwidth at ~3 TB/s with many runs side by side); operand tiles go through LDS with a leading
+// dimension of 66 doubles (conflict-free ds_read_b64), the next step's tiles travel in registers while the MFMAs of
+// the current one run.  The extra last work-group puts the previous panel's diagonal factor in place (see above).
+__global__ __launch_bounds__(256) void k_chol_lookback(double* __restrict__ A, int J, int nblk, int ld,
+                                                       const double* __restrict__ diag_scratch, size_t zs) {
   ZRUN(A); ZRUN(diag_scratch);
   __shared__ __attribute__((aligned(16))) double s_a[BS * TLD];
   __shared__ __attribute__((aligned(16))) double s_b[BS * TLD];
-  if (blockIdx.x == gridDim.x - 1) {                 // one extra group puts panel p's diagonal factor in place (see
-    double* Add = A + (size_t)(p * BS) * ld + p * BS;  // the note above): off the critical path of the tile groups
-    for (int idx = threadIdx.x; idx < BS * BS; idx += 256) Add[(size_t)(idx >> 6) * ld + (idx & 63)] = diag_scratch[idx];
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+  if (blockIdx.x == gridDim.x - 1) {                 // panel J-1's diagonal factor: scratch -> its place
+    double* Add = A + (size_t)((J - 1) * BS) * ld + (J - 1) * BS;
+    for (int idx = tid; idx < BS * BS; idx += 256) Add[(size_t)(idx >> 6) * ld + (idx & 63)] = diag_scratch[idx];
     return;
   }
-  // linear block id -> (I, J) in the lower triangle of the trailing (nblk-p-1)^2 tiles
-  const int m = nblk - p - 1;
-  int t = blockIdx.x, I = 0;
-  while (t >= I + 1) { t -= I + 1; ++I; }
-  const int J = t;
-  if (I >= m) return;
-  const int gi = p + 1 + I, gj = p + 1 + J;
-  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-  // the 16 elements of the target tile this thread updates are fetched up front, together with the operand tiles: read
-  // after the MFMAs in a load-subtract-store loop they cost 16 dependent global round trips (the compiler cannot
-  // hoist the loads over the stores to the same array), which was most of the kernel's 15.8 us
-  double* dst = A + (size_t)(gi * BS) * ld + gj * BS;
+  const int I = J + blockIdx.x;
+  const bool diag = I == J;
+  double* dst = A + (size_t)(I * BS) * ld + J * BS;
+  const double* Arow = A + (size_t)(I * BS) * ld;    // L[I][p] tiles
+  const double* Brow = A + (size_t)(J * BS) * ld;    // L[J][p] tiles
+  // the 16 elements of the target tile this thread owns, fetched up front
   double cold[4][4];
 #pragma unroll
   for (int q = 0; q < 4; ++q)
 #pragma unroll
     for (int r = 0; r < 4; ++r) cold[q][r] = dst[(size_t)(16 * w + (l >> 4) + 4 * r) * ld + 16 * q + (l & 15)];
-  load_tile(A + (size_t)(gi * BS) * ld + p * BS, ld, s_a);
-  load_tile(A + (size_t)(gj * BS) * ld + p * BS, ld, s_b);
-  __syncthreads();
-  double4_t acc[4];
-  for (int q = 0; q < 4; ++q) acc[q] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  for (int kk = 0; kk < BS; kk += 4) {
-    double a = s_a[(16 * w + (l & 15)) * TLD + kk + (l >> 4)];
-    for (int q = 0; q < 4; ++q) {
-      double bb = s_b[(16 * q + (l & 15)) * TLD + kk + (l >> 4)];     // B[k][j] = L[J-row j][k]
-      acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[q], 0, 0, 0);
+  double pa[16], pb[16];
+  auto fetch = [&](int p) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int idx = tid + 256 * u, r = idx >> 6, c = idx & 63;
+      pa[u] = Arow[(size_t)r * ld + p * BS + c];
+      pb[u] = Brow[(size_t)r * ld + p * BS + c];          // (the same tile on the diagonal: an L2 hit)
     }
+  };
+  auto put = [&]() {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int idx = tid + 256 * u, r = idx >> 6, c = idx & 63;
+      s_a[r * TLD + c] = pa[u];
+      s_b[r * TLD + c] = pb[u];
+    }
+  };
+  (void)diag;
+  fetch(0);
+  for (int p = 0; p < J; ++p) {
+    // per panel: the 64-term products accumulate from zero and are then subtracted from the tile - the arithmetic (and the
+    // bits) of a right-looking update applied panel by panel, without the tile leaving the registers in between
+    double4_t acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    __syncthreads();                                  // the previous step's MFMAs have read the LDS tiles
+    put();
+    if (p + 1 < J) fetch(p + 1);
+    __syncthreads();
+    for (int kk = 0; kk < BS; kk += 4) {
+      const double a = s_a[(16 * w + (l & 15)) * TLD + kk + (l >> 4)];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double bb = s_b[(16 * q + (l & 15)) * TLD + kk + (l >> 4)];     // B[k][j] = L[J-row j][k]
+        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[q], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cold[q][r] -= acc[q][r];
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      size_t off = (size_t)(16 * w + (l >> 4) + 4 * r) * ld + 16 * q + (l & 15);
-      dst[off] = cold[q][r] - acc[q][r];
-    }
+    for (int r = 0; r < 4; ++r) dst[(size_t)(16 * w + (l >> 4) + 4 * r) * ld + 16 * q + (l & 15)] = cold[q][r];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -267,12 +293,10 @@ void launch_add_jitter(hipStream_t s, double* K, int n, int ld, double jitter) {
 }
 void launch_cholesky(hipStream_t s, double* L, int NP, int ld, int* info, double* diag_scratch, ZB zb) {
   const int nblk = NP / BS;
-  for (int p = 0; p < nblk; ++p) {
+  for (int p = 0; p < nblk; ++p) {                   // left-looking: bring block column p up to date, then factor it
+    if (p > 0)
+      hipLaunchKernelGGL(k_chol_lookback, dim3(nblk - p + 1, 1, zb.B), dim3(256), 0, s, L, p, nblk, ld, diag_scratch, zb.zs);
     launch_chol_panel_w(s, L, p, nblk - p, ld, info, diag_scratch, zb);
-    int m = nblk - p - 1;
-    if (m > 0)
-      hipLaunchKernelGGL(k_chol_update, dim3(m * (m + 1) / 2 + 1, 1, zb.B), dim3(256), 0, s, L, p, nblk, ld, diag_scratch,
-                         zb.zs);
   }
 }
 void launch_trinv(hipStream_t s, const double* L, int NP, int ld, double* R, ZB zb) {

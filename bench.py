@@ -278,7 +278,7 @@ def main():
         if g["launches"] and c["launches"] and (g["ms"] + c["ms"]) > 0:
             sec = (g["ms"] + c["ms"]) * 1e-3
             tf = (g["flops"] + c["flops"]) / sec / 1e12
-            kchol = {"kernels": "k_zstats + k_znorm + k_gram; k_chol_panel_w + k_chol_update per 64-wide panel",
+            kchol = {"kernels": "k_zstats + k_znorm + k_gram; k_chol_lookback + k_chol_panel_w per 64-wide panel",
                      "bound": "mfma", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": tf / FP64_PEAK_TFLOPS, "hbm_GBs": (g["bytes"] + c["bytes"]) / sec / 1e9,
                      "hbm_frac": (g["bytes"] + c["bytes"]) / sec / 1e9 / HBM_PEAK_GBS,
@@ -292,6 +292,12 @@ def main():
         from pcabo import batchrun
         batch = batchrun.bench_block(device, args.batch, FID, DIM)
         batch.pop("best_f", None)
+        if args.batch >= 4:
+            # the same runs as two lock-step batches side by side (one host thread each): one batch's host-paced L-BFGS-B
+            # rounds overlap the other's launches and bookkeeping (ExperimentRunner(batched=, side_by_side=2))
+            two = batchrun.bench_block(device, args.batch, FID, DIM, sub_batches=2)
+            batch["side_by_side"] = {k: two[k] for k in ("sub_batches", "aggregate_bo_iterations_per_s", "seconds", "bo_iterations",
+                                                          "host_phase_seconds", "retries", "failed_runs")}
     if rank == 0 and size == 1 and not args.no_kchol_grid and not args.no_roofline:
         from pcabo import kchol_bench
         grid = kchol_bench.run(device, (1, 30), reps=3)

@@ -214,6 +214,11 @@ int pcabo_reset_profile(pcabo_ctx* ctx);
 typedef struct pcabo_batch pcabo_batch;
 int pcabo_batch_create(int device, int B, int max_n, int max_d, int max_q, pcabo_batch** out);
 int pcabo_batch_destroy(pcabo_batch* batch);
+/* Worker threads of the L-BFGS-B phase (one gang of runs and one HIP stream each; default min(8, B), PCABO_BATCH_THREADS).
+ * A worker spins while its launch is in flight: when several batches of one process advance side by side (one host thread
+ * per batch - the reference's cells of different dimension, or two halves of one cell) give each its share of the cores.
+ * Results do not depend on the number.  Not during a call on this batch. */
+int pcabo_batch_set_workers(pcabo_batch* batch, int workers);
 int pcabo_batch_last_error(pcabo_batch* batch, char* buf, int buflen);
 pcabo_ctx* pcabo_batch_ctx(pcabo_batch* batch, int b);
 

@@ -58,7 +58,7 @@ class ExperimentRunner:
                  budget_factor: int = 10, doe_factor: float = 3.0, root_dir: str = os.getcwd(),
                  experiment_name: str = "experiment", acquisition_function: str = "expected_improvement",
                  pca_components: Optional[int] = None, var_threshold: float = 0.95, verbose: bool = False,
-                 progress: bool = True, batched: int = 0):
+                 progress: bool = True, batched: int = 0, side_by_side: int = 2):
         self.algorithms = algorithms
         self.dimensions = dimensions
         self.problem_ids = problem_ids
@@ -76,6 +76,9 @@ class ExperimentRunner:
         # `batched` at a time, through pcabo.batchrun (one launch sequence for all of them per phase).  Same runs, same
         # files: a run's rows are written once its batch has finished.  Needs the in-repo BBOB problems (no ioh logger).
         self.batched = int(batched)
+        # side_by_side: that many lock-step batches advance at once, one host thread each (pcabo.batchrun.run_side_by_side):
+        # one batch's host-paced L-BFGS-B rounds overlap the other's launches and bookkeeping.  Same runs, same numbers.
+        self.side_by_side = max(1, int(side_by_side))
 
         self.triggers = [ALWAYS]
         self.logger_properties = [RAWYBEST]
@@ -135,24 +138,32 @@ class ExperimentRunner:
             yield LoggedProblem(BBOBProblem(pid, inst, dim), logger)
 
     def _run_pca_batched(self, logger, ebar) -> None:
-        """This rank's PCA_BO runs, `self.batched` runs of one dimension at a time in lock-step (pcabo.batchrun)."""
-        from pcabo.batchrun import BatchedPCABO
+        """This rank's PCA_BO runs, `self.batched` runs of one dimension at a time in lock-step (pcabo.batchrun),
+        `self.side_by_side` such batches at once."""
+        from pcabo.batchrun import BatchedPCABO, run_side_by_side, workers_for
         from pcabo.bbob import BBOBProblem
         from pcabo.iohlog import LoggedProblem
         mine = self._my_runs()
+        chunks = []
         for dim in sorted({r[1] for r in mine}, key=self.dimensions.index):
             cell = [r for r in mine if r[1] == dim]
-            for i in range(0, len(cell), self.batched):
-                chunk = cell[i:i + self.batched]
+            chunks += [(dim, cell[i:i + self.batched]) for i in range(0, len(cell), self.batched)]
+        for i in range(0, len(chunks), self.side_by_side):
+            group = chunks[i:i + self.side_by_side]
+            jobs = []
+            for dim, chunk in group:
                 probs = [BBOBProblem(pid, inst, dim) for pid, _, inst in chunk]
                 budget, n_doe = self.budget_factor * dim + 50, int(self.doe_factor * dim)
                 seeds = [1000 * pid + 10 * dim + inst for pid, _, inst in chunk]
                 runner = BatchedPCABO(probs, seeds, budget, n_doe, n_components=self.pca_components or 0,
                                       var_threshold=self.var_threshold, acquisition_function=self.acquisition_function,
-                                      device=self.device)
-                start_time = time()
-                runner.run()
-                elapsed = (time() - start_time) / len(chunk)          # a run's share of its batch
+                                      device=self.device, workers=workers_for(len(group)) if len(group) > 1 else 0,
+                                      host_threads=max(1, 8 // len(group)))
+                jobs.append((dim, chunk, probs, n_doe, runner))
+            start_time = time()
+            run_side_by_side([j[4] for j in jobs])
+            elapsed = (time() - start_time) / sum(len(j[1]) for j in jobs)          # a run's share of its group of batches
+            for dim, chunk, probs, n_doe, runner in jobs:
                 for b, (pid, _, inst) in enumerate(chunk):
                     replay = LoggedProblem(BBOBProblem(pid, inst, dim), logger)     # the run's rows, in its own order
                     for _, x in probs[b].log:

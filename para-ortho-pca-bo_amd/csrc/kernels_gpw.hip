@@ -3,6 +3,15 @@
 #include "pcabo_internal.h"
 
 #define BS PCABO_BS
+#ifdef PCABO_ACQ_TIMING
+__device__ unsigned long long g_panel_stamps[16];
+extern "C" int pcabo_debug_panel_stamps(unsigned long long* out16) {
+  return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_panel_stamps), sizeof(g_panel_stamps)) == hipSuccess ? 0 : -3;
+}
+#define PSTAMP(i) do { if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_panel_stamps[i] = wall_clock64(); } while (0)
+#else
+#define PSTAMP(i)
+#endif
 #define WLD 65   // LDS leading dimension of the transposing tile (row reads and column writes both conflict-free)
 
 // ---- Cholesky panel: two waves per 64x64 block, a matrix ROW per lane ---------------------------------------------
@@ -66,6 +75,7 @@ __device__ inline void trailing_all(double (&a)[BS], const double* s_d, int jb) 
 __device__ inline void panel_diag_rows(double (&dr)[BS], double* s_d, double* s_rs, int r, int& bad) {
   for (int jb = 0; jb < BS / 16; ++jb) {
     const int base = 16 * jb;
+    PSTAMP(2 + 3 * jb);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       double piv = lane_get(dr[j], base + j);
@@ -78,9 +88,11 @@ __device__ inline void panel_diag_rows(double (&dr)[BS], double* s_d, double* s_
       for (int c = j + 1; c < 16; ++c) dr[c] = fma(-dl, lane_get(dl, base + c), dr[c]);   // L[base+c][base+j]
       __builtin_amdgcn_sched_barrier(0);
     }
+    PSTAMP(3 + 3 * jb);
 #pragma unroll
     for (int j = 0; j < 16; ++j) s_d[r * WLD + base + j] = (base + j <= r) ? dr[j] : 0.0;
     __syncthreads();                               // sub-panel jb is published
+    PSTAMP(4 + 3 * jb);
     trailing_all(dr, s_d, jb);
   }
 }
@@ -124,6 +136,7 @@ __global__ __launch_bounds__(128) void k_chol_panel_w(double* __restrict__ A, in
   __shared__ double s_a[BS * WLD];
   __shared__ double s_rs[BS];
   const int r = threadIdx.x & 63, role = threadIdx.x >> 6, b = blockIdx.x;
+  PSTAMP(0);
   double* Add = A + (size_t)(p * BS) * ld + p * BS;
   double* Abd = A + (size_t)((p + b) * BS) * ld + p * BS;
   double a[BS];
@@ -143,6 +156,7 @@ __global__ __launch_bounds__(128) void k_chol_panel_w(double* __restrict__ A, in
   if (role == 0) {
 #pragma unroll
     for (int c = 0; c < BS; ++c) a[c] = s_d[r * WLD + c];
+    PSTAMP(1);
     int bad = 0;
     panel_diag_rows(a, s_d, s_rs, r, bad);
     if (bad && b == 0 && r == 0) atomicCAS(info, 0, p * BS + bad);
@@ -153,6 +167,7 @@ __global__ __launch_bounds__(128) void k_chol_panel_w(double* __restrict__ A, in
   } else {
     for (int jb = 0; jb < BS / 16; ++jb) __syncthreads();      // block 0 has no off-diagonal block: keep the barriers paired
   }
+  PSTAMP(14);
   __syncthreads();
   if (b == 0) {
     if (role == 0) {
@@ -167,6 +182,7 @@ __global__ __launch_bounds__(128) void k_chol_panel_w(double* __restrict__ A, in
 #pragma unroll 8
     for (int i = 0; i < BS; ++i) Abd[(size_t)i * ld + r] = s_a[i * WLD + r];
   }
+  PSTAMP(15);
 }
 
 // Inverse of the 64x64 diagonal blocks of L, a COLUMN of the inverse per lane: right-looking forward substitution,

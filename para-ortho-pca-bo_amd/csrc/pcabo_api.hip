@@ -1503,9 +1503,10 @@ struct GangPool {
   int pending = 0;
   bool quit = false;
   void start(int n) {
+    const unsigned epoch0 = epoch;                         // (a restarted pool must not take the last call for a new one)
     for (int i = 1; i < n; ++i)
-      th.emplace_back([this, i] {
-        unsigned seen = 0;
+      th.emplace_back([this, i, epoch0] {
+        unsigned seen = epoch0;
         for (;;) {
           std::function<void(int)> f;
           {
@@ -1537,6 +1538,7 @@ struct GangPool {
     cv.notify_all();
     for (auto& t : th) if (t.joinable()) t.join();
     th.clear();
+    quit = false;
   }
 };
 
@@ -1654,6 +1656,24 @@ int pcabo_batch_create(int device, int B, int max_n, int max_d, int max_q, pcabo
 int pcabo_batch_destroy(pcabo_batch* batch) {
   if (!batch) return PCABO_ERR_ARG;
   batch_free(batch);
+  return PCABO_OK;
+}
+
+// Worker threads (= gangs) of the L-BFGS-B phase.  Every worker spins while its launch is in flight, so the workers of all
+// batches of a process should fit the cores the process owns: two batches advancing side by side on two host threads take
+// 4 each on a 16-core share.  Not during a call on this batch.  The runs' results do not depend on it.
+int pcabo_batch_set_workers(pcabo_batch* batch, int workers) {
+  if (!batch || workers < 1) return PCABO_ERR_ARG;
+  BHIPCHK(hipSetDevice(batch->device));
+  const int T = std::max(1, std::min(workers, std::min(batch->B, 32)));
+  if (T == batch->G) return PCABO_OK;
+  batch->pool.shutdown();
+  BHIPCHK(hipStreamSynchronize(batch->stream));
+  for (hipStream_t& s : batch->gstream) if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); s = nullptr; }
+  batch->gstream.assign((size_t)T * PCABO_BATCH_MAXSPLIT, nullptr);
+  for (size_t g = 0; g < batch->gstream.size(); ++g) BHIPCHK(hipStreamCreateWithFlags(&batch->gstream[g], hipStreamNonBlocking));
+  batch->G = T;
+  batch->pool.start(T);
   return PCABO_OK;
 }
 

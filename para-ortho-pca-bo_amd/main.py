@@ -26,6 +26,9 @@ def parse_arguments():
     p.add_argument("--algorithms", type=str, nargs="+", default=["pca", "vanilla"], choices=["pca", "vanilla"])
     p.add_argument("--verbose", action="store_true")
     p.add_argument("--quick", action="store_true", help="5-D, f15 + f20, budget factor 5, DoE factor 2")
+    # not in the reference: PCA_BO runs of one dimension advance in lock-step, `--batched` at a time (0: one run after the other)
+    p.add_argument("--batched", type=int, default=0, help="PCA_BO runs per lock-step batch (same runs, same numbers)")
+    p.add_argument("--side_by_side", type=int, default=2, help="lock-step batches advancing at once (one host thread each)")
     return p.parse_args()
 
 
@@ -38,7 +41,7 @@ def main():
         algorithms=a.algorithms, dimensions=a.dimensions, problem_ids=a.problems, num_runs=a.runs,
         budget_factor=a.budget_factor, doe_factor=a.doe_factor, root_dir=os.getcwd(), experiment_name=a.experiment_dir,
         acquisition_function=a.acquisition, pca_components=0, var_threshold=a.var_threshold, verbose=a.verbose,
-        progress=(rank == 0))
+        progress=(rank == 0), batched=a.batched, side_by_side=a.side_by_side)
     t0 = time.time()
     experiment.run_experiment()
     dt = time.time() - t0

@@ -36,7 +36,7 @@ EXPORTS = [
     "pcabo_batch_create", "pcabo_batch_destroy", "pcabo_batch_last_error", "pcabo_batch_ctx",
     "pcabo_batch_wpca_gp_condition_begin", "pcabo_batch_wpca_results", "pcabo_batch_acq_bounds",
     "pcabo_batch_gp_condition_end_eval", "pcabo_batch_optimize_acqf", "pcabo_batch_inverse_map",
-    "pcabo_batch_set_profiling", "pcabo_batch_get_profile", "pcabo_batch_set_active",
+    "pcabo_batch_set_profiling", "pcabo_batch_get_profile", "pcabo_batch_set_active", "pcabo_batch_set_workers",
     "pcabo_bbob_table_doubles", "pcabo_bbob_create", "pcabo_bbob_destroy", "pcabo_bbob_eval",
 ]
 
@@ -92,6 +92,7 @@ def _load() -> C.CDLL:
     lib.pcabo_reset_profile.argtypes = [vp]
     lib.pcabo_batch_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     lib.pcabo_batch_destroy.argtypes = [vp]
+    lib.pcabo_batch_set_workers.argtypes = [vp, C.c_int]
     lib.pcabo_batch_last_error.argtypes = [vp, C.c_char_p, C.c_int]
     lib.pcabo_batch_ctx.argtypes = [vp, C.c_int]
     lib.pcabo_batch_wpca_gp_condition_begin.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
@@ -340,7 +341,7 @@ class Batch:
     """B per-run contexts advancing in lock-step (pcabo_batch_* of include/pcabo.h): one launch sequence for the
     rows A-H of all runs, one scoring launch, shared acquisition launches for the L-BFGS-B rounds of all runs."""
 
-    def __init__(self, B: int, max_n: int, max_d: int, max_q: int = 512, device: int = 0):
+    def __init__(self, B: int, max_n: int, max_d: int, max_q: int = 512, device: int = 0, workers: int = 0):
         self._h = C.c_void_p()
         rc = LIB.pcabo_batch_create(int(device), int(B), int(max_n), int(max_d), int(max_q), C.byref(self._h))
         if rc != 0:
@@ -353,6 +354,12 @@ class Batch:
         self.n = self.d = 0
         self.k = np.zeros(B, dtype=np.int32)
         self.ctx = [_BorrowedContext(LIB.pcabo_batch_ctx(self._h, b), max_n, max_d, max_q, device) for b in range(B)]
+        if workers:
+            self.set_workers(workers)
+
+    def set_workers(self, workers: int) -> None:
+        """Worker threads of the L-BFGS-B phase (they spin: several batches of one process share the process's cores)."""
+        self._chk(LIB.pcabo_batch_set_workers(self._h, int(workers)))
 
     def _err(self) -> str:
         buf = C.create_string_buffer(512)

@@ -38,7 +38,7 @@ class BatchedPCABO:
     def __init__(self, problems: Sequence, seeds: Sequence[int], budget: int, n_DoE: int, n_components: int = 0,
                  var_threshold: float = 0.95, acquisition_function: str = "expected_improvement",
                  maximization: bool = False, device: int = 0, num_restarts: int = 10, raw_samples: int = 512,
-                 record_trace: bool = False, host_threads: int = 0, device_objective: bool = False):
+                 record_trace: bool = False, host_threads: int = 0, device_objective: bool = False, workers: int = 0):
         self.problems, self.seeds = list(problems), [int(s) for s in seeds]
         self.B = len(self.problems)
         assert self.B == len(self.seeds) and self.B >= 1
@@ -79,6 +79,7 @@ class BatchedPCABO:
         self._device_objective, self._dev_obj = bool(device_objective), None
         self._pool = None
         self._host_threads = int(host_threads) if host_threads else min(8, self.B)
+        self._workers = int(workers)                 # 0: the library's default (pcabo_batch_set_workers)
 
     # ---- seeding + DoE (AbstractAlgorithm.py:310-328, AbstractBayesianOptimizer.py:142-176) --------------------------
     def start(self) -> None:
@@ -94,7 +95,8 @@ class BatchedPCABO:
                 self.f_evals[b].append(self.problems[b](point))
             self._assign_new_best(b)
             self._X[b, : self.n_DoE] = np.vstack(self.x_evals[b])
-        self._batch = _native.Batch(B, max_n=self.budget, max_d=d, max_q=max(self.raw_samples, 16), device=self.device)
+        self._batch = _native.Batch(B, max_n=self.budget, max_d=d, max_q=max(self.raw_samples, 16), device=self.device,
+                                    workers=self._workers)
         if self._device_objective:
             from .bbob_device import DeviceObjectives
             self._dev_obj = DeviceObjectives(self.problems, device=self.device, penalty=OOB_PENALTY)
@@ -290,28 +292,78 @@ class BatchedPCABO:
             self.finish()
 
 
-def bench_block(device: int, B: int, fid: int, dim: int, budget_factor: int = 10, doe_factor: float = 3.0) -> dict:
+def workers_for(side_by_side: int) -> int:
+    """Gang threads per batch when `side_by_side` batches of this process advance at once: the workers spin, and a GPU of
+    a shared node comes with ~16 cores - 8 for one batch, 4 each for two, never fewer than 2."""
+    return max(2, 8 // max(1, int(side_by_side)))
+
+
+def run_side_by_side(runners: Sequence["BatchedPCABO"], started: bool = False) -> None:
+    """Advance several batches at once, one host thread each (the library calls release the interpreter lock): while one
+    batch is in its L-BFGS-B rounds - host-paced, the GPU lightly used - another one has the device for its wPCA /
+    conditioning / scoring launches and the interpreter for its bookkeeping.  The batches are independent (their own
+    contexts, streams and generators), so every run is bit-identical to the same run in any other grouping.  An
+    exception of one batch is re-raised after all of them have ended."""
+    import threading
+    errors: List[BaseException] = []
+
+    def drive(r: "BatchedPCABO") -> None:
+        try:
+            if not started:
+                r.start()
+            while r.n < r.budget:
+                r.iteration()
+        except BaseException as e:      # noqa: BLE001 - handed to the caller below
+            errors.append(e)
+        finally:
+            if not started:
+                r.finish()
+
+    if len(runners) == 1:
+        drive(runners[0])
+    else:
+        threads = [threading.Thread(target=drive, args=(r,), name=f"pcabo-batch-{i}") for i, r in enumerate(runners)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    if errors:
+        raise errors[0]
+
+
+def bench_block(device: int, B: int, fid: int, dim: int, budget_factor: int = 10, doe_factor: float = 3.0,
+                sub_batches: int = 1) -> dict:
     """Aggregate BO iterations / second of B runs (instances 0..B-1 of one BBOB function and dimension, seeds per
-    ExperimentRunner.py:146) advancing together on one GPU; DoE and set-up untimed."""
+    ExperimentRunner.py:146) advancing together on one GPU - as one lock-step batch, or as `sub_batches` lock-step batches
+    side by side (run_side_by_side); DoE and set-up untimed."""
     from .bbob import BBOBProblem
     budget, n_doe = budget_factor * dim + 50, int(doe_factor * dim)
-    probs = [BBOBProblem(fid, i, dim) for i in range(B)]
-    seeds = [1000 * fid + 10 * dim + i for i in range(B)]
-    r = BatchedPCABO(probs, seeds, budget, n_doe, device=device)
-    r.start()
+    S = max(1, min(int(sub_batches), B))
+    subs = []
+    for t in range(S):
+        inst = list(range(t, B, S))
+        subs.append(BatchedPCABO([BBOBProblem(fid, i, dim) for i in inst], [1000 * fid + 10 * dim + i for i in inst], budget, n_doe,
+                                 device=device, workers=workers_for(S) if S > 1 else 0, host_threads=max(1, 8 // S)))
+    for r in subs:
+        r.start()
     torch.cuda.synchronize()
     t0 = perf_counter()
     try:
-        while r.n < budget:
-            r.iteration()
+        run_side_by_side(subs, started=True)
         torch.cuda.synchronize()
         dt = perf_counter() - t0
     finally:
-        r.finish()
-    iters = sum(len(f) - n_doe for f in r.f_evals)           # (parked runs count what they completed)
-    return {"runs": B, "function": fid, "dimension": dim, "budget": budget, "n_DoE": n_doe,
+        for r in subs:
+            r.finish()
+    iters = sum(len(f) - n_doe for r in subs for f in r.f_evals)           # (parked runs count what they completed)
+    phases = {k: sum(r.timing[k] for r in subs) / S for k in subs[0].timing}
+    best = [None] * B
+    for t, r in enumerate(subs):
+        for j, i in enumerate(range(t, B, S)):
+            best[i] = float(r.current_best[j])
+    return {"runs": B, "sub_batches": S, "function": fid, "dimension": dim, "budget": budget, "n_DoE": n_doe,
             "aggregate_bo_iterations_per_s": iters / dt, "seconds": dt, "bo_iterations": iters,
-            "ms_per_lockstep_iteration": 1e3 * dt / (budget - n_doe), "host_phase_seconds": dict(r.timing),
-            "retries": r.retries, "failed_runs": sum(f is not None for f in r.failed), "best_f": [float(v) for v in r.current_best],
+            "ms_per_lockstep_iteration": 1e3 * dt / (budget - n_doe), "host_phase_seconds": phases,
+            "retries": sum(r.retries for r in subs), "failed_runs": sum(f is not None for r in subs for f in r.failed), "best_f": best,
             "note": "B runs of configs[1]'s cell advancing in lock-step through pcabo_batch_* (one launch sequence for rows "
-                    "A-H of all runs, shared acquisition launches for the L-BFGS-B rounds); one Python host thread"}
+                    "A-H of all runs, shared acquisition launches for the L-BFGS-B rounds); one Python host thread per sub-batch"}

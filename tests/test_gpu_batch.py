@@ -206,3 +206,55 @@ def test_a_parked_run_does_not_disturb_the_others(native):
     for b in (0, 2):
         X, f, best, bi = _single(15, insts[b], 10, 60, 30, seeds[b], "group")
         assert np.array_equal(np.vstack(r.x_evals[b]), X) and np.array_equal(np.array(r.f_evals[b]), f)
+
+
+def test_batches_side_by_side_equal_one_batch(native, tmp_path):
+    """run_side_by_side: the runs of a cell as two lock-step batches on two host threads (gang workers re-sized through
+    pcabo_batch_set_workers) - every run must come out bit for bit as in ONE batch of all of them; the experiment runner with
+    side_by_side=2 must write the files it writes with side_by_side=1."""
+    import os
+    from pcabo.batchrun import BatchedPCABO, run_side_by_side, workers_for
+    from Algorithms import ExperimentRunner
+    dim, budget, n_doe, insts = 10, 70, 30, list(range(6))
+    seeds = [15000 + 10 * dim + i for i in insts]
+    whole = _batched(15, insts, dim, budget, n_doe, seeds)
+    halves = [BatchedPCABO([BBOBProblem(15, i, dim) for i in insts[t::2]], seeds[t::2], budget, n_doe, workers=workers_for(2))
+              for t in range(2)]
+    run_side_by_side(halves)
+    for t in range(2):
+        for j, i in enumerate(insts[t::2]):
+            assert np.array_equal(np.vstack(halves[t].x_evals[j]), np.vstack(whole.x_evals[i])), i
+            assert np.array_equal(np.array(halves[t].f_evals[j]), np.array(whole.f_evals[i])), i
+    outs = []
+    for sbs in (1, 2):
+        root = tmp_path / f"s{sbs}"
+        er = ExperimentRunner(algorithms=["pca"], dimensions=[5, 10], problem_ids=[15], num_runs=4, budget_factor=5,
+                              doe_factor=2.0, root_dir=str(root), experiment_name="experiment", progress=False, batched=2,
+                              side_by_side=sbs)
+        er.run_experiment()
+        assert len(er.results) == 8 and not er.failed_runs
+        outs.append(root)
+    for d in (5, 10):
+        rel = os.path.join("pca-experiment", "data_f15_RastriginRotated", f"IOHprofiler_f15_DIM{d}.dat")
+        assert open(os.path.join(outs[0], rel)).read() == open(os.path.join(outs[1], rel)).read()
+
+
+def test_batch_worker_count_can_change_between_calls(native):
+    """pcabo_batch_set_workers between two iterations of a batch: same candidates as without the change."""
+    from pcabo.batchrun import BatchedPCABO
+    dim, budget, n_doe, insts = 10, 50, 30, [0, 1, 2, 3, 4]
+    seeds = [15000 + 10 * dim + i for i in insts]
+    ref = _batched(15, insts, dim, budget, n_doe, seeds)
+    r = BatchedPCABO([BBOBProblem(15, i, dim) for i in insts], seeds, budget, n_doe)
+    r.start()
+    try:
+        for it, w in zip(range(budget - n_doe), [0, 1, 3, 0, 5, 2] * 10):
+            if w:
+                r._batch.set_workers(w)
+            r.iteration()
+    finally:
+        r.finish()
+    for b in range(len(insts)):
+        assert np.array_equal(np.vstack(r.x_evals[b]), np.vstack(ref.x_evals[b])), b
+    with pytest.raises(Exception):
+        native.Batch(2, max_n=40, max_d=5).set_workers(0)

@@ -1,4 +1,4 @@
-"""Aggregate rate of B runs advancing in lock-step (pcabo.batchrun) - diagnostic.  usage: gpu_batch_clock.py B [dim] [fid]"""
+"""Aggregate rate of B runs advancing in lock-step (pcabo.batchrun) - diagnostic.  usage: gpu_batch_clock.py B [dim] [fid] [sub_batches]"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "para-ortho-pca-bo_amd"))
@@ -8,6 +8,7 @@ torch.set_num_threads(4)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 dim = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 fid = int(sys.argv[3]) if len(sys.argv) > 3 else 15
-out = batchrun.bench_block(0, B, fid, dim)
+S = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+out = batchrun.bench_block(0, B, fid, dim, sub_batches=S)
 out.pop("best_f")
 print(json.dumps(out))

@@ -73,7 +73,7 @@ class ExperimentRunner:
         self.verbose = verbose
         self.progress = progress and tqdm is not None
         # batched > 1 (not in the reference): the PCA_BO runs of this rank that share a dimension advance in lock-step,
-        # `batched` at a time, through pcabo.batchrun (one launch sequence for all of them per phase).  Same runs, same
+        # about `batched` at a time, through pcabo.batchrun (one launch sequence for all of them per phase).  Same runs, same
         # files: a run's rows are written once its batch has finished.  Needs the in-repo BBOB problems (no ioh logger).
         self.batched = int(batched)
         # side_by_side: that many lock-step batches advance at once, one host thread each (pcabo.batchrun.run_side_by_side):
@@ -146,8 +146,13 @@ class ExperimentRunner:
         mine = self._my_runs()
         chunks = []
         for dim in sorted({r[1] for r in mine}, key=self.dimensions.index):
+            # the runs of a dimension are divided EVENLY over a multiple of `side_by_side` batches of about `batched` runs
+            # (a lone last batch would advance with nothing beside it; larger batches amortise the rounds of the slowest
+            # restart better: 90 runs with batched=30, side_by_side=2 go as 2 x 45 rather than 30 + 30 | 30)
             cell = [r for r in mine if r[1] == dim]
-            chunks += [(dim, cell[i:i + self.batched]) for i in range(0, len(cell), self.batched)]
+            nb = min(len(cell), self.side_by_side * max(1, len(cell) // (self.batched * self.side_by_side)))
+            cuts = [len(cell) * i // nb for i in range(nb + 1)]
+            chunks += [(dim, cell[cuts[i]:cuts[i + 1]]) for i in range(nb)]
         for i in range(0, len(chunks), self.side_by_side):
             group = chunks[i:i + self.side_by_side]
             jobs = []

@@ -183,8 +183,9 @@ int pcabo_lbfgsb_minimize(int nvar, double* x, const double* lower, const double
 
 /* Host-only helper for the initial-condition draw (botorch -> torch.quasirandom.SobolEngine, row K):
  * the matrix scramble of torch's `_sobol_engine_scramble_` on state[k*30] (in/out) with the k lower-
- * triangular 30x30 0/1 matrices ltm[k*30*30] (as drawn by torch.randint(...).tril()); bit-identical to torch,
- * ~50x faster than torch's accessor loop.  The random bits themselves still come from torch's generator. */
+ * triangular 30x30 0/1 matrices ltm[k*30*30] (as drawn by torch.randint(...); entries on and above the diagonal are not
+ * read - torch's .tril() need not be applied); bit-identical to torch, ~100x faster than torch's accessor loop.  The random
+ * bits themselves still come from torch's generator. */
 int pcabo_sobol_scramble(int64_t* state, const int64_t* ltm, int k);
 
 /* Device-time accounting: accumulated HIP-event time (ms, events recorded on the context's own

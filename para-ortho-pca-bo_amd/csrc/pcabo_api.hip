@@ -1358,22 +1358,22 @@ int pcabo_sobol_scramble(int64_t* state, const int64_t* ltm, int k) {
   if (!state || !ltm || k < 1) return PCABO_ERR_ARG;
   const int MAXBIT = 30;
   for (int d = 0; d < k; ++d) {
-    int64_t lsm[30];
-    for (int p = 0; p < MAXBIT; ++p) {                  // row p of matrix d (diagonal forced to 1) as a bit vector
-      int64_t v = 0;
+    // matrix d over GF(2): unit diagonal, entries below it from ltm, nothing above (whatever ltm holds there - the caller
+    // need not clear the upper triangle).  col[c] = column c as a bit vector, row p at bit MAXBIT-1-p.
+    int64_t col[30];
+    for (int c = 0; c < MAXBIT; ++c) col[c] = (int64_t)1 << (MAXBIT - 1 - c);
+    for (int p = 1; p < MAXBIT; ++p) {
       const int64_t* row = ltm + ((size_t)d * MAXBIT + p) * MAXBIT;
-      for (int c = 0; c < MAXBIT; ++c) {
-        int64_t bit = (c == p) ? 1 : (row[c] & 1);
-        v += bit << (MAXBIT - 1 - c);
-      }
-      lsm[p] = v;
+      const int64_t pbit = (int64_t)1 << (MAXBIT - 1 - p);
+      for (int c = 0; c < p; ++c) col[c] |= (row[c] & 1) ? pbit : 0;
     }
-    for (int j = 0; j < MAXBIT; ++j) {
-      const int64_t vdj = state[(size_t)d * MAXBIT + j];
+    for (int j = 0; j < MAXBIT; ++j) {                  // state <- matrix * state, bit MAXBIT-1-c of the state = component c
+      unsigned long long v = (unsigned long long)state[(size_t)d * MAXBIT + j] & ((1ull << MAXBIT) - 1);
       int64_t t2 = 0;
-      for (int p = MAXBIT - 1; p >= 0; --p) {
-        int64_t t1 = __builtin_popcountll((unsigned long long)(lsm[p] & vdj)) & 1;
-        t2 += t1 << (MAXBIT - 1 - p);
+      while (v) {
+        const int b = __builtin_ctzll(v);
+        t2 ^= col[MAXBIT - 1 - b];
+        v &= v - 1;
       }
       state[(size_t)d * MAXBIT + j] = t2;
     }

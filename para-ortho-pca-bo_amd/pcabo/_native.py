@@ -22,7 +22,7 @@ PROFILE_GROUPS = ("wpca", "gram", "cholesky", "root_inverse_alpha", "acq_partial
 # Independent runs drive the GPU from several host threads on separate HIP streams (the gangs of a Batch, one context
 # per thread): the runtime's default of 4 hardware queues per process makes streams share queues, and kernels that share
 # a queue run one after the other.  Read by the HIP runtime when it initialises; an explicit setting wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "lib", "libpcabo.so")
 

@@ -33,7 +33,7 @@ def scrambled_sobol_engine(k: int, generator=None) -> torch.quasirandom.SobolEng
     eng = torch.quasirandom.SobolEngine(k, scramble=False)
     shift_ints = torch.randint(2, (k, _MAXBIT), generator=generator)
     eng.shift = torch.mv(shift_ints, _POW_LOW)
-    ltm = torch.randint(2, (k, _MAXBIT, _MAXBIT), generator=generator).tril()
+    ltm = torch.randint(2, (k, _MAXBIT, _MAXBIT), generator=generator)     # (torch's .tril(): the helper reads below the diagonal only)
     state = eng.sobolstate.numpy()                                  # (k, 30) int64, shares memory with the engine
     _native.sobol_scramble(state, ltm.numpy())
     eng.quasi = eng.shift.clone(memory_format=torch.contiguous_format)

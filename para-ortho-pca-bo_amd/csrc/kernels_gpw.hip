@@ -185,6 +185,210 @@ __global__ __launch_bounds__(128) void k_chol_panel_w(double* __restrict__ A, in
   PSTAMP(15);
 }
 
+// ---- The same panel step with the trailing updates on the matrix cores ------------------------------------------------
+// In k_chol_panel_w the 16-wide rank updates of the columns still to come (trailing_all) are the largest item of the
+// timeline: 8.7 of 23 us, bound by the LDS broadcasts of the multipliers that BOTH waves pull (tools/gpu_panel_phases.py).
+// v_mfma_f64_16x16x4 accumulates its four products as a chain of fused multiply-adds in ascending k ON TOP of the
+// accumulator (profiles/tools/mfma_f64_order.hip: 512 000 of 512 000 elements equal the fma chain bit for bit), which is
+// exactly what the VALU loop does per element - so the updates move to the matrix cores without changing a single bit:
+// a wave keeps its 64 x 64 block as 16 accumulator tiles (the same 64 doubles per lane), and only the 16 columns of the
+// current sub-panel take the trip through the LDS tile into the row-per-lane form that the pivot / substitution chain needs.
+#define PANEL_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")     // LDS hand-over inside one wave
+// acc[rt][ct][q] = T[16 rt + (l >> 4) + 4 q][16 ct + (l & 15)]
+template <int JB, bool LOWER>
+__device__ inline void tiles_colblock_to_lds(const double4_t (&acc)[4][4], double* s_t, int l) {
+#pragma unroll
+  for (int rt = LOWER ? JB : 0; rt < 4; ++rt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s_t[(16 * rt + (l >> 4) + 4 * q) * WLD + 16 * JB + (l & 15)] = acc[rt][JB][q];
+}
+// acc[rt][ct] -= X[rows of rt][16 JB ..] * L[rows of ct][16 JB ..]^T for the column tiles ct > JB (LOWER: row tiles rt >= ct).
+// s_x: the tile that holds the wave's own finished sub-panel, s_l: the factor's.
+template <int JB, bool LOWER>
+__device__ inline void trailing_mfma(double4_t (&acc)[4][4], const double* s_x, const double* s_l, int l) {
+  const int base = 16 * JB;
+  double bl[4][4];                                  // bl[ct][kk] = L[16 ct + (l & 15)][base + 4 kk + (l >> 4)]
+#pragma unroll
+  for (int ct = JB + 1; ct < 4; ++ct)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) bl[ct][kk] = s_l[(16 * ct + (l & 15)) * WLD + base + 4 * kk + (l >> 4)];
+#pragma unroll
+  for (int rt = LOWER ? JB + 1 : 0; rt < 4; ++rt) {
+    double ax[4];                                   // - X[16 rt + (l & 15)][base + 4 kk + (l >> 4)]
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) ax[kk] = LOWER ? -bl[rt][kk] : -s_x[(16 * rt + (l & 15)) * WLD + base + 4 * kk + (l >> 4)];
+#pragma unroll
+    for (int ct = JB + 1; ct < (LOWER ? rt + 1 : 4); ++ct)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[kk], bl[ct][kk], acc[rt][ct], 0, 0, 0);
+  }
+}
+
+// wave 0, sub-panel JB of the diagonal block.
+// The chain pivot -> 1/sqrt -> column -> next pivot is what the panel waits for, so only the two columns the NEXT two
+// pivots need take their multiplier the quick way (v_readlane -> SGPR operand); the other columns' multipliers of pivot j
+// go through an LDS column (one write, broadcast reads) and are applied one pivot LATER, after the chain of pivot j+1 has
+// been issued - their LDS round trip runs under that chain.  Per element the updates still arrive in ascending pivot order
+// with the same operands: same bits as the all-readlane loop (28 v_readlane per pivot, issue-bound: 110 ns per pivot).
+template <int JB>
+__device__ inline void panel_m_diag_step(double4_t (&acc)[4][4], double* s_d, double* s_rs, double* s_col, int r, int& bad) {
+  constexpr int base = 16 * JB;
+  double dr[16];
+  if (JB > 0) { tiles_colblock_to_lds<JB, true>(acc, s_d, r); PANEL_LDS_SYNC(); }     // (JB = 0: the loaded tile is still there)
+#pragma unroll
+  for (int j = 0; j < 16; ++j) dr[j] = s_d[r * WLD + base + j];
+  PSTAMP(2 + 3 * JB);
+  double dl_prev = 0.0, mp[16];                    // pivot j-1's column and its multipliers for the deferred columns
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    // chain of pivot j
+    double piv = lane_get(dr[j], base + j);
+    if (!(piv > 0.0)) { if (bad == 0) bad = base + j + 1; piv = 1.0; }      // uniform
+    const double rs = fast_rsq(piv);
+    if (r == 0) s_rs[base + j] = rs;
+    const double dl = dr[j] * rs;                // lanes r >= base+j: L[r][base+j] (lane base+j: sqrt(piv))
+    dr[j] = dl;
+    if (j + 1 < 16) dr[j + 1] = fma(-dl, lane_get(dl, base + j + 1), dr[j + 1]);
+    __builtin_amdgcn_sched_barrier(0);
+    // pivot j-1's deferred columns (their multipliers have had the time of the chain above to arrive)
+    if (j > 0) {
+#pragma unroll
+      for (int c = j + 2; c < 16; ++c) dr[c] = fma(-dl_prev, mp[c], dr[c]);
+    }
+    // pivot j: the column after next, then its own deferred multipliers are requested
+    if (j + 2 < 16) dr[j + 2] = fma(-dl, lane_get(dl, base + j + 2), dr[j + 2]);
+    if (j + 3 < 16) {
+      s_col[(j & 1) * BS + r] = dl;
+      asm volatile("" ::: "memory");             // (a wave's LDS instructions execute in order: the reads below see the write)
+#pragma unroll
+      for (int c = j + 3; c < 16; ++c) mp[c] = s_col[(j & 1) * BS + base + c];
+    }
+    dl_prev = dl;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  PSTAMP(3 + 3 * JB);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) s_d[r * WLD + base + j] = (base + j <= r) ? dr[j] : 0.0;
+  __syncthreads();                               // sub-panel JB is published
+  PSTAMP(4 + 3 * JB);
+  if (JB < 3) trailing_mfma<JB, true>(acc, s_d, s_d, r);
+}
+
+// wave 1, sub-panel JB of the work-group's off-diagonal block: A <- A L^-T one sub-panel behind wave 0
+template <int JB>
+__device__ inline void panel_m_solve_step(double4_t (&acc)[4][4], const double* s_d, const double* s_rs, double* s_a, int r) {
+  constexpr int base = 16 * JB;
+  double ar[16];
+  if (JB > 0) { tiles_colblock_to_lds<JB, false>(acc, s_a, r); PANEL_LDS_SYNC(); }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) ar[j] = s_a[r * WLD + base + j];
+  __syncthreads();                               // wait for sub-panel JB of the factor
+  const double* tri = s_d + base * WLD + base;   // the 16x16 triangle: L[base+c][base+j] = tri[c*WLD + j]
+  double rsv[16], tb[3][16];                     // tb[j % 3][c]: column j of the triangle, prefetched two steps ahead
+#pragma unroll
+  for (int j = 0; j < 16; ++j) rsv[j] = s_rs[base + j];
+#pragma unroll
+  for (int c = 1; c < 16; ++c) tb[0][c] = tri[c * WLD];
+#pragma unroll
+  for (int c = 2; c < 16; ++c) tb[1][c] = tri[c * WLD + 1];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    if (j + 2 < 15) {
+#pragma unroll
+      for (int c = j + 3; c < 16; ++c) tb[(j + 2) % 3][c] = tri[c * WLD + j + 2];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const double al = ar[j] * rsv[j];
+    ar[j] = al;
+#pragma unroll
+    for (int c = j + 1; c < 16; ++c) ar[c] = fma(-al, tb[j % 3][c], ar[c]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) s_a[r * WLD + base + j] = ar[j];
+  if (JB < 3) { PANEL_LDS_SYNC(); trailing_mfma<JB, false>(acc, s_a, s_d, r); }
+}
+
+__global__ __launch_bounds__(128) void k_chol_panel_m(double* __restrict__ A, int p, int ld, int* __restrict__ info,
+                                                      double* __restrict__ diag_scratch, size_t zs) {
+  ZRUN(A); ZRUN(info); ZRUN(diag_scratch);
+  __shared__ double s_d[BS * WLD];
+  __shared__ double s_a[BS * WLD];
+  __shared__ double s_rs[BS];
+  __shared__ double s_col[2 * BS];
+  const int r = threadIdx.x & 63, role = threadIdx.x >> 6, b = blockIdx.x;
+  PSTAMP(0);
+  double* Add = A + (size_t)(p * BS) * ld + p * BS;
+  double* Abd = A + (size_t)((p + b) * BS) * ld + p * BS;
+  double4_t acc[4][4];
+  {
+    // coalesced (lane = column), every load of the tile in flight before the first use; into the LDS tile
+    double a[BS];
+    if (role == 0) {
+#pragma unroll
+      for (int i = 0; i < BS; ++i) a[i] = Add[(size_t)i * ld + r];
+#pragma unroll
+      for (int i = 0; i < BS; ++i) s_d[i * WLD + r] = a[i];
+    } else if (b > 0) {
+#pragma unroll
+      for (int i = 0; i < BS; ++i) a[i] = Abd[(size_t)i * ld + r];
+#pragma unroll
+      for (int i = 0; i < BS; ++i) s_a[i * WLD + r] = a[i];
+    }
+  }
+  __syncthreads();
+  if (role == 0) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int ct = 1; ct <= rt; ++ct)               // (column tile 0 is read row-wise by the first step)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[rt][ct][q] = s_d[(16 * rt + (r >> 4) + 4 * q) * WLD + 16 * ct + (r & 15)];
+    PSTAMP(1);
+    int bad = 0;
+    panel_m_diag_step<0>(acc, s_d, s_rs, s_col, r, bad);
+    panel_m_diag_step<1>(acc, s_d, s_rs, s_col, r, bad);
+    panel_m_diag_step<2>(acc, s_d, s_rs, s_col, r, bad);
+    panel_m_diag_step<3>(acc, s_d, s_rs, s_col, r, bad);
+    if (bad && b == 0 && r == 0) atomicCAS(info, 0, p * BS + bad);
+  } else if (b > 0) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int ct = 1; ct < 4; ++ct)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[rt][ct][q] = s_a[(16 * rt + (r >> 4) + 4 * q) * WLD + 16 * ct + (r & 15)];
+    panel_m_solve_step<0>(acc, s_d, s_rs, s_a, r);
+    panel_m_solve_step<1>(acc, s_d, s_rs, s_a, r);
+    panel_m_solve_step<2>(acc, s_d, s_rs, s_a, r);
+    panel_m_solve_step<3>(acc, s_d, s_rs, s_a, r);
+  } else {
+    for (int jb = 0; jb < BS / 16; ++jb) __syncthreads();      // block 0 has no off-diagonal block: keep the barriers paired
+  }
+  PSTAMP(14);
+  __syncthreads();
+  // the finished block leaves through both waves, 32 rows each
+  const int i0 = 32 * role;
+  if (b == 0) {
+    const bool direct = gridDim.x == 1;              // last panel: nobody else reads the block (see kernels_gp.hip)
+    double t[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) t[i] = s_d[(i0 + i) * WLD + r];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      if (direct) Add[(size_t)(i0 + i) * ld + r] = t[i];
+      else diag_scratch[(i0 + i) * BS + r] = t[i];
+    }
+  } else {
+    double t[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) t[i] = s_a[(i0 + i) * WLD + r];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) Abd[(size_t)(i0 + i) * ld + r] = t[i];
+  }
+  PSTAMP(15);
+}
+
 // Inverse of the 64x64 diagonal blocks of L, a COLUMN of the inverse per lane: right-looking forward substitution,
 //   x[m] = acc[m] / L[m][m];  acc[r] -= L[r][m] x[m]  (r > m),
 // all of x in registers, the L[r][m] are LDS broadcasts (same address for every lane, contiguous in r), no cross-lane
@@ -252,7 +456,9 @@ __global__ __launch_bounds__(64) void k_trinv_diag_w(const double* __restrict__ 
 
 
 void launch_chol_panel_w(hipStream_t s, double* L, int p, int nblocks, int ld, int* info, double* diag_scratch, ZB zb) {
-  hipLaunchKernelGGL(k_chol_panel_w, dim3(nblocks, 1, zb.B), dim3(128), 0, s, L, p, ld, info, diag_scratch, zb.zs);
+  static const bool valu = getenv("PCABO_PANEL_VALU") != nullptr;       // A/B switch: the kernel this one replaced (same bits)
+  if (valu) hipLaunchKernelGGL(k_chol_panel_w, dim3(nblocks, 1, zb.B), dim3(128), 0, s, L, p, ld, info, diag_scratch, zb.zs);
+  else hipLaunchKernelGGL(k_chol_panel_m, dim3(nblocks, 1, zb.B), dim3(128), 0, s, L, p, ld, info, diag_scratch, zb.zs);
 }
 void launch_trinv_diag_w(hipStream_t s, const double* L, int nblk, int ld, double* R, ZB zb) {
   hipLaunchKernelGGL(k_trinv_diag_w, dim3(nblk, 1, zb.B), dim3(64), 0, s, L, ld, R, zb.zs);

@@ -278,7 +278,7 @@ def main():
         if g["launches"] and c["launches"] and (g["ms"] + c["ms"]) > 0:
             sec = (g["ms"] + c["ms"]) * 1e-3
             tf = (g["flops"] + c["flops"]) / sec / 1e12
-            kchol = {"kernels": "k_zstats + k_znorm + k_gram; k_chol_lookback + k_chol_panel_w per 64-wide panel",
+            kchol = {"kernels": "k_zstats + k_znorm + k_gram; k_chol_lookback + k_chol_panel_m per 64-wide panel",
                      "bound": "mfma", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": tf / FP64_PEAK_TFLOPS, "hbm_GBs": (g["bytes"] + c["bytes"]) / sec / 1e9,
                      "hbm_frac": (g["bytes"] + c["bytes"]) / sec / 1e9 / HBM_PEAK_GBS,

@@ -74,7 +74,7 @@ __global__ void k_add_jitter(double* __restrict__ K, int n, int ld, double jitte
 }
 
 // ---------------------------------------------------------------------------------------------
-// Blocked left-looking Cholesky, panel width 64: per panel k_chol_panel_w (kernels_gpw.hip: two waves per 64 x 64
+// Blocked left-looking Cholesky, panel width 64: per panel k_chol_panel_m (kernels_gpw.hip: two waves per 64 x 64
 // block, a matrix row per lane) factors the diagonal block and solves the off-diagonal blocks, k_chol_lookback below
 // brings a block column up to date on MFMA before it is factored (left-looking).
 __device__ inline void load_tile(const double* __restrict__ src, int ld, double* s_t) {
@@ -296,7 +296,7 @@ void launch_cholesky(hipStream_t s, double* L, int NP, int ld, int* info, double
   for (int p = 0; p < nblk; ++p) {                   // left-looking: bring block column p up to date, then factor it
     if (p > 0)
       hipLaunchKernelGGL(k_chol_lookback, dim3(nblk - p + 1, 1, zb.B), dim3(256), 0, s, L, p, nblk, ld, diag_scratch, zb.zs);
-    launch_chol_panel_w(s, L, p, nblk - p, ld, info, diag_scratch, zb);
+    launch_chol_panel(s, L, p, nblk - p, ld, info, diag_scratch, zb);
   }
 }
 void launch_trinv(hipStream_t s, const double* L, int NP, int ld, double* R, ZB zb) {

@@ -14,180 +14,27 @@ extern "C" int pcabo_debug_panel_stamps(unsigned long long* out16) {
 #endif
 #define WLD 65   // LDS leading dimension of the transposing tile (row reads and column writes both conflict-free)
 
-// ---- Cholesky panel: two waves per 64x64 block, a matrix ROW per lane ---------------------------------------------
+// ---- Cholesky panel: two waves per 64x64 block, a matrix ROW per lane in the sequential parts -------------------------
 // The panel step is a chain of 64 dependent pivots; with four lanes per row (the first version of this kernel) every link
-// of the chain cost a work-group barrier and two LDS round trips (44-48 us per panel).  Here a lane keeps a whole row in
-// registers (static indices after unrolling; after every 16-column sub-panel the array shifts down by 16 so that the
-// loop body is the same for all four sub-panels):
-//   wave 0, lane r: row r of the diagonal block D.  Inside a sub-panel the factor column of a step is broadcast lane
-//     by lane with v_readlane (SGPR operand of the FMAs); the finished 16 columns go to the LDS tile, one barrier,
-//     then the trailing columns take their multipliers from that tile as LDS broadcasts.
+// of the chain cost a work-group barrier and two LDS round trips (44-48 us per panel).  Here, inside a 16-column sub-panel,
+// a lane holds its row's 16 entries in registers:
+//   wave 0, lane r: row r of the diagonal block D.  The factor column of a step is broadcast lane by lane with v_readlane
+//     (SGPR operand of the FMAs) for the columns the chain needs next, through an LDS column for the others; the finished
+//     16 columns go to the LDS tile, one barrier.
 //   wave 1, lane r: row r of the work-group's off-diagonal block A.  It solves A <- A L^-T one sub-panel BEHIND wave 0
 //     with every multiplier an LDS broadcast - no cross-lane traffic at all.
 // Four barriers per panel instead of 64, and the two chains run on two SIMDs side by side.  LDS multipliers are
 // double-buffered by hand: left to itself the compiler emits read - wait - use, a full LDS latency per pair of FMAs.
+// The columns still to come live as 16 x 16 accumulator tiles of the matrix cores and take their rank-16 updates there.
 __device__ inline double lane_get(double v, int lane) {          // lane: wave-uniform
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
                           __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
 
-// a[c] -= sum_j a[j] * L[base+c][base+j] for the 16 columns c = 16g.. of the shifted array, j = 0..15.
-// ltile = &L[base+16g][base] in the LDS tile.  Batches of 4 columns x 4 multiplier columns (16 LDS values, 4 independent
-// FMA chains); the reads of batch t+1 are issued before the FMAs of batch t.
-template <int G>
-__device__ inline void trailing16(double (&a)[BS], const double* ltile) {
-  double sb[2][16];
-#pragma unroll
-  for (int u = 0; u < 4; ++u)
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) sb[0][u * 4 + jj] = ltile[u * WLD + jj];
-#pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    const int c4 = 4 * (t >> 2), j4 = 4 * (t & 3);
-    if (t + 1 < 16) {
-      const int nc4 = 4 * ((t + 1) >> 2), nj4 = 4 * ((t + 1) & 3);
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) sb[(t + 1) & 1][u * 4 + jj] = ltile[(nc4 + u) * WLD + nj4 + jj];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int c = 16 * G + c4 + u, j = j4 + jj;
-        a[c] = fma(-a[j], sb[t & 1][u * 4 + jj], a[c]);
-      }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-__device__ inline void trailing_all(double (&a)[BS], const double* s_d, int jb) {
-  const int base = 16 * jb;
-  if (jb + 1 < BS / 16) trailing16<1>(a, s_d + (base + 16) * WLD + base);       // uniform branches
-  if (jb + 2 < BS / 16) trailing16<2>(a, s_d + (base + 32) * WLD + base);
-  if (jb + 3 < BS / 16) trailing16<3>(a, s_d + (base + 48) * WLD + base);
-#pragma unroll
-  for (int c = 0; c < BS - 16; ++c) a[c] = a[c + 16];                            // everything else moves down
-}
 
-// wave 0: factor D.  s_rs[j] = 1/sqrt(pivot j) for wave 1.
-__device__ inline void panel_diag_rows(double (&dr)[BS], double* s_d, double* s_rs, int r, int& bad) {
-  for (int jb = 0; jb < BS / 16; ++jb) {
-    const int base = 16 * jb;
-    PSTAMP(2 + 3 * jb);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      double piv = lane_get(dr[j], base + j);
-      if (!(piv > 0.0)) { if (bad == 0) bad = base + j + 1; piv = 1.0; }      // uniform
-      const double rs = fast_rsq(piv);
-      if (r == 0) s_rs[base + j] = rs;
-      const double dl = dr[j] * rs;                // lanes r >= base+j: L[r][base+j] (lane base+j: sqrt(piv))
-      dr[j] = dl;
-#pragma unroll
-      for (int c = j + 1; c < 16; ++c) dr[c] = fma(-dl, lane_get(dl, base + c), dr[c]);   // L[base+c][base+j]
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    PSTAMP(3 + 3 * jb);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) s_d[r * WLD + base + j] = (base + j <= r) ? dr[j] : 0.0;
-    __syncthreads();                               // sub-panel jb is published
-    PSTAMP(4 + 3 * jb);
-    trailing_all(dr, s_d, jb);
-  }
-}
-
-// wave 1: A <- A L^-T, sub-panel by sub-panel behind wave 0.
-__device__ inline void panel_solve_rows(double (&ar)[BS], const double* s_d, const double* s_rs, double* s_a, int r) {
-  for (int jb = 0; jb < BS / 16; ++jb) {
-    const int base = 16 * jb;
-    __syncthreads();                               // wait for sub-panel jb of the factor
-    const double* tri = s_d + base * WLD + base;   // the 16x16 triangle: L[base+c][base+j] = tri[c*WLD + j]
-    double rsv[16], tb[3][16];                     // tb[j % 3][c]: column j of the triangle, prefetched two steps ahead
-#pragma unroll
-    for (int j = 0; j < 16; ++j) rsv[j] = s_rs[base + j];
-#pragma unroll
-    for (int c = 1; c < 16; ++c) tb[0][c] = tri[c * WLD];
-#pragma unroll
-    for (int c = 2; c < 16; ++c) tb[1][c] = tri[c * WLD + 1];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      if (j + 2 < 15) {
-#pragma unroll
-        for (int c = j + 3; c < 16; ++c) tb[(j + 2) % 3][c] = tri[c * WLD + j + 2];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      const double al = ar[j] * rsv[j];
-      ar[j] = al;
-#pragma unroll
-      for (int c = j + 1; c < 16; ++c) ar[c] = fma(-al, tb[j % 3][c], ar[c]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) s_a[r * WLD + base + j] = ar[j];
-    trailing_all(ar, s_d, jb);
-  }
-}
-
-__global__ __launch_bounds__(128) void k_chol_panel_w(double* __restrict__ A, int p, int ld, int* __restrict__ info,
-                                                      double* __restrict__ diag_scratch, size_t zs) {
-  ZRUN(A); ZRUN(info); ZRUN(diag_scratch);
-  __shared__ double s_d[BS * WLD];
-  __shared__ double s_a[BS * WLD];
-  __shared__ double s_rs[BS];
-  const int r = threadIdx.x & 63, role = threadIdx.x >> 6, b = blockIdx.x;
-  PSTAMP(0);
-  double* Add = A + (size_t)(p * BS) * ld + p * BS;
-  double* Abd = A + (size_t)((p + b) * BS) * ld + p * BS;
-  double a[BS];
-  // coalesced (lane = column), every load of the tile in flight before the first use; transposed through LDS
-  if (role == 0) {
-#pragma unroll
-    for (int i = 0; i < BS; ++i) a[i] = Add[(size_t)i * ld + r];
-#pragma unroll
-    for (int i = 0; i < BS; ++i) s_d[i * WLD + r] = a[i];
-  } else if (b > 0) {
-#pragma unroll
-    for (int i = 0; i < BS; ++i) a[i] = Abd[(size_t)i * ld + r];
-#pragma unroll
-    for (int i = 0; i < BS; ++i) s_a[i * WLD + r] = a[i];
-  }
-  __syncthreads();
-  if (role == 0) {
-#pragma unroll
-    for (int c = 0; c < BS; ++c) a[c] = s_d[r * WLD + c];
-    PSTAMP(1);
-    int bad = 0;
-    panel_diag_rows(a, s_d, s_rs, r, bad);
-    if (bad && b == 0 && r == 0) atomicCAS(info, 0, p * BS + bad);
-  } else if (b > 0) {
-#pragma unroll
-    for (int c = 0; c < BS; ++c) a[c] = s_a[r * WLD + c];
-    panel_solve_rows(a, s_d, s_rs, s_a, r);
-  } else {
-    for (int jb = 0; jb < BS / 16; ++jb) __syncthreads();      // block 0 has no off-diagonal block: keep the barriers paired
-  }
-  PSTAMP(14);
-  __syncthreads();
-  if (b == 0) {
-    if (role == 0) {
-      const bool direct = gridDim.x == 1;            // last panel: nobody else reads the block (see kernels_gp.hip)
-#pragma unroll 8
-      for (int i = 0; i < BS; ++i) {
-        if (direct) Add[(size_t)i * ld + r] = s_d[i * WLD + r];
-        else diag_scratch[i * BS + r] = s_d[i * WLD + r];
-      }
-    }
-  } else if (role == 1) {
-#pragma unroll 8
-    for (int i = 0; i < BS; ++i) Abd[(size_t)i * ld + r] = s_a[i * WLD + r];
-  }
-  PSTAMP(15);
-}
-
-// ---- The same panel step with the trailing updates on the matrix cores ------------------------------------------------
-// In k_chol_panel_w the 16-wide rank updates of the columns still to come (trailing_all) are the largest item of the
-// timeline: 8.7 of 23 us, bound by the LDS broadcasts of the multipliers that BOTH waves pull (tools/gpu_panel_phases.py).
+// ---- Trailing updates on the matrix cores ---------------------------------------------------------------------------
+// With a whole row per lane (round 1 / early round 2: k_chol_panel_w) the 16-wide rank updates of the columns still to come
+// were the largest item of the timeline: 8.7 of 23 us, bound by the LDS broadcasts of the multipliers that BOTH waves pulled.
 // v_mfma_f64_16x16x4 accumulates its four products as a chain of fused multiply-adds in ascending k ON TOP of the
 // accumulator (profiles/tools/mfma_f64_order.hip: 512 000 of 512 000 elements equal the fma chain bit for bit), which is
 // exactly what the VALU loop does per element - so the updates move to the matrix cores without changing a single bit:
@@ -455,10 +302,8 @@ __global__ __launch_bounds__(64) void k_trinv_diag_w(const double* __restrict__ 
 }
 
 
-void launch_chol_panel_w(hipStream_t s, double* L, int p, int nblocks, int ld, int* info, double* diag_scratch, ZB zb) {
-  static const bool valu = getenv("PCABO_PANEL_VALU") != nullptr;       // A/B switch: the kernel this one replaced (same bits)
-  if (valu) hipLaunchKernelGGL(k_chol_panel_w, dim3(nblocks, 1, zb.B), dim3(128), 0, s, L, p, ld, info, diag_scratch, zb.zs);
-  else hipLaunchKernelGGL(k_chol_panel_m, dim3(nblocks, 1, zb.B), dim3(128), 0, s, L, p, ld, info, diag_scratch, zb.zs);
+void launch_chol_panel(hipStream_t s, double* L, int p, int nblocks, int ld, int* info, double* diag_scratch, ZB zb) {
+  hipLaunchKernelGGL(k_chol_panel_m, dim3(nblocks, 1, zb.B), dim3(128), 0, s, L, p, ld, info, diag_scratch, zb.zs);
 }
 void launch_trinv_diag_w(hipStream_t s, const double* L, int nblk, int ld, double* R, ZB zb) {
   hipLaunchKernelGGL(k_trinv_diag_w, dim3(nblk, 1, zb.B), dim3(64), 0, s, L, ld, R, zb.zs);

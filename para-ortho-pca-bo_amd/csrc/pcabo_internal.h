@@ -181,7 +181,7 @@ void launch_gram(hipStream_t s, const double* AT, const double* nrm, int n, int 
 void launch_add_jitter(hipStream_t s, double* K, int n, int ld, double jitter);
 void launch_cholesky(hipStream_t s, double* L, int NP, int ld, int* info, double* diag_scratch, ZB zb = ZB());
 void launch_trinv(hipStream_t s, const double* L, int NP, int ld, double* R, ZB zb = ZB());
-void launch_chol_panel_w(hipStream_t s, double* L, int p, int nblocks, int ld, int* info, double* diag_scratch, ZB zb = ZB());
+void launch_chol_panel(hipStream_t s, double* L, int p, int nblocks, int ld, int* info, double* diag_scratch, ZB zb = ZB());
 void launch_trinv_diag_w(hipStream_t s, const double* L, int nblk, int ld, double* R, ZB zb = ZB());
 void launch_alpha(hipStream_t s, const double* R, const double* ys, int n, int NP, int ld, double* tmp, double* alpha,
                   ZB zb = ZB());

@@ -897,3 +897,23 @@ print("RESULT", hashlib.md5(np.array(opt.f_evals).tobytes() + np.vstack(opt.x_ev
         out.append([l for l in p.stdout.splitlines() if l.startswith("RESULT")][-1].split())
     assert out[0][1] == out[1][1]                  # same run
     assert float(out[1][2]) > float(out[0][2]) + 3.0      # and it really was stopped for a while
+
+
+def test_gp_factor_bits_are_pinned(native):
+    """L, R = L^-1 and alpha of seeded conditionings, bit for bit against tests/golden/gp_factor_hashes.json (written by
+    tools/gpu_factor_hashes.py --write).  The conditioning kernels are deterministic and were rewritten several times under
+    the promise "same bits" (left-looking Cholesky; matrix-core trailing updates in the panel kernel, profiles/r02/panel_ab.txt);
+    the batch path, the single run and the L-BFGS-B trajectories that the late-phase statistics were measured on all sit on
+    these bits.  A change here is either a bug or an intended change of arithmetic - then regenerate the file and say so."""
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gpu_factor_hashes", os.path.join(root, "tools", "gpu_factor_hashes.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    golden = json.load(open(os.path.join(root, "tests", "golden", "gp_factor_hashes.json")))["cases"]
+    got = mod.compute()
+    assert set(got) == set(golden)
+    for case in golden:
+        assert got[case] == golden[case], case

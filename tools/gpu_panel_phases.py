@@ -1,4 +1,4 @@
-"""In-kernel timeline of k_chol_panel_w (timing build): wave 0 of block 0 of the LAST panel launch of a conditioning at
+"""In-kernel timeline of k_chol_panel_m (timing build): wave 0 of block 0 of the LAST panel launch of a conditioning at
 n = 450 (8 panels; the last launch has one block).  Stamps in microseconds from kernel entry."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

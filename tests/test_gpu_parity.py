@@ -917,3 +917,21 @@ def test_gp_factor_bits_are_pinned(native):
     assert set(got) == set(golden)
     for case in golden:
         assert got[case] == golden[case], case
+
+
+def test_acq_group_bits_are_pinned(native):
+    """Value + gradient of the throughput kernel k_acq_group (and one whole optimize call in that mode) on seeded states,
+    bit for bit against tests/golden/acq_group_hashes.json (tools/gpu_group_hashes.py --write).  Batches and single runs in
+    group mode sit on these bits; phases of the kernel were moved to the matrix cores under the promise not to change them."""
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gpu_group_hashes", os.path.join(root, "tools", "gpu_group_hashes.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    golden = json.load(open(os.path.join(root, "tests", "golden", "acq_group_hashes.json")))["cases"]
+    got = mod.compute()
+    assert set(got) == set(golden)
+    for case in golden:
+        assert got[case] == golden[case], case

@@ -26,7 +26,9 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ AT, con
                                               int* __restrict__ info_reset, size_t zs) {
   ZRUN(AT); ZRUN(nrm); ZRUN(K); ZRUN(k_dev); ZRUN(K2); ZRUN(info_reset);
   const int ti = blockIdx.x, tj = blockIdx.y;
-  // K2: the copy the factorisation works on in place; info_reset: its failure flag (saves a copy and a fill launch)
+  // K2: the copy the factorisation works on in place; info_reset: its failure flag (saves a copy and a fill launch).
+  // K itself is written only when somebody asks for it (pcabo_get_gram): a second full-size store doubled the kernel's
+  // HBM traffic for a matrix that a retry can just as well build again.
   if (info_reset && ti == 0 && tj == 0 && threadIdx.x == 0) *info_reset = 0;
   if (tj > ti) return;
   if (k_dev) KP = (*k_dev + 3) & ~3;
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ AT, con
         }
         if (i == j) v += noise;
       }
-      K[(size_t)i * ld + j] = v;
+      if (K) K[(size_t)i * ld + j] = v;
       if (K2) K2[(size_t)i * ld + j] = v;
     }
   }

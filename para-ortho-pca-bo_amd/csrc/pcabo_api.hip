@@ -629,11 +629,10 @@ int pcabo_wpca(pcabo_ctx* ctx, const double* X, const double* f, const int64_t* 
 
 static int launch_factorisation(pcabo_ctx* ctx, double jitter) {
   hipStream_t s = ctx->stream;
-  if (jitter > 0.0) {      // a retry: the first attempt got its copy of K and a cleared flag from k_gram itself
-    const size_t bytes = (size_t)ctx->NP * ctx->ld * sizeof(double);
-    HIPCHK(hipMemcpyAsync(ctx->dL, ctx->dGram, bytes, hipMemcpyDeviceToDevice, s));
+  if (jitter > 0.0) {      // a retry: K is built again (same kernel, same bits, flag cleared), then the jitter goes on its diagonal
+    launch_gram(s, ctx->dAT, ctx->dNrm, ctx->n, ctx->NP, round_up(ctx->k, 4), ctx->ld, ctx->noise, ctx->kernel, nullptr, nullptr,
+                ctx->dL, ctx->dInfo);
     launch_add_jitter(s, ctx->dL, ctx->n, ctx->ld, jitter);
-    HIPCHK(hipMemsetAsync(ctx->dInfo, 0, sizeof(int), s));
   }
   { ProfScope ps(ctx, 2, 16.0 * ctx->n * ctx->n, (double)ctx->n * ctx->n * ctx->n / 3.0); launch_cholesky(s, ctx->dL, ctx->NP, ctx->ld, ctx->dInfo, ctx->dDiag); }
   {
@@ -670,8 +669,7 @@ static int enqueue_condition(pcabo_ctx* ctx, const double* y_dev, int n, int k, 
     HIPCHK(hipEventRecord(ctx->evBounds, s));
     launch_znorm(s, ctx->dZ, n, k, ctx->NP, ctx->KP, ctx->ld, ctx->dBounds4, ctx->dZnMean, 1.0 / lengthscale, ctx->dZnT,
                  ctx->dAT, ctx->dNrm, k_dev);
-    launch_gram(s, ctx->dAT, ctx->dNrm, n, ctx->NP, ctx->KP, ctx->ld, noise, kernel, ctx->dGram, k_dev, ctx->dL,
-                ctx->dInfo);
+    launch_gram(s, ctx->dAT, ctx->dNrm, n, ctx->NP, ctx->KP, ctx->ld, noise, kernel, nullptr, k_dev, ctx->dL, ctx->dInfo);
   }
   return launch_factorisation(ctx, 0.0);       // asynchronous: pcabo_gp_condition_end() waits and checks
 }
@@ -1310,6 +1308,9 @@ int pcabo_get_gram(pcabo_ctx* ctx, double* K) {
   if (!ctx->have_gp) return set_err(ctx, PCABO_ERR_ARG, "pcabo_get_gram: call pcabo_gp_condition first%s", "");
   HIPCHK(hipSetDevice(ctx->device));
   const size_t n = ctx->n, w = n * sizeof(double), pitch = (size_t)ctx->ld * sizeof(double);
+  // built on demand: the conditioning itself writes only the copy that the factorisation then overwrites
+  launch_gram(ctx->stream, ctx->dAT, ctx->dNrm, ctx->n, ctx->NP, round_up(ctx->k, 4), ctx->ld, ctx->noise, ctx->kernel, ctx->dGram,
+              nullptr, nullptr, nullptr);
   HIPCHK(hipMemcpy2DAsync(K, w, ctx->dGram, pitch, w, n, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   for (size_t i = 0; i < n; ++i)                  // only the lower tiles are built on the device
@@ -1769,7 +1770,7 @@ int pcabo_batch_wpca_gp_condition_begin(pcabo_batch* batch, const double* X, con
   BHIPCHK(hipEventRecord(batch->evBounds, s));
   launch_znorm(s, c0->dZ, n, -1, NP, 0, c0->ld, c0->dBounds4, c0->dZnMean, 1.0 / lengthscale, c0->dZnT, c0->dAT, c0->dNrm,
                c0->dK, zb);
-  launch_gram(s, c0->dAT, c0->dNrm, n, NP, 0, c0->ld, gp_noise, kernel, c0->dGram, c0->dK, c0->dL, c0->dInfo, zb);
+  launch_gram(s, c0->dAT, c0->dNrm, n, NP, 0, c0->ld, gp_noise, kernel, nullptr, c0->dK, c0->dL, c0->dInfo, zb);
   mark(2);
   launch_cholesky(s, c0->dL, NP, c0->ld, c0->dInfo, c0->dDiag, zb);
   mark(3);

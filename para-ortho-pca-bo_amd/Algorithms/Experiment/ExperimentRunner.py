@@ -51,6 +51,19 @@ class _NoBar:
     def close(self): pass
 
 
+def split_evenly(cell, batched: int, side_by_side: int):
+    """Divide the runs of one dimension over a multiple of `side_by_side` lock-step batches of about `batched` runs each,
+    as evenly as possible and in order (fewer, larger batches rather than a small last one: 90 runs, batched=30,
+    side_by_side=2 -> 45 + 45; 30 runs -> 15 + 15; never more batches than runs)."""
+    n = len(cell)
+    if n == 0:
+        return []
+    side_by_side, batched = max(1, int(side_by_side)), max(1, int(batched))
+    nb = min(n, side_by_side * max(1, n // (batched * side_by_side)))
+    cuts = [n * i // nb for i in range(nb + 1)]
+    return [cell[cuts[i]:cuts[i + 1]] for i in range(nb)]
+
+
 class ExperimentRunner:
     """Class to run and manage experiments comparing Vanilla BO and PCA-BO algorithms."""
 
@@ -150,9 +163,7 @@ class ExperimentRunner:
             # (a lone last batch would advance with nothing beside it; larger batches amortise the rounds of the slowest
             # restart better: 90 runs with batched=30, side_by_side=2 go as 2 x 45 rather than 30 + 30 | 30)
             cell = [r for r in mine if r[1] == dim]
-            nb = min(len(cell), self.side_by_side * max(1, len(cell) // (self.batched * self.side_by_side)))
-            cuts = [len(cell) * i // nb for i in range(nb + 1)]
-            chunks += [(dim, cell[cuts[i]:cuts[i + 1]]) for i in range(nb)]
+            chunks += [(dim, part) for part in split_evenly(cell, self.batched, self.side_by_side)]
         for i in range(0, len(chunks), self.side_by_side):
             group = chunks[i:i + self.side_by_side]
             jobs = []

@@ -129,3 +129,44 @@ def test_gc_guard_is_reference_counted_and_undone():
     assert gc.get_threshold() == before and gc.get_freeze_count() == frozen_before
     gcguard.leave()                                 # unbalanced leave is harmless
     assert gc.get_threshold() == before
+
+
+def test_runner_divides_a_dimension_evenly_over_side_by_side_batches():
+    from Algorithms.Experiment.ExperimentRunner import split_evenly
+    sizes = lambda n, b, s: [len(p) for p in split_evenly(list(range(n)), b, s)]
+    assert sizes(90, 30, 2) == [45, 45] and sizes(30, 30, 2) == [15, 15] and sizes(300, 30, 2) == [30] * 10
+    assert sizes(1, 30, 2) == [1] and sizes(3, 4, 2) == [1, 2] and sizes(6, 2, 1) == [2, 2, 2] and sizes(0, 30, 2) == []
+    for n, b, s in [(7, 3, 2), (100, 30, 3), (61, 30, 2), (5, 1, 4)]:
+        parts = split_evenly(list(range(n)), b, s)
+        assert [x for p in parts for x in p] == list(range(n))              # every run once, in order
+        assert max(map(len, parts)) - min(map(len, parts)) <= 1             # even
+        assert len(parts) % s == 0 or len(parts) == n                       # whole groups of side-by-side batches
+
+
+def test_run_side_by_side_drives_every_batch_and_reraises():
+    """Host logic of pcabo.batchrun.run_side_by_side with stand-in batches (no device): every batch is started, stepped to
+    its budget and finished on its own thread; an exception in one of them surfaces after the others have ended."""
+    import threading
+    from pcabo.batchrun import run_side_by_side, workers_for
+
+    class Fake:
+        def __init__(self, budget, fail_at=None):
+            self.budget, self.n, self.fail_at, self.log, self.thread = budget, 0, fail_at, [], None
+        def start(self): self.log.append("start"); self.thread = threading.current_thread().name
+        def iteration(self):
+            if self.fail_at is not None and self.n == self.fail_at:
+                raise RuntimeError("boom")
+            self.n += 1
+        def finish(self): self.log.append("finish")
+
+    a, b = Fake(5), Fake(9)
+    run_side_by_side([a, b])
+    assert (a.n, b.n) == (5, 9) and a.log == b.log == ["start", "finish"] and a.thread != b.thread
+    c, d = Fake(6, fail_at=2), Fake(4)
+    with pytest.raises(RuntimeError, match="boom"):
+        run_side_by_side([c, d])
+    assert d.n == 4 and c.log == d.log == ["start", "finish"]
+    one = Fake(3)
+    run_side_by_side([one])
+    assert one.n == 3 and one.thread == threading.current_thread().name     # a single batch stays on the caller's thread
+    assert workers_for(1) == 8 and workers_for(2) == 4 and workers_for(8) == 2

@@ -121,6 +121,7 @@ struct pcabo_ctx {
   int srv_penalty = 0;                   // > 0: the next calls use plain launches (the GPU looked shared, see pcabo_optimize_acqf)
   unsigned long long seq = 0;
   OptHelper helper;
+  std::vector<std::unique_ptr<OptHelper>> more_helpers;   // many restart groups (>= 12): more threads step the state machines
   bool registered = false;
   bool alone = true; int alone_age = 0;   // cached answer of presence_alone(), refreshed every few calls
   char err[512] = {0};
@@ -460,6 +461,8 @@ static void ctx_teardown(pcabo_ctx* ctx) {
   if (ctx->evPca) (void)hipEventDestroy(ctx->evPca);
   if (ctx->stream && !ctx->in_batch) (void)hipStreamDestroy(ctx->stream);
   ctx->helper.shutdown();
+  for (auto& h : ctx->more_helpers) h->shutdown();
+  ctx->more_helpers.clear();
   if (ctx->registered) presence_unregister(ctx->device);
 }
 
@@ -1065,8 +1068,19 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
   // The groups are independent between evaluations: odd-numbered groups advance on the context's helper thread
   // while the calling thread advances the even ones (hand-off through two monotonic round counters, spin-waiting).
   OptHelper& hp = ctx->helper;
-  if (ngroups > 1) hp.begin([&] { for (int gi = 1; gi < ngroups; gi += 2) advance(gi); });
-  struct Ender { OptHelper& h; bool on; ~Ender() { if (on) h.end(); } } ender{hp, ngroups > 1};
+  // With many groups (the stress configuration: 256 restarts = 52 joint problems of up to 5 x 78 variables) two threads
+  // spend longer on the state machines than the device on the evaluations (90-150 us against 100-180 us per round): then up
+  // to five more helpers share the groups (stride T over the group index; the calling thread takes every T-th).
+  const int T = ngroups >= 12 ? std::min(7, 1 + ngroups / 8) : 2;          // threads that step groups, the caller included
+  if (T > 2) while ((int)ctx->more_helpers.size() < T - 2) ctx->more_helpers.emplace_back(new OptHelper());
+  std::vector<OptHelper*> hs;                                               // hs[i] steps the groups gi = i + 1 (mod T)
+  if (ngroups > 1) hs.push_back(&hp);
+  for (int i = 0; i < T - 2; ++i) hs.push_back(ctx->more_helpers[i].get());
+  for (size_t i = 0; i < hs.size(); ++i) {
+    const int first = (int)i + 1;
+    hs[i]->begin([&, first] { for (int gi = first; gi < ngroups; gi += T) advance(gi); });
+  }
+  struct Ender { std::vector<OptHelper*>& h; ~Ender() { for (OptHelper* x : h) x->end(); } } ender{hs};
   unsigned round_no = 0;
   std::vector<int> qoff(ngroups, -1);
   int srv_cap = 0;                       // > 0 while a resident kernel of that many queries is in flight
@@ -1083,11 +1097,14 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
   while (true) {
     const double ta = trace ? now() : 0.0;
     ++round_no;
-    unsigned ticket = 0;
-    if (ngroups > 1) { ticket = hp.go.load(std::memory_order_relaxed) + 1; hp.go.store(ticket, std::memory_order_release); }
-    for (int gi = 0; gi < ngroups; gi += 2) advance(gi);
-    if (ngroups > 1)
-      while (hp.done.load(std::memory_order_acquire) != ticket) __builtin_ia32_pause();
+    unsigned tickets[8] = {0};
+    for (size_t i = 0; i < hs.size(); ++i) {
+      tickets[i] = hs[i]->go.load(std::memory_order_relaxed) + 1;
+      hs[i]->go.store(tickets[i], std::memory_order_release);
+    }
+    for (int gi = 0; gi < ngroups; gi += T) advance(gi);
+    for (size_t i = 0; i < hs.size(); ++i)
+      while (hs[i]->done.load(std::memory_order_acquire) != tickets[i]) __builtin_ia32_pause();
     int nq = 0;
     for (int gi = 0; gi < ngroups; ++gi) {
       qoff[gi] = -1;
@@ -1179,7 +1196,7 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
         if (fdbg) fprintf(stderr, "[free] main loop done r=%llu timed_out=%d\n", used[0], timed_out[0]);
         while (hp.done.load(std::memory_order_acquire) != fticket) __builtin_ia32_pause();
         if (fdbg) fprintf(stderr, "[free] helper done r=%llu timed_out=%d\n", used[1], timed_out[1]);
-        hp.fn = [&] { for (int gi = 1; gi < ngroups; gi += 2) advance(gi); };
+        hp.fn = [&] { for (int gi = 1; gi < ngroups; gi += T) advance(gi); };
         HIPCHK(hipStreamSynchronize(ctx->stream));      // every group of the grid has been told to leave
         if (fdbg) fprintf(stderr, "[free] kernel gone\n");
         ctx->seq = seq0 + std::max(used[0], used[1]) + 1;

@@ -187,6 +187,10 @@ int pcabo_lbfgsb_minimize(int nvar, double* x, const double* lower, const double
  * read - torch's .tril() need not be applied); bit-identical to torch, ~100x faster than torch's accessor loop.  The random
  * bits themselves still come from torch's generator. */
 int pcabo_sobol_scramble(int64_t* state, const int64_t* ltm, int k);
+/* The draw of such an engine (fresh: nothing generated yet), bit-identical to SobolEngine.draw(n, dtype=float64) followed by
+ * botorch's map into the box, out[i*k + j] = lo[j] + rng[j] * u[i][j] (lo = rng = NULL: u itself).  state[k*30] after
+ * pcabo_sobol_scramble, shift[k] = sum_b bit_b 2^b of the k x 30 shift bits (torch's `shift`). */
+int pcabo_sobol_draw(const int64_t* state, const int64_t* shift, int k, int n, const double* lo, const double* rng, double* out);
 
 /* Device-time accounting: accumulated HIP-event time (ms, events recorded on the context's own
  * stream), launch count and ALGORITHMIC bytes / flops of the kernel groups since the last reset.

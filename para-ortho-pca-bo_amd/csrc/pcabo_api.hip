@@ -1399,6 +1399,36 @@ int pcabo_sobol_scramble(int64_t* state, const int64_t* ltm, int k) {
   return PCABO_OK;
 }
 
+// n points of a FRESH scrambled Sobol engine (state after pcabo_sobol_scramble, shift = the engine's shift vector), as
+// torch.quasirandom.SobolEngine.draw(n, dtype=float64) returns them for num_generated = 0 (first point = float32(shift) / 2^30, then
+// Gray-code steps: the state column of the lowest zero bit of the running index is XORed in), mapped into a box as botorch's
+// draw_sobol_samples does: out[i][j] = lo[j] + rng[j] * u[i][j] (multiply, then add: two roundings, as torch's two kernels).
+// lo = rng = NULL: u itself.
+int pcabo_sobol_draw(const int64_t* state, const int64_t* shift, int k, int n, const double* lo, const double* rng, double* out) {
+#pragma clang fp contract(off)
+  if (!state || !shift || !out || k < 1 || n < 1 || (lo == nullptr) != (rng == nullptr)) return PCABO_ERR_ARG;
+  const int MAXBIT = 30;
+  const double recip = 9.31322574615478515625e-10;      // 2^-30
+  std::vector<int64_t> q(shift, shift + k);
+  for (int i = 0; i < n; ++i) {
+    if (i > 0) {
+      unsigned v = (unsigned)(i - 1);
+      int l = 0;
+      while (v & 1u) { v >>= 1; ++l; }
+      if (l >= MAXBIT) return PCABO_ERR_ARG;
+      for (int j = 0; j < k; ++j) q[j] ^= state[(size_t)j * MAXBIT + l];
+    }
+    double* o = out + (size_t)i * k;
+    for (int j = 0; j < k; ++j) {
+      // (torch keeps the FIRST point as `quasi / 2**30` of an int64 tensor: a float32 tensor - that point has 24 bits)
+      const double u = i == 0 ? (double)((float)q[j]) * recip : (double)q[j] * recip;
+      if (lo) { const double t = rng[j] * u; o[j] = lo[j] + t; }
+      else o[j] = u;
+    }
+  }
+  return PCABO_OK;
+}
+
 int pcabo_set_profiling(pcabo_ctx* ctx, int enabled) {
   if (!ctx) return PCABO_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));

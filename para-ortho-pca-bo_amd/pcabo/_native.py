@@ -32,7 +32,7 @@ EXPORTS = [
     "pcabo_gp_condition_end", "pcabo_gp_condition_end_eval", "pcabo_wpca_gp_condition_begin", "pcabo_wpca_results",
     "pcabo_acq_bounds",
     "pcabo_acq_eval", "pcabo_logei", "pcabo_optimize_acqf", "pcabo_inverse_map", "pcabo_get_gp_state",
-    "pcabo_get_gram", "pcabo_lbfgsb_minimize", "pcabo_sobol_scramble", "pcabo_set_profiling", "pcabo_get_profile", "pcabo_reset_profile",
+    "pcabo_get_gram", "pcabo_lbfgsb_minimize", "pcabo_sobol_scramble", "pcabo_sobol_draw", "pcabo_set_profiling", "pcabo_get_profile", "pcabo_reset_profile",
     "pcabo_batch_create", "pcabo_batch_destroy", "pcabo_batch_last_error", "pcabo_batch_ctx",
     "pcabo_batch_wpca_gp_condition_begin", "pcabo_batch_wpca_results", "pcabo_batch_acq_bounds",
     "pcabo_batch_gp_condition_end_eval", "pcabo_batch_optimize_acqf", "pcabo_batch_inverse_map",
@@ -87,6 +87,7 @@ def _load() -> C.CDLL:
     lib.pcabo_get_gp_state.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.pcabo_get_gram.argtypes = [vp, vp]
     lib.pcabo_sobol_scramble.argtypes = [vp, vp, C.c_int]
+    lib.pcabo_sobol_draw.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp]
     lib.pcabo_set_profiling.argtypes = [vp, C.c_int]
     lib.pcabo_get_profile.argtypes = [vp, C.c_int, dp, C.POINTER(C.c_int64), dp, dp]
     lib.pcabo_reset_profile.argtypes = [vp]
@@ -478,6 +479,20 @@ def sobol_scramble(state: np.ndarray, ltm: np.ndarray) -> None:
     rc = LIB.pcabo_sobol_scramble(_ptr(state), _ptr(ltm), int(state.shape[0]))
     if rc != 0:
         raise PcaboError(rc, "pcabo_sobol_scramble: bad argument")
+
+
+def sobol_draw(state: np.ndarray, shift: np.ndarray, n: int, lo=None, rng=None) -> np.ndarray:
+    """n points of a fresh scrambled engine ((k, 30) int64 state after `sobol_scramble`, (k,) int64 shift), optionally mapped
+    into the box lo + rng * u - bit-identical to torch's SobolEngine.draw + botorch's scaling (pcabo_sobol_draw)."""
+    assert state.dtype == np.int64 and shift.dtype == np.int64 and state.flags.c_contiguous and shift.flags.c_contiguous
+    k = int(state.shape[0])
+    out = np.empty((int(n), k))
+    if lo is not None:
+        lo, rng = np.ascontiguousarray(lo, dtype=np.float64), np.ascontiguousarray(rng, dtype=np.float64)
+    rc = LIB.pcabo_sobol_draw(_ptr(state), _ptr(shift), k, int(n), _ptr(lo), _ptr(rng), _ptr(out))
+    if rc != 0:
+        raise PcaboError(rc, "pcabo_sobol_draw: bad argument")
+    return out
 
 
 def lbfgsb_minimize(fun, x0, bounds, m=10, factr=1e7, pgtol=1e-5, maxiter=15000, maxfun=15000, maxls=20):

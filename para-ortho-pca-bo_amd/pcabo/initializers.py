@@ -20,38 +20,51 @@ _MAXBIT = 30
 _POW_LOW = torch.pow(2, torch.arange(0, _MAXBIT))
 
 
-def scrambled_sobol_engine(k: int, generator=None) -> torch.quasirandom.SobolEngine:
-    """Bit-identical to `SobolEngine(k, scramble=True, seed=None)`, ~3x faster to construct.
+_UNSCRAMBLED = {}      # k -> (k, 30) int64 direction numbers of torch's unscrambled engine (its table; copied per use)
+
+
+class ScrambledSobol:
+    """State of a fresh `SobolEngine(k, scramble=True)`: the scrambled direction numbers and the shift.  `draw(n)` gives the
+    points torch's engine would give on its first draw (bit-identical; the engine is single-use, like the ones botorch
+    builds per call)."""
+    __slots__ = ("k", "state", "shift")
+
+    def __init__(self, k, state, shift):
+        self.k, self.state, self.shift = k, state, shift
+
+    def draw(self, n: int, dtype=torch.float64) -> torch.Tensor:
+        from . import _native
+        return torch.from_numpy(_native.sobol_draw(self.state, self.shift, n)).to(dtype)
+
+
+def scrambled_sobol_engine(k: int, generator=None) -> ScrambledSobol:
+    """The engine `SobolEngine(k, scramble=True, seed=None)` would be, ~4x faster to construct.
     `generator`: a `torch.Generator` standing in for torch's global CPU generator (same stream for the same seed) - used
     where several runs share one process (pcabo.batchrun); None = the global generator, as botorch.
 
-    The two `torch.randint` draws are exactly the ones torch makes (same consumption of the global CPU
-    generator, same order) and `draw` stays torch's; only the matrix scramble (torch's
-    `_sobol_engine_scramble_`, a scalar accessor loop) runs in libpcabo's host helper
-    `pcabo_sobol_scramble`.  Pinned against the real engine in tests/test_abi_and_host.py."""
+    The two `torch.randint` draws are exactly the ones torch makes (same consumption of the CPU generator, same order);
+    the matrix scramble (torch's `_sobol_engine_scramble_`, a scalar accessor loop) and the draw run in libpcabo's host
+    helpers `pcabo_sobol_scramble` / `pcabo_sobol_draw`.  Pinned against the real engine in tests/test_abi_and_host.py."""
     from . import _native
-    eng = torch.quasirandom.SobolEngine(k, scramble=False)
+    base = _UNSCRAMBLED.get(k)
+    if base is None:
+        base = _UNSCRAMBLED[k] = torch.quasirandom.SobolEngine(k, scramble=False).sobolstate.numpy().copy()
     shift_ints = torch.randint(2, (k, _MAXBIT), generator=generator)
-    eng.shift = torch.mv(shift_ints, _POW_LOW)
+    shift = torch.mv(shift_ints, _POW_LOW).numpy()
     ltm = torch.randint(2, (k, _MAXBIT, _MAXBIT), generator=generator)     # (torch's .tril(): the helper reads below the diagonal only)
-    state = eng.sobolstate.numpy()                                  # (k, 30) int64, shares memory with the engine
+    state = base.copy()
     _native.sobol_scramble(state, ltm.numpy())
-    eng.quasi = eng.shift.clone(memory_format=torch.contiguous_format)
-    eng._first_point = (eng.quasi / 2 ** _MAXBIT).reshape(1, -1)
-    eng.scramble = True
-    return eng
+    return ScrambledSobol(k, state, shift)
 
 
 def draw_sobol(bounds: np.ndarray, n: int, engine=None) -> np.ndarray:
     """botorch `draw_sobol_samples(bounds, n, q=1, seed=None)` -> n x k points inside `bounds` (2 x k).
     `engine`: a fresh engine from `scrambled_sobol_engine(k)` built earlier (same RNG consumption, earlier in time)."""
+    from . import _native
     k = bounds.shape[1]
     if engine is None:
         engine = scrambled_sobol_engine(k)
-    u = engine.draw(n, dtype=torch.float64)
-    lo = torch.from_numpy(np.ascontiguousarray(bounds[0]))
-    rng = torch.from_numpy(np.ascontiguousarray(bounds[1] - bounds[0]))
-    return (lo + rng * u).numpy()
+    return _native.sobol_draw(engine.state, engine.shift, n, bounds[0], bounds[1] - bounds[0])
 
 
 @torch.inference_mode()

@@ -114,6 +114,32 @@ def test_host_initializers_consume_torch_rng_like_the_oracle():
     assert int(np.argmax(va)) in ia
 
 
+def test_sobol_helpers_equal_the_real_torch_engine_bit_for_bit():
+    """pcabo_sobol_scramble + pcabo_sobol_draw (host helpers of libpcabo) against torch.quasirandom.SobolEngine(k, scramble=True):
+    same consumption of the CPU generator, same points - including torch's float32 first point - and the same map into a box
+    as botorch's draw_sobol_samples (lo + rng * u)."""
+    import torch
+    from pcabo import initializers as I
+    for k in (1, 2, 7, 36, 40, 100):
+        lo = np.linspace(-3, 1, k)
+        hi = lo + np.linspace(0.5, 7, k)
+        for n in (1, 2, 3, 64, 512, 1000):
+            torch.manual_seed(5 + k)
+            u = torch.quasirandom.SobolEngine(k, scramble=True).draw(n, dtype=torch.float64)
+            ref = (torch.from_numpy(lo) + torch.from_numpy(hi - lo) * u).numpy()
+            state = torch.get_rng_state()
+            torch.manual_seed(5 + k)
+            mine = I.draw_sobol(np.vstack([lo, hi]), n)
+            assert torch.equal(torch.get_rng_state(), state)
+            torch.manual_seed(5 + k)
+            assert torch.equal(I.scrambled_sobol_engine(k).draw(n), u) and np.array_equal(mine, ref), (k, n)
+    g1, g2 = torch.Generator().manual_seed(3), torch.Generator().manual_seed(3)     # a run's own generator, as in pcabo.batchrun
+    a = I.draw_sobol(np.vstack([np.zeros(5), np.ones(5)]), 16, I.scrambled_sobol_engine(5, g1))
+    torch.manual_seed(3)
+    assert np.array_equal(a, I.draw_sobol(np.vstack([np.zeros(5), np.ones(5)]), 16)) and torch.equal(g1.get_state(), torch.get_rng_state())
+    del g2
+
+
 def test_gc_guard_is_reference_counted_and_undone():
     """pcabo/gcguard.py: freeze + raised young-generation threshold while at least one run is open, everything back to
     what it was afterwards (nested runs: the outermost leave restores)."""

@@ -8,6 +8,7 @@ dependency uses it: `SobolEngine(scramble=True, seed=None)` and `torch.multinomi
 """
 from __future__ import annotations
 
+import math
 import warnings
 
 import numpy as np
@@ -77,20 +78,23 @@ def initialize_q_batch(acq_vals: np.ndarray, n: int, eta: float = INIT_ETA, gene
     if n == n_samples:
         return np.arange(n)
     std = v.std(dim=0)
-    if bool(torch.any(std == 0)):
+    if float(std) == 0.0:
         warnings.warn("All acquisition values for raw samples points are the same. "
                       "Choosing initial conditions at random.", RuntimeWarning)
         return torch.randperm(n=n_samples, generator=generator)[:n].numpy()
-    max_idx = torch.max(v, dim=0)[1]
+    max_idx = int(torch.max(v, dim=0)[1])
     eta_z = eta * ((v - v.mean(dim=0)) / std)
     weights = torch.exp(eta_z)
-    while bool(torch.isinf(weights).any()):
-        eta_z = eta_z * 0.5
-        weights = torch.exp(eta_z)
-    idcs = torch.multinomial(weights, n, generator=generator)
+    # botorch halves eta_z while exp overflows.  |z| <= (n - 1) / sqrt(n) for a sample of n with the unbiased std, so for
+    # eta (n - 1) / sqrt(n) < 700 the check cannot fire and its two tensor ops are skipped
+    if eta * (n_samples - 1) / math.sqrt(n_samples) >= 700.0:
+        while bool(torch.isinf(weights).any()):
+            eta_z = eta_z * 0.5
+            weights = torch.exp(eta_z)
+    idcs = torch.multinomial(weights, n, generator=generator).numpy()
     if max_idx not in idcs:
         idcs[-1] = max_idx
-    return idcs.numpy()
+    return idcs
 
 
 def initialize_q_batch_nonneg(acq_vals: np.ndarray, n: int, eta: float = 1.0, alpha: float = 1e-4,

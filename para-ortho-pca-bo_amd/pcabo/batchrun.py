@@ -38,7 +38,8 @@ class BatchedPCABO:
     def __init__(self, problems: Sequence, seeds: Sequence[int], budget: int, n_DoE: int, n_components: int = 0,
                  var_threshold: float = 0.95, acquisition_function: str = "expected_improvement",
                  maximization: bool = False, device: int = 0, num_restarts: int = 10, raw_samples: int = 512,
-                 record_trace: bool = False, host_threads: int = 0, device_objective: bool = False, workers: int = 0):
+                 record_trace: bool = False, host_threads: int = 0, device_objective: bool = False, workers: int = 0,
+                 trace_filter=None):
         self.problems, self.seeds = list(problems), [int(s) for s in seeds]
         self.B = len(self.problems)
         assert self.B == len(self.seeds) and self.B >= 1
@@ -68,7 +69,10 @@ class BatchedPCABO:
         self.failed = [None] * self.B
         self._frozen = [None] * self.B
         self.timing = {"pca": 0.0, "wait_score": 0.0, "init_pick": 0.0, "lbfgsb": 0.0, "tail": 0.0, "host_prep": 0.0}
-        self.record_trace, self.trace = bool(record_trace), []
+        # record_trace: one entry per (run, iteration) that `trace_filter(b, n)` admits (None: all) with what the oracle
+        # needs to replay that iteration from the same state - the run's numpy / torch generator states in front of the
+        # iteration (in the form np.random.set_state / torch.set_rng_state take), best_f, and what the device produced
+        self.record_trace, self.trace, self._trace_filter = bool(record_trace), [], trace_filter
         self._batch: Optional[_native.Batch] = None
         self._rs = self._tg = None
         self._X = None
@@ -144,6 +148,13 @@ class BatchedPCABO:
     def iteration(self) -> None:
         B, d, n, bt = self.B, self.dimension, self.n, self._batch
         t0 = perf_counter()
+        pre = {}
+        if self.record_trace:
+            for b in range(B):
+                if self.failed[b] is None and (self._trace_filter is None or self._trace_filter(b, n)):
+                    pre[b] = {"numpy_state": self._rs[b].get_state(), "torch_state": self._tg[b].get_state().clone(),
+                              "best_f": self.current_best[b]}
+        self._pre_states = pre            # (kept on the object: still there when a run stops in this iteration)
         F = np.array([self._f_for_device(b, n) for b in range(B)], dtype=np.float64)    # B x n
         ranks = np.empty((B, n), dtype=np.int64)
         noise = np.empty((B, n, d))
@@ -229,10 +240,10 @@ class BatchedPCABO:
             best = int(np.argmax(v))
             z_new.append(cand[best])
             infos.append(info)
-            if self.record_trace:
+            if b in pre:
                 self.trace.append({"b": b, "n": n, "k": int(bt.k[b]), "ic_idx": np.asarray(idx[b]).copy(), "ics": ics[b].copy(),
                                    "cands": cand.copy(), "vals": v.copy(), "info": info.copy(), "chosen": best,
-                                   "retried": retried})
+                                   "retried": retried, **pre[b]})
         self.lbfgsb_info.append(infos)
         X_new = bt.inverse_map(z_new)
         f_dev = None

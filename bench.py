@@ -29,6 +29,7 @@ import json
 import os
 import sys
 import time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # read by the HIP runtime at its first call: a Batch uses a stream per worker thread
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (os.path.join(ROOT, "para-ortho-pca-bo_amd"), ROOT):

@@ -1310,10 +1310,23 @@ void launch_acq_group(hipStream_t st, const QueryArgs* tab, int entries, const d
                       double* host_grad, HostMirror* hm, unsigned long long seq, AcqBatch ab) {
   const size_t lds = ((size_t)GQ * NP + 4 * 64 * GT_LD + 64 * 8 + GQ * 64 + 2 * GQ + 4 + 2 * GQ + GQ * (((size_t)k + 1) & ~(size_t)1) + 8) * sizeof(double);
   const dim3 grid(NP / 64, entries), block(256);
-  static std::once_flag attr_once;       // (launched from the worker threads of a batch)
-  std::call_once(attr_once, [] {
-    (void)hipFuncSetAttribute((const void*)k_acq_group<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-  });
+  // Dynamic LDS beyond the 64 KB default needs the attribute - per DEVICE, and for every instantiation that can ask for
+  // more: <2> does from (NP, k) = (512, 83) on (65 808 bytes at k = 89), <5> always.  Launched from the worker threads of
+  // a batch, hence the lock; a failure stays in the thread's last error and the launch below is skipped.
+  {
+    static std::mutex attr_mu;
+    static bool attr_done[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+    std::lock_guard<std::mutex> lk(attr_mu);
+    if (!attr_done[dev]) {
+      if (hipFuncSetAttribute((const void*)k_acq_group<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
+          hipFuncSetAttribute((const void*)k_acq_group<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
+        return;
+      attr_done[dev] = true;
+    }
+  }
+  if (lds > 96 * 1024) return;           // (cannot happen for NP <= 1280, k <= 128: 98 048 bytes at most)
 #define GROUP_ARGS *tab, Xq, n, k, NP, ld, ZnT, R, alpha, bounds4, ystats, p, partial, counters, val, grad, host_val, host_grad, \
                    hm, seq, ab
   if (NP <= 256) hipLaunchKernelGGL(k_acq_group<1>, grid, block, lds, st, GROUP_ARGS);

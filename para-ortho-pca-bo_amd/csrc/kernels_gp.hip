@@ -295,7 +295,17 @@ void launch_add_jitter(hipStream_t s, double* K, int n, int ld, double jitter) {
 }
 void launch_cholesky(hipStream_t s, double* L, int NP, int ld, int* info, double* diag_scratch, ZB zb) {
   const int nblk = NP / BS;
-  for (int p = 0; p < nblk; ++p) {                   // left-looking: bring block column p up to date, then factor it
+  // Two forms of the same left-looking factorisation, bit-identical (tests/golden/gp_factor_hashes.json):
+  //  * k_chol_step (kernels_gpw.hip): ONE launch per panel - final update + panel of column J beside the look-ahead of
+  //    column J+1.  Its groups are heavy (the panel's registers, two sets of operand tiles: one group per CU), which is
+  //    right while a launch's groups fit the chip at once: one run at any size, 30 runs up to n = 512
+  //    (measured round 3, us: n=450: 223 -> 161 (1 run), 248 -> 221 (30 runs); n=1050: 709 -> 514 (1 run));
+  //  * look-back launch + panel launch per panel (round 2) where the chip is oversubscribed anyway and the lighter
+  //    look-back groups (2-3 per CU) keep the matrix cores busier: 30 runs at n = 1050: 983 us against 1132 fused.
+  static const int force = getenv("PCABO_CHOL_FORM") ? atoi(getenv("PCABO_CHOL_FORM")) : 0;     // 1 fused, 2 two launches (A/B only)
+  const bool fused = force ? force == 1 : zb.B * nblk <= 256;
+  if (fused) { launch_chol_steps(s, L, NP, ld, info, diag_scratch, zb); return; }
+  for (int p = 0; p < nblk; ++p) {                   // bring block column p up to date, then factor it
     if (p > 0)
       hipLaunchKernelGGL(k_chol_lookback, dim3(nblk - p + 1, 1, zb.B), dim3(256), 0, s, L, p, nblk, ld, diag_scratch, zb.zs);
     launch_chol_panel(s, L, p, nblk - p, ld, info, diag_scratch, zb);

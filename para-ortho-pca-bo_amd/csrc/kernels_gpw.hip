@@ -1,6 +1,7 @@
 // Wave-per-block variants of the two latency-bound steps of the GP conditioning (panel factorisation + solve,
 // inverse of the diagonal blocks).  See DESIGN.md section 4.
 #include "pcabo_internal.h"
+#include <mutex>
 
 #define BS PCABO_BS
 #ifdef PCABO_ACQ_TIMING
@@ -236,6 +237,223 @@ __global__ __launch_bounds__(128) void k_chol_panel_m(double* __restrict__ A, in
   PSTAMP(15);
 }
 
+// ---- One launch per panel: final update + panel of block column J, look-ahead of block column J+1 ----------------------
+// Round 2 ran the left-looking factorisation as two launches per panel (k_chol_lookback over ALL earlier panels, then
+// k_chol_panel_m), and the look-back's chain of J tile steps sat in front of every panel.  Here the chain leaves the
+// critical path: launch J holds
+//   * panel groups (tile (J+b, J), b = 0 .. nblk-J-1): apply the ONE update that could not be known earlier,
+//       A[J+b][J] -= L[J+b][J-1] L[J][J-1]^T   (and the same for the diagonal tile, which every group factors for itself),
+//     on the matrix cores with all four waves, then factor / solve exactly as k_chol_panel_m did (waves 0 and 1);
+//   * look-ahead groups (tile (I, J+1), I = J+1 .. nblk-1): A[I][J+1] -= sum_{p<J} L[I][p] L[J+1][p]^T - everything block
+//     column J+1 needs EXCEPT panel J, which is being factored in this very launch - they run beside the panel groups and
+//     the next launch's panel groups add the missing term;
+//   * one group that puts panel J-1's diagonal factor into its place (the panel groups of a launch all read their
+//     diagonal tile as INPUT, so the factor leaves through a scratch tile; two scratch tiles alternate because the
+//     writer of panel J and the copier of panel J-1 now share a launch).
+// Per element the arithmetic is what it was: the products of panel p accumulate from zero over ascending k on
+// v_mfma_f64_16x16x4 and are then subtracted from the tile, panels in ascending order (the value just passes through
+// memory between p = J-2 and p = J-1) - tests/golden/gp_factor_hashes.json holds bit for bit.
+#define SLD PCABO_TLD
+__global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, int J, int nblk, int ld, int* __restrict__ info,
+                                                   double* __restrict__ diag_scratch, size_t zs) {
+  ZRUN(A); ZRUN(info); ZRUN(diag_scratch);
+  extern __shared__ __attribute__((aligned(16))) double s_mem[];
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+  const int nP = nblk - J, nLA = J >= 1 ? nblk - J - 1 : 0;
+  const int bx = blockIdx.x;
+  if (bx == nP + nLA) {                                // (only launched for J >= 1) panel J-1's diagonal factor -> its place
+    double* Add = A + (size_t)((J - 1) * BS) * ld + (J - 1) * BS;
+    const double* src = diag_scratch + (size_t)((J - 1) & 1) * BS * BS;
+    for (int idx = tid; idx < BS * BS; idx += 256) Add[(size_t)(idx >> 6) * ld + (idx & 63)] = src[idx];
+    return;
+  }
+  double* s_x = s_mem;                                 // operand tiles of the matrix-core updates, leading dimension 66
+  double* s_y = s_mem + BS * SLD;
+  if (bx >= nP) {
+    // ---- look-ahead: tile (I, J+1) takes the panels p < J --------------------------------------------------------
+    const int Jc = J + 1, I = Jc + (bx - nP);
+    double* dst = A + (size_t)(I * BS) * ld + Jc * BS;
+    const double* Arow = A + (size_t)(I * BS) * ld;    // L[I][p] tiles
+    const double* Brow = A + (size_t)(Jc * BS) * ld;   // L[J+1][p] tiles
+    double cold[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cold[q][r] = dst[(size_t)(16 * w + (l >> 4) + 4 * r) * ld + 16 * q + (l & 15)];
+    double pa[16], pb[16];
+    auto fetch = [&](int p) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int idx = tid + 256 * u, r = idx >> 6, c = idx & 63;
+        pa[u] = Arow[(size_t)r * ld + p * BS + c];
+        pb[u] = Brow[(size_t)r * ld + p * BS + c];
+      }
+    };
+    // two sets of operand tiles in the LDS: while the matrix cores work on panel p, panel p+1's tiles (fetched one step
+    // earlier) go into the other set and panel p+2's loads are issued - one barrier per step, a whole step to hide a load
+    auto put = [&](int set) {
+      double* bx_ = s_mem + (size_t)set * 2 * BS * SLD;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int idx = tid + 256 * u, r = idx >> 6, c = idx & 63;
+        bx_[r * SLD + c] = pa[u];
+        bx_[BS * SLD + r * SLD + c] = pb[u];
+      }
+    };
+    fetch(0);
+    put(0);
+    if (J > 1) fetch(1);
+    __syncthreads();
+    for (int p = 0; p < J; ++p) {
+      const double* cx = s_mem + (size_t)(p & 1) * 2 * BS * SLD;
+      const double* cy = cx + BS * SLD;
+      double4_t acc[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = (double4_t){0.0, 0.0, 0.0, 0.0};
+      for (int kk = 0; kk < BS; kk += 4) {
+        const double a = cx[(16 * w + (l & 15)) * SLD + kk + (l >> 4)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double bb = cy[(16 * q + (l & 15)) * SLD + kk + (l >> 4)];
+          acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[q], 0, 0, 0);
+        }
+      }
+      if (p + 1 < J) {
+        put((p + 1) & 1);
+        if (p + 2 < J) fetch(p + 2);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cold[q][r] -= acc[q][r];
+      __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[(size_t)(16 * w + (l >> 4) + 4 * r) * ld + 16 * q + (l & 15)] = cold[q][r];
+    return;
+  }
+  // ---- panel group b: tile (J+b, J) ----------------------------------------------------------------------------------
+  const int b = bx;
+  double* s_d = s_mem;                                 // the panel's two tiles (leading dimension 65) share the operand
+  double* s_a = s_mem + BS * WLD;                      // tiles' memory: a barrier separates the two uses
+  double* s_rs = s_mem + 4 * BS * SLD;
+  double* s_col = s_rs + BS;
+  double* Add = A + (size_t)(J * BS) * ld + J * BS;
+  double* Abd = A + (size_t)((J + b) * BS) * ld + J * BS;
+  if (J == 0) {
+    // nothing to add: the tiles go straight into the LDS (coalesced: lane = column, all loads in flight first)
+    if (w < 2 && (w == 0 || b > 0)) {
+      const double* src = w == 0 ? Add : Abd;
+      double* dstl = w == 0 ? s_d : s_a;
+      double a[BS];
+#pragma unroll
+      for (int i = 0; i < BS; ++i) a[i] = src[(size_t)i * ld + l];
+#pragma unroll
+      for (int i = 0; i < BS; ++i) dstl[i * WLD + l] = a[i];
+    }
+  } else {
+    // the one update that had to wait for panel J-1:  D -= Y Y^T,  T -= X Y^T  with  X = L[J+b][J-1], Y = L[J][J-1]
+    const double* X = A + (size_t)((J + b) * BS) * ld + (J - 1) * BS;
+    const double* Y = A + (size_t)(J * BS) * ld + (J - 1) * BS;
+    double told[4][4], dold[4][4], pa[16], pb[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int idx = tid + 256 * u, r = idx >> 6, c = idx & 63;
+      pb[u] = Y[(size_t)r * ld + c];
+      pa[u] = b > 0 ? X[(size_t)r * ld + c] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const size_t off = (size_t)(16 * w + (l >> 4) + 4 * r) * ld + 16 * q + (l & 15);
+        dold[q][r] = Add[off];
+        told[q][r] = b > 0 ? Abd[off] : 0.0;
+      }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int idx = tid + 256 * u, r = idx >> 6, c = idx & 63;
+      s_y[r * SLD + c] = pb[u];
+      if (b > 0) s_x[r * SLD + c] = pa[u];
+    }
+    __syncthreads();
+    double4_t accd[4], acct[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { accd[q] = (double4_t){0.0, 0.0, 0.0, 0.0}; acct[q] = (double4_t){0.0, 0.0, 0.0, 0.0}; }
+    for (int kk = 0; kk < BS; kk += 4) {
+      const double ay = s_y[(16 * w + (l & 15)) * SLD + kk + (l >> 4)];
+      const double ax = b > 0 ? s_x[(16 * w + (l & 15)) * SLD + kk + (l >> 4)] : 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double bb = s_y[(16 * q + (l & 15)) * SLD + kk + (l >> 4)];
+        accd[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, bb, accd[q], 0, 0, 0);
+        if (b > 0) acct[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, bb, acct[q], 0, 0, 0);
+      }
+    }
+    __syncthreads();                                   // every wave has read the operand tiles: their memory becomes s_d / s_a
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * w + (l >> 4) + 4 * r, col = 16 * q + (l & 15);
+        s_d[row * WLD + col] = dold[q][r] - accd[q][r];
+        if (b > 0) s_a[row * WLD + col] = told[q][r] - acct[q][r];
+      }
+  }
+  __syncthreads();
+  const int r = l;
+  double4_t acc[4][4];
+  if (w == 0) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int ct = 1; ct <= rt; ++ct)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[rt][ct][q] = s_d[(16 * rt + (r >> 4) + 4 * q) * WLD + 16 * ct + (r & 15)];
+    int bad = 0;
+    panel_m_diag_step<0>(acc, s_d, s_rs, s_col, r, bad);
+    panel_m_diag_step<1>(acc, s_d, s_rs, s_col, r, bad);
+    panel_m_diag_step<2>(acc, s_d, s_rs, s_col, r, bad);
+    panel_m_diag_step<3>(acc, s_d, s_rs, s_col, r, bad);
+    if (bad && b == 0 && r == 0) atomicCAS(info, 0, J * BS + bad);
+  } else if (w == 1 && b > 0) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int ct = 1; ct < 4; ++ct)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[rt][ct][q] = s_a[(16 * rt + (r >> 4) + 4 * q) * WLD + 16 * ct + (r & 15)];
+    panel_m_solve_step<0>(acc, s_d, s_rs, s_a, r);
+    panel_m_solve_step<1>(acc, s_d, s_rs, s_a, r);
+    panel_m_solve_step<2>(acc, s_d, s_rs, s_a, r);
+    panel_m_solve_step<3>(acc, s_d, s_rs, s_a, r);
+  } else {
+    for (int jb = 0; jb < BS / 16; ++jb) __syncthreads();      // the other waves keep the four barriers of the sub-panels paired
+  }
+  __syncthreads();
+  // the finished block leaves through all four waves, 16 rows each
+  const int i0 = 16 * w;
+  const double* srcl = b == 0 ? s_d : s_a;
+  double t[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) t[i] = srcl[(i0 + i) * WLD + r];
+  if (b == 0) {
+    const bool direct = nP == 1;                       // last panel: nobody else reads the block
+    double* scr = diag_scratch + (size_t)(J & 1) * BS * BS;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (direct) Add[(size_t)(i0 + i) * ld + r] = t[i];
+      else scr[(i0 + i) * BS + r] = t[i];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Abd[(size_t)(i0 + i) * ld + r] = t[i];
+  }
+}
+#define CHOL_STEP_LDS ((4 * BS * SLD + 3 * BS) * sizeof(double))     // look-ahead: two sets of two operand tiles
+
 // Inverse of the 64x64 diagonal blocks of L, a COLUMN of the inverse per lane: right-looking forward substitution,
 //   x[m] = acc[m] / L[m][m];  acc[r] -= L[r][m] x[m]  (r > m),
 // all of x in registers, the L[r][m] are LDS broadcasts (same address for every lane, contiguous in r), no cross-lane
@@ -304,6 +522,25 @@ __global__ __launch_bounds__(64) void k_trinv_diag_w(const double* __restrict__ 
 
 void launch_chol_panel(hipStream_t s, double* L, int p, int nblocks, int ld, int* info, double* diag_scratch, ZB zb) {
   hipLaunchKernelGGL(k_chol_panel_m, dim3(nblocks, 1, zb.B), dim3(128), 0, s, L, p, ld, info, diag_scratch, zb.zs);
+}
+// diag_scratch: TWO 64 x 64 tiles
+void launch_chol_steps(hipStream_t s, double* L, int NP, int ld, int* info, double* diag_scratch, ZB zb) {
+  static std::mutex attr_mu;
+  static bool attr_done[64] = {false};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+  {
+    std::lock_guard<std::mutex> lk(attr_mu);
+    if (!attr_done[dev]) {
+      if (hipFuncSetAttribute((const void*)k_chol_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHOL_STEP_LDS) != hipSuccess) return;
+      attr_done[dev] = true;
+    }
+  }
+  const int nblk = NP / BS;
+  for (int J = 0; J < nblk; ++J) {
+    const int groups = (nblk - J) + (J >= 1 ? nblk - J - 1 : 0) + (J >= 1 ? 1 : 0);
+    hipLaunchKernelGGL(k_chol_step, dim3(groups, 1, zb.B), dim3(256), CHOL_STEP_LDS, s, L, J, nblk, ld, info, diag_scratch, zb.zs);
+  }
 }
 void launch_trinv_diag_w(hipStream_t s, const double* L, int nblk, int ld, double* R, ZB zb) {
   hipLaunchKernelGGL(k_trinv_diag_w, dim3(nblk, 1, zb.B), dim3(64), 0, s, L, ld, R, zb.zs);

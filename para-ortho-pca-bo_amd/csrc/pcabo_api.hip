@@ -365,7 +365,7 @@ static size_t carve_device(pcabo_ctx* ctx, char* base) {
   ctx->dNrm = c.take<double>(N);
   ctx->dGram = c.take<double>(N * N);     ctx->dL = c.take<double>(N * N);       ctx->dR = c.take<double>(N * N);
   ctx->dTmp = c.take<double>(N);          ctx->dAlpha = c.take<double>(N);
-  ctx->dDiag = c.take<double>((size_t)PCABO_BS * PCABO_BS);
+  ctx->dDiag = c.take<double>((size_t)2 * PCABO_BS * PCABO_BS);      // two hand-over tiles (k_chol_step)
   ctx->dXq = c.take<double>(Q * d + 8);   // (+ the run's best_f behind the query block in batched scoring)
   ctx->dPartial = c.take<double>(Q * (size_t)ctx->Scap * (2 + 2 * PCABO_MAXD));
   ctx->dVal = c.take<double>(Q);          ctx->dGrad = c.take<double>(Q * d);

@@ -9,7 +9,8 @@
 #define PCABO_MAXD 128       // largest ambient / reduced dimension supported
 #define PCABO_TLD 66         // LDS leading dimension (doubles) of a 64x64 tile: conflict-free ds_read_b64
 
-#define PCABO_QA_MAX 448      // query coordinates that travel as kernel arguments (3.5 KB; 10 restarts x 40 dims = 400 fit)
+#define PCABO_QA_MAX 416      // query coordinates that travel as kernel arguments (3.25 KB; 10 restarts x 40 dims = 400 fit).  With 448 the
+                              // kernarg segment of k_acq_fast was exactly HIP's 4096-byte maximum; 416 leaves 256 bytes of head room
 #define PCABO_CNT_DONE 0x3fff // capacity of the per-query ticket array
 #define PCABO_INLAUNCH_MAXQ 32 // largest batch finished inside the launch (results + flags straight to the host)
 
@@ -182,6 +183,7 @@ void launch_add_jitter(hipStream_t s, double* K, int n, int ld, double jitter);
 void launch_cholesky(hipStream_t s, double* L, int NP, int ld, int* info, double* diag_scratch, ZB zb = ZB());
 void launch_trinv(hipStream_t s, const double* L, int NP, int ld, double* R, ZB zb = ZB());
 void launch_chol_panel(hipStream_t s, double* L, int p, int nblocks, int ld, int* info, double* diag_scratch, ZB zb = ZB());
+void launch_chol_steps(hipStream_t s, double* L, int NP, int ld, int* info, double* diag_scratch /* two tiles */, ZB zb = ZB());
 void launch_trinv_diag_w(hipStream_t s, const double* L, int nblk, int ld, double* R, ZB zb = ZB());
 void launch_alpha(hipStream_t s, const double* R, const double* ys, int n, int NP, int ld, double* tmp, double* alpha,
                   ZB zb = ZB());

@@ -8,6 +8,7 @@
 import argparse
 import os
 import time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # read by the HIP runtime at its first call: a Batch uses a stream per worker thread
 
 from Algorithms import ExperimentRunner
 

@@ -19,10 +19,26 @@ PTR_HOST, PTR_DEVICE = 0, 1
 OPT_RESIDENT, OPT_BESTF_F32, OPT_GROUP_ACQ = 0, 1, 2
 PROFILE_GROUPS = ("wpca", "gram", "cholesky", "root_inverse_alpha", "acq_partial", "acq_large_batches")
 
-# Independent runs drive the GPU from several host threads on separate HIP streams (the gangs of a Batch, one context
-# per thread): the runtime's default of 4 hardware queues per process makes streams share queues, and kernels that share
-# a queue run one after the other.  Read by the HIP runtime when it initialises; an explicit setting wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# Hardware queues.  A Batch drives the GPU from several worker threads on separate HIP streams (its gangs): the runtime's
+# default of 4 hardware queues per process makes streams share queues, and kernels that share a queue run one after the other
+# (-15 % for a 30-run batch).  The HIP runtime reads GPU_MAX_HW_QUEUES when it initialises; this library does NOT touch the
+# environment - the entry points that own the process (main.py, bench.py, tools/) set it before the first GPU call, and
+# Batch() warns when it is missing or too small.
+HW_QUEUES_ENV, HW_QUEUES_WANTED = "GPU_MAX_HW_QUEUES", 16
+
+
+def hw_queues_advice(streams: int) -> Optional[str]:
+    """None if the environment provides enough hardware queues for `streams` concurrent streams, else what to set."""
+    try:
+        have = int(os.environ.get(HW_QUEUES_ENV, "4"))
+    except ValueError:
+        have = 4
+    if have >= streams:
+        return None
+    return (f"{HW_QUEUES_ENV}={os.environ.get(HW_QUEUES_ENV, 'unset (default 4)')}: {streams} streams of this batch will share "
+            f"hardware queues and their kernels serialise; set {HW_QUEUES_ENV}={max(HW_QUEUES_WANTED, streams)} in the environment "
+            "before the process makes its first GPU call")
+
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "lib", "libpcabo.so")
 
@@ -357,6 +373,10 @@ class Batch:
         self.ctx = [_BorrowedContext(LIB.pcabo_batch_ctx(self._h, b), max_n, max_d, max_q, device) for b in range(B)]
         if workers:
             self.set_workers(workers)
+        advice = hw_queues_advice(min(B, int(workers) if workers else 8) + 2)      # gang streams + the batch's + the default stream
+        if advice:
+            import warnings
+            warnings.warn(advice, RuntimeWarning, stacklevel=2)
 
     def set_workers(self, workers: int) -> None:
         """Worker threads of the L-BFGS-B phase (they spin: several batches of one process share the process's cores)."""

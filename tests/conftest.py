@@ -3,6 +3,8 @@ import sys
 
 import pytest
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # the test process owns its environment (pcabo/_native.py: Batch() warns otherwise)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "para-ortho-pca-bo_amd")
 for p in (PKG, os.path.join(ROOT, "oracle"), ROOT):

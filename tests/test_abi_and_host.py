@@ -160,12 +160,14 @@ def test_gc_guard_is_reference_counted_and_undone():
 def test_runner_divides_a_dimension_evenly_over_side_by_side_batches():
     from Algorithms.Experiment.ExperimentRunner import split_evenly
     sizes = lambda n, b, s: [len(p) for p in split_evenly(list(range(n)), b, s)]
-    assert sizes(90, 30, 2) == [45, 45] and sizes(30, 30, 2) == [15, 15] and sizes(300, 30, 2) == [30] * 10
+    assert sizes(90, 45, 2) == [45, 45] and sizes(30, 30, 2) == [15, 15] and sizes(300, 30, 2) == [30] * 10
+    assert sizes(90, 30, 2) == [22, 23, 22, 23] and sizes(119, 30, 2) == [29, 30, 30, 30]      # `batched` is an upper bound
     assert sizes(1, 30, 2) == [1] and sizes(3, 4, 2) == [1, 2] and sizes(6, 2, 1) == [2, 2, 2] and sizes(0, 30, 2) == []
-    for n, b, s in [(7, 3, 2), (100, 30, 3), (61, 30, 2), (5, 1, 4)]:
+    for n, b, s in [(7, 3, 2), (100, 30, 3), (61, 30, 2), (5, 1, 4), (119, 30, 2), (31, 30, 1)]:
         parts = split_evenly(list(range(n)), b, s)
         assert [x for p in parts for x in p] == list(range(n))              # every run once, in order
         assert max(map(len, parts)) - min(map(len, parts)) <= 1             # even
+        assert max(map(len, parts)) <= b                                    # never more runs in a batch than asked for
         assert len(parts) % s == 0 or len(parts) == n                       # whole groups of side-by-side batches
 
 

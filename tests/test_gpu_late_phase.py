@@ -119,7 +119,8 @@ def _check_state(native, ctx, rec, tr, stats):
     s["grad_large"] = _rel(gb, og96)
     # (value-only batches of >= 64 points run as a GEMM on MFMA, batches with gradient through the slab kernels: same
     # numbers up to summation order)
-    assert np.abs(vb - vr[:96]).max() <= 1e-11 * max(1.0, np.abs(vb).max()) and s["grad_large"] < 1e-6, s
+    # (1e-10: with |u| ~ 200 - values ~ -2e4 on f16..f24 states - the value amplifies the rounding of |v|^2; measured 1.2e-11)
+    assert np.abs(vb - vr[:96]).max() <= 1e-10 * max(1.0, np.abs(vb).max()) and s["grad_large"] < 1e-6, s
     assert np.array_equal(gb[:12], g[20:32])                   # both finishing paths sum in the same order
     # ---- finite differences of the device value against the device gradient --------------------------------------
     h = 1e-6

@@ -1,5 +1,6 @@
 """Aggregate rate of B runs advancing in lock-step (pcabo.batchrun) - diagnostic.  usage: gpu_batch_clock.py B [dim] [fid] [sub_batches]"""
 import json, os, sys
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # read by the HIP runtime at its first call: a Batch uses a stream per worker thread
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "para-ortho-pca-bo_amd"))
 import torch

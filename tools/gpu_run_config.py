@@ -4,6 +4,7 @@ JSON line: runs, BO iterations, wall seconds, aggregate BO iterations/s, per-dim
     python tools/gpu_run_config.py 2 [batched] [side_by_side]     # configs[2]: f15/f16/f17 x d in {10, 20, 40} x 30 runs
     python tools/gpu_run_config.py 3      # configs[3] on one GPU: f15-f24 x d in {20, 40} x 30 runs (the N = 1 point)"""
 import json, os, sys, tempfile, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # read by the HIP runtime at its first call: a Batch uses a stream per worker thread
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "para-ortho-pca-bo_amd"))
 import torch

@@ -137,8 +137,65 @@ def profiled_pass(device: int, timed_at):
         else:
             r.step()
     prof = ctx.profile()
+    calib = ctx.profile_calibration()
     r.close()
-    return prof, ns
+    return prof, ns, calib
+
+
+def rocprof_summary():
+    """Per-kernel averages of the committed rocprofv3 --kernel-trace --stats run of THIS command (tools/gpu_profile.sh writes
+    it, profiles/<round>/bench_steps20_kernel_stats.csv): the plain-launch acquisition kernel (one launch per round, what the
+    profiled pass executes) and the resident one (what the timed region executes, one launch per optimize call)."""
+    import csv
+    for rel in ("r03", "r02"):
+        path = os.path.join(ROOT, "profiles", rel, "bench_steps20_kernel_stats.csv")
+        if not os.path.exists(path):
+            continue
+        plain = resident = (0, 0.0)
+        for row in csv.DictReader(open(path)):
+            name = row["Name"]
+            if "k_acq_fast<" not in name:
+                continue
+            calls, tot = int(row["Calls"]), float(row["TotalDurationNs"])
+            if ", false>" in name.split("(")[0]:
+                plain = (plain[0] + calls, plain[1] + tot)
+            elif ", true>" in name.split("(")[0]:
+                resident = (resident[0] + calls, resident[1] + tot)
+        return {"source": f"profiles/{rel}/bench_steps20_kernel_stats.csv",
+                "plain_launches": plain[0], "plain_avg_us": plain[1] / plain[0] / 1e3 if plain[0] else None,
+                "resident_launches": resident[0], "resident_avg_us_per_call": resident[1] / resident[0] / 1e3 if resident[0] else None}
+    return None
+
+
+def batch_per_gpu(device: int, rank: int, size: int, B: int = 30):
+    """N > 1: what the product ships per GPU - ONE lock-step batch of B runs, taken from this rank's share of configs[3]'s d = 40
+    run list (f15..f24 x 30 instances, partitioned by pcabo.sharding.assign_runs); barrier before and after, the job's time is
+    the maximum over ranks, the aggregate the sum of the ranks' BO iterations over that time."""
+    from pcabo import batchrun
+    runs = sharding.enumerate_runs(list(range(15, 25)), [DIM], 30)
+    mine = sorted(sharding.assign_runs(runs, size)[rank])[:B]
+    r = batchrun.BatchedPCABO([BBOBProblem(f, i, d) for f, d, i in mine], [sharding.run_settings(x)["seed"] for x in mine],
+                              BUDGET, NDOE, device=device)
+    r.start()
+    torch.cuda.synchronize()
+    D.barrier()
+    t0 = time.perf_counter()
+    try:
+        batchrun.run_side_by_side([r], started=True)
+        torch.cuda.synchronize()
+        dt_local = time.perf_counter() - t0
+    finally:
+        r.finish()
+    D.barrier()
+    iters = sum(len(f) - NDOE for f in r.f_evals)
+    dt = D.max_over_ranks(dt_local)
+    total = D.sum_over_ranks(iters)
+    per_rank = D.gather_best([iters / dt_local])
+    return {"runs_per_gpu": len(mine), "functions_on_rank0": sorted({f for f, _, _ in mine}), "seconds": dt,
+            "aggregate_bo_iterations_per_s": total / dt, "per_rank_bo_iterations_per_s": [p[0] for p in per_rank],
+            "bo_iterations": total, "stopped_early_on_rank0": sum(x is not None for x in r.failed),
+            "note": "one lock-step batch per GPU over pcabo.sharding.assign_runs of configs[3]'s d=40 list (first B runs of the "
+                    "rank's share); no data-path collective"}
 
 
 def nearest_pmc(n_mean: float):
@@ -249,16 +306,38 @@ def main():
     # ---- roofline: second, profiled pass over the SAME iterations (HIP events on the context's stream) -----------
     roof, kchol, extra = None, None, {}
     if rank == 0 and not args.no_roofline:
-        prof, ns = profiled_pass(device, timed_at)
+        prof, ns, calib = profiled_pass(device, timed_at)
         n_mean = float(np.mean(ns))
         a = prof["acq_partial"]
         if a["launches"]:
-            dur = a["ms"] * 1e-3 / a["launches"]
+            # THREE clocks on this kernel, all stated: HIP events as recorded (an event pair around the launch; includes the
+            # command processor's own work between the two records), the same minus the reading of two events recorded back
+            # to back (a lower bound: with a kernel in between part of that reading overlaps), and rocprofv3's dispatch
+            # begin/end average from the committed summary of this command.  `achieved` / `frac` use the RAW event time -
+            # the longest of the three, so the fraction is not flattered by the calibration.
+            dur_cal = a["ms"] * 1e-3 / a["launches"]
+            dur = dur_cal + calib["pair_ms"] * 1e-3
             byt = a["bytes"] / a["launches"]
             near, table, src = nearest_pmc(n_mean)
-            roof = {"kernel": "k_acq_fast<SLAB,NB> (acquisition value+gradient, one launch per L-BFGS-B round)",
+            rp = rocprof_summary()
+            rounds = max(1, int(timing.get("lbfgsb_rounds", 0)))
+            roof = {"kernel": "k_acq_fast<SLAB,NB,false> (acquisition value+gradient, one launch per L-BFGS-B round; the timed "
+                              "region runs the same arithmetic as the RESIDENT instantiation <SLAB,NB,true>, see `timed_region_kernel`)",
                     "bound": "hbm", "achieved": byt / dur / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": byt / dur / 1e9 / HBM_PEAK_GBS,
+                    "clocks_us": {"hip_events_raw": dur * 1e6, "hip_events_minus_back_to_back_pair": dur_cal * 1e6,
+                                  "back_to_back_pair": calib["pair_ms"] * 1e3, "pair_around_empty_kernel": calib["empty_kernel_ms"] * 1e3,
+                                  "rocprofv3_committed": rp["plain_avg_us"] if rp else None,
+                                  "rocprofv3_source": rp["source"] if rp else None},
+                    "frac_from_rocprofv3": (byt / (rp["plain_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS) if rp and rp["plain_avg_us"] else None,
+                    "timed_region_kernel": {
+                        "kernel": "k_acq_fast<SLAB,NB,true>: ONE resident launch per optimize call, evaluations fed through the mailbox",
+                        "lbfgsb_rounds_in_job": rounds,
+                        "us_per_round_host_clock": 1e6 * timing.get("optimize_acqf/lbfgsb", 0.0) / rounds,
+                        "note": "host clock of the L-BFGS-B phase of ALL BO iterations of the job's runs / their rounds (host "
+                                "step + mailbox round trip + evaluation); rocprofv3 sees the resident kernel as one dispatch "
+                                "per call",
+                        "rocprofv3_resident_avg_us_per_call": rp["resident_avg_us_per_call"] if rp else None},
                     "traffic": near["traffic_bytes"] if near else None,
                     "traffic_shape": {k: near[k] for k in ("n", "k", "q", "algorithmic_bytes", "ratio")} if near else None,
                     "traffic_table": table, "traffic_source": src,
@@ -279,7 +358,7 @@ def main():
         if g["launches"] and c["launches"] and (g["ms"] + c["ms"]) > 0:
             sec = (g["ms"] + c["ms"]) * 1e-3
             tf = (g["flops"] + c["flops"]) / sec / 1e12
-            kchol = {"kernels": "k_zstats + k_znorm + k_gram; k_chol_lookback + k_chol_panel_m per 64-wide panel",
+            kchol = {"kernels": "k_zstats + k_znorm + k_gram; k_chol_step, one launch per 64-wide panel (final update + panel + look-ahead)",
                      "bound": "mfma", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": tf / FP64_PEAK_TFLOPS, "hbm_GBs": (g["bytes"] + c["bytes"]) / sec / 1e9,
                      "hbm_frac": (g["bytes"] + c["bytes"]) / sec / 1e9 / HBM_PEAK_GBS,
@@ -310,6 +389,10 @@ def main():
                                 "note": "same kernels, blockIdx.z = run: the headline shape with 30 runs' factorisations side by "
                                         "side (pcabo_batch_*); full grid in `kchol_grid`"}
 
+    multi = None
+    if size > 1 and args.batch > 1:
+        multi = batch_per_gpu(device, rank, size, args.batch)
+
     cpu = None
     if rank == 0 and size == 1 and not args.no_cpu_baseline and states:      # N = 1 only (contract)
         # the oracle's tiny fp64 tensors run fastest single-threaded on this host (measured 0.246 s/iteration at 1
@@ -331,7 +414,8 @@ def main():
             "n_range": [int(min(n_seen)), int(max(n_seen))], "n_mean": float(np.mean(n_seen)),
             "timed_iterations": len(n_seen), "timed_seconds": elapsed, "job_wall_seconds": job_wall,
             "backend": D.backend_name(),
-            "roofline": roof, "roofline_kchol": kchol, "cpu_baseline": cpu, "batched": batch, "kchol_grid": grid,
+            "roofline": roof, "roofline_kchol": kchol, "cpu_baseline": cpu, "batched": batch, "batched_per_gpu": multi,
+            "rccl_ranks": D.ranks_seen(), "kchol_grid": grid,
             "kernels": extra, "host_phase_seconds": timing, "best_f": gathered,
             "runs": [list(r) for r in runs],
             "speedup_vs_cpu_baseline": (value / size / cpu["value"]) if cpu else None,

@@ -180,6 +180,10 @@ int pcabo_lbfgsb_minimize(int nvar, double* x, const double* lower, const double
                           pcabo_fg_callback fg, void* user, int m, double factr, double pgtol,
                           int maxiter, int maxfun, int maxls, double* f_out, int* nit, int* nfev,
                           int* task_out);
+/* The O(m n) loops of the host L-BFGS-B have AVX2 forms that take, bit for bit, the scalar loops' iterates (same operands,
+ * same order, no fma); on by default where the CPU has AVX2.  0 selects the scalar loops (process-wide; the test that
+ * compares the two uses it), 1 the default again.  Returns the previous setting. */
+int pcabo_lbfgsb_set_vector_kernels(int enabled);
 
 /* Host-only helper for the initial-condition draw (botorch -> torch.quasirandom.SobolEngine, row K):
  * the matrix scramble of torch's `_sobol_engine_scramble_` on state[k*30] (in/out) with the k lower-
@@ -198,8 +202,11 @@ int pcabo_sobol_draw(const int64_t* state, const int64_t* shift, int k, int n, c
  * 3 root inverse + alpha (5 launches), 4 acquisition kernel, single-launch evaluations (<= 32 queries: the L-BFGS-B
  * rounds), 5 acquisition, large batches (two launches: partials + combine).
  * Enabled by pcabo_set_profiling(ctx, 1) (adds an event pair per bracketed group of launches; the reading of two events
- * recorded back to back, calibrated when profiling is switched on, is subtracted from every pair). */
+ * recorded back to back, calibrated when profiling is switched on, is subtracted from every pair).
+ * pcabo_get_profile_calibration: that reading (ms) and the reading of an event pair around an EMPTY kernel (ms), both medians
+ * of 64, so that a caller can state raw event times next to the calibrated ones (bench.py does). */
 int pcabo_set_profiling(pcabo_ctx* ctx, int enabled);
+int pcabo_get_profile_calibration(pcabo_ctx* ctx, double* pair_ms, double* empty_kernel_ms);
 int pcabo_get_profile(pcabo_ctx* ctx, int which, double* ms, int64_t* launches, double* bytes, double* flops);
 int pcabo_reset_profile(pcabo_ctx* ctx);
 
@@ -219,11 +226,15 @@ int pcabo_reset_profile(pcabo_ctx* ctx);
 typedef struct pcabo_batch pcabo_batch;
 int pcabo_batch_create(int device, int B, int max_n, int max_d, int max_q, pcabo_batch** out);
 int pcabo_batch_destroy(pcabo_batch* batch);
-/* Worker threads of the L-BFGS-B phase (one gang of runs and one HIP stream each; default min(8, B), PCABO_BATCH_THREADS).
+/* Worker threads of the L-BFGS-B phase (one gang of runs and one HIP stream each; default min(8, B)).
  * A worker spins while its launch is in flight: when several batches of one process advance side by side (one host thread
  * per batch - the reference's cells of different dimension, or two halves of one cell) give each its share of the cores.
  * Results do not depend on the number.  Not during a call on this batch. */
 int pcabo_batch_set_workers(pcabo_batch* batch, int workers);
+/* PCABO_OPT_GROUP_ACQ (default 1): the L-BFGS-B rounds of the batch go through the throughput kernel (k_acq_group); 0: through
+ * the per-query kernels a stand-alone context uses by default - a run of the batch is then bit-identical to the same run in a
+ * context of its own with default options (with 1 it is bit-identical to such a context with PCABO_OPT_GROUP_ACQ set). */
+int pcabo_batch_set_option(pcabo_batch* batch, int option, int value);
 int pcabo_batch_last_error(pcabo_batch* batch, char* buf, int buflen);
 pcabo_ctx* pcabo_batch_ctx(pcabo_batch* batch, int b);
 

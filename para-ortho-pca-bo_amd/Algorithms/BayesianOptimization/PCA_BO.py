@@ -107,8 +107,6 @@ class PCA_BO(AbstractBayesianOptimizer):
         # global stream BEFORE the objective of this iteration is evaluated - harmless exactly when the objective does
         # not draw from numpy's global RNG.  None = automatic: on for the in-repo BBOB problems, off otherwise.
         self.__prefetch = kwargs.pop("prefetch_noise", None)
-        if self.__prefetch is None and os.environ.get("PCABO_PREFETCH_NOISE") in ("0", "1"):   # A/B diagnostics
-            self.__prefetch = os.environ["PCABO_PREFETCH_NOISE"] == "1"
         self.__prefetch_on = False
         self.__noise_thread, self.__noise_pending = None, False
         self.__noise_req = self.__noise_res = None
@@ -125,7 +123,15 @@ class PCA_BO(AbstractBayesianOptimizer):
         self.__acq_kernel = str(kwargs.pop("acq_kernel", "latency"))
         if self.__acq_kernel not in ("latency", "group"):
             raise ValueError("acq_kernel must be 'latency' or 'group'")
-        self.__gc_freeze = bool(kwargs.pop("gc_freeze", _gcguard.enabled_by_default()))
+        self.__gc_freeze = bool(kwargs.pop("gc_freeze", True))
+        # resident=False: one launch per acquisition evaluation instead of the resident kernel of pcabo_optimize_acqf
+        # (PCABO_OPT_RESIDENT; same arithmetic - the tests compare whole runs bit for bit)
+        self.__resident = bool(kwargs.pop("resident", True))
+        # fused_enqueue=False: pcabo_wpca and pcabo_gp_condition_begin as two calls instead of ONE enqueue of rows A-H (the
+        # tests compare the two); early_scoring / engine_guess likewise switch the two host/device overlaps off
+        self.__fused = bool(kwargs.pop("fused_enqueue", True))
+        self.__early_scoring = bool(kwargs.pop("early_scoring", True))
+        self.__speculate_engine = bool(kwargs.pop("engine_guess", True))
         self.__gc_entered = False
         super().__init__(budget, n_DoE, **kwargs)
         self.random_seed = random_seed
@@ -153,9 +159,6 @@ class PCA_BO(AbstractBayesianOptimizer):
             warnings.warn("visualize=True: the GIF visualiser of the reference is not part of the MI355X path; ignored.")
         self.__z_evals = []
         self.__gp_pending = False
-        self.__fused = os.environ.get("PCABO_NO_FUSED_ENQUEUE") is None
-        self.__early_scoring = os.environ.get("PCABO_NO_EARLY_SCORING") is None
-        self.__speculate_engine = os.environ.get("PCABO_NO_ENGINE_GUESS") is None
         self.__engine_ready = None
         self.__X_buf, self.__X_rows = None, 0
         self.__ctx: Optional[_native.Context] = None
@@ -197,6 +200,8 @@ class PCA_BO(AbstractBayesianOptimizer):
                                      max_q=max(self.__torch_config["RAW_SAMPLES"], 16), device=self.__device)
         if self.__acq_kernel == "group":
             self.__ctx.set_option(_native.OPT_GROUP_ACQ, 1)
+        if not self.__resident:
+            self.__ctx.set_option(_native.OPT_RESIDENT, 0)
         self.__X_buf, self.__X_rows = None, 0
         if self.__prefetch is None:
             from pcabo.bbob import BBOBProblem

@@ -36,8 +36,9 @@ class Vanilla_BO(AbstractBayesianOptimizer):
         self.__record_trace = bool(kwargs.pop("record_trace", False))
         self.__torch_threads = kwargs.pop("torch_threads", 4)      # see PCA_BO: spinning OpenMP workers starve the loop
         self.__saved_torch_threads = None
-        self.__gc_freeze = bool(kwargs.pop("gc_freeze", _gcguard.enabled_by_default()))      # see pcabo/gcguard.py
+        self.__gc_freeze = bool(kwargs.pop("gc_freeze", True))      # see pcabo/gcguard.py
         self.__gc_entered = False
+        self.__resident = bool(kwargs.pop("resident", True))         # see PCA_BO: False = one launch per evaluation
         super().__init__(budget, n_DoE, **kwargs)
         self.random_seed = random_seed
         smoke_test = os.environ.get("SMOKE_TEST")
@@ -84,6 +85,8 @@ class Vanilla_BO(AbstractBayesianOptimizer):
             self._pbar.update(self.n_DoE)
         self.__ctx = _native.Context(max_n=self.budget, max_d=self.dimension,
                                      max_q=max(self.__torch_config["RAW_SAMPLES"], 16), device=self.__device)
+        if not self.__resident:
+            self.__ctx.set_option(_native.OPT_RESIDENT, 0)
         d = self.dimension
         self.__identity = np.vstack([np.zeros(d), np.ones(d)])          # Normalize is switched off in the reference
         self.__box = np.ascontiguousarray(self.bounds.T, dtype=np.float64)   # 2 x d search box

@@ -74,7 +74,7 @@ class ExperimentRunner:
                  budget_factor: int = 10, doe_factor: float = 3.0, root_dir: str = os.getcwd(),
                  experiment_name: str = "experiment", acquisition_function: str = "expected_improvement",
                  pca_components: Optional[int] = None, var_threshold: float = 0.95, verbose: bool = False,
-                 progress: bool = True, batched: int = 0, side_by_side: int = 2):
+                 progress: bool = True, batched: int = 0, side_by_side: int = 2, batch_acq_kernel: str = "group"):
         self.algorithms = algorithms
         self.dimensions = dimensions
         self.problem_ids = problem_ids
@@ -95,6 +95,7 @@ class ExperimentRunner:
         # side_by_side: that many lock-step batches advance at once, one host thread each (pcabo.batchrun.run_side_by_side):
         # one batch's host-paced L-BFGS-B rounds overlap the other's launches and bookkeeping.  Same runs, same numbers.
         self.side_by_side = max(1, int(side_by_side))
+        self.batch_acq_kernel = batch_acq_kernel      # pcabo.batchrun.BatchedPCABO(acq_kernel=...)
 
         self.triggers = [ALWAYS]
         self.logger_properties = [RAWYBEST]
@@ -177,7 +178,7 @@ class ExperimentRunner:
                 runner = BatchedPCABO(probs, seeds, budget, n_doe, n_components=self.pca_components or 0,
                                       var_threshold=self.var_threshold, acquisition_function=self.acquisition_function,
                                       device=self.device, workers=workers_for(len(group)) if len(group) > 1 else 0,
-                                      host_threads=max(1, 8 // len(group)))
+                                      host_threads=max(1, 8 // len(group)), acq_kernel=self.batch_acq_kernel)
                 jobs.append((dim, chunk, probs, n_doe, runner))
             start_time = time()
             run_side_by_side([j[4] for j in jobs])

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void k_acq_fused(
     const double* __restrict__ bounds4, const double* __restrict__ ystats, AcqParams prm, double* partial,
     unsigned int* counters, double* __restrict__ val, double* __restrict__ grad,
     double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq, int combine, int /*qb*/,
-    const MailPair* /*host_mail*/, MailPair* /*dev_mail*/, MailPair* /*part_pairs*/, AcqBatch ab) {
+    MailPair* /*dev_mail*/, MailPair* /*part_pairs*/, AcqBatch ab) {
   ACQ_BATCH_PROLOGUE()
   const double inv_ls = prm.inv_ls;
   const int kernel = prm.kernel, want_grad = prm.want_grad;
@@ -421,10 +421,9 @@ __device__ inline bool acq_server_finisher(const MailPair* rec, int S, int k, in
 // Resident finishing groups: group (S, q) of the resident grid.  The whole role lives in this function, entered at the
 // very top of k_acq_fast before any register tile exists, so the kernel's register allocation is the maximum of the
 // two roles, not their sum.  (A separate kernel on a second stream would be simpler, but two streams of one process may
-// share a hardware queue, and then the two kernels wait for each other until they time out.)  Group (S, 0) also relays
-// the round's mailbox from the host's pinned copy to the device copy that everybody else polls.
+// share a hardware queue, and then the two kernels wait for each other until they time out.)
 #define FIN_LDS_DOUBLES (6 * PCABO_MAXD + 2 + 3 * FIN_STAGE_PER_WAVE + 2)   // ... + two flag words in the last double
-__device__ __noinline__ void acq_server_finish_main(double* s_mem, const MailPair* host_mail, MailPair* dev_mail, int npairs,
+__device__ __noinline__ void acq_server_finish_main(double* s_mem, MailPair* dev_mail,
                                                     int ctrl_idx, const MailPair* part_pairs, int S, int k, int q,
                                                     const double* __restrict__ bounds4, const double* __restrict__ ystats,
                                                     const AcqParams& prm, double* val, double* grad, double* host_val,
@@ -439,33 +438,6 @@ __device__ __noinline__ void acq_server_finish_main(double* s_mem, const MailPai
     const unsigned long long t0 = wall_clock64();
     if (tid == 0) { s_srvp[0] = 0; s_srvp[1] = 0; }
     __syncthreads();
-    if (q == 0 && host_mail) {                                   // relay: host mailbox -> device mailbox (host_mail == NULL:
-      // the host writes the device mailbox itself, through the PCIe BAR - nothing to relay)
-      // Wave 0 polls ALL pairs (<= 8 per lane, one asm block = one PCIe round trip) and stores a complete round to the
-      // device copy.  (All four waves polling a quarter of a round trip apart was tried: the extra traffic made every
-      // poll slower, 13-15 instead of 11-12.5 us per evaluation.)
-      volatile int* flags = s_srvp;                              // [0] leave
-      if (w == 0) {
-        const void* ptr[8];
-        int idx[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) { const int pi = 1 + l + 64 * t; idx[t] = pi <= npairs ? pi : -1; ptr[t] = host_mail + (pi <= npairs ? pi : 1); }
-        for (;;) {
-          pcabo_u4 o[8];
-          ld_pairs_sys8(ptr, o);
-          bool ok = true;
-#pragma unroll
-          for (int t = 0; t < 8; ++t) ok = ok && (idx[t] < 0 || mail_seq(o[t]) == cur_seq);
-          if (__all(ok)) {
-#pragma unroll
-            for (int t = 0; t < 8; ++t) if (idx[t] >= 0) st_pair_sys(dev_mail + idx[t], o[t]);
-            break;
-          }
-          if (__any(wall_clock64() - t0 > PCABO_SERVER_TIMEOUT_TICKS)) { if (l == 0) flags[0] = 1; break; }
-        }
-      }
-      __syncthreads();
-    }
     if (w == 0) {                                               // this query's control pair of the round: 1 evaluate, 0 leave
       for (;;) {
         const pcabo_u4 hd = ld_pair_sys(dev_mail + ctrl_idx);
@@ -484,11 +456,8 @@ __device__ __noinline__ void acq_server_finish_main(double* s_mem, const MailPai
 }
 
 // number of slab groups per query that launch_acq uses for this size
-int acq_slabs(int NP) {
-  static int slab_thr = -1;
-  if (slab_thr < 0) { const char* e = getenv("PCABO_SLAB32_NP"); slab_thr = e ? atoi(e) : 448; }
-  return NP / (NP >= slab_thr ? 32 : 16);
-}
+#define ACQ_SLAB32_NP 448          // 16 rows per work-group below this padded size, 32 from it on (see launch_acq)
+int acq_slabs(int NP) { return NP / (NP >= ACQ_SLAB32_NP ? 32 : 16); }
 
 // ---- fast path: NP = 64 NB <= 512 and k <= 40, everything static ---------------------------------------------
 // The generic kernel above re-reads its operands (ZnT for ks and again for the gradient contraction, the R slab
@@ -511,7 +480,7 @@ __global__ __launch_bounds__(256) void k_acq_fast(
     const double* __restrict__ bounds4, const double* __restrict__ ystats, AcqParams prm, double* partial,
     unsigned int* counters, double* __restrict__ val, double* __restrict__ grad,
     double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq, int combine, int qb,
-    const MailPair* host_mail, MailPair* dev_mail, MailPair* part_pairs, AcqBatch ab) {
+    MailPair* dev_mail, MailPair* part_pairs, AcqBatch ab) {
   if (!SRV) { ACQ_BATCH_PROLOGUE() }
   constexpr int NP = NB * 64;
   constexpr int CU = 10;                 // components per wave
@@ -531,7 +500,7 @@ __global__ __launch_bounds__(256) void k_acq_fast(
   constexpr bool server = SRV;                                  // resident mode (own instantiation: the plain one keeps its registers), see below
   const int s = blockIdx.x, S = server ? (int)gridDim.x - 1 : (int)gridDim.x;
   if (server && s == S) {                                        // the finishing group of query blockIdx.y
-    acq_server_finish_main(s_dyn, host_mail, dev_mail, q_total * (k + 1), 1 + q_total * k + (int)blockIdx.y, part_pairs, S, k,
+    acq_server_finish_main(s_dyn, dev_mail, 1 + q_total * k + (int)blockIdx.y, part_pairs, S, k,
                            blockIdx.y, bounds4, ystats, prm, val, grad, host_val, host_grad, hm, seq);
     return;
   }
@@ -568,8 +537,7 @@ __global__ __launch_bounds__(256) void k_acq_fast(
   // queries, so the register tiles above are loaded once for all of them; the in-launch combine uses qb = 1
   // ---- resident mode (dev_mail != nullptr): the kernel stays for all the evaluations of one optimize call.  Round r of
   // a query carries sequence number seq + r - 1; its coordinates and its control pair (1 evaluate, 0 leave) arrive
-  // through the device mailbox, which the host fills through the PCIe BAR (or, host_mail != NULL, finishing group 0 relays
-  // from the host's pinned copy).  Every query counts its own rounds - the host may drive the restart groups
+  // through the device mailbox, which the host fills through the PCIe BAR.  Every query counts its own rounds - the host may drive the restart groups
   // independently of each other.  A round costs neither a launch nor a refill of the register tiles.  Every wait is
   // bounded (PCABO_SERVER_TIMEOUT_TICKS): a group that times out simply leaves, the host then times out on the
   // missing result and finishes the call with plain launches.
@@ -1485,51 +1453,39 @@ void launch_score(hipStream_t st, const double* Xq, int q, int n, int k, int NP,
 // Resident mode needs every group of the grid on the chip at the same time (groups wait for one another through the
 // mailbox and the tickets): one group per CU is always possible for these kernels, so S q <= number of CUs is enough.
 bool acq_server_possible(int q, int n, int k, int NP) {
-  static int enabled = -1, cus = 0;
-  if (enabled < 0) {
-    const char* e = getenv("PCABO_ACQ_SERVER");
-    enabled = !(e && atoi(e) == 0);
-    const char* g = getenv("PCABO_ACQ_GENERIC");
-    if (g && atoi(g)) enabled = 0;
+  static int cus = -1;
+  if (cus < 0) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
   }
-  if (!enabled || k > 40 || NP > 512 || q < 1 || q > PCABO_INLAUNCH_MAXQ || (size_t)q * k > PCABO_QA_MAX) return false;
-  static int slab_thr = -1;
-  if (slab_thr < 0) { const char* e = getenv("PCABO_SLAB32_NP"); slab_thr = e ? atoi(e) : 448; }
-  const int S = NP / (NP >= slab_thr ? 32 : 16);
-  return (S + 1) * q <= cus && S <= 32;      // slab groups + one finishing group per query (k_acq_server_finish)
+  if (k > 40 || NP > 512 || q < 1 || q > PCABO_INLAUNCH_MAXQ || (size_t)q * k > PCABO_QA_MAX) return false;
+  const int S = acq_slabs(NP);
+  return (S + 1) * q <= cus && S <= 32;      // slab groups + one finishing group per query (acq_server_finish_main)
 }
 
 void launch_acq(hipStream_t st, const QueryArgs* qa, const double* Xq, int q, int n, int k, int NP, int ld,
                 const double* ZnT, const double* R, const double* alpha, const double* bounds4, const double* ystats,
                 AcqParams p, double* partial, unsigned int* counters, double* val,
                 double* grad, double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq,
-                const MailPair* host_mail, MailPair* dev_mail, MailPair* part_pairs, AcqBatch ab, int B,
+                MailPair* dev_mail, MailPair* part_pairs, AcqBatch ab, int B,
                 int table_entries) {
   // 16 rows per work-group while S*q groups fit the 256 CUs (NP <= 384 at q = 10), 32 rows beyond that: measured
   // on MI355X (q=10, with gradient) 16 rows win at n=120/250 (22.2 vs 23.0, 26.9 vs 27.8 us), 32 rows at n=449 (34.4 vs
-  // 37.3 us).  PCABO_SLAB32_NP overrides the switch point (tuning only).
-  static int slab_thr = -1;
-  if (slab_thr < 0) { const char* e = getenv("PCABO_SLAB32_NP"); slab_thr = e ? atoi(e) : 448; }
-  const int slab = NP >= slab_thr ? 32 : 16;
+  // 37.3 us).
+  const int slab = NP >= ACQ_SLAB32_NP ? 32 : 16;
   const int S = NP / slab;
   static const QueryArgs empty = {};
   const int combine = hm != nullptr;      // small batches: finish inside the launch and publish to the host
   const int nb = NP / 64;
-  static int use_fast = -1;
-  if (use_fast < 0) { const char* e = getenv("PCABO_ACQ_GENERIC"); use_fast = !(e && atoi(e)); }
   // large batches on the fast path: 8 queries per group share one load of the register tiles (qb); the generic
   // kernel and the in-launch combine take one query per group
-  const bool fast = use_fast && k <= 40 && nb <= 8;      // (the resident mode is only requested when this holds)
-  static int qb_large = -1;
-  if (qb_large < 0) { const char* e = getenv("PCABO_ACQ_QB"); qb_large = e ? atoi(e) : 8; if (qb_large < 1) qb_large = 1; }
-  const int qb = (fast && !combine && q >= 64) ? qb_large : 1;
+  const bool fast = k <= 40 && nb <= 8;      // (the resident mode is only requested when this holds)
+  const int qb = (fast && !combine && q >= 64) ? 8 : 1;
   // batched: table mode -> one grid row per active (run, query) entry; otherwise grid.z = run
   const int gy = ab.table ? table_entries : (q + qb - 1) / qb;
   const int gz = ab.table ? 1 : B;
 #define ACQ_ARGS qa ? *qa : empty, Xq, q, n, k, NP, ld, ZnT, R, alpha, bounds4, ystats, p, partial, counters, val, grad, \
-                 host_val, host_grad, hm, seq, combine, qb, host_mail, dev_mail, part_pairs, ab
+                 host_val, host_grad, hm, seq, combine, qb, dev_mail, part_pairs, ab
   const int FIN_LDS = 6 * PCABO_MAXD + 2;   // finishing group's LDS beyond s_v
 #define ACQ_LDS(SL, NBV) (3 * NBV * 64 + PCABO_MAXD + SL + 2 + (4 * NBV * 64 > FIN_LDS ? 4 * NBV * 64 : FIN_LDS))
 #define ACQ_FAST(SL, NBV)                                                                                      \

@@ -238,6 +238,25 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi(const double* __restrict
   __syncthreads();
   const bool warm = V0 && !s_rot;
   __syncthreads();
+  // Range guard.  The sweeps square the entries of G = C V (column norms, a b in the convergence test): with |x| ~ 1e80 -
+  // reached by the reference's own dynamics on some functions, where every out-of-box candidate widens the next search
+  // box (PCA_BO.py:253,260-263,558-573) - C ~ 1e160 and those squares leave the double range, while LAPACK's eigh
+  // behind sklearn scales such a matrix and carries on.  So C is scaled by a power of FOUR when its largest entry (on the
+  // diagonal: C is a covariance) lies outside 2^+-100.  Eigenvectors and variance ratios do not depend on the scale, and
+  // every operation of the sweep (products, sums, rcp / rsq estimates and their Newton steps, the square roots at the
+  // end) commutes with a power of four exactly - inside that range the factor is 1 and nothing changes.
+  if (tid < d) s_lam[tid] = fabs(C[(size_t)tid * DP + tid]);
+  __syncthreads();
+  double cscale = 1.0;
+  {
+    double mx = 0.0;
+    for (int j = 0; j < d; ++j) mx = s_lam[j] > mx ? s_lam[j] : mx;      // (LDS broadcast reads; NaN / inf: left alone)
+    if (mx > 0.0 && mx < INFINITY) {
+      const int e = ilogb(mx);
+      if (e > 100 || e < -100) cscale = ldexp(1.0, -(e & ~1));
+    }
+  }
+  __syncthreads();                           // (s_lam is written again below)
   for (int idx = tid; idx < d * d; idx += (int)blockDim.x) {
     int col = idx / d, row = idx % d;
     double v;
@@ -245,14 +264,14 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi(const double* __restrict
       v = 0.0;
       const double* crow = s_c + row * LD;
       const double* vcol = s_v + col * LD;
-      for (int j = 0; j < d; ++j) v += crow[j] * vcol[j];
+      for (int j = 0; j < d; ++j) v += (crow[j] * cscale) * vcol[j];
     } else if (warm) {
       v = 0.0;
       const double* crow = C + (size_t)row * DP;
       const double* vcol = V0 + (size_t)col * d;
-      for (int j = 0; j < d; ++j) v += crow[j] * vcol[j];
+      for (int j = 0; j < d; ++j) v += (crow[j] * cscale) * vcol[j];
     } else {
-      v = C[(size_t)row * DP + col];
+      v = C[(size_t)row * DP + col] * cscale;
     }
     s_g[col * LD + row] = v;
   }
@@ -372,7 +391,7 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi(const double* __restrict
       Gout[(size_t)col * d + r] = v;
       s_g[col * LD + r] = v;                                     // the selection below works on the normalised columns
     }
-    if (l == 0) { lam[col] = nrm; s_lam[col] = nrm; }
+    if (l == 0) { lam[col] = nrm / cscale; s_lam[col] = nrm; }      // (the ratios below do not see the scale)
   }
   if (tid == 0) *sweeps_out = sweep;
   // ---- selection (was a launch of its own: k_pca_finalize): eigenpairs by decreasing variance, explained-variance
@@ -573,9 +592,7 @@ void launch_jacobi(hipStream_t s, const double* C, int d, int DP, const double* 
     attr_set = true;
   }
   const int npairs = ((d + 1) & ~1) / 2;
-  static int lp_env = -1;
-  if (lp_env < 0) { const char* e = getenv("PCABO_JACOBI_LP"); lp_env = e ? atoi(e) : 0; }
-  int threads = (npairs * 16 <= JAC_THREADS && lp_env != 8) ? npairs * 16 : npairs * 8;
+  int threads = npairs * 16 <= JAC_THREADS ? npairs * 16 : npairs * 8;      // 16 lanes per column pair while they fit
   threads = (threads + 63) & ~63;
   if (threads < d) threads = (d + 63) & ~63;          // the selection step at the end uses one thread per component
   PcaSelect sel{n, var_threshold, n_components, comps, evr, k_dev, hm};

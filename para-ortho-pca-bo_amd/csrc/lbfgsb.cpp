@@ -3,6 +3,7 @@
 // for S and Y) so that every inner product is accumulated in the same order.
 #include "lbfgsb.h"
 
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
@@ -106,16 +107,19 @@ __attribute__((target("avx2"))) void chain_d_avx2(double* out, const double* wy,
 #endif
 
 struct VecKernels { accum_fn accum; chain_fn chain_r, chain_d; };
-const VecKernels& vec_kernels() {
-  static const VecKernels k = [] {
-    VecKernels v{accum_scalar, chain_r_scalar, chain_d_scalar};
+const VecKernels g_scalar_kernels{accum_scalar, chain_r_scalar, chain_d_scalar};
+std::atomic<const VecKernels*> g_kernels{nullptr};
+const VecKernels* default_kernels() {
 #if defined(__x86_64__)
-    const char* off = std::getenv("PCABO_LBFGSB_SCALAR");
-    if (!(off && off[0] == '1') && __builtin_cpu_supports("avx2")) v = VecKernels{accum_avx2, chain_r_avx2, chain_d_avx2};
+  static const VecKernels avx2{accum_avx2, chain_r_avx2, chain_d_avx2};
+  if (__builtin_cpu_supports("avx2")) return &avx2;
 #endif
-    return v;
-  }();
-  return k;
+  return &g_scalar_kernels;
+}
+inline const VecKernels& vec_kernels() {
+  const VecKernels* k = g_kernels.load(std::memory_order_acquire);
+  if (!k) { k = default_kernels(); g_kernels.store(k, std::memory_order_release); }
+  return *k;
 }
 
 inline double ddot(int n, const double* x, const double* y) {
@@ -164,6 +168,12 @@ int dtrsl(const double* t, int ldt, int nn, double* b, int job) {
 }
 
 }  // namespace
+
+int lbfgsb_set_vector_kernels(int enabled) {
+  const bool was = &vec_kernels() != &g_scalar_kernels;
+  g_kernels.store(enabled ? default_kernels() : &g_scalar_kernels, std::memory_order_release);
+  return was ? 1 : 0;
+}
 
 void Lbfgsb::init(int n, int m, const double* lower, const double* upper, double factr, double pgtol, int maxls) {
   if (m > LBFGSB_MAXM) m = LBFGSB_MAXM;

@@ -24,6 +24,9 @@ enum {
   LBFGSB_ERROR = 90        // invalid input (l > u, ...)
 };
 
+// 0: scalar O(m n) loops, 1: the default (AVX2 where available); same iterates either way.  Returns the previous setting.
+int lbfgsb_set_vector_kernels(int enabled);
+
 class Lbfgsb {
  public:
   // lower/upper may be null (unbounded); +-inf entries mean "no bound on that side".

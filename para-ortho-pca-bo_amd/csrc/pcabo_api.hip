@@ -112,8 +112,8 @@ struct pcabo_ctx {
   // pinned host
   HostMirror* hm = nullptr;
   double *hXq = nullptr, *hVal = nullptr, *hGrad = nullptr, *hSmall = nullptr, *hBestF = nullptr;
-  MailPair *hMail = nullptr, *dMail = nullptr;   // mailbox of the resident acquisition kernel (pinned host copy, device copy)
-  bool mail_bar = false;                 // the host writes dMail itself through the PCIe BAR (no relay group, no hMail)
+  MailPair* dMail = nullptr;             // mailbox of the resident acquisition kernel, in device memory
+  bool mail_bar = false;                 // the host can write dMail itself through the PCIe BAR (the resident mode needs it)
   MailPair* dPairs = nullptr;            // its partial records as (value, tag) pairs: 32 queries x 32 slabs
   bool opt_resident = true;             // PCABO_OPT_RESIDENT: may pcabo_optimize_acqf use the resident acquisition kernel
   bool opt_group_acq = false;           // PCABO_OPT_GROUP_ACQ: gradient evaluations through k_acq_group (throughput variant)
@@ -130,7 +130,8 @@ struct pcabo_ctx {
   std::vector<ProfPair> pairs;
   size_t pairs_used = 0;
   double prof_ms[PROF_GROUPS] = {0};
-  double prof_pair_ms = 0.0;             // event-pair reading of an empty kernel (calibrated when profiling is enabled)
+  double prof_pair_ms = 0.0;             // reading of two events recorded back to back (calibrated when profiling is enabled)
+  double prof_empty_ms = 0.0;            // reading of an event pair around an empty kernel
   int64_t prof_launches[PROF_GROUPS] = {0};
   double prof_bytes[PROF_GROUPS] = {0}, prof_flops[PROF_GROUPS] = {0};
 };
@@ -201,9 +202,7 @@ static int set_err(pcabo_ctx* c, int code, const char* fmt, const char* a = "", 
 // runtime's short active-wait window; it then comes back late and cold (measured: the first ~0.15 ms of host work after a
 // 0.2 ms wait ran several times slower).  The waits of a BO iteration are 0.1-0.4 ms, so they poll instead, and only a
 // wait that lasts longer than 2 ms falls back to the blocking call.
-static const bool g_blocking_waits = getenv("PCABO_BLOCKING_WAITS") != nullptr;      // A/B switch
 static hipError_t wait_stream(hipStream_t s) {
-  if (g_blocking_waits) return hipStreamSynchronize(s);
   const auto t0 = std::chrono::steady_clock::now();
   for (unsigned spins = 1;; ++spins) {
     hipError_t e = hipStreamQuery(s);
@@ -214,7 +213,6 @@ static hipError_t wait_stream(hipStream_t s) {
   return hipStreamSynchronize(s);
 }
 static hipError_t wait_event(hipEvent_t ev) {
-  if (g_blocking_waits) return hipEventSynchronize(ev);
   const auto t0 = std::chrono::steady_clock::now();
   for (unsigned spins = 1;; ++spins) {
     hipError_t e = hipEventQuery(ev);
@@ -230,7 +228,8 @@ static hipError_t wait_event(hipEvent_t ev) {
 // DEVICE mailbox itself (16-byte stores, write-combined, one sfence) and the relay work-group that used to fetch them
 // from pinned host memory over PCIe has nothing to do: 5.5 -> 4.6 us per round trip in profiles/tools/bar_mailbox_rtt.hip.
 // Used when the device reports a large BAR, the process maps the mailbox read-write (/proc/self/maps - no store is tried
-// otherwise, no fault is caught) AND a probe store is read back from the device (PCABO_MAIL_BAR=0 switches it off).
+// otherwise, no fault is caught) AND a probe store is read back from the device.  Without it there is no resident mode
+// (round 1's relay work-group, which fetched the pairs from pinned host memory, is gone): one launch per evaluation.
 static inline void put_mail_pair(MailPair* dst, double v, unsigned long long seq) {
   unsigned long long vb; memcpy(&vb, &v, 8);
   const __m128i x = _mm_set_epi64x((long long)(seq ^ mail_mix(vb)), (long long)vb);
@@ -255,8 +254,6 @@ static bool host_mapping_writable(const void* p, size_t len) {
   return ok;
 }
 static bool mail_bar_usable(pcabo_ctx* ctx) {
-  const char* e = getenv("PCABO_MAIL_BAR");
-  if (e && atoi(e) == 0) return false;
   int large = 0;
   if (hipDeviceGetAttribute(&large, hipDeviceAttributeIsLargeBar, ctx->device) != hipSuccess) { (void)hipGetLastError(); large = 0; }
   if (!large) return false;
@@ -421,8 +418,6 @@ static int ctx_setup(pcabo_ctx* ctx, int device, int max_n, int max_d, int max_q
   if (!dreg) {
     // zero: the per-query tickets, the padded tail of y_s, and R (its blocks above the diagonal stay zero for good)
     HIPCHK(hipMemsetAsync(ctx->dRegion, 0, ctx->region_bytes, ctx->stream));
-    HIPCHK(hipHostMalloc((void**)&ctx->hMail, PCABO_MAIL_PAIRS * sizeof(MailPair), hipHostMallocMapped | hipHostMallocCoherent));
-    memset(ctx->hMail, 0, PCABO_MAIL_PAIRS * sizeof(MailPair));
     if (hipExtMallocWithFlags((void**)&ctx->dMail, PCABO_MAIL_PAIRS * sizeof(MailPair), hipDeviceMallocFinegrained) != hipSuccess) {
       (void)hipGetLastError();
       HIPCHK(dalloc(&ctx->dMail, PCABO_MAIL_PAIRS));
@@ -455,7 +450,6 @@ static void ctx_teardown(pcabo_ctx* ctx) {
     if (ctx->hRegion) (void)hipHostFree(ctx->hRegion);
     if (ctx->dMail) (void)hipFree(ctx->dMail);
     if (ctx->dPairs) (void)hipFree(ctx->dPairs);
-    if (ctx->hMail) (void)hipHostFree((void*)ctx->hMail);
   }
   if (ctx->evBounds) (void)hipEventDestroy(ctx->evBounds);
   if (ctx->evPca) (void)hipEventDestroy(ctx->evPca);
@@ -815,8 +809,7 @@ static int eval_staged(pcabo_ctx* ctx, int nq, AcqParams& p, bool allow_gemm = t
     xdev = ctx->dXq;
   }
   const bool small = nq <= PCABO_INLAUNCH_MAXQ;   // in-launch combine + host flag; larger batches: two launches + copy
-  static const bool gemm_env = !(getenv("PCABO_SCORE_GEMM") && atoi(getenv("PCABO_SCORE_GEMM")) == 0);
-  if (!small && !p.want_grad && gemm_env && allow_gemm && score_gemm_possible(nq)) {
+  if (!small && !p.want_grad && allow_gemm && score_gemm_possible(nq)) {
     // value-only scoring of a large batch (the raw samples): V = R KS^T on MFMA
     if (!xdev) {
       HIPCHK(hipMemcpyAsync(ctx->dXq, ctx->hXq, (size_t)nq * k * sizeof(double), hipMemcpyHostToDevice, s));
@@ -974,11 +967,11 @@ int pcabo_logei(pcabo_ctx* ctx, const double* Xq, int q, double best_f, int maxi
 // whatever is left in hXq), then one control pair per query (1 = evaluate, 0 = leave for good).  A pair leaves in one 16-byte store and
 // its tag is mixed with the value's bits (mail_mix), so a reader never takes a value that does not belong to its tag.
 static void server_post(pcabo_ctx* ctx, int cap, int nq, int k, unsigned long long tag) {
-  MailPair* m = ctx->mail_bar ? ctx->dMail : ctx->hMail;       // device memory through the BAR, or the pinned copy
+  MailPair* m = ctx->dMail;                                    // device memory, through the PCIe BAR
   const int np = cap * k;
   for (int i = 0; i < np; ++i) put_mail_pair(m + 1 + i, ctx->hXq[i], tag);
   for (int q = 0; q < cap; ++q) put_mail_pair(m + 1 + np + q, q < nq ? 1.0 : 0.0, tag);     // control pairs: evaluate / leave
-  if (ctx->mail_bar) _mm_sfence();                             // flush the write-combining buffers now
+  _mm_sfence();                                                // flush the write-combining buffers now
 }
 static int server_wait(pcabo_ctx* ctx, int nq, unsigned long long tag) {
   const auto t0 = std::chrono::steady_clock::now();
@@ -1009,7 +1002,6 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
   HIPCHK(hipSetDevice(ctx->device));
   const int k = ctx->k;
   const int ngroups = (num_restarts + batch_limit - 1) / batch_limit;
-  const auto t_enter = std::chrono::steady_clock::now();
   std::vector<Lbfgsb> opt(ngroups);
   std::vector<int> gstart(ngroups), gsize(ngroups), niter(ngroups, 0), nfev(ngroups, 0);
   std::vector<char> active(ngroups, 1);     // char, not vector<bool>: groups are touched from two threads
@@ -1033,8 +1025,6 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
   }
   AcqParams p = make_params(ctx, best_f, maximize, acq, 1);
   const int maxfun = 15000;
-  static const bool trace = getenv("PCABO_TRACE_OPT") != nullptr;
-  double t_step = 0.0, t_eval = 0.0; int rounds = 0;
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   int any_failed = 0;
   // advance one group's state machine until it needs f,g at x[gi] (or stops)
@@ -1095,7 +1085,6 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
     ~ServerStop() { stop(); }
   } server_stop{ctx, srv_cap, k};
   while (true) {
-    const double ta = trace ? now() : 0.0;
     ++round_no;
     unsigned tickets[8] = {0};
     for (size_t i = 0; i < hs.size(); ++i) {
@@ -1114,22 +1103,20 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
       nq += gsize[gi];
     }
     if (nq == 0) break;
-    const double tb = trace ? now() : 0.0;
     int rc;
     if (round_no == 1 && (ctx->alone_age++ & 7) == 0) ctx->alone = presence_alone(ctx->device);
     // several contexts in ONE process (one run per host thread, or a batch next to a single run): their resident kernels
     // would each want most of the chip at the same time - one launch per evaluation then, which interleaves well
     const bool only_context_here = presence_local_contexts(ctx->device) == 1;
     if (round_no == 1 && ctx->srv_penalty > 0) --ctx->srv_penalty;
-    else if (round_no == 1 && ctx->opt_resident && !ctx->opt_group_acq && ctx->alone && only_context_here && !ctx->prof && acq_server_possible(nq, ctx->n, k, ctx->NP)) {
+    else if (round_no == 1 && ctx->opt_resident && ctx->mail_bar && !ctx->opt_group_acq && ctx->alone && only_context_here && !ctx->prof && acq_server_possible(nq, ctx->n, k, ctx->NP)) {
       // the evaluations of this call go to ONE resident launch (see k_acq_fast): no launch and no operand refill per round
       srv_cap = nq;
       launch_acq(ctx->stream, nullptr, nullptr, srv_cap, ctx->n, k, ctx->NP, ctx->ld, ctx->dZnT, ctx->dR, ctx->dAlpha,
                  ctx->dBounds4, ctx->dYstats, p, ctx->dPartial, ctx->dCounters, ctx->dVal, ctx->dGrad, ctx->hVal, ctx->hGrad,
-                 ctx->hm, ctx->seq + 1, ctx->mail_bar ? nullptr : ctx->hMail, ctx->dMail, ctx->dPairs);
+                 ctx->hm, ctx->seq + 1, ctx->dMail, ctx->dPairs);
       HIPCHK(hipGetLastError());
-      static const bool free_env = !(getenv("PCABO_FREE_GROUPS") && atoi(getenv("PCABO_FREE_GROUPS")) == 0);
-      if (free_env && ctx->mail_bar && ngroups == 2 && active[0] && active[1] && nq == num_restarts) {
+      if (ngroups == 2 && active[0] && active[1] && nq == num_restarts) {
         // ---- the two restart groups free of each other ------------------------------------------------------------
         // Each group has its own slots, control pairs and round counter in the mailbox, so each host thread drives its
         // own group (post - wait - L-BFGS-B step) without meeting the other: a round no longer waits for the slower of
@@ -1187,18 +1174,13 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
           left[gi] = 1;
           used[gi] = r + 1;
         };
-        static const bool fdbg = getenv("PCABO_FREE_DEBUG") != nullptr;
-        if (fdbg) fprintf(stderr, "[free] enter n=%d k=%d cap=%d seq0=%llx\n", ctx->n, k, cap, seq0);
         hp.fn = [&] { free_loop(1); };                 // the helper is idle here (its ticket of this round is done)
         const unsigned fticket = hp.go.load(std::memory_order_relaxed) + 1;
         hp.go.store(fticket, std::memory_order_release);
         free_loop(0);
-        if (fdbg) fprintf(stderr, "[free] main loop done r=%llu timed_out=%d\n", used[0], timed_out[0]);
         while (hp.done.load(std::memory_order_acquire) != fticket) __builtin_ia32_pause();
-        if (fdbg) fprintf(stderr, "[free] helper done r=%llu timed_out=%d\n", used[1], timed_out[1]);
         hp.fn = [&] { for (int gi = 1; gi < ngroups; gi += T) advance(gi); };
         HIPCHK(hipStreamSynchronize(ctx->stream));      // every group of the grid has been told to leave
-        if (fdbg) fprintf(stderr, "[free] kernel gone\n");
         ctx->seq = seq0 + std::max(used[0], used[1]) + 1;
         srv_cap = 0;
         if (got_nan[0] || got_nan[1]) return set_err(ctx, PCABO_ERR_NAN, "NaN in acquisition gradient%s", "");
@@ -1231,7 +1213,6 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
       rc = eval_staged(ctx, nq, p);
     }
     if (rc != PCABO_OK) return rc;
-    if (trace) { const double tc = now(); t_step += tb - ta; t_eval += tc - tb; ++rounds; }
     for (int gi = 0; gi < ngroups; ++gi) {
       if (qoff[gi] < 0) continue;
       double fs = 0.0;
@@ -1250,7 +1231,6 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
     }
   }
   server_stop.stop();
-  const double t_loop_end = trace ? now() : 0.0;
   // final clamp and acquisition values at the candidates (no gradient)
   for (int gi = 0; gi < ngroups; ++gi) {
     for (int t = 0; t < gsize[gi] * k; ++t) {
@@ -1282,12 +1262,6 @@ int pcabo_optimize_acqf(pcabo_ctx* ctx, const double* ics, int num_restarts, int
     for (int j = 0; j < num_restarts; ++j) vals[j] = ctx->hVal[j];
   }
   if (failed) *failed = any_failed;
-  if (trace) {
-    const double t0 = std::chrono::duration<double>(t_enter.time_since_epoch()).count();
-    fprintf(stderr, "[pcabo] optimize: rounds %d, host L-BFGS-B %.1f us/round, eval %.1f us/round (n=%d k=%d) total %.0f us, "
-            "after loop %.0f us\n", rounds, 1e6 * t_step / std::max(1, rounds), 1e6 * t_eval / std::max(1, rounds), ctx->n,
-            ctx->k, 1e6 * (now() - t0), 1e6 * (now() - t_loop_end));
-  }
   return PCABO_OK;
 }
 
@@ -1372,6 +1346,8 @@ int pcabo_lbfgsb_minimize(int nvar, double* x, const double* lower, const double
   return opt.warnflag();
 }
 
+int pcabo_lbfgsb_set_vector_kernels(int enabled) { return lbfgsb_set_vector_kernels(enabled); }
+
 int pcabo_sobol_scramble(int64_t* state, const int64_t* ltm, int k) {
   if (!state || !ltm || k < 1) return PCABO_ERR_ARG;
   const int MAXBIT = 30;
@@ -1454,10 +1430,16 @@ int pcabo_set_profiling(pcabo_ctx* ctx, int enabled) {
       if (!r.empty()) { std::sort(r.begin(), r.end()); med[mode] = r[r.size() / 2]; }
     }
     ctx->prof_pair_ms = med[0];
-    static const bool trace = getenv("PCABO_TRACE_OPT") != nullptr;
-    if (trace) fprintf(stderr, "[pcabo] profiling: back-to-back event pair reads %.2f us, around an empty kernel %.2f us\n", 1e3 * med[0], 1e3 * med[1]);
+    ctx->prof_empty_ms = med[1];
   }
   ctx->prof = enabled != 0;
+  return PCABO_OK;
+}
+
+int pcabo_get_profile_calibration(pcabo_ctx* ctx, double* pair_ms, double* empty_kernel_ms) {
+  if (!ctx) return PCABO_ERR_ARG;
+  if (pair_ms) *pair_ms = ctx->prof_pair_ms;
+  if (empty_kernel_ms) *empty_kernel_ms = ctx->prof_empty_ms;
   return PCABO_OK;
 }
 
@@ -1590,7 +1572,6 @@ struct GangPool {
   }
 };
 
-#define PCABO_BATCH_MAXSPLIT 4
 struct pcabo_batch {
   int device = 0, B = 0, max_n = 0, max_d = 0, max_q = 0;
   hipStream_t stream = nullptr;
@@ -1606,8 +1587,7 @@ struct pcabo_batch {
   int gcur = 0, vprev_d = 0;             // eigenvector ping-pong of ALL runs (they advance together)
   int cnt_S = 0; bool cnt_dirty = true;
   bool prof = false; hipEvent_t pev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // phase marks of the last conditioning
-  int split = 1;                         // halves per gang that take turns (PCABO_BATCH_SPLIT)
-  bool group_acq = true;                 // L-BFGS-B rounds through k_acq_group (PCABO_BATCH_ACQ=slab: the per-query kernels)
+  bool group_acq = true;                 // L-BFGS-B rounds through k_acq_group (pcabo_batch_set_option(PCABO_OPT_GROUP_ACQ, 0): the per-query kernels)
   int G = 0;                             // gangs = worker threads of the L-BFGS-B phase
   std::vector<hipStream_t> gstream;
   GangPool pool;
@@ -1687,15 +1667,12 @@ int pcabo_batch_create(int device, int B, int max_n, int max_d, int max_q, pcabo
   // worker threads of the L-BFGS-B phase: one gang of runs per thread, a HIP stream per gang
   // (hardware_concurrency reports the host, not this process's share of it: a GPU of a shared node comes with ~16 cores,
   // and every worker spins while it waits - 8 by default)
-  int T = std::min(8, (int)std::thread::hardware_concurrency() - 2);
-  if (const char* e = getenv("PCABO_BATCH_THREADS")) T = atoi(e);
+  int T = std::min(8, (int)std::thread::hardware_concurrency() - 2);        // (pcabo_batch_set_workers changes it)
   T = std::max(1, std::min(T, std::min(B, 32)));
   batch->G = T;
-  if (const char* e = getenv("PCABO_BATCH_SPLIT")) batch->split = std::max(1, std::min(atoi(e), PCABO_BATCH_MAXSPLIT));
-  batch->gstream.assign((size_t)T * PCABO_BATCH_MAXSPLIT, nullptr);
+  batch->gstream.assign((size_t)T, nullptr);
   for (size_t g = 0; g < batch->gstream.size(); ++g) BHIPCHK(hipStreamCreateWithFlags(&batch->gstream[g], hipStreamNonBlocking));
   batch->pool.start(T);
-  if (const char* e = getenv("PCABO_BATCH_ACQ")) batch->group_acq = strcmp(e, "slab") != 0;
   for (pcabo_ctx* c : batch->ctx) c->opt_group_acq = batch->group_acq;      // a run's single-context calls match its batch
   batch->seq.store(((unsigned long long)(getpid() & 0xffff) << 44) + (1ull << 43));
   return PCABO_OK;
@@ -1718,10 +1695,21 @@ int pcabo_batch_set_workers(pcabo_batch* batch, int workers) {
   batch->pool.shutdown();
   BHIPCHK(hipStreamSynchronize(batch->stream));
   for (hipStream_t& s : batch->gstream) if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); s = nullptr; }
-  batch->gstream.assign((size_t)T * PCABO_BATCH_MAXSPLIT, nullptr);
+  batch->gstream.assign((size_t)T, nullptr);
   for (size_t g = 0; g < batch->gstream.size(); ++g) BHIPCHK(hipStreamCreateWithFlags(&batch->gstream[g], hipStreamNonBlocking));
   batch->G = T;
   batch->pool.start(T);
+  return PCABO_OK;
+}
+
+// PCABO_OPT_GROUP_ACQ (default 1): the L-BFGS-B rounds of the batch go through the throughput kernel k_acq_group; 0: through
+// the per-query kernels a single context uses by default (same formulas, another summation order) - with it a run of the batch
+// is bit-identical to the same run in a stand-alone context with default options.  Not during a call on this batch.
+int pcabo_batch_set_option(pcabo_batch* batch, int option, int value) {
+  if (!batch) return PCABO_ERR_ARG;
+  if (option != PCABO_OPT_GROUP_ACQ) return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_set_option: unknown option %s%d", "", option);
+  batch->group_acq = value != 0;
+  for (pcabo_ctx* c : batch->ctx) c->opt_group_acq = batch->group_acq;
   return PCABO_OK;
 }
 
@@ -1920,13 +1908,12 @@ int pcabo_batch_gp_condition_end_eval(pcabo_batch* batch, const double* Xq, int 
   if (rc != PCABO_OK) return rc;
   AcqParams p = make_params(c0, 0.0, maximize, acq, 0);
   p.inv_ls = 1.0 / batch->lengthscale; p.kernel = batch->kernel;
-  static const bool gemm_env = !(getenv("PCABO_SCORE_GEMM") && atoi(getenv("PCABO_SCORE_GEMM")) == 0);
-  if (gemm_env && score_gemm_possible(q))
+  if (score_gemm_possible(q))
     launch_score(s, c0->dXq, q, batch->n, kmax, batch->NP, c0->ld, c0->dZnT, c0->dR, c0->dAlpha, c0->dBounds4, c0->dYstats, p,
                  c0->dKS, c0->dPartial, c0->dVal, batch_ab(batch, 0, 0), B);
   else
     launch_acq(s, nullptr, c0->dXq, q, batch->n, kmax, batch->NP, c0->ld, c0->dZnT, c0->dR, c0->dAlpha, c0->dBounds4, c0->dYstats,
-               p, c0->dPartial, c0->dCounters, c0->dVal, c0->dGrad, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr,
+               p, c0->dPartial, c0->dCounters, c0->dVal, c0->dGrad, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
                batch_ab(batch, 0, 0), B, 0);
   BHIPCHK(hipMemcpy2DAsync(c0->hVal, batch->hzs, c0->dVal, batch->zs, (size_t)q * sizeof(double), B, hipMemcpyDeviceToHost, s));
   BHIPCHK(wait_stream(s));
@@ -2005,108 +1992,68 @@ int pcabo_batch_optimize_acqf(pcabo_batch* batch, const double* ics, int num_res
     for (int b = g; b < B; b += G) if (run_status[b] == PCABO_OK) mine.push_back(b);
     struct Pending { int b, gi; };
     const bool use_group = batch->group_acq && batch_limit <= PCABO_GROUP_Q && acq_group_possible(batch->NP, kmax);
-    // The gang's runs are split into `H` halves that take turns: while the kernel of one half is in flight, the host
-    // steps the L-BFGS-B state machines of the other and launches it (its own stream) - a round of a half costs
-    // max(kernel latency, host steps of the other halves) instead of their sum.
-    struct Half {
-      std::vector<int> runs; QueryArgs tab; int nent = 0; std::vector<Pending> pend; unsigned long long seq = 0;
-      bool inflight = false, done = false; hipStream_t st = nullptr;
-    };
-    const int H = std::max(1, std::min(batch->split, (int)mine.size()));
-    std::vector<Half> halves(H);
-    for (size_t i = 0; i < mine.size(); ++i) halves[i % H].runs.push_back(mine[i]);
-    // (streams are handed to hardware queues in creation order: consecutive indices for the gangs, so that gangs that run at
-    // the same time do not share a queue - kernels in one queue run one after the other)
-    for (int h = 0; h < H; ++h) halves[h].st = batch->gstream[(size_t)h * G + g];
-    auto flags_ready = [&](const Half& hf) -> bool {
-      const unsigned* e2 = reinterpret_cast<const unsigned*>(hf.tab.x);
-      for (int e = 0; e < hf.nent; ++e) {
-        const pcabo_ctx* c = batch->ctx[e2[e] >> 16];
+    hipStream_t st = batch->gstream[g];
+    QueryArgs tab;                                   // the round's launch table (travels in the kernel arguments)
+    unsigned* ent = reinterpret_cast<unsigned*>(tab.x);
+    std::vector<Pending> pend;
+    auto flags_ready = [&](int nent, unsigned long long seq) -> bool {
+      for (int e = 0; e < nent; ++e) {
+        const pcabo_ctx* c = batch->ctx[ent[e] >> 16];
         if (use_group) {
-          const int q0 = (int)((e2[e] >> 8) & 0xffu), nqe = (int)(e2[e] & 0xffu);
-          for (int j = 0; j < nqe; ++j) if (__atomic_load_n(&c->hm->qflag[q0 + j], __ATOMIC_ACQUIRE) != hf.seq) return false;
-        } else if (__atomic_load_n(&c->hm->qflag[e2[e] & 0xffffu], __ATOMIC_ACQUIRE) != hf.seq) return false;
+          const int q0 = (int)((ent[e] >> 8) & 0xffu), nqe = (int)(ent[e] & 0xffu);
+          for (int j = 0; j < nqe; ++j) if (__atomic_load_n(&c->hm->qflag[q0 + j], __ATOMIC_ACQUIRE) != seq) return false;
+        } else if (__atomic_load_n(&c->hm->qflag[ent[e] & 0xffffu], __ATOMIC_ACQUIRE) != seq) return false;
       }
       return true;
     };
-    int remaining = H;
-    auto t_last = std::chrono::steady_clock::now();
-    unsigned long idle = 0;
-    static const bool btrace = getenv("PCABO_BATCH_TRACE") != nullptr;
-    double tr_step = 0.0, tr_launch = 0.0, tr_total = 0.0; long tr_launches = 0, tr_entries = 0;
-    auto nowd = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double tr_t0 = btrace ? nowd() : 0.0;
-    while (remaining > 0) {
-      bool progressed = false;
-      for (Half& hf : halves) {
-        if (hf.done) continue;
-        if (hf.inflight) {
-          if (!flags_ready(hf)) continue;
-          for (const Pending& pe : hf.pend) {
-            pcabo_ctx* c = batch->ctx[pe.b];
-            if (!groups[pe.b][pe.gi].absorb(c->hVal, c->hGrad)) {
-              run_status[pe.b] = PCABO_ERR_NAN;
-              set_err(c, PCABO_ERR_NAN, "NaN in acquisition gradient%s", "");
-            }
-          }
-          hf.inflight = false;
-          progressed = true;
+    for (;;) {
+      // step every active restart group of the gang to its next evaluation point
+      pend.clear();
+      int nent = 0;
+      for (int b : mine) {
+        if (run_status[b] != PCABO_OK) continue;
+        pcabo_ctx* c = batch->ctx[b];
+        for (int gi = 0; gi < ngroups; ++gi) {
+          RestartGroup& rg = groups[b][gi];
+          if (!rg.active) continue;
+          rg.advance();
+          if (!rg.active) continue;
+          memcpy(c->hXq + (size_t)rg.q0 * c->k, rg.x.data(), (size_t)rg.nq * c->k * sizeof(double));
+          if (use_group) ent[nent++] = ((unsigned)b << 16) | ((unsigned)rg.q0 << 8) | (unsigned)rg.nq;
+          else for (int j = 0; j < rg.nq; ++j) ent[nent++] = ((unsigned)b << 16) | (unsigned)(rg.q0 + j);
+          pend.push_back({b, gi});
         }
-        unsigned* he = reinterpret_cast<unsigned*>(hf.tab.x);
-        hf.pend.clear();
-        hf.nent = 0;
-        const double tr_a = btrace ? nowd() : 0.0;
-        for (int b : hf.runs) {
-          if (run_status[b] != PCABO_OK) continue;
-          pcabo_ctx* c = batch->ctx[b];
-          for (int gi = 0; gi < ngroups; ++gi) {
-            RestartGroup& rg = groups[b][gi];
-            if (!rg.active) continue;
-            rg.advance();
-            if (!rg.active) continue;
-            memcpy(c->hXq + (size_t)rg.q0 * c->k, rg.x.data(), (size_t)rg.nq * c->k * sizeof(double));
-            if (use_group) he[hf.nent++] = ((unsigned)b << 16) | ((unsigned)rg.q0 << 8) | (unsigned)rg.nq;
-            else for (int j = 0; j < rg.nq; ++j) he[hf.nent++] = ((unsigned)b << 16) | (unsigned)(rg.q0 + j);
-            hf.pend.push_back({b, gi});
-          }
-        }
-        progressed = true;
-        const double tr_b = btrace ? nowd() : 0.0;
-        tr_step += tr_b - tr_a;
-        if (hf.nent == 0) { hf.done = true; --remaining; continue; }
-        hf.seq = batch->seq.fetch_add(1) + 1;
-        if (use_group) {
-          launch_acq_group(hf.st, &hf.tab, hf.nent, c0->hXq, batch->n, kmax, batch->NP, c0->ld, c0->dZnT, c0->dR, c0->dAlpha,
-                           c0->dBounds4, c0->dYstats, pg, c0->dPartial, c0->dCounters + PCABO_GROUP_CNT_OFFSET, c0->dVal,
-                           c0->dGrad, c0->hVal, c0->hGrad, c0->hm, hf.seq, batch_ab(batch, 1, 1));
-        } else {
-          launch_acq(hf.st, &hf.tab, c0->hXq, PCABO_INLAUNCH_MAXQ, batch->n, kmax, batch->NP, c0->ld, c0->dZnT, c0->dR,
-                     c0->dAlpha, c0->dBounds4, c0->dYstats, pg, c0->dPartial, c0->dCounters, c0->dVal, c0->dGrad, c0->hVal,
-                     c0->hGrad, c0->hm, hf.seq, nullptr, nullptr, nullptr, batch_ab(batch, 1, 1), B, hf.nent);
-        }
-        if (hipGetLastError() != hipSuccess) { hip_failed.store(1); return; }
-        hf.inflight = true;
-        if (btrace) { tr_launch += nowd() - tr_b; ++tr_launches; tr_entries += hf.nent; }
       }
-      if (progressed) { t_last = std::chrono::steady_clock::now(); idle = 0; }
-      else if ((++idle & 0xFFFF) == 0 &&
-               std::chrono::duration<double>(std::chrono::steady_clock::now() - t_last).count() > 20.0) {
-        hip_failed.store(1); return;                         // a launch did not publish its results
+      if (nent == 0) break;
+      const unsigned long long seq = batch->seq.fetch_add(1) + 1;
+      if (use_group) {
+        launch_acq_group(st, &tab, nent, c0->hXq, batch->n, kmax, batch->NP, c0->ld, c0->dZnT, c0->dR, c0->dAlpha,
+                         c0->dBounds4, c0->dYstats, pg, c0->dPartial, c0->dCounters + PCABO_GROUP_CNT_OFFSET, c0->dVal,
+                         c0->dGrad, c0->hVal, c0->hGrad, c0->hm, seq, batch_ab(batch, 1, 1));
+      } else {
+        launch_acq(st, &tab, c0->hXq, PCABO_INLAUNCH_MAXQ, batch->n, kmax, batch->NP, c0->ld, c0->dZnT, c0->dR,
+                   c0->dAlpha, c0->dBounds4, c0->dYstats, pg, c0->dPartial, c0->dCounters, c0->dVal, c0->dGrad, c0->hVal,
+                   c0->hGrad, c0->hm, seq, nullptr, nullptr, batch_ab(batch, 1, 1), B, nent);
+      }
+      if (hipGetLastError() != hipSuccess) { hip_failed.store(1); return; }
+      const auto t0 = std::chrono::steady_clock::now();
+      for (unsigned long spins = 1; !flags_ready(nent, seq); ++spins) {
+        if ((spins & 0xFFFF) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 20.0) {
+          hip_failed.store(1); return;                       // the launch did not publish its results
+        }
+      }
+      for (const Pending& pe : pend) {
+        pcabo_ctx* c = batch->ctx[pe.b];
+        if (!groups[pe.b][pe.gi].absorb(c->hVal, c->hGrad)) {
+          run_status[pe.b] = PCABO_ERR_NAN;
+          set_err(c, PCABO_ERR_NAN, "NaN in acquisition gradient%s", "");
+        }
       }
     }
-    if (btrace) {
-      tr_total = nowd() - tr_t0;
-      fprintf(stderr, "[pcabo batch] gang %d: %zu runs, %ld launches (%.1f entries each), host steps %.2f ms, launch calls %.2f ms, "
-              "waiting %.2f ms of %.2f ms\n", g, mine.size(), tr_launches, tr_launches ? (double)tr_entries / tr_launches : 0.0,
-              1e3 * tr_step, 1e3 * tr_launch, 1e3 * (tr_total - tr_step - tr_launch), 1e3 * tr_total);
-    }
-    hipStream_t st = halves[0].st;
-    QueryArgs& tab = halves[0].tab;
-    unsigned* ent = reinterpret_cast<unsigned*>(tab.x);
     auto launch_and_wait = [&](int nent, const AcqParams& p, unsigned long long seq) -> bool {
       launch_acq(st, &tab, c0->hXq, PCABO_INLAUNCH_MAXQ, batch->n, kmax, batch->NP, c0->ld, c0->dZnT, c0->dR, c0->dAlpha,
                  c0->dBounds4, c0->dYstats, p, c0->dPartial, c0->dCounters, c0->dVal, c0->dGrad, c0->hVal, c0->hGrad, c0->hm,
-                 seq, nullptr, nullptr, nullptr, batch_ab(batch, 1, 1), B, nent);
+                 seq, nullptr, nullptr, batch_ab(batch, 1, 1), B, nent);
       if (hipGetLastError() != hipSuccess) return false;
       const auto t0 = std::chrono::steady_clock::now();
       unsigned long spins = 0;

@@ -191,7 +191,7 @@ void launch_acq(hipStream_t s, const QueryArgs* qa, const double* Xq, int q, int
                 const double* ZnT, const double* R, const double* alpha, const double* bounds4, const double* ystats,
                 AcqParams p, double* partial, unsigned int* counters, double* val,
                 double* grad, double* host_val, double* host_grad, HostMirror* hm, unsigned long long seq,
-                const MailPair* host_mail = nullptr, MailPair* dev_mail = nullptr, MailPair* part_pairs = nullptr,
+                MailPair* dev_mail = nullptr, MailPair* part_pairs = nullptr,
                 AcqBatch ab = AcqBatch(), int B = 1, int table_entries = 0);
 // throughput variant: one work-group per (restart group of <= 5 queries, 64-row slab); `tab` holds `entries` 32-bit words
 // run << 16 | first query << 8 | count (see k_acq_group)

@@ -48,11 +48,12 @@ EXPORTS = [
     "pcabo_gp_condition_end", "pcabo_gp_condition_end_eval", "pcabo_wpca_gp_condition_begin", "pcabo_wpca_results",
     "pcabo_acq_bounds",
     "pcabo_acq_eval", "pcabo_logei", "pcabo_optimize_acqf", "pcabo_inverse_map", "pcabo_get_gp_state",
-    "pcabo_get_gram", "pcabo_lbfgsb_minimize", "pcabo_sobol_scramble", "pcabo_sobol_draw", "pcabo_set_profiling", "pcabo_get_profile", "pcabo_reset_profile",
+    "pcabo_get_gram", "pcabo_lbfgsb_minimize", "pcabo_lbfgsb_set_vector_kernels", "pcabo_sobol_scramble", "pcabo_sobol_draw", "pcabo_set_profiling",
+    "pcabo_get_profile", "pcabo_get_profile_calibration", "pcabo_reset_profile",
     "pcabo_batch_create", "pcabo_batch_destroy", "pcabo_batch_last_error", "pcabo_batch_ctx",
     "pcabo_batch_wpca_gp_condition_begin", "pcabo_batch_wpca_results", "pcabo_batch_acq_bounds",
     "pcabo_batch_gp_condition_end_eval", "pcabo_batch_optimize_acqf", "pcabo_batch_inverse_map",
-    "pcabo_batch_set_profiling", "pcabo_batch_get_profile", "pcabo_batch_set_active", "pcabo_batch_set_workers",
+    "pcabo_batch_set_profiling", "pcabo_batch_get_profile", "pcabo_batch_set_active", "pcabo_batch_set_workers", "pcabo_batch_set_option",
     "pcabo_bbob_table_doubles", "pcabo_bbob_create", "pcabo_bbob_destroy", "pcabo_bbob_eval",
 ]
 
@@ -107,9 +108,12 @@ def _load() -> C.CDLL:
     lib.pcabo_set_profiling.argtypes = [vp, C.c_int]
     lib.pcabo_get_profile.argtypes = [vp, C.c_int, dp, C.POINTER(C.c_int64), dp, dp]
     lib.pcabo_reset_profile.argtypes = [vp]
+    lib.pcabo_get_profile_calibration.argtypes = [vp, dp, dp]
+    lib.pcabo_lbfgsb_set_vector_kernels.argtypes = [C.c_int]
     lib.pcabo_batch_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     lib.pcabo_batch_destroy.argtypes = [vp]
     lib.pcabo_batch_set_workers.argtypes = [vp, C.c_int]
+    lib.pcabo_batch_set_option.argtypes = [vp, C.c_int, C.c_int]
     lib.pcabo_batch_last_error.argtypes = [vp, C.c_char_p, C.c_int]
     lib.pcabo_batch_ctx.argtypes = [vp, C.c_int]
     lib.pcabo_batch_wpca_gp_condition_begin.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
@@ -341,6 +345,13 @@ class Context:
             out[name] = {"ms": ms.value, "launches": cnt.value, "bytes": by.value, "flops": fl.value}
         return out
 
+    def profile_calibration(self) -> dict:
+        """Milliseconds an event pair reads with nothing in between (subtracted from every profiled pair) and around an
+        empty kernel - medians of 64, taken when profiling was switched on."""
+        a, b = C.c_double(0), C.c_double(0)
+        self._chk(LIB.pcabo_get_profile_calibration(self._h, C.byref(a), C.byref(b)))
+        return {"pair_ms": a.value, "empty_kernel_ms": b.value}
+
 
 class _BorrowedContext(Context):
     """Run b's context inside a Batch: every single-context call works on it; the batch owns and frees it."""
@@ -358,7 +369,8 @@ class Batch:
     """B per-run contexts advancing in lock-step (pcabo_batch_* of include/pcabo.h): one launch sequence for the
     rows A-H of all runs, one scoring launch, shared acquisition launches for the L-BFGS-B rounds of all runs."""
 
-    def __init__(self, B: int, max_n: int, max_d: int, max_q: int = 512, device: int = 0, workers: int = 0):
+    def __init__(self, B: int, max_n: int, max_d: int, max_q: int = 512, device: int = 0, workers: int = 0,
+                 group_acq: bool = True):
         self._h = C.c_void_p()
         rc = LIB.pcabo_batch_create(int(device), int(B), int(max_n), int(max_d), int(max_q), C.byref(self._h))
         if rc != 0:
@@ -373,6 +385,8 @@ class Batch:
         self.ctx = [_BorrowedContext(LIB.pcabo_batch_ctx(self._h, b), max_n, max_d, max_q, device) for b in range(B)]
         if workers:
             self.set_workers(workers)
+        if not group_acq:            # L-BFGS-B rounds through the per-query kernels (a stand-alone context's default)
+            self._chk(LIB.pcabo_batch_set_option(self._h, OPT_GROUP_ACQ, 0))
         advice = hw_queues_advice(min(B, int(workers) if workers else 8) + 2)      # gang streams + the batch's + the default stream
         if advice:
             import warnings
@@ -513,6 +527,11 @@ def sobol_draw(state: np.ndarray, shift: np.ndarray, n: int, lo=None, rng=None) 
     if rc != 0:
         raise PcaboError(rc, "pcabo_sobol_draw: bad argument")
     return out
+
+
+def lbfgsb_set_vector_kernels(enabled: bool) -> bool:
+    """Host L-BFGS-B: AVX2 (default) or scalar O(m n) loops - same iterates; returns the previous setting (tests)."""
+    return bool(LIB.pcabo_lbfgsb_set_vector_kernels(int(bool(enabled))))
 
 
 def lbfgsb_minimize(fun, x0, bounds, m=10, factr=1e7, pgtol=1e-5, maxiter=15000, maxfun=15000, maxls=20):

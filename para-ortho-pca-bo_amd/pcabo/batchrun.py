@@ -39,7 +39,7 @@ class BatchedPCABO:
                  var_threshold: float = 0.95, acquisition_function: str = "expected_improvement",
                  maximization: bool = False, device: int = 0, num_restarts: int = 10, raw_samples: int = 512,
                  record_trace: bool = False, host_threads: int = 0, device_objective: bool = False, workers: int = 0,
-                 trace_filter=None):
+                 trace_filter=None, acq_kernel: str = "group"):
         self.problems, self.seeds = list(problems), [int(s) for s in seeds]
         self.B = len(self.problems)
         assert self.B == len(self.seeds) and self.B >= 1
@@ -84,6 +84,11 @@ class BatchedPCABO:
         self._pool = None
         self._host_threads = int(host_threads) if host_threads else min(8, self.B)
         self._workers = int(workers)                 # 0: the library's default (pcabo_batch_set_workers)
+        # acq_kernel: "group" (default: the throughput kernel k_acq_group for the L-BFGS-B rounds; a run is bit-identical to
+        # PCA_BO(acq_kernel="group")) or "latency" (the per-query kernels: bit-identical to PCA_BO's default)
+        if acq_kernel not in ("group", "latency"):
+            raise ValueError("acq_kernel must be 'group' or 'latency'")
+        self._group_acq = acq_kernel == "group"
 
     # ---- seeding + DoE (AbstractAlgorithm.py:310-328, AbstractBayesianOptimizer.py:142-176) --------------------------
     def start(self) -> None:
@@ -100,7 +105,7 @@ class BatchedPCABO:
             self._assign_new_best(b)
             self._X[b, : self.n_DoE] = np.vstack(self.x_evals[b])
         self._batch = _native.Batch(B, max_n=self.budget, max_d=d, max_q=max(self.raw_samples, 16), device=self.device,
-                                    workers=self._workers)
+                                    workers=self._workers, group_acq=self._group_acq)
         if self._device_objective:
             from .bbob_device import DeviceObjectives
             self._dev_obj = DeviceObjectives(self.problems, device=self.device, penalty=OOB_PENALTY)

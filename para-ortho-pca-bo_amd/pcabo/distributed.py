@@ -16,6 +16,7 @@ def world() -> tuple:
 
 
 def init(backend: str = None) -> tuple:
+    global _RANKS_SEEN
     rank, local_rank, size = world()
     if size > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -38,9 +39,21 @@ def init(backend: str = None) -> tuple:
             torch.cuda.synchronize()
             if int(t.item()) != size:
                 raise SystemExit(f"rank {rank}: RCCL all-reduce saw {t.item()} ranks instead of {size}")
+            _RANKS_SEEN = int(t.item())
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=size)
+            t = torch.ones(1, dtype=torch.float64)
+            dist.all_reduce(t)
+            _RANKS_SEEN = int(t.item())
     return rank, local_rank, size
+
+
+_RANKS_SEEN = 1
+
+
+def ranks_seen() -> int:
+    """Number of ranks the opening all-reduce counted on this process's backend (1 for a single rank)."""
+    return _RANKS_SEEN
 
 
 def backend_name() -> str:

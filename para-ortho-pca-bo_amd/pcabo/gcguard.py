@@ -6,23 +6,17 @@ thresholds regularly, and every full collection walks all of those old objects a
 0.3-0.45 ms per BO iteration (of 3.0-3.6), landing wherever the threshold happens to trip - typically in the torch ops of
 the initial pick.  `gc.freeze()` moves everything that exists when a run starts into the permanent generation, so the
 collections during the run only see the run's own objects; `gc.unfreeze()` gives the objects back when the last run
-ends.  Nothing is leaked and the collector stays enabled.  `PCABO_GC_FREEZE=0` (or the optimisers' `gc_freeze=False`)
-switches this off.
+ends.  Nothing is leaked and the collector stays enabled.  The optimisers' `gc_freeze=False` switches this off.
 """
 from __future__ import annotations
 
 import gc
-import os
 import threading
 
 _lock = threading.Lock()
 _depth = 0
 _saved_threshold = None
 _YOUNG_THRESHOLD = 50000
-
-
-def enabled_by_default() -> bool:
-    return os.environ.get("PCABO_GC_FREEZE", "1") != "0"
 
 
 def enter() -> None:

@@ -1,6 +1,6 @@
-"""Summarise the round-2 rocprofv3 runs of tools/gpu_pmc_shapes.py.
+"""Summarise the rocprofv3 counter passes of tools/gpu_pmc_shapes.py.
 
-  python profiles/tools/summarise_r02.py <dir with pmc_mfma/ pmc_fetch/ pmc_write/ subdirs> > profiles/r02/pmc_summary.txt
+  python profiles/tools/summarise_pmc_passes.py <dir with pmc_mfma/ pmc_fetch/ pmc_write/ subdirs> > profiles/r02/pmc_summary.txt
 
 Per (kernel, grid size): mean duration from the kernel trace of the pmc_mfma pass; f64 MFMA flops = 512 *
 SQ_INSTS_VALU_MFMA_MOPS_F64 (rocprofv3's MfmaFlopsF64 expression); MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES /

@@ -17,24 +17,23 @@ def _single(fid, inst, dim, budget, n_doe, seed, acq_kernel="latency"):
     return np.vstack(opt.x_evals), np.array(opt.f_evals), opt.current_best, opt.current_best_index
 
 
-def _batched(fid, insts, dim, budget, n_doe, seeds, monkeypatch=None, threads=None):
+def _batched(fid, insts, dim, budget, n_doe, seeds, acq_kernel="group"):
     from pcabo.batchrun import BatchedPCABO
-    r = BatchedPCABO([BBOBProblem(fid, i, dim) for i in insts], seeds, budget, n_doe)
+    r = BatchedPCABO([BBOBProblem(fid, i, dim) for i in insts], seeds, budget, n_doe, acq_kernel=acq_kernel)
     r.run()
     return r
 
 
 @pytest.mark.parametrize("mode", ["group", "slab"])
 @pytest.mark.parametrize("dim,budget,n_doe,B", [(10, 70, 30, 5), (40, 200, 120, 3)])
-def test_batched_runs_equal_single_runs_bit_for_bit(native, monkeypatch, dim, budget, n_doe, B, mode):
+def test_batched_runs_equal_single_runs_bit_for_bit(native, dim, budget, n_doe, B, mode):
     """mode "group": the batch's default - L-BFGS-B rounds through the throughput kernel k_acq_group; the single run takes
     the same kernel (acq_kernel="group").  mode "slab": the per-query kernels on both sides (the single run's default,
     resident kernel included: same arithmetic as one launch per evaluation)."""
     torch.set_num_threads(4)
-    monkeypatch.setenv("PCABO_BATCH_ACQ", mode)
     insts = list(range(B))
     seeds = [15000 + 10 * dim + i for i in insts]
-    r = _batched(15, insts, dim, budget, n_doe, seeds)
+    r = _batched(15, insts, dim, budget, n_doe, seeds, "group" if mode == "group" else "latency")
     for b, i in enumerate(insts):
         X, f, best, bi = _single(15, i, dim, budget, n_doe, seeds[b], "group" if mode == "group" else "latency")
         assert np.array_equal(np.vstack(r.x_evals[b]), X), (dim, b)
@@ -139,18 +138,18 @@ def test_batched_run_with_device_objectives(native):
         assert len(out[1].problems[b].log) == out[1].problems[b].evaluations
 
 
-def test_experiment_runner_batched_writes_the_same_files(native, tmp_path, monkeypatch):
+def test_experiment_runner_batched_writes_the_same_files(native, tmp_path):
     """ExperimentRunner(batched=B): the PCA_BO runs of a dimension advance in lock-step; with the per-query kernels on both
     sides the files must equal those of the run-by-run runner byte for byte (apart from the wall-time attributes)."""
     import os
     from Algorithms import ExperimentRunner
     from pcabo import iohlog
-    monkeypatch.setenv("PCABO_BATCH_ACQ", "slab")
     outs = []
     for batched in (0, 4):
         root = tmp_path / f"b{batched}"
         er = ExperimentRunner(algorithms=["pca"], dimensions=[5], problem_ids=[15, 20], num_runs=3, budget_factor=5,
-                              doe_factor=2.0, root_dir=str(root), experiment_name="experiment", progress=False, batched=batched)
+                              doe_factor=2.0, root_dir=str(root), experiment_name="experiment", progress=False, batched=batched,
+                              batch_acq_kernel="latency")
         er.run_experiment()
         assert len(er.results) == 6
         outs.append((root, sorted((r["problem_id"], r["instance"], r["best"]) for r in er.results)))

@@ -2,7 +2,7 @@
 
   configs[2]  f15/f16/f17 x d in {10, 20, 40} x 30 runs on one GPU       -> test_configs2_30_run_batches_replayed_by_oracle
   configs[3]  30 runs x f15..f24 x d in {20, 40}, runs sharded over GPUs -> test_configs3_functions_f16_to_f24_states_against_oracle,
-              (reference: ExperimentRunner.py:90,137-183)                   test_run_ending_nan_path_matches_the_oracle
+              (reference: ExperimentRunner.py:90,137-183)                   test_blown_up_run_follows_the_oracle_to_the_end
   configs[4]  d = 100, doe_factor 3, 256 EI multi-starts                 -> test_configs4_256_restarts_d100_against_oracle
 
 The device runs are the product's own lock-step batches (`pcabo.batchrun.BatchedPCABO`, k_acq_group for the L-BFGS-B rounds);
@@ -119,13 +119,16 @@ def test_configs2_30_run_batches_replayed_by_oracle(native, fid, dim, every):
     assert total["iters"] >= 3 * ((budget - n_doe) // every) - 3
 
 
-def test_run_ending_nan_path_matches_the_oracle(native):
+def test_blown_up_run_follows_the_oracle_to_the_end(native):
     """The reference keeps out-of-box candidates (penalised, not clipped: PCA_BO.py:253,260-263); each widens the next search
-    box by half, coordinates grow geometrically, and some d=40 runs of configs[3] (f19, f21-f24) end where botorch's
-    gen_candidates_scipy meets a NaN acquisition gradient and raises.  Here: f21, instance 25 (stops at n = 412 in
-    profiles/r02/configs2_configs3_runs.json).  The device run must stop with PCABO_ERR_NAN (-4), the oracle -
-    teacher-forced from the same state - must raise its NaN-gradient error AT THE SAME n and not before, and a batch must park the run
-    at that n while its neighbour finishes."""
+    box by half (PCA_BO.py:558-573), so on some functions of configs[3] (f19, f21-f24 at d = 40) coordinates grow
+    geometrically - 1e55 and beyond by the end of the budget, k collapsed to 1.  sklearn / torch carry such a state (LAPACK
+    scales the covariance), so the reference's run goes on to its budget, and so must the device's.  Round 2's device run
+    of f21 / instance 25 stopped at n = 412 with PCABO_ERR_NAN: its Jacobi sweep squared covariance entries of ~1e160 and
+    left the double range (the oracle, teacher-forced from that very state, raised nothing - this test, round 3); the
+    sweep now scales the matrix by a power of four first.  Here: the device run reaches its budget, and the oracle
+    replays the iterations around the first |x| > 1e30 state and the last six from the device's own states - same k,
+    same raw-sample picks, same end points, same chosen candidate; a batch holding the run parks nothing."""
     from Algorithms import PCA_BO
     from pcabo.batchrun import BatchedPCABO
     torch.set_num_threads(4)
@@ -133,28 +136,35 @@ def test_run_ending_nan_path_matches_the_oracle(native):
     budget, n_doe = 450, 120
     opt = PCA_BO(budget=budget, n_DoE=n_doe, random_seed=_seed(fid, dim, inst), maximization=False, record_trace=True,
                  acq_kernel="group")
-    with pytest.raises(native.PcaboError) as ei:
-        opt(BBOBProblem(fid, inst, dim))
-    assert ei.value.code == -4, ei.value
-    n_fail = len(opt.f_evals)
-    assert n_doe < n_fail < budget and opt.trace[-1]["n"] == n_fail
+    opt(BBOBProblem(fid, inst, dim))
+    assert len(opt.f_evals) == budget
     X, f = np.vstack(opt.x_evals), np.array(opt.f_evals, dtype=float)
-    assert np.abs(X).max() > 1e20                        # the blow-up the reference's dynamics produce
-    # the oracle at the same state: raises where the device reports the NaN ...
-    with pytest.raises(RuntimeError, match="NaN gradient"):
-        _teacher_force(X, f, opt.trace[-1], BBOBProblem(fid, inst, dim), dim)
-    # ... and not in the iterations before it (same k there, finite candidates)
-    for tr in opt.trace[-4:-1]:
-        rec = _teacher_force(X, f, tr, BBOBProblem(fid, inst, dim), dim)
-        assert rec.k == tr["k"] and np.isfinite(rec.cand_z).all(), tr["n"]
-    # the lock-step batch parks the run at the same n (same kernels -> same path as the single run) and goes on
+    assert np.abs(X).max() > 1e40 and np.isfinite(X).all()                 # the blow-up the reference's dynamics produce
+    first_big = next(t["n"] for t in opt.trace if np.abs(X[:t["n"]]).max() > 1e30)
+    checked = 0
+    for tr in opt.trace:
+        n = tr["n"]
+        if not (first_big <= n < first_big + 2 or n >= budget - 6):
+            continue
+        rec = _teacher_force(X, f, tr, BBOBProblem(fid, inst, dim), dim)      # (raises if the oracle meets a NaN gradient)
+        assert rec.k == tr["k"], n
+        if rec.trace.retried or tr["retried"]:
+            assert rec.trace.retried == tr["retried"], n
+            continue
+        assert sorted(rec.trace.ic_idx.tolist()) == sorted(tr["ic_idx"].tolist()), n
+        scale = max(1.0, np.abs(rec.trace.cands).max())
+        assert np.abs(rec.trace.cands - tr["cands"]).max() < 1e-8 * scale, n
+        assert np.abs(rec.cand_x - X[n]).max() < 1e-8 * max(1.0, np.abs(rec.cand_x).max()), n
+        vo = rec.acq(torch.from_numpy(np.ascontiguousarray(tr["cands"]))).detach().numpy()
+        assert float((np.abs(vo - tr["vals"]) / np.maximum(1.0, np.abs(tr["vals"]))).max()) < 1e-8, n
+        checked += 1
+    assert checked >= 6
+    # the lock-step batch: the same run beside a tame one - nothing parked, and the run takes the path it takes alone
     r = BatchedPCABO([BBOBProblem(fid, inst, dim), BBOBProblem(15, 0, dim)], [_seed(fid, dim, inst), _seed(15, dim, 0)],
                      budget, n_doe)
-    with pytest.warns(RuntimeWarning, match="stopped at n"):
-        r.run()
-    assert r.failed[0] is not None and r.failed[0][0] == n_fail and "NaN" in r.failed[0][1], r.failed
-    assert len(r.f_evals[0]) == n_fail and np.array_equal(np.vstack(r.x_evals[0]), X)
-    assert r.failed[1] is None and len(r.f_evals[1]) == budget
+    r.run()
+    assert r.failed == [None, None]
+    assert np.array_equal(np.vstack(r.x_evals[0]), X) and np.array_equal(np.array(r.f_evals[0]), f)
 
 
 def test_configs4_256_restarts_d100_against_oracle(native):

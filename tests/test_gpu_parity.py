@@ -782,7 +782,7 @@ def test_noise_prefetch_does_not_change_a_run(native):
         assert np.array_equal(f, runs[0][0]) and np.array_equal(x, runs[0][1])
 
 
-def test_single_enqueue_of_wpca_and_conditioning_equals_the_two_calls(native, monkeypatch):
+def test_single_enqueue_of_wpca_and_conditioning_equals_the_two_calls(native):
     """pcabo_wpca_gp_condition_begin queues the conditioning behind the projection before the host knows k (the kernels
     read it on the device) and moves all inputs in one packed copy: same kernels, same operands - whole runs must
     agree bit for bit with pcabo_wpca + pcabo_gp_condition_begin, and so must the state after one direct call."""
@@ -790,11 +790,7 @@ def test_single_enqueue_of_wpca_and_conditioning_equals_the_two_calls(native, mo
     torch.set_num_threads(4)
     runs = []
     for fused in (True, False):
-        if fused:
-            monkeypatch.delenv("PCABO_NO_FUSED_ENQUEUE", raising=False)
-        else:
-            monkeypatch.setenv("PCABO_NO_FUSED_ENQUEUE", "1")
-        opt = PCA_BO(budget=70, n_DoE=30, random_seed=15101, maximization=False)
+        opt = PCA_BO(budget=70, n_DoE=30, random_seed=15101, maximization=False, fused_enqueue=fused)
         prob = BBOBProblem(15, 1, 10)
         opt._start(prob)
         ks = []
@@ -832,36 +828,21 @@ def test_single_enqueue_of_wpca_and_conditioning_equals_the_two_calls(native, mo
 
 def test_resident_kernel_reproduces_per_round_launches(native):
     """The resident ("server") mode of the acquisition kernel - one launch per optimize call, query points through the
-    mailbox - runs the same arithmetic as one launch per evaluation, whoever fills the mailbox and however the host
-    threads drive the restart groups: whole runs must agree bit for bit (the switches are read once per process, hence
-    the subprocesses)."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = r'''
-import sys, os, hashlib
-import numpy as np
-sys.path.insert(0, os.path.join(%r, "para-ortho-pca-bo_amd"))
-from Algorithms import PCA_BO, Vanilla_BO
-from pcabo.bbob import BBOBProblem
-out = []
-for cls, kw, dim, budget, ndoe in ((PCA_BO, {}, 10, 70, 30), (PCA_BO, {}, 40, 150, 120), (Vanilla_BO, {}, 6, 40, 18),
-                                    (Vanilla_BO, {}, 40, 140, 120)):      # k = 40: the widest mailbox (400 coordinates)
-    opt = cls(budget=budget, n_DoE=ndoe, random_seed=15000 + dim, maximization=False, **kw)
-    opt(BBOBProblem(15, 1, dim))
-    out.append(hashlib.md5(np.array(opt.f_evals).tobytes() + np.vstack(opt.x_evals).tobytes()).hexdigest())
-print("DIGESTS", " ".join(out))
-''' % root
+    mailbox in device memory (written by the host through the PCIe BAR), the two restart groups driven by two host threads
+    free of each other - runs the same arithmetic as one launch per evaluation: whole runs must agree bit for bit."""
+    import hashlib
+    from Algorithms import PCA_BO, Vanilla_BO
+    torch.set_num_threads(4)
     res = []
-    # resident with the host writing the device mailbox through the BAR and the restart groups free of each other (the
-    # default where the device has a large BAR); the same in lock-step; mailbox through pinned memory + relay group;
-    # one launch per evaluation
-    for env in ({"PCABO_ACQ_SERVER": "1"}, {"PCABO_ACQ_SERVER": "1", "PCABO_FREE_GROUPS": "0"},
-                {"PCABO_ACQ_SERVER": "1", "PCABO_MAIL_BAR": "0"}, {"PCABO_ACQ_SERVER": "0"}):
-        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True,
-                           text=True, timeout=600)
-        assert p.returncode == 0, p.stderr[-3000:]
-        res.append([l for l in p.stdout.splitlines() if l.startswith("DIGESTS")][-1])
-    assert res[0] == res[1] == res[2] == res[3]
+    for resident in (True, False):
+        out = []
+        for cls, dim, budget, ndoe in ((PCA_BO, 10, 70, 30), (PCA_BO, 40, 150, 120), (Vanilla_BO, 6, 40, 18),
+                                       (Vanilla_BO, 40, 140, 120)):      # k = 40: the widest mailbox (400 coordinates)
+            opt = cls(budget=budget, n_DoE=ndoe, random_seed=15000 + dim, maximization=False, resident=resident)
+            opt(BBOBProblem(15, 1, dim))
+            out.append(hashlib.md5(np.array(opt.f_evals).tobytes() + np.vstack(opt.x_evals).tobytes()).hexdigest())
+        res.append(out)
+    assert res[0] == res[1]
 
 
 def test_resident_kernel_survives_a_stopped_host(native):

@@ -90,36 +90,32 @@ def test_abnormal_line_search_and_memoised_repeats_like_scipy(native):
         assert np.array_equal(ref.x, mine["x"])
 
 
-def test_vector_kernels_take_the_scalar_iterates():
+def test_vector_kernels_take_the_scalar_iterates(native):
     """The AVX2 kernels of lbfgsb.cpp (row-major mirror reductions, per-variable chains) must not change a single
-    bit of any iterate: the same bounded problems in two subprocesses, one with PCABO_LBFGSB_SCALAR=1."""
-    import os, subprocess, sys
-    code = r'''
-import sys, os, json
-import numpy as np
-sys.path.insert(0, os.path.join(%r, "para-ortho-pca-bo_amd"))
-from pcabo import _native as N
-out = []
-for seed in range(6):
-    rng = np.random.default_rng(seed)
-    nv = [7, 40, 85, 165, 33, 120][seed]
-    c = rng.uniform(-0.2, 1.2, nv); s = rng.uniform(0.5, 2.0, nv)
-    def fun(x):
-        d = x - c
-        f = float(np.sum(s * d * d + 0.1 * d ** 4) + 0.05 * np.sum(np.cos(5 * x + np.roll(x, -1))))
-        g = 2 * s * d + 0.4 * d ** 3 - 0.25 * np.sin(5 * x + np.roll(x, -1)) - 0.05 * np.roll(np.sin(5 * x + np.roll(x, -1)), 1)
-        return f, g
-    r = N.lbfgsb_minimize(fun, rng.uniform(0, 1, nv), [(0.0, 1.0)] * nv, maxiter=200)
-    out.append([r["nit"], r["nfev"], r["task"], r["fun"].hex(), [v.hex() for v in r["x"]]])
-print(json.dumps(out))
-''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = []
-    for scalar in ("0", "1"):
-        env = dict(os.environ, PCABO_LBFGSB_SCALAR=scalar)
-        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-        assert p.returncode == 0, p.stderr[-2000:]
-        res.append(p.stdout.strip().splitlines()[-1])
-    assert res[0] == res[1]
-    import json
-    runs = json.loads(res[0])
-    assert all(r[0] > 3 for r in runs)            # real optimisation runs, not immediate exits
+    bit of any iterate: the same bounded problems with the vector kernels and with the scalar loops
+    (pcabo_lbfgsb_set_vector_kernels)."""
+    def run_all():
+        out = []
+        for seed in range(6):
+            rng = np.random.default_rng(seed)
+            nv = [7, 40, 85, 165, 33, 120][seed]
+            c = rng.uniform(-0.2, 1.2, nv)
+            s = rng.uniform(0.5, 2.0, nv)
+
+            def fun(x):
+                d = x - c
+                f = float(np.sum(s * d * d + 0.1 * d ** 4) + 0.05 * np.sum(np.cos(5 * x + np.roll(x, -1))))
+                g = 2 * s * d + 0.4 * d ** 3 - 0.25 * np.sin(5 * x + np.roll(x, -1)) - 0.05 * np.roll(np.sin(5 * x + np.roll(x, -1)), 1)
+                return f, g
+            r = native.lbfgsb_minimize(fun, rng.uniform(0, 1, nv), [(0.0, 1.0)] * nv, maxiter=200)
+            out.append((r["nit"], r["nfev"], r["task"], float(r["fun"]).hex(), [float(v).hex() for v in r["x"]]))
+        return out
+
+    was = native.lbfgsb_set_vector_kernels(False)
+    try:
+        scalar = run_all()
+    finally:
+        native.lbfgsb_set_vector_kernels(was)
+    vector = run_all()
+    assert scalar == vector
+    assert all(r[0] > 3 for r in vector)            # real optimisation runs, not immediate exits

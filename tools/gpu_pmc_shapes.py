@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.join(ROOT, "para-ortho-pca-bo_amd"))
 import numpy as np
 from pcabo import _native as N
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-os.environ.setdefault("PCABO_BATCH_THREADS", "1")      # every launch from the main thread (profiler)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 for n, k in ((450, 36), (1050, 89)):
     for B in (1, 30):
         rng = np.random.default_rng(1000 * n + B)

@@ -348,7 +348,7 @@ def run_side_by_side(runners: Sequence["BatchedPCABO"], started: bool = False) -
 
 
 def bench_block(device: int, B: int, fid: int, dim: int, budget_factor: int = 10, doe_factor: float = 3.0,
-                sub_batches: int = 1) -> dict:
+                sub_batches: int = 1, workers: int = 0) -> dict:
     """Aggregate BO iterations / second of B runs (instances 0..B-1 of one BBOB function and dimension, seeds per
     ExperimentRunner.py:146) advancing together on one GPU - as one lock-step batch, or as `sub_batches` lock-step batches
     side by side (run_side_by_side); DoE and set-up untimed."""
@@ -359,7 +359,7 @@ def bench_block(device: int, B: int, fid: int, dim: int, budget_factor: int = 10
     for t in range(S):
         inst = list(range(t, B, S))
         subs.append(BatchedPCABO([BBOBProblem(fid, i, dim) for i in inst], [1000 * fid + 10 * dim + i for i in inst], budget, n_doe,
-                                 device=device, workers=workers_for(S) if S > 1 else 0, host_threads=max(1, 8 // S)))
+                                 device=device, workers=workers or (workers_for(S) if S > 1 else 0), host_threads=max(1, 8 // S)))
     for r in subs:
         r.start()
     torch.cuda.synchronize()

@@ -15,9 +15,6 @@ evaluation), and a finite-difference check of the analytic gradient.
 
 Tolerances are fp64 round-off amplified by the conditioning of the state (stated per assertion); north_star asks 1e-5.
 """
-import json
-import os
-
 import numpy as np
 import pytest
 import torch
@@ -191,16 +188,6 @@ def _check_state(native, ctx, rec, tr, stats):
     return s
 
 
-def _dump(stats, name):
-    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
-    try:
-        os.makedirs(out, exist_ok=True)
-        with open(os.path.join(out, f"late_phase_{name}.json"), "w") as fh:
-            json.dump(stats, fh, indent=1, default=lambda o: np.asarray(o).tolist())
-    except OSError:
-        pass
-
-
 def _summarise(stats, name):
     counts = [c for s in stats for c in s["counts_equal"]]
     cands = [c for s in stats for c in s.get("cand", [])]
@@ -220,12 +207,9 @@ def _summarise(stats, name):
 def test_headline_run_late_phase_against_oracle(native, headline_run):
     ctx = native.Context(max_n=450, max_d=40, max_q=512)
     stats = []
-    try:
-        for n in HEADLINE_NS:
-            rec, tr = _oracle_step(headline_run, n, 40, 0)
-            _check_state(native, ctx, rec, tr, stats)
-    finally:
-        _dump(stats, "d40")
+    for n in HEADLINE_NS:
+        rec, tr = _oracle_step(headline_run, n, 40, 0)
+        _check_state(native, ctx, rec, tr, stats)
     ctx.close()
     _summarise(stats, "d40")
     assert {s["n"] for s in stats} == set(HEADLINE_NS)
@@ -234,12 +218,9 @@ def test_headline_run_late_phase_against_oracle(native, headline_run):
 def test_d20_states_against_oracle(native, d20_run):
     ctx = native.Context(max_n=250, max_d=20, max_q=512)
     stats = []
-    try:
-        for n in D20_NS:
-            rec, tr = _oracle_step(d20_run, n, 20, 0)
-            _check_state(native, ctx, rec, tr, stats)
-    finally:
-        _dump(stats, "d20")
+    for n in D20_NS:
+        rec, tr = _oracle_step(d20_run, n, 20, 0)
+        _check_state(native, ctx, rec, tr, stats)
     ctx.close()
     _summarise(stats, "d20")
 
@@ -256,5 +237,4 @@ def test_headline_late_iterations_replayed_by_oracle(native, headline_run):
     v.x_evals, v.f_evals, v.maximization = headline_run.x_evals, headline_run.f_evals, False
     v.trace = [headline_run.trace[i] for i in range(10, 330, 24)]
     st = _replay_with_oracle(v, lambda: BBOBProblem(15, 0, 40), 40)
-    _dump(st, "replay_d40")
     _check_replay(st, min_iters=len(v.trace) - 2, late=True)

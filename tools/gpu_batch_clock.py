@@ -1,4 +1,5 @@
-"""Aggregate rate of B runs advancing in lock-step (pcabo.batchrun) - diagnostic.  usage: gpu_batch_clock.py B [dim] [fid] [sub_batches]"""
+"""Aggregate rate of B runs advancing in lock-step (pcabo.batchrun) - diagnostic.
+usage: gpu_batch_clock.py B [dim] [fid] [sub_batches] [workers per batch, 0 = default]"""
 import json, os, sys
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # read by the HIP runtime at its first call: a Batch uses a stream per worker thread
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,6 +11,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 dim = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 fid = int(sys.argv[3]) if len(sys.argv) > 3 else 15
 S = int(sys.argv[4]) if len(sys.argv) > 4 else 1
-out = batchrun.bench_block(0, B, fid, dim, sub_batches=S)
+W = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+out = batchrun.bench_block(0, B, fid, dim, sub_batches=S, workers=W)
+out["workers"] = W
 out.pop("best_f")
 print(json.dumps(out))

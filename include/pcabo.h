@@ -282,6 +282,24 @@ int pcabo_bbob_create(int device, int B, int d, const int* fid, const double* ta
 int pcabo_bbob_destroy(pcabo_objective* obj);
 int pcabo_bbob_eval(pcabo_objective* obj, const double* X, double lb, double ub, double penalty, double* raw, int* oob);
 
+/* ---- Final gather of best-so-far values across the GPUs of a node -------------------------------------
+ * Runs are independent (ExperimentRunner.py:137-183: one optimiser object per (function, dimension, instance)), so the
+ * multi-GPU path has NO collective inside the loop; the one exchange of the design is an all-gather of each rank's
+ * best-so-far values after its runs, over RCCL (xGMI inside a node).  One process per GPU:
+ *   rank 0:      pcabo_comm_unique_id(id)            128 bytes (ncclUniqueId); the CALLER hands them to the other ranks
+ *                                                    (a file, the launcher's environment, its own store)
+ *   every rank:  pcabo_comm_create(id, world, rank, device, &comm)       (collective: returns once all ranks have joined)
+ *                pcabo_gather_best(comm, local, n_local, all)            all[world * n_local] [host], rank-major; n_local equal on all ranks
+ *                pcabo_comm_destroy(comm)
+ * librccl.so is opened on first use (no link-time dependency).  pcabo/distributed.py offers the same gather through
+ * torch.distributed for callers that already run under it (bench.py does). */
+typedef struct pcabo_comm pcabo_comm;
+int pcabo_comm_unique_id(char* id128);
+int pcabo_comm_create(const char* id128, int world, int rank, int device, pcabo_comm** out);
+int pcabo_gather_best(pcabo_comm* comm, const double* local, int n_local, double* all);
+int pcabo_comm_last_error(pcabo_comm* comm, char* buf, int buflen);
+int pcabo_comm_destroy(pcabo_comm* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2144,3 +2144,131 @@ int pcabo_batch_inverse_map(pcabo_batch* batch, const double* z, double* x) {
 }
 
 }  // extern "C"
+
+// =====================================================================================================================
+// Final gather of best-so-far values over RCCL (declared in include/pcabo.h).
+// The data path has no collective: runs are independent and every rank drives its own GPU.  The ONE exchange of the design -
+// the all-gather of a few doubles after the runs - is available here for callers without torch.distributed.  librccl.so is
+// opened on first use (no link-time dependency: a process that never gathers never loads it).
+// =====================================================================================================================
+#include <dlfcn.h>
+
+namespace {
+typedef struct { char internal[128]; } rccl_unique_id;            // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128)
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(rccl_unique_id*) = nullptr;
+  int (*CommInitRank)(void**, int, rccl_unique_id, int) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool ok = false;
+};
+RcclApi& rccl() {
+  static RcclApi api = [] {
+    RcclApi a;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (a.lib) break;
+    }
+    if (!a.lib) return a;
+    a.GetUniqueId = (int (*)(rccl_unique_id*))dlsym(a.lib, "ncclGetUniqueId");
+    a.CommInitRank = (int (*)(void**, int, rccl_unique_id, int))dlsym(a.lib, "ncclCommInitRank");
+    a.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(a.lib, "ncclAllGather");
+    a.CommDestroy = (int (*)(void*))dlsym(a.lib, "ncclCommDestroy");
+    a.GetErrorString = (const char* (*)(int))dlsym(a.lib, "ncclGetErrorString");
+    a.ok = a.GetUniqueId && a.CommInitRank && a.AllGather && a.CommDestroy;
+    return a;
+  }();
+  return api;
+}
+}  // namespace
+
+struct pcabo_comm {
+  void* comm = nullptr;
+  int world = 0, rank = 0, device = 0;
+  hipStream_t stream = nullptr;
+  double* dbuf = nullptr;
+  size_t cap = 0;                       // doubles per rank the device buffer holds
+  char err[256] = {0};
+};
+static int cset_err(pcabo_comm* c, int code, const char* what, int rc) {
+  if (c) {
+    const RcclApi& a = rccl();
+    snprintf(c->err, sizeof(c->err), "%s (%d%s%s)", what, rc, a.GetErrorString ? ": " : "", a.GetErrorString ? a.GetErrorString(rc) : "");
+  }
+  return code;
+}
+
+extern "C" {
+
+int pcabo_comm_unique_id(char* id128) {
+  if (!id128) return PCABO_ERR_ARG;
+  RcclApi& a = rccl();
+  if (!a.ok) return PCABO_ERR_HIP;
+  rccl_unique_id id;
+  if (a.GetUniqueId(&id) != 0) return PCABO_ERR_HIP;
+  memcpy(id128, id.internal, 128);
+  return PCABO_OK;
+}
+
+int pcabo_comm_create(const char* id128, int world, int rank, int device, pcabo_comm** out) {
+  if (!out) return PCABO_ERR_ARG;
+  *out = nullptr;
+  if (!id128 || world < 1 || rank < 0 || rank >= world) return PCABO_ERR_ARG;
+  RcclApi& a = rccl();
+  if (!a.ok) return PCABO_ERR_HIP;
+  pcabo_comm* c = new (std::nothrow) pcabo_comm();
+  if (!c) return PCABO_ERR_HIP;
+  *out = c;                             // handed back even on failure (message in pcabo_comm_last_error)
+  c->world = world; c->rank = rank; c->device = device;
+  if (hipSetDevice(device) != hipSuccess) return cset_err(c, PCABO_ERR_HIP, "hipSetDevice failed", (int)hipGetLastError());
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return cset_err(c, PCABO_ERR_HIP, "stream", (int)hipGetLastError());
+  rccl_unique_id id;
+  memcpy(id.internal, id128, 128);
+  const int rc = a.CommInitRank(&c->comm, world, id, rank);
+  if (rc != 0) { c->comm = nullptr; return cset_err(c, PCABO_ERR_HIP, "ncclCommInitRank failed", rc); }
+  return PCABO_OK;
+}
+
+int pcabo_gather_best(pcabo_comm* c, const double* local, int n_local, double* all) {
+  if (!c || !c->comm || !local || !all || n_local < 1) return PCABO_ERR_ARG;
+  RcclApi& a = rccl();
+  if (hipSetDevice(c->device) != hipSuccess) return cset_err(c, PCABO_ERR_HIP, "hipSetDevice failed", (int)hipGetLastError());
+  if ((size_t)n_local > c->cap) {
+    if (c->dbuf) (void)hipFree(c->dbuf);
+    c->dbuf = nullptr; c->cap = 0;
+    if (hipMalloc((void**)&c->dbuf, (size_t)n_local * (c->world + 1) * sizeof(double)) != hipSuccess)
+      return cset_err(c, PCABO_ERR_HIP, "hipMalloc failed", (int)hipGetLastError());
+    c->cap = (size_t)n_local;
+  }
+  double* send = c->dbuf;
+  double* recv = c->dbuf + c->cap;
+  if (hipMemcpyAsync(send, local, (size_t)n_local * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess)
+    return cset_err(c, PCABO_ERR_HIP, "copy to the device failed", (int)hipGetLastError());
+  const int rc = a.AllGather(send, recv, (size_t)n_local, /* ncclFloat64 */ 8, c->comm, c->stream);
+  if (rc != 0) return cset_err(c, PCABO_ERR_HIP, "ncclAllGather failed", rc);
+  if (hipMemcpyAsync(all, recv, (size_t)n_local * c->world * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+      hipStreamSynchronize(c->stream) != hipSuccess)
+    return cset_err(c, PCABO_ERR_HIP, "copy from the device failed", (int)hipGetLastError());
+  return PCABO_OK;
+}
+
+int pcabo_comm_last_error(pcabo_comm* c, char* buf, int buflen) {
+  if (!c || !buf || buflen <= 0) return PCABO_ERR_ARG;
+  snprintf(buf, buflen, "%s", c->err);
+  return PCABO_OK;
+}
+
+int pcabo_comm_destroy(pcabo_comm* c) {
+  if (!c) return PCABO_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->comm) (void)rccl().CommDestroy(c->comm);
+  if (c->dbuf) (void)hipFree(c->dbuf);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return PCABO_OK;
+}
+
+}  // extern "C"

@@ -55,6 +55,7 @@ EXPORTS = [
     "pcabo_batch_gp_condition_end_eval", "pcabo_batch_optimize_acqf", "pcabo_batch_inverse_map",
     "pcabo_batch_set_profiling", "pcabo_batch_get_profile", "pcabo_batch_set_active", "pcabo_batch_set_workers", "pcabo_batch_set_option",
     "pcabo_bbob_table_doubles", "pcabo_bbob_create", "pcabo_bbob_destroy", "pcabo_bbob_eval",
+    "pcabo_comm_unique_id", "pcabo_comm_create", "pcabo_gather_best", "pcabo_comm_last_error", "pcabo_comm_destroy",
 ]
 
 
@@ -111,6 +112,11 @@ def _load() -> C.CDLL:
     lib.pcabo_get_profile_calibration.argtypes = [vp, dp, dp]
     lib.pcabo_lbfgsb_set_vector_kernels.argtypes = [C.c_int]
     lib.pcabo_batch_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.pcabo_comm_unique_id.argtypes = [C.c_char_p]
+    lib.pcabo_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.pcabo_gather_best.argtypes = [vp, vp, C.c_int, vp]
+    lib.pcabo_comm_last_error.argtypes = [vp, C.c_char_p, C.c_int]
+    lib.pcabo_comm_destroy.argtypes = [vp]
     lib.pcabo_batch_destroy.argtypes = [vp]
     lib.pcabo_batch_set_workers.argtypes = [vp, C.c_int]
     lib.pcabo_batch_set_option.argtypes = [vp, C.c_int, C.c_int]
@@ -527,6 +533,54 @@ def sobol_draw(state: np.ndarray, shift: np.ndarray, n: int, lo=None, rng=None) 
     if rc != 0:
         raise PcaboError(rc, "pcabo_sobol_draw: bad argument")
     return out
+
+
+def comm_unique_id() -> bytes:
+    """128 bytes (ncclUniqueId) from rank 0 for `Comm`; the caller distributes them to the other ranks."""
+    buf = C.create_string_buffer(128)
+    rc = LIB.pcabo_comm_unique_id(buf)
+    if rc != 0:
+        raise PcaboError(rc, "librccl.so could not be opened or ncclGetUniqueId failed")
+    return buf.raw
+
+
+class Comm:
+    """RCCL communicator for the final gather of best-so-far values (pcabo_comm_* / pcabo_gather_best of include/pcabo.h)."""
+
+    def __init__(self, unique_id: bytes, world: int, rank: int, device: int = 0):
+        self._h = C.c_void_p()
+        rc = LIB.pcabo_comm_create(C.c_char_p(unique_id), int(world), int(rank), int(device), C.byref(self._h))
+        if rc != 0:
+            msg = self._err() if self._h else "librccl.so could not be opened"
+            if self._h:
+                LIB.pcabo_comm_destroy(self._h)
+                self._h = C.c_void_p()
+            raise PcaboError(rc, msg)
+        self.world, self.rank = int(world), int(rank)
+
+    def _err(self) -> str:
+        buf = C.create_string_buffer(256)
+        LIB.pcabo_comm_last_error(self._h, buf, 256)
+        return buf.value.decode(errors="replace")
+
+    def gather_best(self, local) -> np.ndarray:
+        local = _f64(local).reshape(-1)
+        out = np.empty((self.world, local.shape[0]))
+        rc = LIB.pcabo_gather_best(self._h, _ptr(local), int(local.shape[0]), _ptr(out))
+        if rc != 0:
+            raise PcaboError(rc, self._err())
+        return out
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            LIB.pcabo_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 def lbfgsb_set_vector_kernels(enabled: bool) -> bool:

@@ -257,3 +257,21 @@ def test_batch_worker_count_can_change_between_calls(native):
         assert np.array_equal(np.vstack(r.x_evals[b]), np.vstack(ref.x_evals[b])), b
     with pytest.raises(Exception):
         native.Batch(2, max_n=40, max_d=5).set_workers(0)
+
+
+def test_rccl_gather_best_through_the_c_abi(native):
+    """pcabo_comm_* / pcabo_gather_best (include/pcabo.h): the final all-gather of best-so-far values over RCCL without
+    torch.distributed.  One GPU here, so one rank: the communicator comes up, the gather returns the rank's own values, twice
+    (a larger payload re-sizes the device buffer), and argument errors are reported."""
+    uid = native.comm_unique_id()
+    assert len(uid) == 128
+    comm = native.Comm(uid, world=1, rank=0, device=0)
+    try:
+        a = np.array([3.5, -1.25, 1e300])
+        assert np.array_equal(comm.gather_best(a), a.reshape(1, 3))
+        b = np.linspace(-5, 5, 300)
+        assert np.array_equal(comm.gather_best(b), b.reshape(1, 300))
+    finally:
+        comm.close()
+    with pytest.raises(native.PcaboError):
+        native.Comm(uid, world=2, rank=5, device=0)

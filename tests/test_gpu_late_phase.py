@@ -192,6 +192,10 @@ def _summarise(stats, name):
     counts = [c for s in stats for c in s["counts_equal"]]
     cands = [c for s in stats for c in s.get("cand", [])]
     vals = [c for s in stats for c in s.get("vals", [])]
+    print("[late %s] states %d: counts equal %.3f; scipy on the device surface %.3f; end points median %.2e <1e-2 %.3f <1e-5 %.3f; "
+          "values median %.2e <1e-3 %.3f" % (name, len(stats), np.mean(counts), np.mean([c for s in stats for c in s["scipy_on_device_surface"]]),
+                                             np.median(cands), np.mean(np.array(cands) < 1e-2), np.mean(np.array(cands) < 1e-5),
+                                             np.median(vals), np.mean(np.array(vals) < 1e-3)))
     # Device optimiser vs ORACLE optimiser (each on its own f/g, which agree to ~1e-13): L-BFGS-B on 5k joint variables
     # stops on a relative f-reduction of 2.2e-9, i.e. on a flat optimum the end point is fixed to ~1e-4 only, and a
     # line-search branch can flip on a 1e-14 difference.  In the late phase of the headline run

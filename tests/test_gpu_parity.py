@@ -365,6 +365,11 @@ def _check_replay(st, min_iters, frac=0.9, late=False):
     driven by the DEVICE's own f/g parts from lbfgsb.cpp just as often (tests/test_gpu_late_phase.py).  Measured (14
     iterations): counts equal 61 %, end points q50 1.2e-7 / q90 5.8e-4, chosen x q50 6.6e-7 / max 4.9e-4, surface 2.8e-13."""
     q = lambda a, p: float(np.quantile(np.array(a), p))
+    print("[replay] iters %d late %s: counts equal %.3f; end points q50 %.2e q90 %.2e <1e-5 %.3f; values q50 %.2e q90 %.2e; chosen x "
+          "q50 %.2e max %.2e <1e-5 %.3f; ties %d, other optimum %d; surface %.2e" % (
+              st["iters"], late, np.mean(st["count_equal"]), q(st["dcand"], 0.5), q(st["dcand"], 0.9), np.mean(np.array(st["dcand"]) < 1e-5),
+              q(st["dval"], 0.5), q(st["dval"], 0.9), q(st["dx"], 0.5) if st["dx"] else -1, max(st["dx"]) if st["dx"] else -1,
+              np.mean(np.array(st["dx"]) < 1e-5) if st["dx"] else -1, st["ties"], st["diverged_choice"], max(st["dsurf"])))
     frac_cnt = 0.45 if late else frac
     frac_pts = 0.5 if late else frac
     assert st["iters"] >= min_iters

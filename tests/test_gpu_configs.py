@@ -87,8 +87,9 @@ def test_configs3_functions_f16_to_f24_states_against_oracle(native, dim):
           "alpha %.1e value %.1e grad %.1e raw %.1e" % (dim, len(stats), np.mean(counts), np.median(cands), np.mean(np.array(cands) < 1e-5),
                                                        *[max(s[key] for s in stats) for key in ("Z", "K", "L", "alpha", "val", "grad", "raw")]))
     # optimiser statistics as in the late-phase test of the headline run (kernel-level agreement is asserted per state)
-    assert np.mean(counts) >= 0.45, counts
-    assert np.median(cands) < 1e-3, np.sort(cands)[-10:]
+    # (measured round 3: counts equal 0.78 (d=20) / 0.83 (d=40); end points median 0 / 4e-13, within 1e-5 0.80 / 0.83)
+    assert np.mean(counts) >= 0.70, counts
+    assert np.median(cands) < 1e-9 and np.mean(np.array(cands) < 1e-5) >= 0.72, np.sort(cands)[-10:]
 
 
 @pytest.mark.parametrize("fid,dim,every", [(16, 20, 24), (17, 40, 44)])
@@ -199,12 +200,13 @@ def test_configs4_256_restarts_d100_against_oracle(native):
     ocand, ovals = np.vstack(ocand), np.concatenate(ovals)
     dc = np.abs(cand - ocand).max(axis=1) / scale
     dv = np.abs(vals - ovals) / np.maximum(1.0, np.abs(ovals))
-    # measured on MI355X (round 3): see DESIGN.md section 6; thresholds = measured with a margin
+    # measured on MI355X (round 3): counts identical in 52 of 52 groups, end points max 1.2e-5 (99.6 % within 1e-5), values all
+    # within 1e-6 - thresholds = measured with a margin
     print("[configs4 256 restarts] counts identical %d / 52, within (2, 3) %d; end points median %.2e <1e-5 %.3f max %.2e; values median "
           "%.2e <1e-6 %.3f" % (same_counts, near_counts, np.median(dc), np.mean(dc < 1e-5), dc.max(), np.median(dv), np.mean(dv < 1e-6)))
-    assert same_counts >= 40 and near_counts >= 46, (same_counts, near_counts)
-    assert np.median(dc) < 1e-7 and np.mean(dc < 1e-5) >= 0.85 and dc.max() < 2e-2, np.sort(dc)[-8:]
-    assert np.median(dv) < 1e-10 and np.mean(dv < 1e-6) >= 0.85, np.sort(dv)[-8:]
+    assert same_counts >= 47 and near_counts >= 49, (same_counts, near_counts)
+    assert np.median(dc) < 1e-9 and np.mean(dc < 1e-5) >= 0.9 and dc.max() < 1e-3, np.sort(dc)[-8:]
+    assert np.median(dv) < 1e-12 and np.mean(dv < 1e-6) >= 0.9, np.sort(dv)[-8:]
     vo = acq(torch.from_numpy(np.ascontiguousarray(cand))).detach().numpy()
     assert float((np.abs(vo - vals) / np.maximum(1.0, np.abs(vals))).max()) < 1e-8
     bo, bd = int(np.argmax(ovals)), int(np.argmax(vals))

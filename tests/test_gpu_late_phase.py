@@ -202,10 +202,13 @@ def _summarise(stats, name):
     # (k = 8..16, many penalised points) that happens in about a third of the restart groups - measured on MI355X: counts
     # identical for 62 % (d=40, n = 120..449) / 70 % (d=20), end points: median 8e-7 / 6e-12, values: median 3e-11.  The optimiser itself is pinned
     # exactly above (scipy on the device surface); these bounds only catch a surface that has gone wrong.
-    assert np.mean(counts) >= 0.45, counts
-    assert np.mean([c for s in stats for c in s["scipy_on_device_surface"]]) >= 0.3      # measured 0.44 (d=40), 0.70 (d=20)
-    assert np.median(cands) < 1e-3 and np.mean(np.array(cands) < 1e-2) >= 0.75, np.sort(cands)[-10:]      # measured 0.94 / 0.84
-    assert np.median(vals) < 1e-7 and np.mean(np.array(vals) < 1e-3) >= 0.85, np.sort(vals)[-10:]
+    # thresholds = measured (round 3, MI355X; deterministic per build) minus 10 %: counts equal 0.625 (d=40) / 0.70 (d=20);
+    # real scipy on the device surface 0.4375 / 0.70; end points median 7.9e-7 / 5.8e-12, within 1e-2 0.94 / 0.84, within
+    # 1e-5 0.56 / 0.72; values median 3.5e-11 / 3.7e-12, within 1e-3 0.975 / 0.90
+    assert np.mean(counts) >= 0.56, counts
+    assert np.mean([c for s in stats for c in s["scipy_on_device_surface"]]) >= 0.39
+    assert np.median(cands) < 1e-5 and np.mean(np.array(cands) < 1e-2) >= 0.75 and np.mean(np.array(cands) < 1e-5) >= 0.50, np.sort(cands)[-10:]
+    assert np.median(vals) < 1e-9 and np.mean(np.array(vals) < 1e-3) >= 0.81, np.sort(vals)[-10:]
 
 
 def test_headline_run_late_phase_against_oracle(native, headline_run):

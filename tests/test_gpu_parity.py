@@ -370,13 +370,17 @@ def _check_replay(st, min_iters, frac=0.9, late=False):
               st["iters"], late, np.mean(st["count_equal"]), q(st["dcand"], 0.5), q(st["dcand"], 0.9), np.mean(np.array(st["dcand"]) < 1e-5),
               q(st["dval"], 0.5), q(st["dval"], 0.9), q(st["dx"], 0.5) if st["dx"] else -1, max(st["dx"]) if st["dx"] else -1,
               np.mean(np.array(st["dx"]) < 1e-5) if st["dx"] else -1, st["ties"], st["diverged_choice"], max(st["dsurf"])))
-    frac_cnt = 0.45 if late else frac
-    frac_pts = 0.5 if late else frac
+    # late: measured round 3 over the headline run and the two configs[2] batches (7 replays): counts equal 0.56 .. 0.88, end
+    # points within 1e-5 0.65 .. 0.89, chosen x within 1e-5 0.57 .. 0.88 - thresholds = the lowest measured value minus 10 %
+    # (tests/test_lbfgsb_divergence.py shows where the rest comes from)
+    frac_cnt = 0.50 if late else frac
+    frac_pts = 0.58 if late else frac
+    frac_x = 0.51 if late else frac
     assert st["iters"] >= min_iters
     assert max(st["dic"]) < 1e-9                                     # initial conditions essentially identical
     # q90 of the end points moves between 1e-5 and 1e-3 from build to build (it counts restart groups whose line search
     # branched differently; the same run has 31..46 of 400 such restarts depending on rounding in the Cholesky kernels)
-    assert q(st["dcand"], 0.5) < (1e-5 if late else 1e-8) and q(st["dcand"], 0.9) < 1e-2
+    assert q(st["dcand"], 0.5) < (1e-6 if late else 1e-8) and q(st["dcand"], 0.9) < 1e-2        # (late: q50 <= 1.2e-7, q90 <= 5.6e-3 measured)
     assert np.mean(np.array(st["dcand"]) < 1e-5) >= frac_pts
     # (late: q90 of the values measured 1.4e-5 on the f17 / d=40 batch of configs[2], 5.8e-6 on the headline run)
     assert q(st["dval"], 0.5) < 1e-10 and q(st["dval"], 0.9) < (5e-5 if late else 1e-6)
@@ -385,8 +389,8 @@ def _check_replay(st, min_iters, frac=0.9, late=False):
         # a single restart left short of its optimum (joint stopping rule) can move the chosen point by ~1e-2:
         # allowed for 1 in 20 iterations (measured: 1 of 40)
         assert q(st["dx"], 0.5) < (1e-5 if late else 1e-7) and np.mean(np.array(st["dx"]) < 1e-2) >= 0.95 and max(st["dx"]) < 0.5
-        assert np.mean(np.array(st["dx"]) < 1e-5) >= frac_pts
-        assert q(st["df"], 0.5) < 1e-9 and np.mean(np.array(st["df"]) < 1e-5) >= frac_pts
+        assert np.mean(np.array(st["dx"]) < 1e-5) >= frac_x
+        assert q(st["df"], 0.5) < 1e-9 and np.mean(np.array(st["df"]) < 1e-5) >= frac_x
     assert st["ties"] <= max(2, st["iters"] // 2)
     assert st["diverged_choice"] <= max(1, st["iters"] // 20)      # best restart in another local optimum: rare
     assert max(st["dsurf"]) < 1e-9               # the surface itself agrees wherever the device ended (measured 6e-15)

@@ -11,15 +11,31 @@
 #define WP_THREADS 1024
 
 // ---- deterministic block-wide sum (tree in LDS), result broadcast to every thread -----------
+// The sum is DEFINED as the stride-halving tree  s[t] += s[t + off], off = 512, 256, .., 1  (round 1 executed it literally:
+// eleven work-group barriers of sixteen waves, ~5 us per sum).  Same tree, two barriers: thread t = 64 j + l holds leaf (j, l);
+// the levels 512 .. 64 pair wave j with wave j + 8, 4, 2, 1 at a fixed lane - wave 0 adds them for its lane from the LDS in
+// exactly that order - and the levels 32 .. 1 pair lane l with lane l + off inside wave 0.  Bit-identical to the literal tree.
 __device__ inline double block_sum_1024(double v, double* s_red) {
-  int tid = threadIdx.x;
+  const int tid = threadIdx.x, l = tid & 63;
   s_red[tid] = v;
   __syncthreads();
-  for (int off = WP_THREADS / 2; off > 0; off >>= 1) {
-    if (tid < off) s_red[tid] += s_red[tid + off];
-    __syncthreads();
+  if (tid < 64) {
+    double a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = s_red[64 * j + l] + s_red[64 * (j + 8) + l];      // level 512
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = a[j] + a[j + 4];                                   // level 256
+    a[0] = a[0] + a[2]; a[1] = a[1] + a[3];                                              // level 128
+    double x = a[0] + a[1];                                                              // level 64
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {                                             // levels 32 .. 1
+      const double y = __shfl_down(x, off, 64);
+      if (l < off) x = x + y;
+    }
+    if (l == 0) s_red[0] = x;
   }
-  double r = s_red[0];
+  __syncthreads();
+  const double r = s_red[0];
   __syncthreads();
   return r;
 }
@@ -489,11 +505,22 @@ __global__ __launch_bounds__(WP_THREADS) void k_zstats(const double* __restrict_
   const int G = WP_THREADS / CP;
   const int c = tid % CP, g = tid / CP;
   double mn = INFINITY, mx = -INFINITY, sm = 0.0;
-  if (c < k)
-    for (int i = g; i < n; i += G) {
+  if (c < k) {
+    // (eight loads in flight per trip: left to itself the loop waited for every load in turn - 28 L2 round trips at n = 450
+    // were most of this kernel's 28 us; the min / max / sum chains keep their order)
+    int i = g;
+    for (; i + 7 * G < n; i += 8 * G) {
+      double z[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) z[u] = Z[(size_t)(i + u * G) * k + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { mn = fmin(mn, z[u]); mx = fmax(mx, z[u]); sm += z[u]; }
+    }
+    for (; i < n; i += G) {
       double z = Z[(size_t)i * k + c];
       mn = fmin(mn, z); mx = fmax(mx, z); sm += z;
     }
+  }
   s_min[tid] = mn; s_max[tid] = mx; s_red[tid] = sm;
   __syncthreads();
   if (tid < k) {
@@ -539,16 +566,24 @@ __global__ __launch_bounds__(256) void k_znorm(const double* __restrict__ Z, int
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= NP) return;
   double s = 0.0;
-  for (int c = 0; c < KP; ++c) {
-    double zn = 0.0, a = 0.0;
-    if (i < n && c < k) {
-      double lo = bounds4[c], hi = bounds4[PCABO_MAXD + c];
-      zn = (Z[(size_t)i * k + c] - lo) / (hi - lo);
-      a = (zn - zn_mean[c]) * inv_ls;
+  const size_t row = (size_t)(i < n ? i : n - 1) * k;
+  for (int c0 = 0; c0 < KP; c0 += 4) {                 // (KP is a multiple of 4; four loads in flight, from clamped addresses)
+    double zr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) zr[u] = Z[row + (c0 + u < k ? c0 + u : k - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = c0 + u;
+      double zn = 0.0, a = 0.0;
+      if (i < n && c < k) {
+        double lo = bounds4[c], hi = bounds4[PCABO_MAXD + c];
+        zn = (zr[u] - lo) / (hi - lo);
+        a = (zn - zn_mean[c]) * inv_ls;
+      }
+      ZnT[(size_t)c * ld + i] = zn;
+      AT[(size_t)c * ld + i] = a;
+      s += a * a;
     }
-    ZnT[(size_t)c * ld + i] = zn;
-    AT[(size_t)c * ld + i] = a;
-    s += a * a;
   }
   nrm[i] = s;
 }
@@ -557,14 +592,32 @@ __global__ __launch_bounds__(256) void k_znorm(const double* __restrict__ Z, int
 __global__ __launch_bounds__(128) void k_inverse_map(const double* __restrict__ z, const double* __restrict__ comps,
                                                      const double* __restrict__ data_mean,
                                                      const double* __restrict__ pca_mean, int k, int d,
-                                                     double* __restrict__ x, const int* __restrict__ k_dev, size_t zs) {
+                                                     double* __restrict__ x, const int* __restrict__ k_dev, size_t zs,
+                                                     double* __restrict__ host_x, HostMirror* hm, unsigned long long seq) {
   ZRUN(z); ZRUN(comps); ZRUN(data_mean); ZRUN(pca_mean); ZRUN(x); ZRUN(k_dev);
   if (k_dev) k = *k_dev;
   const int j = threadIdx.x;
-  if (j >= d) return;
-  double s = 0.0;
-  for (int c = 0; c < k; ++c) s += z[c] * comps[(size_t)c * d + j];
-  x[j] = (s + pca_mean[j]) + data_mean[j];
+  if (j < d) {
+    double s = 0.0;
+    int c = 0;
+    for (; c + 8 <= k; c += 8) {                       // eight loads in flight; the sum keeps its order
+      double cv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) cv[u] = comps[(size_t)(c + u) * d + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += z[c + u] * cv[u];
+    }
+    for (; c < k; ++c) s += z[c] * comps[(size_t)c * d + j];
+    const double xj = (s + pca_mean[j]) + data_mean[j];
+    x[j] = xj;
+    if (host_x) host_x[j] = xj;                        // single context: straight to pinned host memory, then the flag below
+  }
+  if (hm) {
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0)
+      __hip_atomic_store(const_cast<unsigned long long*>(&hm->qflag[0]), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // ---- launchers --------------------------------------------------------------------------------
@@ -614,6 +667,8 @@ void launch_znorm(hipStream_t s, const double* Z, int n, int k, int NP, int KP, 
                      ZnT, AT, nrm, k_dev, zb.zs);
 }
 void launch_inverse_map(hipStream_t s, const double* z, const double* comps, const double* data_mean,
-                        const double* pca_mean, int k, int d, double* x, const int* k_dev, ZB zb) {
-  hipLaunchKernelGGL(k_inverse_map, dim3(1, 1, zb.B), dim3(128), 0, s, z, comps, data_mean, pca_mean, k, d, x, k_dev, zb.zs);
+                        const double* pca_mean, int k, int d, double* x, const int* k_dev, ZB zb, double* host_x,
+                        HostMirror* hm, unsigned long long seq) {
+  hipLaunchKernelGGL(k_inverse_map, dim3(1, 1, zb.B), dim3(128), 0, s, z, comps, data_mean, pca_mean, k, d, x, k_dev, zb.zs,
+                     host_x, hm, seq);
 }

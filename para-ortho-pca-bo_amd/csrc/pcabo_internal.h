@@ -211,4 +211,5 @@ void launch_score(hipStream_t st, const double* Xq, int q, int n, int k, int NP,
 bool acq_server_possible(int q, int n, int k, int NP);
 int acq_slabs(int NP);
 void launch_inverse_map(hipStream_t s, const double* z, const double* comps, const double* data_mean,
-                        const double* pca_mean, int k, int d, double* x, const int* k_dev = nullptr, ZB zb = ZB());
+                        const double* pca_mean, int k, int d, double* x, const int* k_dev = nullptr, ZB zb = ZB(),
+                        double* host_x = nullptr, HostMirror* hm = nullptr, unsigned long long seq = 0);   // host_x / hm: results + flag to pinned host

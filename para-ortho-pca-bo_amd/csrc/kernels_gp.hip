@@ -302,9 +302,7 @@ void launch_cholesky(hipStream_t s, double* L, int NP, int ld, int* info, double
   //    (measured round 3, us: n=450: 223 -> 161 (1 run), 248 -> 221 (30 runs); n=1050: 709 -> 514 (1 run));
   //  * look-back launch + panel launch per panel (round 2) where the chip is oversubscribed anyway and the lighter
   //    look-back groups (2-3 per CU) keep the matrix cores busier: 30 runs at n = 1050: 983 us against 1132 fused.
-  static const int force = getenv("PCABO_CHOL_FORM") ? atoi(getenv("PCABO_CHOL_FORM")) : 0;     // 1 fused, 2 two launches (A/B only)
-  const bool fused = force ? force == 1 : zb.B * nblk <= 256;
-  if (fused) { launch_chol_steps(s, L, NP, ld, info, diag_scratch, zb); return; }
+  if (zb.B * nblk <= 256) { launch_chol_steps(s, L, NP, ld, info, diag_scratch, zb); return; }
   for (int p = 0; p < nblk; ++p) {                   // bring block column p up to date, then factor it
     if (p > 0)
       hipLaunchKernelGGL(k_chol_lookback, dim3(nblk - p + 1, 1, zb.B), dim3(256), 0, s, L, p, nblk, ld, diag_scratch, zb.zs);

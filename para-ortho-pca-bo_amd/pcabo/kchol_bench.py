@@ -15,10 +15,11 @@ FP64_PEAK_TFLOPS = 78.6
 HBM_PEAK_GBS = 8000.0
 
 
-def run(device: int = 0, batches=(1, 30), grid=GRID, reps: int = 5) -> list:
+def run(device: int = 0, batches=(1, 30), grid=GRID, reps: int = 5, big_batch: int = 0) -> list:
+    """`big_batch` > 0: the two larger shapes also with that many runs side by side (the regime in which the matrix cores fill)."""
     out = []
     for n, k in grid:
-        for B in batches:
+        for B in tuple(batches) + ((big_batch,) if big_batch and n >= 450 else ()):
             rng = np.random.default_rng(1000 * n + B)
             X = rng.uniform(1.0 / 12, 11.0 / 12, (B, n, k))
             y = rng.normal(size=(B, n))

@@ -323,6 +323,39 @@ void Lbfgsb::cauchy(const double* x, const double* g) {
   const int col2 = 2 * col;
   double f1 = 0.0;
   for (int i = 0; i < col2; ++i) p[i] = 0.0;
+  if (boxed_) {
+    // every variable has both bounds (the acquisition's search box): the same classification with the sign of the gradient
+    // handled by selects instead of branches (it is unpredictable: half of the ~25 cycles per variable were mispredictions) -
+    // tl / (-neggi) for neggi < 0 and tu / neggi for neggi > 0 are both "distance to the bound ahead / |neggi|"
+    for (int i = 0; i < n; ++i) {
+      const double neggi = -g[i];
+      const double tl = x[i] - l_[i], tu = u_[i] - x[i];
+      int iw = iwhere_[i];
+      if (iw != 3) {
+        iw = 0;
+        if (tl <= 0.0) { if (neggi <= 0.0) iw = 1; }
+        else if (tu <= 0.0) { if (neggi >= 0.0) iw = 2; }
+        else if (std::fabs(neggi) <= 0.0) iw = -3;
+        iwhere_[i] = iw;
+      }
+      if (iw != 0) { d[i] = 0.0; continue; }
+      d[i] = neggi;
+      f1 -= neggi * neggi;
+      sc_rows_[nmove] = i;
+      sc_coef_[nmove++] = neggi;
+      if (neggi != 0.0) {                      // (NaN never gets here; neggi == 0 with iw == 0 cannot happen either)
+        const double ahead = neggi < 0.0 ? tl : tu;
+        const double tb = ahead / std::fabs(neggi);
+        iorder[nbreak] = i;
+        t[nbreak] = tb;
+        if (nbreak == 0 || tb < bkmin) { bkmin = tb; ibkmin = nbreak; }
+        ++nbreak;
+      } else {
+        --nfree;
+        iorder[nfree] = i;
+      }
+    }
+  } else
   for (int i = 0; i < n; ++i) {
     const double neggi = -g[i];
     double tl = 0.0, tu = 0.0;
@@ -658,17 +691,21 @@ void Lbfgsb::subsm(const double* xx, const double* gg) {
     const int k = ind[i];
     const double dk = d[i];
     double xk = x[k];
+    // (plain comparisons instead of fmax / fmin: those are libm calls without -ffinite-math, 360 of them per step at 180
+    // variables; no NaN reaches this point and on a tie both operands are the same number)
     if (nbd_[k] != 0) {
+      const double v = xk + dk, lk = l_[k], uk = u_[k];
       if (nbd_[k] == 1) {
-        x[k] = std::fmax(l_[k], xk + dk);
-        if (x[k] == l_[k]) iword_ = 1;
+        x[k] = lk > v ? lk : v;
+        if (x[k] == lk) iword_ = 1;
       } else if (nbd_[k] == 2) {
-        xk = std::fmax(l_[k], xk + dk);
-        x[k] = std::fmin(u_[k], xk);
-        if (x[k] == l_[k] || x[k] == u_[k]) iword_ = 1;
+        xk = lk > v ? lk : v;
+        const double w = uk < xk ? uk : xk;
+        x[k] = w;
+        if (w == lk || w == uk) iword_ = 1;
       } else if (nbd_[k] == 3) {
-        x[k] = std::fmin(u_[k], xk + dk);
-        if (x[k] == u_[k]) iword_ = 1;
+        x[k] = uk < v ? uk : v;
+        if (x[k] == uk) iword_ = 1;
       }
     } else {
       x[k] = xk + dk;

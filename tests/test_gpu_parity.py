@@ -544,6 +544,28 @@ def test_largest_size_n1050_properties(native):
     c.close()
 
 
+def test_group_kernel_with_more_than_64_kb_of_lds(native):
+    """k_acq_group<2> asks for more than the 64 KB default of dynamic LDS from (NP, k) = (512, 83) on (65 808 bytes at k = 89):
+    a d = 100 batch reaches that at n = 449..512.  The launch must work (the attribute is set per device for every
+    instantiation that can need it) and agree with the per-query kernels on the same points."""
+    rng = np.random.default_rng(31)
+    for n, k in ((512, 89), (449, 85), (480, 128)):
+        Z = rng.normal(size=(n, k))
+        y = rng.normal(size=n) * 30 + 200
+        c = native.Context(max_n=n, max_d=k, max_q=64)
+        c.gp_condition(y, Z=Z)
+        b = c.acq_bounds()
+        X = rng.uniform(b[0], b[1], size=(13, k)) * 0.5 + 0.5 * Z[:13]
+        best = float(y.min())
+        v, g = c.acq_eval(X, best, False)
+        c.set_option(native.OPT_GROUP_ACQ, 1)
+        vg, gg = c.acq_eval(X, best, False)
+        c.close()
+        assert np.isfinite(vg).all() and np.isfinite(gg).all()
+        assert np.abs(vg - v).max() <= 1e-11 * max(1.0, np.abs(v).max()), (n, k)
+        assert np.abs(gg - g).max() <= 1e-10 * max(1.0, np.abs(g).max()), (n, k)
+
+
 def test_256_restarts_equal_independent_groups(native):
     """256 multi-starts (52 joint groups advancing in lock-step on two host threads): every group must end
     exactly where it ends when optimised on its own."""

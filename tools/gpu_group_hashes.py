@@ -9,7 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "para-ortho-pca-bo_amd"))
 import numpy as np
 
-CASES = [(120, 12), (200, 20), (256, 30), (320, 33), (449, 36), (450, 36), (512, 40), (700, 40), (1050, 89)]
+# (new cases go to the END: one generator runs through all of them)
+CASES = [(120, 12), (200, 20), (256, 30), (320, 33), (449, 36), (450, 36), (512, 40), (700, 40), (1050, 89),
+         (512, 89), (449, 85)]      # round 3: k_acq_group<2> with more than 64 KB of dynamic LDS (k >= 83 at NP = 512)
 GOLDEN = os.path.join(ROOT, "tests", "golden", "acq_group_hashes.json")
 
 
@@ -48,9 +50,10 @@ def compute() -> dict:
 if __name__ == "__main__":
     res = compute()
     if "--write" in sys.argv:
-        with open(GOLDEN, "w") as f:
-            json.dump({"_comment": "tools/gpu_group_hashes.py --write on an MI355X (round 2, VALU v / w phases of k_acq_group)",
-                       "cases": res}, f, indent=1)
-        print("written", GOLDEN)
+        out = sys.argv[sys.argv.index("--write") + 1] if len(sys.argv) > sys.argv.index("--write") + 1 else GOLDEN
+        with open(out, "w") as f:
+            json.dump({"_comment": "tools/gpu_group_hashes.py --write on an MI355X (round 2, VALU v / w phases of k_acq_group; the last "
+                                   "two cases added in round 3)", "cases": res}, f, indent=1)
+        print("written", out)
     else:
         print(json.dumps(res, indent=1))

@@ -198,3 +198,18 @@ def test_run_side_by_side_drives_every_batch_and_reraises():
     run_side_by_side([one])
     assert one.n == 3 and one.thread == threading.current_thread().name     # a single batch stays on the caller's thread
     assert workers_for(1) == 8 and workers_for(2) == 4 and workers_for(8) == 2
+
+
+def test_hardware_queue_advice_reads_the_environment_and_never_writes_it(native, monkeypatch):
+    """pcabo/_native.py leaves GPU_MAX_HW_QUEUES alone (round 2 set it at import): it only says what is missing."""
+    import os
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    msg = native.hw_queues_advice(10)
+    assert msg is not None and "GPU_MAX_HW_QUEUES=16" in msg and "unset" in msg
+    assert "GPU_MAX_HW_QUEUES" not in os.environ                     # asked, not changed
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
+    assert native.hw_queues_advice(8) is None and native.hw_queues_advice(10) is not None
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "16")
+    assert native.hw_queues_advice(10) is None
+    src = open(os.path.join(ROOT, "para-ortho-pca-bo_amd", "pcabo", "_native.py")).read()
+    assert "os.environ.setdefault" not in src and "os.environ[" not in src

@@ -76,6 +76,7 @@ class BatchedPCABO:
         self._batch: Optional[_native.Batch] = None
         self._rs = self._tg = None
         self._X = None
+        self._F = None                     # B x budget objective values as the device sees them (grows with the runs)
         # the runs' noise draws (numpy releases the interpreter lock while it generates) are spread over a few threads;
         # every run has its own generator, so the order in which the threads get to the runs does not matter
         # device_objective: the B candidates of an iteration are evaluated in one launch (pcabo.bbob_device; in-repo BBOB
@@ -84,6 +85,17 @@ class BatchedPCABO:
         self._pool = None
         self._host_threads = int(host_threads) if host_threads else min(8, self.B)
         self._workers = int(workers)                 # 0: the library's default (pcabo_batch_set_workers)
+        # the NEXT iteration's noise blocks (numpy's generator releases the interpreter lock while it fills them) are drawn on
+        # the host threads while the L-BFGS-B rounds of this iteration run inside the library: same numbers from the same
+        # per-run streams - nothing else draws from them after the DoE - 1.5 ms less in front of every lock-step iteration.
+        # Off while per-iteration generator states are recorded (they must be the states BEFORE the draw).
+        self._noise_ahead = {}
+        # likewise the scrambled Sobol engines of the next iteration (torch's two randint draws per run, 0.06 ms each and
+        # serial under the interpreter lock): built by one pool thread with THIS iteration's k as the guess while the main
+        # thread sits in pcabo_batch_optimize_acqf (which releases the lock).  The draws leave each run's torch generator
+        # exactly where the next iteration would take them; a run that needs botorch's retry after the call (fresh initial
+        # conditions from the same generator) gets its generator put back first, a wrong guess of k likewise.
+        self._engines_ahead = {}           # run -> (generator state before the draw, engine), filled during the rounds
         # acq_kernel: "group" (default: the throughput kernel k_acq_group for the L-BFGS-B rounds; a run is bit-identical to
         # PCA_BO(acq_kernel="group")) or "latency" (the per-query kernels: bit-identical to PCA_BO's default)
         if acq_kernel not in ("group", "latency"):
@@ -96,6 +108,7 @@ class BatchedPCABO:
         self._rs = [np.random.RandomState(s) for s in self.seeds]
         self._tg = [torch.Generator().manual_seed(s) for s in self.seeds]
         self._X = np.empty((B, self.budget, d))
+        self._F = np.empty((B, self.budget))
         for b in range(B):
             unit = lhs_center(d, self.n_DoE, self._rs[b])
             span = self.bounds[b][:, 1] - self.bounds[b][:, 0]
@@ -104,6 +117,7 @@ class BatchedPCABO:
                 self.f_evals[b].append(self.problems[b](point))
             self._assign_new_best(b)
             self._X[b, : self.n_DoE] = np.vstack(self.x_evals[b])
+            self._F[b, : self.n_DoE] = self.f_evals[b]
         self._batch = _native.Batch(B, max_n=self.budget, max_d=d, max_q=max(self.raw_samples, 16), device=self.device,
                                     workers=self._workers, group_acq=self._group_acq)
         if self._device_objective:
@@ -130,14 +144,6 @@ class BatchedPCABO:
         live = [len(self.f_evals[b]) for b in range(self.B) if self.failed[b] is None]
         return max(live) if live else self.budget
 
-    def _f_for_device(self, b: int, n: int):
-        """The n objective values run b hands to the device: its own, or - parked - a finite stand-in of the same length
-        (its DoE values repeated; the matching rows of `_X` repeat the DoE points) so that the lock-step launches of the
-        other runs see nothing but finite numbers."""
-        if self.failed[b] is None:
-            return self.f_evals[b]
-        return self._frozen[b][1][:n]
-
     def _park(self, b: int, n: int, message: str) -> None:
         self.failed[b] = (n, message)
         reps = -(-self.budget // self.n_DoE)
@@ -145,6 +151,7 @@ class BatchedPCABO:
         fd = np.array(self.f_evals[b][: self.n_DoE], dtype=float)
         self._frozen[b] = (np.tile(Xd, (reps, 1))[: self.budget], np.tile(fd, reps)[: self.budget])
         self._X[b] = self._frozen[b][0]
+        self._F[b] = self._frozen[b][1]
         self.current_best[b] = float(np.min(fd) if not self.maximization else np.max(fd))
         self._batch.set_active([self.failed[i] is None for i in range(self.B)])
         warnings.warn(f"run {b} (seed {self.seeds[b]}) stopped at n = {n}: {message}", RuntimeWarning)
@@ -160,16 +167,25 @@ class BatchedPCABO:
                     pre[b] = {"numpy_state": self._rs[b].get_state(), "torch_state": self._tg[b].get_state().clone(),
                               "best_f": self.current_best[b]}
         self._pre_states = pre            # (kept on the object: still there when a run stops in this iteration)
-        F = np.array([self._f_for_device(b, n) for b in range(B)], dtype=np.float64)    # B x n
+        F = np.ascontiguousarray(self._F[:, :n])      # B x n (a parked run: its finite stand-in, see _park)
         ranks = np.empty((B, n), dtype=np.int64)
         noise = np.empty((B, n, d))
+
+        ahead, self._noise_ahead = self._noise_ahead, {}
 
         def prep(b):
             # per run, on a 1-D array exactly as the reference does it (PCA_BO.py:330-333): the penalty value repeats, and
             # how numpy's unstable sort orders ties must be what the run sees alone
             fb = F[b].copy()
             ranks[b] = np.argsort(np.argsort(-fb if self.maximization else fb)) + 1
-            noise[b] = self._rs[b].normal(0, 1e-8, size=(n, d))                       # PCA_BO.py:376, the run's own stream
+            fut = ahead.get(b)
+            if fut is not None:
+                nz = fut.result()
+                if nz.shape != (n, d):
+                    raise RuntimeError("noise drawn ahead is out of step with the run")
+                noise[b] = nz
+            else:
+                noise[b] = self._rs[b].normal(0, 1e-8, size=(n, d))                   # PCA_BO.py:376, the run's own stream
         self._each(prep)
         t1 = perf_counter()
         bt.wpca_gp_condition_begin(self._X[:, :n], ranks, noise, F, maximize=self.maximization,
@@ -178,8 +194,12 @@ class BatchedPCABO:
         # while the device runs the eigen-decompositions: the scrambled Sobol engines, with last iteration's k
         engines, saved = [None] * B, [None] * B
 
+        built, self._engines_ahead = self._engines_ahead, {}
+
         def guess(b):
-            if self.k_prev[b]:
+            if b in built:
+                saved[b], engines[b] = built[b]
+            elif self.k_prev[b]:
                 saved[b] = self._tg[b].get_state()
                 engines[b] = _init.scrambled_sobol_engine(self.k_prev[b], self._tg[b])
         for b in range(B):                # (torch's small ops do not gain from the host threads: measured slower)
@@ -216,7 +236,30 @@ class BatchedPCABO:
                else np.arange(self.num_restarts) for b in range(B)]
         ics = [raw[b][idx[b]] for b in range(B)]
         t5 = perf_counter()
+        if self._pool is not None and not self.record_trace and n + 1 < self.budget:
+            for b in range(B):
+                if self.failed[b] is None:
+                    self._noise_ahead[b] = self._pool.submit(self._rs[b].normal, 0, 1e-8, (n + 1, d))
+            live = [b for b in range(B) if self.failed[b] is None and self.k_prev[b]]
+
+            def build_engines():
+                out = {}
+                for b in live:
+                    st = self._tg[b].get_state()
+                    out[b] = (st, _init.scrambled_sobol_engine(self.k_prev[b], self._tg[b]))
+                return out
+            engines_job = self._pool.submit(build_engines)
+        else:
+            engines_job = None
         outs, status = bt.optimize_acqf(ics, bounds, best_f, self.maximization, self.acq_code, batch_limit=5, maxiter=200)
+        if engines_job is not None:
+            # botorch's retry below draws from a run's generator: a run that needs it takes its generator back first
+            built = engines_job.result()
+            for b in list(built):
+                if status[b] != 0 or outs[b][3]:
+                    self._tg[b].set_state(built[b][0])
+                    del built[b]
+            self._engines_ahead = built
         for b in range(B):
             if self.failed[b] is None and status[b] != 0:
                 self._park(b, n, "NaN in the acquisition gradient (botorch raises here)" if status[b] == -4
@@ -268,6 +311,7 @@ class BatchedPCABO:
                 self.x_evals[b].append(new_x)
                 self.f_evals[b].append(new_f)
                 self._X[b, n] = new_x
+                self._F[b, n] = new_f
                 self._assign_new_best(b)
                 continue
             outside = not np.all(new_x >= self.bounds[b][:, 0]) or not np.all(new_x <= self.bounds[b][:, 1])
@@ -276,6 +320,7 @@ class BatchedPCABO:
             self.x_evals[b].append(new_x)
             self.f_evals[b].append(new_f)
             self._X[b, n] = new_x
+            self._F[b, n] = new_f
             self._assign_new_best(b)
         t7 = perf_counter()
         tm = self.timing

@@ -68,7 +68,8 @@ int pcabo_last_error(pcabo_ctx* ctx, char* buf, int buflen);
  *   throughput kernel (one work-group per restart group of <= 5 points and 64-row slab) instead of the per-query
  *   latency kernels; implies one launch per evaluation.  Same formulas, another summation order (~1e-15 relative), so a
  *   run is bit-reproducible within a mode, not across modes. */
-enum { PCABO_OPT_RESIDENT = 0, PCABO_OPT_BESTF_F32 = 1, PCABO_OPT_GROUP_ACQ = 2 };
+enum { PCABO_OPT_RESIDENT = 0, PCABO_OPT_BESTF_F32 = 1, PCABO_OPT_GROUP_ACQ = 2,
+       PCABO_OPT_DEVICE_LBFGSB = 3 /* batches only, see pcabo_batch_set_option */ };
 int pcabo_set_option(pcabo_ctx* ctx, int option, int value);
 
 /* Rows A-C (+D,J): rank-weighted PCA of the evaluated points.
@@ -233,7 +234,13 @@ int pcabo_batch_destroy(pcabo_batch* batch);
 int pcabo_batch_set_workers(pcabo_batch* batch, int workers);
 /* PCABO_OPT_GROUP_ACQ (default 1): the L-BFGS-B rounds of the batch go through the throughput kernel (k_acq_group); 0: through
  * the per-query kernels a stand-alone context uses by default - a run of the batch is then bit-identical to the same run in a
- * context of its own with default options (with 1 it is bit-identical to such a context with PCABO_OPT_GROUP_ACQ set). */
+ * context of its own with default options (with 1 it is bit-identical to such a context with PCABO_OPT_GROUP_ACQ set).
+ * PCABO_OPT_DEVICE_LBFGSB (default 0): 1 = pcabo_batch_optimize_acqf runs every restart group's whole L-BFGS-B optimisation
+ *   (gen_candidates_scipy of PCA_BO.py:607-614) inside ONE kernel launch, a work-group per group: evaluate, step, next point
+ *   without a host round trip (csrc/kernels_lbfgsb.hip; needs n <= 512, k <= 40, batch_limit <= 5 and finite bounds - other
+ *   calls take the host-paced path).  Its evaluation sums in an order of its own (a third arithmetic mode, ~1e-15 relative from
+ *   the other two).  2 = the same evaluation kernel driven by the HOST's L-BFGS-B, one launch per round: slow, the reference
+ *   the device stepping is compared with bit for bit (tests/test_gpu_device_lbfgsb.py). */
 int pcabo_batch_set_option(pcabo_batch* batch, int option, int value);
 int pcabo_batch_last_error(pcabo_batch* batch, char* buf, int buflen);
 pcabo_ctx* pcabo_batch_ctx(pcabo_batch* batch, int b);
@@ -268,6 +275,12 @@ int pcabo_batch_set_profiling(pcabo_batch* batch, int enabled);
 int pcabo_batch_get_profile(pcabo_batch* batch, double* ms);
 /* Row O for every run: z[B][max_d] (k_b entries used) -> x[B][d]. */
 int pcabo_batch_inverse_map(pcabo_batch* batch, const double* z, double* x);
+/* Value and gradient of the acquisition (botorch LogExpectedImprovement / ProbabilityOfImprovement + autograd, PCA_BO.py:199-203,
+ * 681-682) at q <= 32 points per run through the evaluation of the device-resident optimiser (PCABO_OPT_DEVICE_LBFGSB on;
+ * n <= 512, k <= 40).  Xq[B][q*max_d]: run b's points packed with stride k_b; val[B][q]; grad[B][q*max_d], same packing.
+ * For diagnostics and parity tests: pcabo_batch_optimize_acqf evaluates inside its own launch. */
+int pcabo_batch_device_acq_eval(pcabo_batch* batch, const double* Xq, int q, const double* best_f, int maximize, int acq,
+                                double* val, double* grad);
 
 /* ---- BBOB f15-f24 objectives on the device, for runs that advance in lock-step ---------------------------------------
  * The reference evaluates `problem(x)` on the host, one candidate per BO iteration (PCA_BO.py:263; the problems come from

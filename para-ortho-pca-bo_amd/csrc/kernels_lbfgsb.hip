@@ -1,0 +1,1522 @@
+// Device-resident L-BFGS-B for the restart groups of a batch (first option; the reference reaches
+// the algorithm through botorch.optimize_acqf -> gen_candidates_scipy -> scipy's L-BFGS-B,
+// /root/reference/Algorithms/BayesianOptimization/PCA_BO.py:607-614).
+//
+// One work-group of 1024 threads per restart group (<= 5 joint query points, <= 200 variables) runs the whole
+// optimisation without the host: evaluate (all 16 waves) -> L-BFGS-B step (wave 0) -> next point, until the group has
+// converged or reached its limits.  No work-group waits for another one, nothing polls: a plain kernel whose every loop is
+// bounded (maxiter iterations of <= 20 line-search evaluations, a hard cap on evaluations on top).
+//
+//  * The optimiser state (S, Y of the last 10 pairs, the compact-representation matrices, the iterate, gradient, bounds,
+//    index sets) lives in LDS; the step is csrc/lbfgsb.cpp restated for ONE WAVE: loops over the variables run a variable
+//    per lane, the ordered sums of the published algorithm stay ordered (a chain per lane where several sums are
+//    independent, every lane the same chain otherwise), the small dense pieces (10 x 10 and 20 x 20 factorisations and
+//    triangular solves) keep a column or a right-hand side per lane and broadcast pivots with v_readlane.  Every number goes
+//    through the same operations in the same order as on the host (this file is compiled with -ffp-contract=off; IEEE
+//    divide and square root), so that fed the same f / g values the device takes the host's iterates bit for bit
+//    (tests/test_gpu_device_lbfgsb.py compares the two through the evaluation-only mode of the same kernel).
+//  * The evaluation (rows I of SURVEY.md 8a for the group's points: kernel vectors, v = R ks, |v|^2, mu, log-EI / PI chain,
+//    w = R' v, gradient contraction) is thread-per-output with coalesced reads and no cross-lane reduction in the two
+//    triangular passes: pass 1 reads the TRANSPOSED root inverse RT (built once per conditioning by k_rt_build), pass 2 reads
+//    R itself; the rows / columns of a pass are split over 1024 / NP thread groups whose partial sums are added in a fixed
+//    order.  Same formulas as k_acq_group / k_acq_fast, another (fixed) summation order: a third arithmetic mode, selected
+//    per batch (PCABO_OPT_DEVICE_LBFGSB), never mixed within a run.
+#include "pcabo_internal.h"
+#include "lbfgsb.h"
+#include <cfloat>
+#include <cmath>
+#include <mutex>
+
+#define PCABO_ERR_NAN_CODE (-4)      // PCABO_ERR_NAN of include/pcabo.h
+
+#define LB_M 10
+#define LB_THREADS 1024
+#define LB_GQ 5
+#define LB_QS 6             // stride of a point's per-query values in LDS (16-byte aligned pairs)
+#define LB_MAXK 40
+#define LB_MAXNP 512
+#define LB_MAXEVAL 20000    // hard cap on the evaluations of one group (the host's limits stop it long before)
+
+#define LSYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// LDS pointers carry their address space in the type: ds_read / ds_write whether or not a helper is inlined
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) double ldsd;
+typedef __attribute__((address_space(3))) int ldsi;
+#else
+typedef double ldsd;
+typedef int ldsi;
+#endif
+
+// ---- persistent scalars of a group (LDS) ----------------------------------------------------------------------------
+enum { S_THETA, S_FOLD, S_DNORM, S_GD, S_STPMX, S_SBGNRM, S_STP, S_GDOLD, S_DTD, S_F, S_FC,
+       LS_GINIT, LS_GTEST, LS_GX, LS_GY, LS_FINIT, LS_FX, LS_FY, LS_STX, LS_STY, LS_STMIN, LS_STMAX, LS_WIDTH, LS_WIDTH1,
+       S_COUNT };
+enum { I_COL, I_HEAD, I_ITAIL, I_ITER, I_IUPDAT, I_UPDATD, I_WRK, I_NFREE, I_ILEAVE, I_NENTER, I_INFO, I_IFUN, I_IBACK,
+       I_NFGV, I_IWORD, I_TASK, I_PHASE, LS_TASK, LS_BRACKT, LS_STAGE, I_NITER, I_NFEV, I_HAVE_CACHE, I_ACTIVE, I_STATUS,
+       I_TIES, I_EVALS, I_COUNT };
+
+// LDS layout of a group: every array at a compile-time offset from the dynamic block (the optimiser's arrays are sized for the
+// largest group, LB_GQ * LB_MAXK variables), the evaluation's three NP-sized arrays last.  The struct is three words and
+// travels by value.
+#define LB_NVCAP (LB_GQ * LB_MAXK)
+#define LB_LDW (LB_NVCAP | 1)
+#define LB_NVP ((LB_NVCAP + 3) & ~1)
+#define LB_EVEN(x) (((x) + 1) & ~1)
+enum {
+  OFF_WS = 0, OFF_WY = OFF_WS + LB_EVEN(LB_M * LB_LDW), OFF_X = OFF_WY + LB_EVEN(LB_M * LB_LDW),
+  OFF_G = OFF_X + LB_NVP, OFF_LO = OFF_G + LB_NVP, OFF_HI = OFF_LO + LB_NVP, OFF_Z = OFF_HI + LB_NVP, OFF_R = OFF_Z + LB_NVP,
+  OFF_D = OFF_R + LB_NVP, OFF_T = OFF_D + LB_NVP, OFF_XP = OFF_T + LB_NVP, OFF_FULL = OFF_XP + LB_NVP, OFF_COEF = OFF_FULL + LB_NVP,
+  OFF_XC = OFF_COEF + LB_NVP, OFF_GC = OFF_XC + LB_NVP, OFF_PROD = OFF_GC + LB_NVP,
+  OFF_SY = OFF_PROD + LB_NVP, OFF_SS = OFF_SY + LB_M * LB_M, OFF_WT = OFF_SS + LB_M * LB_M, OFF_WN = OFF_WT + LB_M * LB_M,
+  OFF_WN1 = OFF_WN + 4 * LB_M * LB_M, OFF_WA = OFF_WN1 + 4 * LB_M * LB_M, OFF_ACC = OFF_WA + 8 * LB_M, OFF_SC = OFF_ACC + 64,
+  OFF_VC = OFF_SC + LB_EVEN(S_COUNT + 2), OFF_INTS = OFF_VC + 8,
+  OFF_XN = OFF_INTS + LB_EVEN((4 * LB_NVP + I_COUNT + 2) / 2 + 2), OFF_RED = OFF_XN + LB_EVEN(LB_GQ * (LB_MAXK + 2)),
+  OFF_VALS = OFF_RED + 160, OFF_CQ = OFF_VALS + 8, OFF_KS = OFF_CQ + 16
+};
+struct LbLds {
+  ldsd* base;
+  int n, NP;                            // n: variables of the group (nq * k)
+  __device__ ldsd* ws() const { return base + OFF_WS; }
+  __device__ ldsd* wy() const { return base + OFF_WY; }
+  __device__ ldsd* x() const { return base + OFF_X; }
+  __device__ ldsd* g() const { return base + OFF_G; }
+  __device__ ldsd* lo() const { return base + OFF_LO; }
+  __device__ ldsd* hi() const { return base + OFF_HI; }
+  __device__ ldsd* z() const { return base + OFF_Z; }
+  __device__ ldsd* r() const { return base + OFF_R; }
+  __device__ ldsd* d() const { return base + OFF_D; }
+  __device__ ldsd* t() const { return base + OFF_T; }
+  __device__ ldsd* xp() const { return base + OFF_XP; }
+  __device__ ldsd* full() const { return base + OFF_FULL; }
+  __device__ ldsd* coef() const { return base + OFF_COEF; }
+  __device__ ldsd* xc() const { return base + OFF_XC; }
+  __device__ ldsd* gc() const { return base + OFF_GC; }
+  __device__ ldsd* prod() const { return base + OFF_PROD; }
+  __device__ ldsd* sy() const { return base + OFF_SY; }
+  __device__ ldsd* ss() const { return base + OFF_SS; }
+  __device__ ldsd* wt() const { return base + OFF_WT; }
+  __device__ ldsd* wn() const { return base + OFF_WN; }
+  __device__ ldsd* wn1() const { return base + OFF_WN1; }
+  __device__ ldsd* wa() const { return base + OFF_WA; }
+  __device__ ldsd* acc() const { return base + OFF_ACC; }
+  __device__ ldsd* sc() const { return base + OFF_SC; }
+  __device__ ldsd* vc() const { return base + OFF_VC; }
+  __device__ ldsi* index() const { return (ldsi*)(base + OFF_INTS); }
+  __device__ ldsi* iwhere() const { return (ldsi*)(base + OFF_INTS) + LB_NVP; }
+  __device__ ldsi* indx2() const { return (ldsi*)(base + OFF_INTS) + 2 * LB_NVP; }
+  __device__ ldsi* rows() const { return (ldsi*)(base + OFF_INTS) + 3 * LB_NVP; }
+  __device__ ldsi* isc() const { return (ldsi*)(base + OFF_INTS) + 4 * LB_NVP; }
+  __device__ ldsd* xn() const { return base + OFF_XN; }
+  __device__ ldsd* red() const { return base + OFF_RED; }
+  __device__ ldsd* vals() const { return base + OFF_VALS; }
+  __device__ ldsd* cq() const { return base + OFF_CQ; }
+  __device__ ldsd* ks() const { return base + OFF_KS; }
+  __device__ ldsd* vb() const { return base + OFF_KS + LB_QS * NP; }
+  __device__ ldsd* part() const { return base + OFF_KS + 2 * LB_QS * NP; }
+};
+static inline size_t lb_lds_doubles(int NP, int H) { return (size_t)OFF_KS + (size_t)(2 + (H > 1 ? H - 1 : 1)) * LB_QS * NP; }
+
+#define SC(i) L.sc()[i]
+#define ISC(i) L.isc()[i]
+#define WS_(i, p) L.ws()[(p) * LB_LDW + (i)]
+#define WY_(i, p) L.wy()[(p) * LB_LDW + (i)]
+#define SY_(i, j) L.sy()[(j) * LB_M + (i)]
+#define SS_(i, j) L.ss()[(j) * LB_M + (i)]
+#define WT_(i, j) L.wt()[(j) * LB_M + (i)]
+#define WN_(i, j) L.wn()[(j) * 2 * LB_M + (i)]
+#define WN1_(i, j) L.wn1()[(j) * 2 * LB_M + (i)]
+
+__device__ inline int nxt(int p) { return p + 1 == LB_M ? 0 : p + 1; }
+__device__ inline double bcast(double v, int lane) {      // value of `lane` (uniform index) in every lane
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ inline void st0(ldsd* p, double v, int lane) { if (lane == 0) *p = v; }
+__device__ inline void sti0(ldsi* p, int v, int lane) { if (lane == 0) *p = v; }
+__device__ inline unsigned long long lanes_below(int lane) { return lane == 0 ? 0ull : (~0ull >> (64 - lane)); }
+
+// ordered sum of an LDS array, every lane the same chain: s = (((s0 op a[0]) op a[1]) ...)
+__device__ inline double chain_add(double s, const ldsd* a, int n) {
+  int i = 0;
+  for (; i + 8 <= n; i += 8) {
+    const double a0 = a[i], a1 = a[i + 1], a2 = a[i + 2], a3 = a[i + 3], a4 = a[i + 4], a5 = a[i + 5], a6 = a[i + 6], a7 = a[i + 7];
+    s += a0; s += a1; s += a2; s += a3; s += a4; s += a5; s += a6; s += a7;
+  }
+  for (; i < n; ++i) s += a[i];
+  return s;
+}
+__device__ inline double chain_sub(double s, const ldsd* a, int n) {
+  int i = 0;
+  for (; i + 8 <= n; i += 8) {
+    const double a0 = a[i], a1 = a[i + 1], a2 = a[i + 2], a3 = a[i + 3], a4 = a[i + 4], a5 = a[i + 5], a6 = a[i + 6], a7 = a[i + 7];
+    s -= a0; s -= a1; s -= a2; s -= a3; s -= a4; s -= a5; s -= a6; s -= a7;
+  }
+  for (; i < n; ++i) s -= a[i];
+  return s;
+}
+// ddot of two LDS vectors in the host's order (products rounded, then added from 0.0): lanes form the products, every lane the chain
+__device__ inline double wave_ddot(const LbLds L, const ldsd* a, const ldsd* b, int n, int lane) {
+  for (int i = lane; i < n; i += 64) L.prod()[i] = a[i] * b[i];
+  LSYNC();
+  const double s = chain_add(0.0, L.prod(), n);
+  LSYNC();
+  return s;
+}
+// ddot of two short LDS vectors (<= 2 LB_M), every lane the same chain
+__device__ inline double small_ddot(const ldsd* a, const ldsd* b, int n) {
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += a[i] * b[i];
+  return s;
+}
+
+// "reduce over variables": lanes 0 .. 2 LB_M - 1 (physical columns of WY | WS) each run  acc += coef[t] * W(rows[t], column),
+// t in increasing order (lbfgsb.cpp: accum).  A second, independent set (rows2 / coef2 / count2) runs on lanes 32 .. 32 + 2 LB_M - 1.
+// Results in L.acc()[lane].
+__device__ inline void lb_accum2(const LbLds L, const ldsi* rows, const ldsd* coef, int count, const ldsi* rows2,
+                                 const ldsd* coef2, int count2, int lane) {
+  const int half = lane >> 5, c = (lane & 31) % (2 * LB_M);
+  const ldsd* col = c < LB_M ? L.wy() + c * LB_LDW : L.ws() + (c - LB_M) * LB_LDW;
+  const ldsi* rw = half ? rows2 : rows;
+  const ldsd* cf = half ? coef2 : coef;
+  const int cnt = half ? count2 : count;
+  const int cmax = count > count2 ? count : count2;
+  double a = 0.0;
+  int t = 0;
+  for (; t + 4 <= cmax; t += 4) {
+    double w0 = 0, w1 = 0, w2 = 0, w3 = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    if (t + 3 < cnt) {
+      const int r0 = rw ? rw[t] : t, r1 = rw ? rw[t + 1] : t + 1, r2 = rw ? rw[t + 2] : t + 2, r3 = rw ? rw[t + 3] : t + 3;
+      w0 = col[r0]; w1 = col[r1]; w2 = col[r2]; w3 = col[r3];
+      c0 = cf[t]; c1 = cf[t + 1]; c2 = cf[t + 2]; c3 = cf[t + 3];
+      a += c0 * w0; a += c1 * w1; a += c2 * w2; a += c3 * w3;
+    } else {
+      for (int u = t; u < t + 4 && u < cnt; ++u) a += cf[u] * col[rw ? rw[u] : u];
+    }
+  }
+  for (; t < cmax; ++t) if (t < cnt) a += cf[t] * col[rw ? rw[t] : t];
+  L.acc()[lane] = a;
+  LSYNC();
+}
+
+// LINPACK dpofa on an LDS matrix (upper factor, column-major, leading dimension lda), a column per lane: at step k every lane
+// j > k forms  t = (a[k][j] - sum_{i<k} a[i][k] a[i][j]) / a[k][k]  (the host's order), the pivot column is broadcast.
+// Returns 0 or 1 + the index of the failing pivot.
+__device__ inline int lb_dpofa(ldsd* A, int lda, int nn, int lane) {
+  const int j = lane < LB_M ? lane : LB_M - 1;
+  double a[LB_M];
+#pragma unroll
+  for (int i = 0; i < LB_M; ++i) a[i] = (i <= j && j < nn) ? A[j * lda + i] : 0.0;
+  double s = 0.0;
+  int info = 0;
+#pragma unroll
+  for (int k = 0; k < LB_M; ++k) {
+    if (k < nn && info == 0) {
+      const double dk = bcast(a[k] - s, k);
+      if (dk <= 0.0) { info = k + 1; }
+      else {
+        const double akk = sqrt(dk);
+        double dot = 0.0;
+#pragma unroll
+        for (int i = 0; i < k; ++i) dot += bcast(a[i], k) * a[i];
+        const double t = (a[k] - dot) / akk;
+        if (lane == k) a[k] = akk;
+        else if (lane > k) { a[k] = t; s += t * t; }
+      }
+    }
+  }
+  if (lane < nn) {
+#pragma unroll
+    for (int i = 0; i < LB_M; ++i) if (i <= lane) A[lane * lda + i] = a[i];
+  }
+  LSYNC();
+  return info;
+}
+
+// LINPACK dtrsl, upper-triangular T (LDS, leading dimension ldt), ONE right-hand side spread over the lanes (lane l holds b[l],
+// l < nn <= 2 LB_M).  job 11: T' x = b, job 1: T x = b.  Returns the solution in the same lanes.
+__device__ inline double lb_dtrsl_lanes(const ldsd* T, int ldt, int nn, double b, int job, int lane) {
+  const int l = lane < 2 * LB_M ? lane : 2 * LB_M - 1;
+  if (job == 11) {
+    double s = 0.0;
+    for (int j = 0; j < nn; ++j) {
+      // lane j: b[0] / t[0] (no subtraction on the host), b[j] = (b[j] - ddot) / t[j][j] otherwise
+      const double cand = (j == 0) ? b / T[0] : (b - s) / T[j * ldt + j];
+      const double xj = bcast(cand, j);
+      if (lane == j) b = xj;
+      if (l > j && l < nn) s += T[l * ldt + j] * xj;
+    }
+    return b;
+  }
+  // job 1: b[nn-1] /= T(nn-1, nn-1); for j = nn-2 .. 0: b[0..j] += -b[j+1] T(0..j, j+1); b[j] /= T(j, j)
+  {
+    const double last = bcast(b, nn - 1) / T[(nn - 1) * ldt + nn - 1];
+    if (lane == nn - 1) b = last;
+  }
+  for (int j = nn - 2; j >= 0; --j) {
+    const double temp = -bcast(b, j + 1);
+    if (l <= j) b += temp * T[(j + 1) * ldt + l];
+    const double q = bcast(b, j) / T[j * ldt + j];
+    if (lane == j) b = q;
+  }
+  return b;
+}
+
+__device__ inline int lb_trsl_zero_diag(const ldsd* T, int ldt, int nn, int lane) {
+  const bool z = lane < nn && T[lane * ldt + lane] == 0.0;
+  const unsigned long long m = __ballot(z);
+  return m ? __ffsll((long long)m) : 0;
+}
+
+// p = M v with the middle matrix of the compact representation (lbfgsb.cpp: bmv).  v, p: LDS vectors of 2 col entries.
+// Returns info (0 ok).
+__device__ inline int lb_bmv(const LbLds L, const ldsd* v, ldsd* p, int lane) {
+  const int col = ISC(I_COL);
+  if (col == 0) return 0;
+  const int i = lane < LB_M ? lane : LB_M - 1;
+  // p2[i] = v[col + i] + sum_{k < i} SY(i, k) v[k] / SY(k, k)
+  double sum = 0.0;
+  for (int k = 0; k + 1 < col; ++k) if (i > k && i < col) sum += SY_(i, k) * v[k] / SY_(k, k);
+  double p2 = (i == 0) ? v[col] : v[col + (i < col ? i : 0)] + sum;
+  int info = lb_trsl_zero_diag(L.wt(), LB_M, col, lane);
+  if (info != 0) return info;
+  p2 = lb_dtrsl_lanes(L.wt(), LB_M, col, p2, 11, lane);
+  const double sq = sqrt(SY_(i < col ? i : 0, i < col ? i : 0));
+  double p1 = v[i < col ? i : 0] / sq;
+  p2 = lb_dtrsl_lanes(L.wt(), LB_M, col, p2, 1, lane);
+  p1 = -p1 / sq;
+  double s2 = 0.0;
+  for (int k = 1; k < col; ++k) {
+    const double pk = bcast(p2, k);
+    if (i < k) s2 += SY_(k, i) * pk / SY_(i, i);
+  }
+  p1 += s2;
+  LSYNC();                       // every lane has read v (p may alias it)
+  if (lane < col) { p[lane] = p1; p[col + lane] = p2; }
+  LSYNC();
+  return 0;
+}
+
+__device__ inline double wave_max(double v) {
+  for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
+  return v;
+}
+
+__device__ inline void lb_projgr(const LbLds L, int lane) {
+  double m = 0.0;
+  for (int i = lane; i < L.n; i += 64) {
+    const double gi = L.g()[i], hi = L.x()[i] - L.hi()[i], lo = L.x()[i] - L.lo()[i];
+    const double a = hi > gi ? hi : gi, b = lo < gi ? lo : gi;
+    const double pv = fabs(gi < 0.0 ? a : b);
+    m = pv > m ? pv : m;
+  }
+  m = wave_max(m);
+  st0(&SC(S_SBGNRM), m, lane);
+  LSYNC();
+}
+
+__device__ inline void lb_reset_memory(const LbLds L, int lane) {
+  if (lane == 0) { ISC(I_INFO) = 0; ISC(I_COL) = 0; ISC(I_HEAD) = 0; SC(S_THETA) = 1.0; ISC(I_IUPDAT) = 0; ISC(I_UPDATD) = 0; }
+  LSYNC();
+}
+
+// Generalised Cauchy point (lbfgsb.cpp: cauchy, the branch for variables with both bounds)
+__device__ __noinline__ void lb_cauchy(const LbLds L, int lane) {
+  const int n = L.n, col = ISC(I_COL), head = ISC(I_HEAD), col2 = 2 * col;
+  const double theta = SC(S_THETA);
+  ldsd* p = L.wa(); ldsd* c = L.wa() + 2 * LB_M; ldsd* wbp = L.wa() + 4 * LB_M; ldsd* v = L.wa() + 6 * LB_M;
+  ldsd* t = L.t(); ldsd* d = L.d(); ldsd* xcp = L.z();
+  ldsi* iorder = L.indx2();
+  if (SC(S_SBGNRM) <= 0.0) { for (int i = lane; i < n; i += 64) xcp[i] = L.x()[i]; LSYNC(); return; }
+  int nbreak = 0, nmove = 0;
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    double neggi = 0.0, tl = 0.0, tu = 0.0;
+    bool moving = false;
+    if (i < n) {
+      neggi = -L.g()[i]; tl = L.x()[i] - L.lo()[i]; tu = L.hi()[i] - L.x()[i];
+      int iw = L.iwhere()[i];
+      if (iw != 3) {
+        iw = 0;
+        if (tl <= 0.0) { if (neggi <= 0.0) iw = 1; }
+        else if (tu <= 0.0) { if (neggi >= 0.0) iw = 2; }
+        else if (fabs(neggi) <= 0.0) iw = -3;
+        L.iwhere()[i] = iw;
+      }
+      moving = iw == 0;
+      d[i] = moving ? neggi : 0.0;
+      L.prod()[i] = moving ? neggi * neggi : 0.0;
+    }
+    const unsigned long long mm = __ballot(moving);
+    const int pos = nmove + __popcll(mm & lanes_below(lane));
+    if (moving) { L.rows()[pos] = i; L.coef()[pos] = neggi; }
+    nmove += __popcll(mm);
+    const bool brk = moving && neggi != 0.0;
+    const unsigned long long mb = __ballot(brk);
+    const int pb = nbreak + __popcll(mb & lanes_below(lane));
+    if (brk) { const double ahead = neggi < 0.0 ? tl : tu; iorder[pb] = i; t[pb] = ahead / fabs(neggi); }
+    nbreak += __popcll(mb);
+  }
+  LSYNC();
+  double f1 = chain_sub(0.0, L.prod(), n);         // f1 -= neggi^2 over the moving variables, in order (others subtract 0.0)
+  if (col > 0) {
+    lb_accum2(L, L.rows(), L.coef(), nmove, nullptr, nullptr, 0, lane);
+    if (lane < col) {
+      int pointr = head + lane; if (pointr >= LB_M) pointr -= LB_M;
+      p[lane] = L.acc()[pointr];
+      p[col + lane] = L.acc()[LB_M + pointr] * theta;       // (x * 1.0 == x: the host's "if theta != 1" changes nothing)
+    }
+  }
+  for (int i = lane; i < n; i += 64) xcp[i] = L.x()[i];
+  if (lane < col2) c[lane] = 0.0;
+  LSYNC();
+  if (nbreak == 0) return;                        // (with both bounds everywhere nfree stays n)
+  double f2 = -theta * f1;
+  const double f2_org = f2;
+  if (col > 0) {
+    const int info = lb_bmv(L, p, v, lane);
+    if (info != 0) { sti0(&ISC(I_INFO), info, lane); LSYNC(); return; }
+    f2 -= small_ddot(v, p, col2);
+  }
+  double dtm = -f1 / f2;
+  double tsum = 0.0;
+  bool skip_to_999 = false;
+  {
+    int nleft = nbreak;
+    double tj = 0.0;
+    int ties = 0;
+    while (true) {
+      const double tj0 = tj;
+      // smallest remaining breakpoint.  The host pops a heap; the order of DISTINCT values does not depend on the heap's shape -
+      // two bit-equal breakpoints do (counted in I_TIES; the position of the first one in the array decides here)
+      double bv = INFINITY; int bp = 0x7fffffff;
+      for (int e = lane; e < nleft; e += 64) { const double tv = t[e]; if (tv < bv) { bv = tv; bp = e; } }
+      for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(bv, off, 64); const int op = __shfl_xor(bp, off, 64);
+        if (ov < bv || (ov == bv && op < bp)) { bv = ov; bp = op; }
+      }
+      if (bp == 0x7fffffff) bp = 0;               // (all NaN cannot happen; keep the index in range)
+      { int cnt = 0; for (int e = lane; e < nleft; e += 64) cnt += (t[e] == bv) ? 1 : 0;
+        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+        if (cnt > 1) ++ties; }
+      tj = t[bp];
+      const int ibp = iorder[bp];
+      LSYNC();
+      if (lane == 0) { t[bp] = t[nleft - 1]; iorder[bp] = iorder[nleft - 1]; }      // remove it from the set
+      LSYNC();
+      const double dt = tj - tj0;
+      if (dtm < dt) break;
+      tsum += dt;
+      --nleft;
+
+      const double dibp = d[ibp];
+      double zibp;
+      const double xi = L.x()[ibp], ui = L.hi()[ibp], li = L.lo()[ibp];
+      LSYNC();
+      if (dibp > 0.0) { zibp = ui - xi; if (lane == 0) { d[ibp] = 0.0; xcp[ibp] = ui; L.iwhere()[ibp] = 2; } }
+      else { zibp = li - xi; if (lane == 0) { d[ibp] = 0.0; xcp[ibp] = li; L.iwhere()[ibp] = 1; } }
+      LSYNC();
+      if (nleft == 0 && nbreak == n) { dtm = dt; skip_to_999 = true; break; }
+      const double dibp2 = dibp * dibp;
+      f1 = f1 + dt * f2 + dibp2 - theta * dibp * zibp;
+      f2 = f2 - theta * dibp2;
+      if (col > 0) {
+        if (lane < col2) c[lane] += dt * p[lane];
+        if (lane < col) {
+          int pointr = head + lane; if (pointr >= LB_M) pointr -= LB_M;
+          wbp[lane] = WY_(ibp, pointr);
+          wbp[col + lane] = theta * WS_(ibp, pointr);
+        }
+        LSYNC();
+        const int info = lb_bmv(L, wbp, v, lane);
+        if (info != 0) { sti0(&ISC(I_INFO), info, lane); LSYNC(); return; }
+        const double wmc = small_ddot(c, v, col2);
+        const double wmp = small_ddot(p, v, col2);
+        const double wmw = small_ddot(wbp, v, col2);
+        LSYNC();
+        if (lane < col2) p[lane] -= dibp * wbp[lane];
+        LSYNC();
+        f1 += dibp * wmc;
+        f2 = f2 + 2.0 * dibp * wmp - dibp2 * wmw;
+      }
+      f2 = fmax(DBL_EPSILON * f2_org, f2);
+      if (nleft > 0) { dtm = -f1 / f2; continue; }
+      // (bnded: every variable has both bounds)
+      f1 = 0.0; f2 = 0.0; dtm = 0.0;
+      break;
+    }
+    if (ties && lane == 0) ISC(I_TIES) += ties;
+  }
+  if (!skip_to_999) {
+    if (dtm <= 0.0) dtm = 0.0;
+    tsum += dtm;
+    for (int i = lane; i < n; i += 64) xcp[i] += tsum * d[i];
+  }
+  if (col > 0 && lane < col2) c[lane] += dtm * p[lane];
+  LSYNC();
+}
+
+__device__ __noinline__ void lb_freev(const LbLds L, int lane) {
+  const int n = L.n, nfree_old = ISC(I_NFREE), iter = ISC(I_ITER);
+  int nenter = 0, ileave = n;
+  if (iter > 0) {
+    for (int base = 0; base < nfree_old; base += 64) {
+      const int i = base + lane;
+      int k = 0; bool f = false;
+      if (i < nfree_old) { k = L.index()[i]; f = L.iwhere()[k] > 0; }
+      const unsigned long long m = __ballot(f);
+      if (f) L.indx2()[ileave - 1 - __popcll(m & lanes_below(lane))] = k;
+      ileave -= __popcll(m);
+    }
+    for (int base = nfree_old; base < n; base += 64) {
+      const int i = base + lane;
+      int k = 0; bool f = false;
+      if (i < n) { k = L.index()[i]; f = L.iwhere()[k] <= 0; }
+      const unsigned long long m = __ballot(f);
+      if (f) L.indx2()[nenter + __popcll(m & lanes_below(lane))] = k;
+      nenter += __popcll(m);
+    }
+  }
+  LSYNC();
+  const int wrk = (ileave < n) || (nenter > 0) || ISC(I_UPDATD);
+  int nfree = 0, iact = n;
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    const bool in = i < n;
+    const bool fr = in && L.iwhere()[i] <= 0;
+    const unsigned long long mf = __ballot(fr), ma = __ballot(in && !fr);
+    if (fr) L.index()[nfree + __popcll(mf & lanes_below(lane))] = i;
+    else if (in) L.index()[iact - 1 - __popcll(ma & lanes_below(lane))] = i;
+    nfree += __popcll(mf);
+    iact -= __popcll(ma);
+  }
+  if (lane == 0) { ISC(I_NENTER) = nenter; ISC(I_ILEAVE) = ileave; ISC(I_WRK) = wrk; ISC(I_NFREE) = nfree; }
+  LSYNC();
+}
+
+// LEL' factorisation of the indefinite subspace matrix (lbfgsb.cpp: formk)
+__device__ __noinline__ void lb_formk(const LbLds L, int lane) {
+  const int n = L.n, m = LB_M, col = ISC(I_COL), head = ISC(I_HEAD), nsub = ISC(I_NFREE);
+  const int nenter = ISC(I_NENTER), ileave = ISC(I_ILEAVE);
+  const double theta = SC(S_THETA);
+  const ldsi* ind = L.index(); const ldsi* indx2 = L.indx2();
+  int upcl;
+  if (ISC(I_UPDATD)) {
+    if (ISC(I_IUPDAT) > m) {
+      // shift the three blocks of WN1 one step up-left: every source is read before anything is written
+      double src[3]; int dst[3];
+      const int tri = m * (m - 1) / 2, tot = 2 * tri + (m - 1) * (m - 1);      // 171 elements: three per lane
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int e = lane + 64 * u;
+        int di = 0, dj = 0, si = 0, sj = 0;
+        if (e < 2 * tri) {
+          int ee = e < tri ? e : e - tri, jy = 0, rowlen = m - 1;
+          while (ee >= rowlen) { ee -= rowlen; ++jy; --rowlen; }
+          const int tt = ee;
+          if (e < tri) { di = jy + tt; dj = jy; si = jy + 1 + tt; sj = jy + 1; }
+          else { const int js = m + jy; di = js + tt; dj = js; si = js + 1 + tt; sj = js + 1; }
+        } else if (e < tot) {
+          const int ee = e - 2 * tri, jy = ee / (m - 1), tt = ee % (m - 1);
+          di = m + tt; dj = jy; si = m + 1 + tt; sj = jy + 1;
+        }
+        src[u] = e < tot ? WN1_(si, sj) : 0.0;
+        dst[u] = e < tot ? dj * 2 * m + di : -1;
+      }
+      LSYNC();
+#pragma unroll
+      for (int u = 0; u < 3; ++u) if (dst[u] >= 0) L.wn1()[dst[u]] = src[u];
+      LSYNC();
+    }
+    const int ipntr = (head + col - 1) % m;
+    const int iy = col - 1, is = m + col - 1;
+    for (int k = lane; k < n; k += 64) L.coef()[k] = k < nsub ? WY_(ind[k], ipntr) : WS_(ind[k], ipntr);
+    LSYNC();
+    lb_accum2(L, ind, L.coef(), nsub, ind + nsub, L.coef() + nsub, n - nsub, lane);
+    if (lane < col) {
+      int jp = head + lane; if (jp >= m) jp -= m;
+      WN1_(iy, lane) = L.acc()[jp];                 // t1
+      WN1_(is, m + lane) = L.acc()[32 + m + jp];    // t2
+      WN1_(is, lane) = L.acc()[32 + jp];            // t3
+    }
+    LSYNC();
+    if (lane < col) { int jp = head + lane; if (jp >= m) jp -= m; WN1_(m + lane, col - 1) = L.acc()[m + jp]; }    // t4 last
+    LSYNC();
+    upcl = col - 1;
+  } else {
+    upcl = col;
+  }
+  // corrections for the variables that entered / left the free set
+  {
+    const int npair = upcl * (upcl + 1) / 2;
+    for (int e = lane; e < npair; e += 64) {
+      int iy = 0, ee = e;
+      while (ee > iy) { ee -= iy + 1; ++iy; }
+      const int jy = ee, is = m + iy, js = m + jy;
+      int ipntr = head + iy; if (ipntr >= m) ipntr -= m;
+      int jpntr = head + jy; if (jpntr >= m) jpntr -= m;
+      double temp1 = 0.0, temp2 = 0.0, temp3 = 0.0, temp4 = 0.0;
+      for (int k = 0; k < nenter; ++k) { const int k1 = indx2[k]; temp1 += WY_(k1, ipntr) * WY_(k1, jpntr); temp2 += WS_(k1, ipntr) * WS_(k1, jpntr); }
+      for (int k = ileave; k < n; ++k) { const int k1 = indx2[k]; temp3 += WY_(k1, ipntr) * WY_(k1, jpntr); temp4 += WS_(k1, ipntr) * WS_(k1, jpntr); }
+      WN1_(iy, jy) = WN1_(iy, jy) + temp1 - temp3;
+      WN1_(is, js) = WN1_(is, js) - temp2 + temp4;
+    }
+    for (int e = lane; e < upcl * upcl; e += 64) {
+      const int isr = e / upcl, jy = e % upcl, is = m + isr;
+      int ipntr = head + isr; if (ipntr >= m) ipntr -= m;
+      int jpntr = head + jy; if (jpntr >= m) jpntr -= m;
+      double temp1 = 0.0, temp3 = 0.0;
+      for (int k = 0; k < nenter; ++k) { const int k1 = indx2[k]; temp1 += WS_(k1, ipntr) * WY_(k1, jpntr); }
+      for (int k = ileave; k < n; ++k) { const int k1 = indx2[k]; temp3 += WS_(k1, ipntr) * WY_(k1, jpntr); }
+      if (is <= jy + m) WN1_(is, jy) = WN1_(is, jy) + temp1 - temp3;
+      else WN1_(is, jy) = WN1_(is, jy) - temp1 + temp3;
+    }
+    LSYNC();
+  }
+  // upper triangle of WN
+  for (int e = lane; e < col * col; e += 64) {
+    const int iy = e / col, jy = e % col, is = col + iy, is1 = m + iy, js = col + jy, js1 = m + jy;
+    if (jy <= iy) {
+      double w = WN1_(iy, jy) / theta;
+      if (jy == iy) w += SY_(iy, iy);
+      WN_(jy, iy) = w;
+      WN_(js, is) = WN1_(is1, js1) * theta;
+    }
+    WN_(jy, is) = jy < iy ? -WN1_(is1, jy) : WN1_(is1, jy);
+  }
+  LSYNC();
+  int info = lb_dpofa(L.wn(), 2 * m, col, lane);
+  if (info != 0) { sti0(&ISC(I_INFO), -1, lane); LSYNC(); return; }
+  // the col right-hand sides WN(0:col, js), js = col .. 2 col - 1: a system per lane (job 11, the host's order)
+  {
+    const int js = col + (lane < col ? lane : 0);
+    double b[LB_M];
+#pragma unroll
+    for (int i = 0; i < LB_M; ++i) b[i] = i < col ? WN_(i, js) : 0.0;
+#pragma unroll
+    for (int j = 0; j < LB_M; ++j) {
+      if (j < col) {
+        if (j == 0) b[0] = b[0] / WN_(0, 0);
+        else {
+          double s = 0.0;
+#pragma unroll
+          for (int i = 0; i < j; ++i) s += WN_(i, j) * b[i];
+          b[j] = b[j] - s;
+          b[j] = b[j] / WN_(j, j);
+        }
+      }
+    }
+    LSYNC();
+    if (lane < col) {
+#pragma unroll
+      for (int i = 0; i < LB_M; ++i) if (i < col) WN_(i, js) = b[i];
+    }
+    LSYNC();
+  }
+  for (int e = lane; e < col * (col + 1) / 2; e += 64) {
+    int a = 0, ee = e;
+    while (ee > a) { ee -= a + 1; ++a; }           // pair (ee <= a)
+    const int is = col + ee, js = col + a;
+    double s = 0.0;
+    for (int i = 0; i < col; ++i) s += WN_(i, is) * WN_(i, js);
+    WN_(is, js) += s;
+  }
+  LSYNC();
+  info = lb_dpofa(&WN_(col, col), 2 * m, col, lane);
+  if (info != 0) { sti0(&ISC(I_INFO), -2, lane); LSYNC(); }
+}
+
+__device__ __noinline__ void lb_cmprlb(const LbLds L, int lane) {
+  const int n = L.n, col = ISC(I_COL), nfree = ISC(I_NFREE);
+  const double theta = SC(S_THETA);
+  for (int k = lane; k < n; k += 64) L.full()[k] = -theta * (L.z()[k] - L.x()[k]) - L.g()[k];
+  LSYNC();
+  const int info = lb_bmv(L, L.wa() + 2 * LB_M, L.wa(), lane);
+  if (info != 0) { sti0(&ISC(I_INFO), -8, lane); LSYNC(); return; }
+  int pointr = ISC(I_HEAD);
+  for (int j = 0; j < col; ++j) {
+    const double a1 = L.wa()[j], a2 = theta * L.wa()[col + j];
+    for (int k = lane; k < n; k += 64) L.full()[k] += WY_(k, pointr) * a1 + WS_(k, pointr) * a2;
+    pointr = nxt(pointr);
+  }
+  LSYNC();
+  for (int i = lane; i < nfree; i += 64) L.r()[i] = L.full()[L.index()[i]];
+  LSYNC();
+}
+
+__device__ __noinline__ void lb_subsm(const LbLds L, int lane) {
+  const int n = L.n, m = LB_M, col = ISC(I_COL), nsub = ISC(I_NFREE), col2 = 2 * col;
+  const double theta = SC(S_THETA);
+  const ldsi* ind = L.index();
+  ldsd* x = L.z(); ldsd* d = L.r(); ldsd* wv = L.wa();
+  if (nsub <= 0) return;
+  lb_accum2(L, ind, d, nsub, nullptr, nullptr, 0, lane);
+  double b = 0.0;
+  if (lane < col2) {
+    const int i = lane < col ? lane : lane - col;
+    int pointr = ISC(I_HEAD) + i; if (pointr >= m) pointr -= m;
+    b = lane < col ? L.acc()[pointr] : theta * L.acc()[m + pointr];
+  }
+  int info = lb_trsl_zero_diag(L.wn(), 2 * m, col2, lane);
+  if (info != 0) { sti0(&ISC(I_INFO), info, lane); LSYNC(); return; }
+  b = lb_dtrsl_lanes(L.wn(), 2 * m, col2, b, 11, lane);
+  if (lane < col) b = -b;
+  b = lb_dtrsl_lanes(L.wn(), 2 * m, col2, b, 1, lane);
+  if (lane < col2) wv[lane] = b;
+  // full = d scattered to the variables' own places (zeros elsewhere; with every variable free it is d itself)
+  for (int k = lane; k < n; k += 64) L.full()[k] = 0.0;
+  LSYNC();
+  for (int i = lane; i < nsub; i += 64) L.full()[ind[i]] = d[i];
+  LSYNC();
+  int pointr = ISC(I_HEAD);
+  for (int jy = 0; jy < col; ++jy) {
+    const double a1 = wv[jy], a2 = wv[col + jy];
+    for (int k = lane; k < n; k += 64) L.full()[k] = L.full()[k] + WY_(k, pointr) * a1 / theta + WS_(k, pointr) * a2;
+    pointr = nxt(pointr);
+  }
+  LSYNC();
+  const double inv_theta = 1.0 / theta;
+  for (int i = lane; i < nsub; i += 64) d[i] = L.full()[ind[i]] * inv_theta;
+  for (int i = lane; i < n; i += 64) L.xp()[i] = x[i];
+  LSYNC();
+  bool hit = false;
+  for (int i = lane; i < nsub; i += 64) {
+    const int k = ind[i];
+    const double dk = d[i], v = x[k] + dk, lk = L.lo()[k], uk = L.hi()[k];
+    const double xk = lk > v ? lk : v;
+    const double w = uk < xk ? uk : xk;
+    x[k] = w;
+    if (w == lk || w == uk) hit = true;
+  }
+  const int iword = __ballot(hit) ? 1 : 0;
+  sti0(&ISC(I_IWORD), iword, lane);
+  LSYNC();
+  if (iword == 0) return;
+  for (int i = lane; i < n; i += 64) L.prod()[i] = (x[i] - L.x()[i]) * L.g()[i];
+  LSYNC();
+  const double dd_p = chain_add(0.0, L.prod(), n);
+  if (dd_p > 0.0) {
+    for (int i = lane; i < n; i += 64) x[i] = L.xp()[i];
+    LSYNC();
+    double alpha = 1.0, temp1 = alpha;
+    int ibd = 0;
+    for (int i = 0; i < nsub; ++i) {                 // (every lane the same scan: rare path)
+      const int k = ind[i];
+      const double dk = d[i];
+      if (dk < 0.0) {
+        const double temp2 = L.lo()[k] - x[k];
+        if (temp2 >= 0.0) temp1 = 0.0;
+        else if (dk * alpha < temp2) temp1 = temp2 / dk;
+      } else if (dk > 0.0) {
+        const double temp2 = L.hi()[k] - x[k];
+        if (temp2 <= 0.0) temp1 = 0.0;
+        else if (dk * alpha > temp2) temp1 = temp2 / dk;
+      }
+      if (temp1 < alpha) { alpha = temp1; ibd = i; }
+    }
+    if (alpha < 1.0) {
+      const double dk = d[ibd];
+      const int k = ind[ibd];
+      LSYNC();
+      if (lane == 0) {
+        if (dk > 0.0) { x[k] = L.hi()[k]; d[ibd] = 0.0; }
+        else if (dk < 0.0) { x[k] = L.lo()[k]; d[ibd] = 0.0; }
+      }
+      LSYNC();
+    }
+    for (int i = lane; i < nsub; i += 64) { const int k = ind[i]; x[k] += alpha * d[i]; }
+    LSYNC();
+  }
+}
+
+// ---- More-Thuente line search (lbfgsb.cpp: dcstep / dcsrch), every lane the same scalars ------------------------------------------
+struct LsState { int task, brackt, stage; double ginit, gtest, gx, gy, finit, fx, fy, stx, sty, stmin, stmax, width, width1; };
+
+__device__ inline void lb_dcstep(double* stx, double* fx, double* dx, double* sty, double* fy, double* dy, double* stp, double fp,
+                          double dp, int* brackt, double stpmin, double stpmax) {
+  const double sgnd = dp * (*dx / fabs(*dx));
+  double stpf, stpc, stpq, theta, s, gamma, p, q, r;
+  if (fp > *fx) {
+    theta = 3.0 * (*fx - fp) / (*stp - *stx) + *dx + dp;
+    s = fmax(fabs(theta), fmax(fabs(*dx), fabs(dp)));
+    gamma = s * sqrt((theta / s) * (theta / s) - (*dx / s) * (dp / s));
+    if (*stp < *stx) gamma = -gamma;
+    p = (gamma - *dx) + theta;
+    q = ((gamma - *dx) + gamma) + dp;
+    r = p / q;
+    stpc = *stx + r * (*stp - *stx);
+    stpq = *stx + ((*dx / ((*fx - fp) / (*stp - *stx) + *dx)) / 2.0) * (*stp - *stx);
+    if (fabs(stpc - *stx) < fabs(stpq - *stx)) stpf = stpc;
+    else stpf = stpc + (stpq - stpc) / 2.0;
+    *brackt = 1;
+  } else if (sgnd < 0.0) {
+    theta = 3.0 * (*fx - fp) / (*stp - *stx) + *dx + dp;
+    s = fmax(fabs(theta), fmax(fabs(*dx), fabs(dp)));
+    gamma = s * sqrt((theta / s) * (theta / s) - (*dx / s) * (dp / s));
+    if (*stp > *stx) gamma = -gamma;
+    p = (gamma - dp) + theta;
+    q = ((gamma - dp) + gamma) + *dx;
+    r = p / q;
+    stpc = *stp + r * (*stx - *stp);
+    stpq = *stp + (dp / (dp - *dx)) * (*stx - *stp);
+    if (fabs(stpc - *stp) > fabs(stpq - *stp)) stpf = stpc;
+    else stpf = stpq;
+    *brackt = 1;
+  } else if (fabs(dp) < fabs(*dx)) {
+    theta = 3.0 * (*fx - fp) / (*stp - *stx) + *dx + dp;
+    s = fmax(fabs(theta), fmax(fabs(*dx), fabs(dp)));
+    gamma = s * sqrt(fmax(0.0, (theta / s) * (theta / s) - (*dx / s) * (dp / s)));
+    if (*stp > *stx) gamma = -gamma;
+    p = (gamma - dp) + theta;
+    q = (gamma + (*dx - dp)) + gamma;
+    r = p / q;
+    if (r < 0.0 && gamma != 0.0) stpc = *stp + r * (*stx - *stp);
+    else if (*stp > *stx) stpc = stpmax;
+    else stpc = stpmin;
+    stpq = *stp + (dp / (dp - *dx)) * (*stx - *stp);
+    if (*brackt) {
+      if (fabs(stpc - *stp) < fabs(stpq - *stp)) stpf = stpc;
+      else stpf = stpq;
+      if (*stp > *stx) stpf = fmin(*stp + 0.66 * (*sty - *stp), stpf);
+      else stpf = fmax(*stp + 0.66 * (*sty - *stp), stpf);
+    } else {
+      if (fabs(stpc - *stp) > fabs(stpq - *stp)) stpf = stpc;
+      else stpf = stpq;
+      stpf = fmin(stpmax, stpf);
+      stpf = fmax(stpmin, stpf);
+    }
+  } else {
+    if (*brackt) {
+      theta = 3.0 * (fp - *fy) / (*sty - *stp) + *dy + dp;
+      s = fmax(fabs(theta), fmax(fabs(*dy), fabs(dp)));
+      gamma = s * sqrt((theta / s) * (theta / s) - (*dy / s) * (dp / s));
+      if (*stp > *sty) gamma = -gamma;
+      p = (gamma - dp) + theta;
+      q = ((gamma - dp) + gamma) + *dy;
+      r = p / q;
+      stpc = *stp + r * (*sty - *stp);
+      stpf = stpc;
+    } else if (*stp > *stx) stpf = stpmax;
+    else stpf = stpmin;
+  }
+  if (fp > *fx) { *sty = *stp; *fy = fp; *dy = dp; }
+  else {
+    if (sgnd < 0.0) { *sty = *stx; *fy = *fx; *dy = *dx; }
+    *stx = *stp; *fx = fp; *dx = dp;
+  }
+  *stp = stpf;
+}
+
+__device__ inline void lb_dcsrch(double f, double g, double* stp, double ftol, double gtol, double xtol, double stpmin,
+                          double stpmax, LsState& s) {
+  const double xtrapl = 1.1, xtrapu = 4.0, p5 = 0.5, p66 = 0.66;
+  if (s.task == 0) {
+    if (*stp < stpmin || *stp > stpmax || g >= 0.0) { s.task = 4; return; }
+    s.brackt = 0; s.stage = 1; s.finit = f; s.ginit = g; s.gtest = ftol * s.ginit;
+    s.width = stpmax - stpmin; s.width1 = s.width / p5;
+    s.stx = 0.0; s.fx = s.finit; s.gx = s.ginit; s.sty = 0.0; s.fy = s.finit; s.gy = s.ginit;
+    s.stmin = 0.0; s.stmax = *stp + xtrapu * *stp;
+    s.task = 1;
+    return;
+  }
+  const double ftest = s.finit + *stp * s.gtest;
+  if (s.stage == 1 && f <= ftest && g >= 0.0) s.stage = 2;
+  int task = 1;
+  if (s.brackt && (*stp <= s.stmin || *stp >= s.stmax)) task = 3;
+  if (s.brackt && s.stmax - s.stmin <= xtol * s.stmax) task = 3;
+  if (*stp == stpmax && f <= ftest && g <= s.gtest) task = 3;
+  if (*stp == stpmin && (f > ftest || g >= s.gtest)) task = 3;
+  if (f <= ftest && fabs(g) <= gtol * (-s.ginit)) task = 2;
+  if (task == 2 || task == 3) { s.task = task; return; }
+  if (s.stage == 1 && f <= s.fx && f > ftest) {
+    double fm = f - *stp * s.gtest, fxm = s.fx - s.stx * s.gtest, fym = s.fy - s.sty * s.gtest;
+    double gm = g - s.gtest, gxm = s.gx - s.gtest, gym = s.gy - s.gtest;
+    lb_dcstep(&s.stx, &fxm, &gxm, &s.sty, &fym, &gym, stp, fm, gm, &s.brackt, s.stmin, s.stmax);
+    s.fx = fxm + s.stx * s.gtest; s.fy = fym + s.sty * s.gtest; s.gx = gxm + s.gtest; s.gy = gym + s.gtest;
+  } else {
+    lb_dcstep(&s.stx, &s.fx, &s.gx, &s.sty, &s.fy, &s.gy, stp, f, g, &s.brackt, s.stmin, s.stmax);
+  }
+  if (s.brackt) {
+    if (fabs(s.sty - s.stx) >= p66 * s.width1) *stp = s.stx + p5 * (s.sty - s.stx);
+    s.width1 = s.width;
+    s.width = fabs(s.sty - s.stx);
+  }
+  if (s.brackt) { s.stmin = fmin(s.stx, s.sty); s.stmax = fmax(s.stx, s.sty); }
+  else { s.stmin = *stp + xtrapl * (*stp - s.stx); s.stmax = *stp + xtrapu * (*stp - s.stx); }
+  *stp = fmax(*stp, stpmin);
+  *stp = fmin(*stp, stpmax);
+  if ((s.brackt && (*stp <= s.stmin || *stp >= s.stmax)) || (s.brackt && s.stmax - s.stmin <= xtol * s.stmax))
+    *stp = s.stx;
+  s.task = 1;
+}
+
+__device__ inline void ls_load(const LbLds L, LsState& s) {
+  s.task = ISC(LS_TASK); s.brackt = ISC(LS_BRACKT); s.stage = ISC(LS_STAGE);
+  s.ginit = SC(LS_GINIT); s.gtest = SC(LS_GTEST); s.gx = SC(LS_GX); s.gy = SC(LS_GY); s.finit = SC(LS_FINIT);
+  s.fx = SC(LS_FX); s.fy = SC(LS_FY); s.stx = SC(LS_STX); s.sty = SC(LS_STY); s.stmin = SC(LS_STMIN); s.stmax = SC(LS_STMAX);
+  s.width = SC(LS_WIDTH); s.width1 = SC(LS_WIDTH1);
+}
+__device__ inline void ls_store(const LbLds L, const LsState& s, int lane) {
+  if (lane == 0) {
+    ISC(LS_TASK) = s.task; ISC(LS_BRACKT) = s.brackt; ISC(LS_STAGE) = s.stage;
+    SC(LS_GINIT) = s.ginit; SC(LS_GTEST) = s.gtest; SC(LS_GX) = s.gx; SC(LS_GY) = s.gy; SC(LS_FINIT) = s.finit;
+    SC(LS_FX) = s.fx; SC(LS_FY) = s.fy; SC(LS_STX) = s.stx; SC(LS_STY) = s.sty; SC(LS_STMIN) = s.stmin; SC(LS_STMAX) = s.stmax;
+    SC(LS_WIDTH) = s.width; SC(LS_WIDTH1) = s.width1;
+  }
+}
+
+// One call of the line-search driver (lbfgsb.cpp: lnsrlb).  Sets I_TASK to FG (x holds the trial point) or NEW_X.
+__device__ __noinline__ void lb_lnsrlb(const LbLds L, int lane) {
+  const int n = L.n;
+  const double big = 1e10, ftol = 1e-3, gtol = 0.9, xtol = 0.1;
+  const double f = SC(S_F);
+  LsState ls;
+  double stp, stpmx, dnorm;
+  if (ISC(I_PHASE) != 2) {
+    const double dtd = wave_ddot(L, L.d(), L.d(), n, lane);
+    dnorm = sqrt(dtd);
+    stpmx = big;
+    if (ISC(I_ITER) == 0) stpmx = 1.0;
+    else {
+      // the host's scan  "if (a1 stpmx < a2) stpmx = a2 / a1"  in order: stpmx only falls and the products are monotone in it,
+      // so within a chunk of 64 the first lane whose test holds is the next one to change it; the others test again after it
+      for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        double a1 = 0.0, a2 = 0.0; int kind = 0;                  // 1: towards the lower bound, 2: towards the upper
+        if (i < n) {
+          a1 = L.d()[i];
+          if (a1 < 0.0) { a2 = L.lo()[i] - L.x()[i]; kind = 1; }
+          else if (a1 > 0.0) { a2 = L.hi()[i] - L.x()[i]; kind = 2; }
+        }
+        unsigned long long pending = ~0ull;
+        for (;;) {
+          bool upd = false;
+          if (kind == 1) upd = (a2 >= 0.0) || (a1 * stpmx < a2);
+          else if (kind == 2) upd = (a2 <= 0.0) || (a1 * stpmx > a2);
+          const unsigned long long mk = __ballot(upd) & pending;
+          if (!mk) break;
+          const int first = __ffsll((long long)mk) - 1;
+          double nv;
+          if (kind == 1) nv = a2 >= 0.0 ? 0.0 : a2 / a1; else nv = a2 <= 0.0 ? 0.0 : a2 / a1;
+          stpmx = bcast(nv, first);
+          pending = first == 63 ? 0ull : (~0ull << (first + 1));
+        }
+      }
+    }
+    stp = 1.0;                                        // (boxed: never min(1 / dnorm, stpmx))
+    for (int i = lane; i < n; i += 64) { L.t()[i] = L.x()[i]; L.r()[i] = L.g()[i]; }
+    if (lane == 0) { SC(S_DTD) = dtd; SC(S_DNORM) = dnorm; SC(S_STPMX) = stpmx; SC(S_FOLD) = f; ISC(I_IFUN) = 0; ISC(I_IBACK) = 0; }
+    ls.task = 0; ls.brackt = 0; ls.stage = 1;
+    ls.ginit = ls.gtest = ls.gx = ls.gy = ls.finit = ls.fx = ls.fy = ls.stx = ls.sty = ls.stmin = ls.stmax = ls.width = ls.width1 = 0.0;
+    LSYNC();
+  } else {
+    ls_load(L, ls);
+    stp = SC(S_STP); stpmx = SC(S_STPMX); dnorm = SC(S_DNORM);
+  }
+  const double gd = wave_ddot(L, L.g(), L.d(), n, lane);
+  int ifun = ISC(I_IFUN);
+  LSYNC();
+  if (lane == 0) SC(S_GD) = gd;
+  if (ifun == 0) {
+    if (lane == 0) SC(S_GDOLD) = gd;
+    if (gd >= 0.0) { sti0(&ISC(I_INFO), -4, lane); ls_store(L, ls, lane); st0(&SC(S_STP), stp, lane); LSYNC(); return; }
+  }
+  lb_dcsrch(f, gd, &stp, ftol, gtol, xtol, 0.0, stpmx, ls);
+  ls_store(L, ls, lane);
+  if (lane == 0) SC(S_STP) = stp;
+  if (ls.task != 2 && ls.task != 3) {
+    if (lane == 0) { ISC(I_TASK) = LBFGSB_FG; ISC(I_IFUN) = ifun + 1; ISC(I_NFGV) = ISC(I_NFGV) + 1; ISC(I_IBACK) = ifun; }
+    if (stp == 1.0) { for (int i = lane; i < n; i += 64) L.x()[i] = L.z()[i]; }
+    else { for (int i = lane; i < n; i += 64) L.x()[i] = stp * L.d()[i] + L.t()[i]; }
+  } else {
+    if (lane == 0) ISC(I_TASK) = LBFGSB_NEW_X;
+  }
+  LSYNC();
+}
+
+__device__ __noinline__ void lb_matupd(const LbLds L, double rr, double dr, int lane) {
+  const int n = L.n, m = LB_M, iupdat = ISC(I_IUPDAT);
+  int col = ISC(I_COL), head = ISC(I_HEAD), itail = ISC(I_ITAIL);
+  if (iupdat <= m) { col = iupdat; itail = (head + iupdat - 1) % m; }
+  else { itail = nxt(itail); head = nxt(head); }
+  for (int i = lane; i < n; i += 64) { WS_(i, itail) = L.d()[i]; WY_(i, itail) = L.r()[i]; }
+  const double theta = rr / dr;
+  if (iupdat > m) {
+    double src[2]; int dst[2];
+    const int tri = (col - 1) * col / 2;               // 45 + 45 elements: two per lane
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = lane + 64 * u;
+      src[u] = 0.0; dst[u] = 0;
+      if (e < tri) {                                   // SS(t, j) = SS(t + 1, j + 1), t <= j < col - 1
+        int ee = e, j = 0; while (ee > j) { ee -= j + 1; ++j; }
+        src[u] = SS_(ee + 1, j + 1); dst[u] = j * m + ee + 1;
+      } else if (e < 2 * tri) {                        // SY(j + t, j) = SY(j + 1 + t, j + 1), t < col - 1 - j
+        int ee = e - tri, j = 0, rowlen = col - 1; while (ee >= rowlen) { ee -= rowlen; ++j; --rowlen; }
+        src[u] = SY_(j + 1 + ee, j + 1); dst[u] = -(j * m + j + ee) - 1;
+      }
+    }
+    LSYNC();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { if (dst[u] > 0) L.ss()[dst[u] - 1] = src[u]; else if (dst[u] < 0) L.sy()[-dst[u] - 1] = src[u]; }
+  }
+  LSYNC();
+  lb_accum2(L, nullptr, L.d(), n, nullptr, nullptr, 0, lane);
+  if (lane < col - 1) {
+    int pointr = head + lane; if (pointr >= m) pointr -= m;
+    SY_(col - 1, lane) = L.acc()[pointr];
+    SS_(lane, col - 1) = L.acc()[m + pointr];
+  }
+  if (lane == 0) {
+    const double stp = SC(S_STP), dtd = SC(S_DTD);
+    SS_(col - 1, col - 1) = stp == 1.0 ? dtd : stp * stp * dtd;
+    SY_(col - 1, col - 1) = dr;
+    ISC(I_COL) = col; ISC(I_HEAD) = head; ISC(I_ITAIL) = itail; SC(S_THETA) = theta;
+  }
+  LSYNC();
+}
+
+__device__ __noinline__ void lb_formt(const LbLds L, int lane) {
+  const int col = ISC(I_COL);
+  const double theta = SC(S_THETA);
+  for (int e = lane; e < col * (col + 1) / 2; e += 64) {
+    int j = 0, ee = e;
+    while (ee > j) { ee -= j + 1; ++j; }
+    const int i = ee;                                  // i <= j
+    if (i == 0) WT_(0, j) = theta * SS_(0, j);
+    else {
+      double ddum = 0.0;
+      for (int k = 0; k < i; ++k) ddum += SY_(i, k) * SY_(j, k) / SY_(k, k);
+      WT_(i, j) = ddum + theta * SS_(i, j);
+    }
+  }
+  LSYNC();
+  const int info = lb_dpofa(L.wt(), LB_M, col, lane);
+  if (info != 0) { sti0(&ISC(I_INFO), -3, lane); LSYNC(); }
+}
+
+// lbfgsb.cpp: Lbfgsb::step (reverse communication), the state in LDS.  Returns the task.
+__device__ int lb_step(const LbLds L, int lane) {
+  const int n = L.n;
+  const double pgtol = 1e-5, factr = 1e7;
+  if (ISC(I_TASK) >= LBFGSB_CONV_PG) return ISC(I_TASK);
+  bool need_iteration_start = false, resume_linesearch = false;
+  const int phase = ISC(I_PHASE);
+  if (phase == 0) {
+    // (init: the caller has zeroed the state, clamped x into the box and classified the variables)
+    if (lane == 0) { ISC(I_PHASE) = 1; ISC(I_TASK) = LBFGSB_FG; }
+    LSYNC();
+    return LBFGSB_FG;
+  }
+  if (phase == 1) {
+    sti0(&ISC(I_NFGV), 1, lane);
+    lb_projgr(L, lane);
+    if (SC(S_SBGNRM) <= pgtol) { sti0(&ISC(I_TASK), LBFGSB_CONV_PG, lane); LSYNC(); return LBFGSB_CONV_PG; }
+    need_iteration_start = true;
+  } else if (phase == 2) {
+    resume_linesearch = true;
+  } else {
+    if (SC(S_SBGNRM) <= pgtol) { sti0(&ISC(I_TASK), LBFGSB_CONV_PG, lane); LSYNC(); return LBFGSB_CONV_PG; }
+    const double f = SC(S_F), fold = SC(S_FOLD);
+    const double ddum = fmax(fmax(fabs(fold), fabs(f)), 1.0);
+    if ((fold - f) <= (factr * DBL_EPSILON) * ddum) {
+      if (lane == 0) { ISC(I_TASK) = LBFGSB_CONV_F; if (ISC(I_IBACK) >= 10) ISC(I_INFO) = -5; }
+      LSYNC();
+      return LBFGSB_CONV_F;
+    }
+    for (int i = lane; i < n; i += 64) L.r()[i] = L.g()[i] - L.r()[i];
+    LSYNC();
+    const double rr = wave_ddot(L, L.r(), L.r(), n, lane);
+    const double stp = SC(S_STP), gd = SC(S_GD), gdold = SC(S_GDOLD);
+    double dr, ddum2;
+    if (stp == 1.0) { dr = gd - gdold; ddum2 = -gdold; }
+    else {
+      dr = (gd - gdold) * stp;
+      for (int i = lane; i < n; i += 64) L.d()[i] *= stp;
+      LSYNC();
+      ddum2 = -gdold * stp;
+    }
+    if (dr <= DBL_EPSILON * ddum2) {
+      sti0(&ISC(I_UPDATD), 0, lane);
+      LSYNC();
+    } else {
+      if (lane == 0) { ISC(I_UPDATD) = 1; ISC(I_IUPDAT) = ISC(I_IUPDAT) + 1; }
+      LSYNC();
+      lb_matupd(L, rr, dr, lane);
+      lb_formt(L, lane);
+      if (ISC(I_INFO) != 0) lb_reset_memory(L, lane);
+    }
+    need_iteration_start = true;
+  }
+  while (true) {
+    if (need_iteration_start) {
+      need_iteration_start = false;
+      sti0(&ISC(I_IWORD), -1, lane);
+      lb_cauchy(L, lane);
+      if (ISC(I_INFO) != 0) { lb_reset_memory(L, lane); need_iteration_start = true; continue; }
+      lb_freev(L, lane);
+      if (ISC(I_NFREE) != 0 && ISC(I_COL) != 0) {
+        if (ISC(I_WRK)) lb_formk(L, lane);
+        if (ISC(I_INFO) != 0) { lb_reset_memory(L, lane); need_iteration_start = true; continue; }
+        lb_cmprlb(L, lane);
+        if (ISC(I_INFO) == 0) lb_subsm(L, lane);
+        if (ISC(I_INFO) != 0) { lb_reset_memory(L, lane); need_iteration_start = true; continue; }
+      }
+      for (int i = lane; i < n; i += 64) L.d()[i] = L.z()[i] - L.x()[i];
+      sti0(&ISC(I_PHASE), 0, lane);
+      LSYNC();
+    }
+    if (resume_linesearch) { resume_linesearch = false; sti0(&ISC(I_PHASE), 2, lane); LSYNC(); }
+    lb_lnsrlb(L, lane);
+    if (ISC(I_INFO) != 0 || ISC(I_IBACK) >= 20) {
+      for (int i = lane; i < n; i += 64) { L.x()[i] = L.t()[i]; L.g()[i] = L.r()[i]; }
+      if (lane == 0) SC(S_F) = SC(S_FOLD);
+      LSYNC();
+      if (ISC(I_COL) == 0) {
+        if (lane == 0) {
+          if (ISC(I_INFO) == 0) { ISC(I_INFO) = -9; ISC(I_NFGV) -= 1; ISC(I_IFUN) -= 1; ISC(I_IBACK) -= 1; }
+          ISC(I_TASK) = LBFGSB_ABNORMAL; ISC(I_ITER) += 1;
+        }
+        LSYNC();
+        return LBFGSB_ABNORMAL;
+      }
+      if (lane == 0 && ISC(I_INFO) == 0) ISC(I_NFGV) -= 1;
+      LSYNC();
+      lb_reset_memory(L, lane);
+      need_iteration_start = true;
+      continue;
+    }
+    if (ISC(I_TASK) == LBFGSB_FG) { sti0(&ISC(I_PHASE), 2, lane); LSYNC(); return LBFGSB_FG; }
+    sti0(&ISC(I_ITER), ISC(I_ITER) + 1, lane);
+    LSYNC();
+    lb_projgr(L, lane);
+    if (lane == 0) { ISC(I_PHASE) = 3; ISC(I_TASK) = LBFGSB_NEW_X; }
+    LSYNC();
+    return LBFGSB_NEW_X;
+  }
+}
+
+// RestartGroup::advance (pcabo_api.hip): step until the group needs f, g at x (I_TASK == FG on return) or has stopped (I_ACTIVE == 0)
+__device__ void lb_advance(const LbLds L, int maxiter, int lane) {
+  while (ISC(I_ACTIVE)) {
+    const int task = lb_step(L, lane);
+    if (task == LBFGSB_FG) {
+      if (ISC(I_HAVE_CACHE)) {
+        bool diff = false;
+        for (int i = lane; i < L.n; i += 64) diff = diff || (__double_as_longlong(L.x()[i]) != __double_as_longlong(L.xc()[i]));
+        if (!__ballot(diff)) {
+          for (int i = lane; i < L.n; i += 64) L.g()[i] = L.gc()[i];
+          st0(&SC(S_F), SC(S_FC), lane);
+          LSYNC();
+          continue;
+        }
+      }
+      return;
+    }
+    if (task == LBFGSB_NEW_X) {
+      const int niter = ISC(I_NITER) + 1;
+      LSYNC();
+      if (lane == 0) {
+        ISC(I_NITER) = niter;
+        if (niter >= maxiter) ISC(I_TASK) = LBFGSB_STOP_ITER;
+        else if (ISC(I_NFEV) > 15000) ISC(I_TASK) = LBFGSB_STOP_FUN;
+      }
+      LSYNC();
+      continue;
+    }
+    sti0(&ISC(I_ACTIVE), 0, lane);
+    LSYNC();
+  }
+}
+
+// =====================================================================================================================
+// Evaluation: value and gradient of the acquisition at the group's nq points (all LB_THREADS threads)
+// =====================================================================================================================
+struct LbEval {
+  const double *ZnT, *R, *RT, *alpha, *nlo, *nhi;
+  int n, k, NP, ld, H, S;
+  double best_f, ym, ysd, inv_ls;
+  int maximize, acq, kernel;
+};
+
+__device__ inline int slab_of(int w, int S) { return (S & 1) ? w : (w < S / 2 ? w : S - 1 - (w - S / 2)); }
+
+__device__ inline void lb_log_ei_helper(double u, double* h, double* dh) {
+  const double inv_sqrt2 = 0.7071067811865476, inv_sqrt_2pi = 0.3989422804014327, log2pi = 1.8378770664093453;
+  if (u > -1.0) {
+    const double phi = inv_sqrt_2pi * exp(-0.5 * u * u);
+    const double Phi = 0.5 * erfc(-inv_sqrt2 * u);
+    const double ei = phi + u * Phi;
+    *h = log(ei);
+    *dh = Phi / ei;
+    return;
+  }
+  const double log_phi = -0.5 * (u * u + log2pi);
+  if (u > -1e6) {
+    const double ex = erfcx(-inv_sqrt2 * u);
+    const double E = (ex * fabs(u)) * 1.2533141373155003;
+    *h = log_phi + log1p(-E);
+    const double dw = (u + 0.7978845608028654 / ex) + 1.0 / u;
+    *dh = -u - dw * E / (1.0 - E);
+  } else {
+    *h = log_phi - 2.0 * log(fabs(u));
+    *dh = -u - 2.0 / u;
+  }
+}
+// scalar chain of one query (kernels_acq.hip: acq_scalar_core): value and the two coefficients of the gradient's chain rule
+__device__ inline void lb_scalar_core(double vv, double mus, const LbEval& E, double* value, double* c_mu, double* c_sg) {
+  const double mu = E.ym + E.ysd * mus;
+  double var = (1.0 - vv) * (E.ysd * E.ysd);
+  bool clamped = false;
+  if (!(var >= 1e-10)) { var = 1e-10; clamped = true; }
+  if (var < 1e-12) { var = 1e-12; clamped = true; }
+  const double sigma = sqrt(var);
+  double u = (mu - E.best_f) / sigma;
+  const double sgn = E.maximize ? 1.0 : -1.0;
+  u *= sgn;
+  double val, dv_du, dv_dsig;
+  if (E.acq == 0) {
+    double h, dh;
+    lb_log_ei_helper(u, &h, &dh);
+    val = h + log(sigma);
+    dv_du = dh;
+    dv_dsig = 1.0 / sigma;
+  } else {
+    val = 0.5 * erfc(-0.7071067811865476 * u);
+    dv_du = 0.3989422804014327 * exp(-0.5 * u * u);
+    dv_dsig = 0.0;
+  }
+  *value = val;
+  *c_mu = dv_du * sgn * E.ysd / sigma;
+  *c_sg = clamped ? 0.0 : (dv_dsig - dv_du * u / sigma) * (-(E.ysd * E.ysd) / sigma);
+}
+
+// x in L.x() (nq * k) -> L.vals()[q] (acquisition values) and, with want_grad, L.g()[q * k + c] = -d value_q / d x_qc
+// (the gradient of the minimised objective -sum_q value_q).  Ends with a work-group barrier.
+__device__ __noinline__ void lb_eval(const LbLds L, const LbEval& E, int nq, bool want_grad) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n = E.n, k = E.k, NP = E.NP, ld = E.ld, H = E.H, S = E.S;
+  const int XS = LB_MAXK + 2;
+  for (int idx = tid; idx < LB_GQ * k; idx += LB_THREADS) {
+    const int q = idx / k, c = idx - q * k, qq = q < nq ? q : 0;
+    const double lo = E.nlo[c], hi = E.nhi[c];
+    L.xn()[q * XS + c] = (L.x()[qq * k + c] - lo) / (hi - lo);
+  }
+  __syncthreads();
+  // ---- kernel vectors: a thread per training point (the threads of pass 2's first group), all queries per pass over ZnT
+  double cf[LB_GQ];
+  const int hh = w / S, wsub = w - hh * S;
+  const int jmine = 64 * (S - 1 - slab_of(wsub, S)) + lane;           // this thread's column in pass 2 (hh < H)
+  if (hh == 0) {
+    const int j = jmine;
+    double sq[LB_GQ];
+#pragma unroll
+    for (int q = 0; q < LB_GQ; ++q) { sq[q] = 0.0; cf[q] = 0.0; }
+    double ksv[LB_GQ] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if (j < n) {
+      int c = 0;
+      for (; c + 4 <= k; c += 4) {
+        const double z0 = E.ZnT[(size_t)c * ld + j], z1 = E.ZnT[(size_t)(c + 1) * ld + j];
+        const double z2 = E.ZnT[(size_t)(c + 2) * ld + j], z3 = E.ZnT[(size_t)(c + 3) * ld + j];
+#pragma unroll
+        for (int q = 0; q < LB_GQ; ++q) {
+          double dd = L.xn()[q * XS + c] - z0; sq[q] = fma(dd, dd, sq[q]);
+          dd = L.xn()[q * XS + c + 1] - z1; sq[q] = fma(dd, dd, sq[q]);
+          dd = L.xn()[q * XS + c + 2] - z2; sq[q] = fma(dd, dd, sq[q]);
+          dd = L.xn()[q * XS + c + 3] - z3; sq[q] = fma(dd, dd, sq[q]);
+        }
+      }
+      for (; c < k; ++c) {
+        const double z0 = E.ZnT[(size_t)c * ld + j];
+#pragma unroll
+        for (int q = 0; q < LB_GQ; ++q) { const double dd = L.xn()[q * XS + c] - z0; sq[q] = fma(dd, dd, sq[q]); }
+      }
+      const double s5 = 2.23606797749979, il2 = E.inv_ls * E.inv_ls;
+#pragma unroll
+      for (int q = 0; q < LB_GQ; ++q) {
+        const double sqq = sq[q] * il2;
+        if (E.kernel == 1) {
+          ksv[q] = exp(-0.5 * sqq);
+          cf[q] = -ksv[q] * il2;
+        } else {
+          const double dist = sqrt(fmax(sqq, 1e-30));
+          const double e = exp(-s5 * dist);
+          ksv[q] = ((s5 * dist + 1.0) + (5.0 / 3.0) * (dist * dist)) * e;
+          cf[q] = -(5.0 / 3.0) * (1.0 + s5 * dist) * e * il2;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < LB_GQ; ++q) L.ks()[j * LB_QS + q] = ksv[q];
+  }
+  __syncthreads();
+  // ---- pass 1: v_q[i] = sum_j RT[j][i] ks_q[j], thread (row i, part hh of the columns)
+  const int imine = 64 * slab_of(wsub, S) + lane;
+  if (hh < H) {
+    const int i = imine;
+    const int jtot = n < 64 * (i / 64 + 1) ? n : 64 * (i / 64 + 1);
+    const int J0 = (int)((long long)jtot * hh / H), J1 = (int)((long long)jtot * (hh + 1) / H);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0;
+    const double* rp = E.RT + i;
+    int j = J0;
+    for (; j + 4 <= J1; j += 4) {
+      const double r0 = rp[(size_t)j * ld], r1 = rp[(size_t)(j + 1) * ld], r2 = rp[(size_t)(j + 2) * ld], r3 = rp[(size_t)(j + 3) * ld];
+      const ldsd* kp = L.ks() + j * LB_QS;
+      a0 = fma(r0, kp[0], a0); a1 = fma(r0, kp[1], a1); a2 = fma(r0, kp[2], a2); a3 = fma(r0, kp[3], a3); a4 = fma(r0, kp[4], a4);
+      kp += LB_QS;
+      a0 = fma(r1, kp[0], a0); a1 = fma(r1, kp[1], a1); a2 = fma(r1, kp[2], a2); a3 = fma(r1, kp[3], a3); a4 = fma(r1, kp[4], a4);
+      kp += LB_QS;
+      a0 = fma(r2, kp[0], a0); a1 = fma(r2, kp[1], a1); a2 = fma(r2, kp[2], a2); a3 = fma(r2, kp[3], a3); a4 = fma(r2, kp[4], a4);
+      kp += LB_QS;
+      a0 = fma(r3, kp[0], a0); a1 = fma(r3, kp[1], a1); a2 = fma(r3, kp[2], a2); a3 = fma(r3, kp[3], a3); a4 = fma(r3, kp[4], a4);
+    }
+    for (; j < J1; ++j) {
+      const double r0 = rp[(size_t)j * ld];
+      const ldsd* kp = L.ks() + j * LB_QS;
+      a0 = fma(r0, kp[0], a0); a1 = fma(r0, kp[1], a1); a2 = fma(r0, kp[2], a2); a3 = fma(r0, kp[3], a3); a4 = fma(r0, kp[4], a4);
+    }
+    ldsd* dst = hh == 0 ? L.vb() + i * LB_QS : L.part() + ((size_t)(hh - 1) * NP + i) * LB_QS;
+    dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = a3; dst[4] = a4;
+  }
+  __syncthreads();
+  if (hh == 0) {
+    const int i = imine;
+    double v[LB_GQ];
+#pragma unroll
+    for (int q = 0; q < LB_GQ; ++q) v[q] = L.vb()[i * LB_QS + q];
+    for (int h2 = 1; h2 < H; ++h2)
+#pragma unroll
+      for (int q = 0; q < LB_GQ; ++q) v[q] += L.part()[((size_t)(h2 - 1) * NP + i) * LB_QS + q];
+    const double ai = i < n ? E.alpha[i] : 0.0;
+#pragma unroll
+    for (int q = 0; q < LB_GQ; ++q) {
+      L.vb()[i * LB_QS + q] = v[q];
+      const double vv = wave_sum(v[q] * v[q]);
+      const double mu = wave_sum(ai * L.ks()[i * LB_QS + q]);
+      if (lane == 0) { L.red()[wsub * 10 + q] = vv; L.red()[wsub * 10 + LB_GQ + q] = mu; }
+    }
+  }
+  __syncthreads();
+  // ---- scalar chains (lanes 0 .. nq - 1 of wave 0) beside pass 2 of the other waves
+  if (tid < LB_GQ) {
+    double vv = 0.0, mus = 0.0;
+    for (int s = 0; s < S; ++s) { vv += L.red()[s * 10 + tid]; mus += L.red()[s * 10 + LB_GQ + tid]; }
+    double value, cmu, csg;
+    lb_scalar_core(vv, mus, E, &value, &cmu, &csg);
+    L.vals()[tid] = value; L.cq()[2 * tid] = cmu; L.cq()[2 * tid + 1] = csg;
+  }
+  if (!want_grad) { __syncthreads(); return; }
+  // ---- pass 2: w_q[j] = sum_{i >= j} R[i][j] v_q[i], thread (column j, part hh of the rows)
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0;
+  if (hh < H) {
+    const int j = jmine;
+    const int ibeg = 64 * (j / 64), len = n > ibeg ? n - ibeg : 0;
+    const int I0 = ibeg + (int)((long long)len * hh / H), I1 = ibeg + (int)((long long)len * (hh + 1) / H);
+    const double* rp = E.R + j;
+    int i = I0;
+    for (; i + 4 <= I1; i += 4) {
+      const double r0 = rp[(size_t)i * ld], r1 = rp[(size_t)(i + 1) * ld], r2 = rp[(size_t)(i + 2) * ld], r3 = rp[(size_t)(i + 3) * ld];
+      const ldsd* vp = L.vb() + i * LB_QS;
+      a0 = fma(r0, vp[0], a0); a1 = fma(r0, vp[1], a1); a2 = fma(r0, vp[2], a2); a3 = fma(r0, vp[3], a3); a4 = fma(r0, vp[4], a4);
+      vp += LB_QS;
+      a0 = fma(r1, vp[0], a0); a1 = fma(r1, vp[1], a1); a2 = fma(r1, vp[2], a2); a3 = fma(r1, vp[3], a3); a4 = fma(r1, vp[4], a4);
+      vp += LB_QS;
+      a0 = fma(r2, vp[0], a0); a1 = fma(r2, vp[1], a1); a2 = fma(r2, vp[2], a2); a3 = fma(r2, vp[3], a3); a4 = fma(r2, vp[4], a4);
+      vp += LB_QS;
+      a0 = fma(r3, vp[0], a0); a1 = fma(r3, vp[1], a1); a2 = fma(r3, vp[2], a2); a3 = fma(r3, vp[3], a3); a4 = fma(r3, vp[4], a4);
+    }
+    for (; i < I1; ++i) {
+      const double r0 = rp[(size_t)i * ld];
+      const ldsd* vp = L.vb() + i * LB_QS;
+      a0 = fma(r0, vp[0], a0); a1 = fma(r0, vp[1], a1); a2 = fma(r0, vp[2], a2); a3 = fma(r0, vp[3], a3); a4 = fma(r0, vp[4], a4);
+    }
+    if (hh > 0) {
+      ldsd* dst = L.part() + ((size_t)(hh - 1) * NP + j) * LB_QS;
+      dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = a3; dst[4] = a4;
+    }
+  }
+  __syncthreads();
+  if (hh == 0) {
+    const int j = jmine;
+    double wv[LB_GQ] = {a0, a1, a2, a3, a4};
+    for (int h2 = 1; h2 < H; ++h2)
+#pragma unroll
+      for (int q = 0; q < LB_GQ; ++q) wv[q] += L.part()[((size_t)(h2 - 1) * NP + j) * LB_QS + q];
+    const double aj = j < n ? E.alpha[j] : 0.0;
+    // u_q[j] = c_mu (alpha_j cf) + c_sg (w cf): the point's weight in the contraction with (xn_c - zn_cj)
+#pragma unroll
+    for (int q = 0; q < LB_GQ; ++q) L.ks()[j * LB_QS + q] = fma(L.cq()[2 * q], aj * cf[q], L.cq()[2 * q + 1] * (wv[q] * cf[q]));
+  }
+  __syncthreads();
+  // ---- gradient: wave per component, lanes over the points
+  for (int c = w; c < k; c += LB_THREADS / 64) {
+    double acc[LB_GQ] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    double xq[LB_GQ];
+#pragma unroll
+    for (int q = 0; q < LB_GQ; ++q) xq[q] = L.xn()[q * XS + c];
+    for (int j = lane; j < n; j += 64) {
+      const double z = E.ZnT[(size_t)c * ld + j];
+#pragma unroll
+      for (int q = 0; q < LB_GQ; ++q) acc[q] = fma(L.ks()[j * LB_QS + q], xq[q] - z, acc[q]);
+    }
+    const double inv = E.nhi[c] - E.nlo[c];
+#pragma unroll
+    for (int q = 0; q < LB_GQ; ++q) {
+      const double s = wave_sum(acc[q]);
+      if (lane == 0 && q < nq) L.g()[q * k + c] = -(s / inv);
+    }
+  }
+  __syncthreads();
+}
+
+// =====================================================================================================================
+// The kernel.  grid = entries of the table (run << 16 | first query << 8 | count), block = LB_THREADS.
+// mode 1: optimise from the initial conditions; mode 0: one evaluation at the given points (value and gradient to the run's
+// dVal / dGrad: the host-paced twin of the tests and the end-point values).
+// Per run (stride zs): Xq = [num_restarts x k initial points | lower[k] | upper[k]], out_x = candidates (num_restarts x k),
+// out_v = [values (num_restarts) ... | 64 + 8 gi: niter, nfev, warnflag, task, status, evaluations, ties].
+// =====================================================================================================================
+__global__ __launch_bounds__(LB_THREADS) void k_lbfgsb_group(
+    const unsigned* __restrict__ table, int mode, int num_restarts, int maxiter, int n, int NP, int ld, int H,
+    const double* __restrict__ Xq, const double* __restrict__ ZnT, const double* __restrict__ R, const double* __restrict__ RT,
+    const double* __restrict__ alpha, const double* __restrict__ bounds4, const double* __restrict__ ystats,
+    const double* __restrict__ bestf, const int* __restrict__ k_dev, double inv_ls, int maximize, int acq, int kernel,
+    double* __restrict__ out_x, double* __restrict__ out_v, size_t zs) {
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+  const unsigned ent = table[blockIdx.x];
+  const unsigned run_ = ent >> 16;
+  const int q0 = (int)((ent >> 8) & 0xffu), nq = (int)(ent & 0xffu), gi = q0 / LB_GQ;
+  Xq = zrun(Xq, zs, run_); ZnT = zrun(ZnT, zs, run_); R = zrun(R, zs, run_); RT = zrun(RT, zs, run_);
+  alpha = zrun(alpha, zs, run_); bounds4 = zrun(bounds4, zs, run_); ystats = zrun(ystats, zs, run_);
+  bestf = zrun(bestf, zs, run_); k_dev = zrun(k_dev, zs, run_); out_x = zrun(out_x, zs, run_); out_v = zrun(out_v, zs, run_);
+  const int k = *k_dev;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int nv = nq * k;
+  LbLds L;
+  L.base = (ldsd*)s_dyn; L.n = nv; L.NP = NP;
+  LbEval E;
+  E.ZnT = ZnT; E.R = R; E.RT = RT; E.alpha = alpha; E.nlo = bounds4; E.nhi = bounds4 + PCABO_MAXD;
+  E.n = n; E.k = k; E.NP = NP; E.ld = ld; E.H = H; E.S = NP / 64;
+  E.best_f = *bestf; E.ym = ystats[0]; E.ysd = ystats[1]; E.inv_ls = inv_ls; E.maximize = maximize; E.acq = acq; E.kernel = kernel;
+  // ---- initial state
+  for (int i = tid; i < nv; i += LB_THREADS) {
+    const int q = i / k, c = i - q * k;
+    const double l = Xq[(size_t)num_restarts * k + c], h = Xq[(size_t)num_restarts * k + k + c], v = Xq[(size_t)(q0 + q) * k + c];
+    L.lo()[i] = l; L.hi()[i] = h;
+    L.x()[i] = mode == 1 ? (v < l ? l : (v > h ? h : v)) : v;
+    L.g()[i] = 0.0;
+    L.iwhere()[i] = (h - l <= 0.0) ? 3 : 0;
+  }
+  for (int i = tid; i < OFF_X; i += LB_THREADS) L.ws()[i] = 0.0;                     // (ws and wy are adjacent)
+  for (int i = tid; i < LB_M * LB_M; i += LB_THREADS) { L.sy()[i] = 0.0; L.ss()[i] = 0.0; L.wt()[i] = 0.0; }
+  for (int i = tid; i < 4 * LB_M * LB_M; i += LB_THREADS) { L.wn()[i] = 0.0; L.wn1()[i] = 0.0; }
+  if (tid < 8 * LB_M) L.wa()[tid] = 0.0;
+  if (tid < S_COUNT) L.sc()[tid] = 0.0;
+  if (tid < I_COUNT) L.isc()[tid] = 0;
+  __syncthreads();
+  if (tid == 0) { SC(S_THETA) = 1.0; ISC(I_NFREE) = nv; ISC(I_ACTIVE) = 1; ISC(I_TASK) = LBFGSB_START; }
+  __syncthreads();
+  if (mode == 0) {
+    lb_eval(L, E, nq, true);
+    if (tid < nq) out_v[q0 + tid] = L.vals()[tid];
+    for (int i = tid; i < nv; i += LB_THREADS) out_x[(size_t)q0 * k + i] = -L.g()[i];      // the acquisition's own gradient
+    return;
+  }
+  // ---- the optimisation
+  for (int guard = 0; guard < LB_MAXEVAL; ++guard) {
+    if (w == 0) lb_advance(L, maxiter, lane);
+    __syncthreads();
+    if (!ISC(I_ACTIVE)) break;
+    lb_eval(L, E, nq, true);
+    // RestartGroup::absorb: f = -(sum of the values, in order), NaN check of the gradient, cache
+    if (w == 0) {
+      bool nan = false;
+      for (int i = lane; i < nv; i += 64) { const double gv = L.g()[i]; nan = nan || (gv != gv); }
+      if (__ballot(nan)) {
+        if (lane == 0) { ISC(I_STATUS) = PCABO_ERR_NAN_CODE; ISC(I_ACTIVE) = 0; }
+      } else {
+        double fs = 0.0;
+        for (int q = 0; q < nq; ++q) fs += L.vals()[q];
+        for (int i = lane; i < nv; i += 64) { L.xc()[i] = L.x()[i]; L.gc()[i] = L.g()[i]; }
+        if (lane < nq) L.vc()[lane] = L.vals()[lane];
+        if (lane == 0) { SC(S_F) = -fs; SC(S_FC) = -fs; ISC(I_NFEV) += 1; ISC(I_HAVE_CACHE) = 1; ISC(I_EVALS) += 1; }
+      }
+    }
+    __syncthreads();
+    if (!ISC(I_ACTIVE)) break;
+  }
+  __syncthreads();
+  // ---- end points (clamped), their values: the last evaluation's if that was the point, one more evaluation otherwise
+  bool same = ISC(I_HAVE_CACHE) != 0;
+  for (int i = tid; i < nv; i += LB_THREADS) {
+    double v = L.x()[i];
+    v = v < L.lo()[i] ? L.lo()[i] : (v > L.hi()[i] ? L.hi()[i] : v);
+    L.x()[i] = v;
+    if (__double_as_longlong(v) != __double_as_longlong(L.xc()[i])) same = false;
+  }
+  const int all_same = __syncthreads_and(same ? 1 : 0);
+  const int status = ISC(I_STATUS);
+  if (status == 0) {
+    if (!all_same) lb_eval(L, E, nq, false);
+    else { if (tid < nq) L.vals()[tid] = L.vc()[tid]; __syncthreads(); }
+    if (tid < nq) out_v[q0 + tid] = L.vals()[tid];
+  }
+  for (int i = tid; i < nv; i += LB_THREADS) out_x[(size_t)q0 * k + i] = L.x()[i];
+  if (tid == 0) {
+    const int task = ISC(I_TASK);
+    const int wf = (task == LBFGSB_CONV_PG || task == LBFGSB_CONV_F) ? 0 : ((task == LBFGSB_STOP_ITER || task == LBFGSB_STOP_FUN) ? 1 : 2);
+    double* o = out_v + 64 + 8 * gi;
+    o[0] = ISC(I_NITER); o[1] = ISC(I_NFEV); o[2] = wf; o[3] = task; o[4] = status; o[5] = ISC(I_EVALS); o[6] = ISC(I_TIES);
+    o[7] = ISC(I_ACTIVE) ? 1.0 : 0.0;                 // 1: stopped by the evaluation cap (cannot happen within the host's limits)
+  }
+}
+
+// ---- RT = transposed root inverse, clean (zeros above the diagonal and beyond n) --------------------------------------
+__global__ __launch_bounds__(256) void k_rt_build(const double* __restrict__ R, int n, int ld, double* __restrict__ RT, size_t zs) {
+  R = zrun(R, zs, blockIdx.z); RT = zrun(RT, zs, blockIdx.z);
+  __shared__ double tile[64][65];
+  const int bi = blockIdx.y, bj = blockIdx.x;        // source tile: rows 64 bi.., columns 64 bj..
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  if (bi >= bj) {
+    for (int r = ty; r < 64; r += 4) {
+      const int i = 64 * bi + r, j = 64 * bj + tx;
+      tile[r][tx] = (i >= j && i < n && j < n) ? R[(size_t)i * ld + j] : 0.0;
+    }
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    const int j = 64 * bj + r, i = 64 * bi + tx;     // RT[j][i] = R[i][j]
+    RT[(size_t)j * ld + i] = bi >= bj ? tile[tx][r] : 0.0;
+  }
+}
+
+void launch_rt_build(hipStream_t s, const double* R, int n, int NP, int ld, double* RT, ZB zb) {
+  hipLaunchKernelGGL(k_rt_build, dim3(NP / 64, NP / 64, zb.B), dim3(256), 0, s, R, n, ld, RT, zb.zs);
+}
+
+bool lbfgsb_device_possible(int NP, int kmax, int batch_limit) {
+  return NP <= LB_MAXNP && kmax <= LB_MAXK && batch_limit <= LB_GQ && NP >= 64;
+}
+
+static int lb_parts(int NP) { int H = LB_THREADS / NP; return H < 1 ? 1 : (H > 8 ? 8 : H); }
+
+int launch_lbfgsb_group(hipStream_t st, const unsigned* table, int entries, int mode, int num_restarts, int maxiter, int n, int NP,
+                        int ld, const double* Xq, const double* ZnT, const double* R, const double* RT, const double* alpha,
+                        const double* bounds4, const double* ystats, const double* bestf, const int* k_dev, double inv_ls,
+                        int maximize, int acq, int kernel, double* out_x, double* out_v, size_t zs) {
+  const int H = lb_parts(NP);
+  const size_t lds = lb_lds_doubles(NP, H) * sizeof(double);
+  if (lds > 150 * 1024) return -1;
+  {
+    static std::mutex attr_mu;
+    static bool attr_done[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+    std::lock_guard<std::mutex> lk(attr_mu);
+    if (!attr_done[dev]) {
+      if (hipFuncSetAttribute((const void*)k_lbfgsb_group, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) return -1;
+      attr_done[dev] = true;
+    }
+  }
+  hipLaunchKernelGGL(k_lbfgsb_group, dim3(entries), dim3(LB_THREADS), lds, st, table, mode, num_restarts, maxiter, n, NP, ld, H, Xq,
+                     ZnT, R, RT, alpha, bounds4, ystats, bestf, k_dev, inv_ls, maximize, acq, kernel, out_x, out_v, zs);
+  return 0;
+}

@@ -109,6 +109,7 @@ struct pcabo_ctx {
   char *dRegion = nullptr, *hRegion = nullptr;   // the two allocations everything above / below is carved from
   size_t region_bytes = 0, hregion_bytes = 0;
   bool in_batch = false; int batch_index = 0;
+  bool rt_stale = false;                 // pcabo_get_gram has overwritten the transposed root inverse kept in dGram (device-resident L-BFGS-B)
   // pinned host
   HostMirror* hm = nullptr;
   double *hXq = nullptr, *hVal = nullptr, *hGrad = nullptr, *hSmall = nullptr, *hBestF = nullptr;
@@ -1318,6 +1319,7 @@ int pcabo_get_gram(pcabo_ctx* ctx, double* K) {
   HIPCHK(hipSetDevice(ctx->device));
   const size_t n = ctx->n, w = n * sizeof(double), pitch = (size_t)ctx->ld * sizeof(double);
   // built on demand: the conditioning itself writes only the copy that the factorisation then overwrites
+  ctx->rt_stale = true;
   launch_gram(ctx->stream, ctx->dAT, ctx->dNrm, ctx->n, ctx->NP, round_up(ctx->k, 4), ctx->ld, ctx->noise, ctx->kernel, ctx->dGram,
               nullptr, nullptr, nullptr);
   HIPCHK(hipMemcpy2DAsync(K, w, ctx->dGram, pitch, w, n, hipMemcpyDeviceToHost, ctx->stream));
@@ -1606,6 +1608,8 @@ struct pcabo_batch {
   int cnt_S = 0; bool cnt_dirty = true;
   bool prof = false; hipEvent_t pev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // phase marks of the last conditioning
   bool group_acq = true;                 // L-BFGS-B rounds through k_acq_group (pcabo_batch_set_option(PCABO_OPT_GROUP_ACQ, 0): the per-query kernels)
+  int dev_lbfgsb = 0;                    // PCABO_OPT_DEVICE_LBFGSB: 1 device-resident L-BFGS-B, 2 its host-stepped twin
+  unsigned *dOptTab = nullptr, *hOptTab = nullptr;   // launch table of the device-resident optimiser (B * 32 entries)
   int G = 0;                             // gangs = worker threads of the L-BFGS-B phase
   std::vector<hipStream_t> gstream;
   GangPool pool;
@@ -1636,6 +1640,8 @@ static void batch_free(pcabo_batch* batch) {
   for (hipEvent_t e : batch->pev) if (e) (void)hipEventDestroy(e);
   if (batch->dSlab) (void)hipFree(batch->dSlab);
   if (batch->hSlab) (void)hipHostFree(batch->hSlab);
+  if (batch->dOptTab) (void)hipFree(batch->dOptTab);
+  if (batch->hOptTab) (void)hipHostFree(batch->hOptTab);
   if (batch->stream) (void)hipStreamDestroy(batch->stream);
   delete batch;
 }
@@ -1667,6 +1673,8 @@ int pcabo_batch_create(int device, int B, int max_n, int max_d, int max_q, pcabo
   BHIPCHK(hipMalloc((void**)&batch->dSlab, batch->zs * (size_t)B));
   BHIPCHK(hipHostMalloc((void**)&batch->hSlab, batch->hzs * (size_t)B, hipHostMallocDefault));
   memset(batch->hSlab, 0, batch->hzs * (size_t)B);
+  BHIPCHK(hipMalloc((void**)&batch->dOptTab, (size_t)B * PCABO_INLAUNCH_MAXQ * sizeof(unsigned)));
+  BHIPCHK(hipHostMalloc((void**)&batch->hOptTab, (size_t)B * PCABO_INLAUNCH_MAXQ * sizeof(unsigned), hipHostMallocDefault));
   BHIPCHK(hipMemsetAsync(batch->dSlab, 0, batch->zs * (size_t)B, batch->stream));
   BHIPCHK(hipStreamSynchronize(batch->stream));
   batch->ctx.assign(B, nullptr);
@@ -1725,6 +1733,11 @@ int pcabo_batch_set_workers(pcabo_batch* batch, int workers) {
 // is bit-identical to the same run in a stand-alone context with default options.  Not during a call on this batch.
 int pcabo_batch_set_option(pcabo_batch* batch, int option, int value) {
   if (!batch) return PCABO_ERR_ARG;
+  if (option == PCABO_OPT_DEVICE_LBFGSB) {
+    if (value < 0 || value > 2) return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_set_option: PCABO_OPT_DEVICE_LBFGSB takes 0, 1 or 2 (%s%d)", "", value);
+    batch->dev_lbfgsb = value;
+    return PCABO_OK;
+  }
   if (option != PCABO_OPT_GROUP_ACQ) return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_set_option: unknown option %s%d", "", option);
   batch->group_acq = value != 0;
   for (pcabo_ctx* c : batch->ctx) c->opt_group_acq = batch->group_acq;
@@ -1830,6 +1843,8 @@ int pcabo_batch_wpca_gp_condition_begin(pcabo_batch* batch, const double* X, con
   launch_trinv(s, c0->dL, NP, c0->ld, c0->dR, zb);
   launch_alpha(s, c0->dR, c0->dYs, n, NP, c0->ld, c0->dTmp, c0->dAlpha, zb);
   mark(4);
+  // the device-resident optimiser reads the root inverse transposed as well (the Gram buffer is free: K is only kept on demand)
+  if (batch->dev_lbfgsb) launch_rt_build(s, c0->dR, n, NP, c0->ld, c0->dGram, zb);
   BHIPCHK(hipMemcpy2DAsync((void*)&c0->hm->chol_info, batch->hzs, c0->dInfo, batch->zs, sizeof(int), B, hipMemcpyDeviceToHost, s));
   BHIPCHK(hipGetLastError());
   batch->n = n; batch->d = d; batch->NP = NP;
@@ -1954,6 +1969,7 @@ int pcabo_batch_gp_condition_end_eval(pcabo_batch* batch, const double* Xq, int 
       }
       if (st == PCABO_OK) {
         c->have_gp = true;
+        if (batch->dev_lbfgsb) launch_rt_build(c->stream, c->dR, c->n, c->NP, c->ld, c->dGram);
         st = pcabo_acq_eval(c, Xq + (size_t)b * q * batch->max_d, q, best_f[b], maximize, acq, c->hVal, nullptr);
       } else {
         set_err(c, st, "K + s2 I not positive definite after jitter retries (pivot %s%d)", "", c->hm->chol_info);
@@ -1965,6 +1981,179 @@ int pcabo_batch_gp_condition_end_eval(pcabo_batch* batch, const double* Xq, int 
     if (st != PCABO_OK) worst = st;
   }
   if (worst != PCABO_OK && !status) return bset_err(batch, worst, "a run of the batch failed in the conditioning (status array not given)%s", "");
+  return PCABO_OK;
+}
+
+// pcabo_batch_optimize_acqf with PCABO_OPT_DEVICE_LBFGSB: every restart group's L-BFGS-B inside one launch of k_lbfgsb_group
+// (value 1), or the host's L-BFGS-B over the same kernel's evaluation-only mode, one launch per round (value 2: the twin the
+// device stepping is compared with).  Returns PCABO_OK / an error, or 1 when the call is not eligible (the caller then takes
+// the host-paced path).
+static int batch_optimize_device(pcabo_batch* batch, const double* ics, int num_restarts, int batch_limit, const double* bounds,
+                                 int maxiter, int maximize, int acq, double* cand, double* vals, int* info, int* failed,
+                                 int* status) {
+  const int B = batch->B, MD = batch->max_d, kmax = batch_max_k(batch);
+  const int ngroups = (num_restarts + batch_limit - 1) / batch_limit;
+  pcabo_ctx* c0 = batch->ctx[0];
+  if (!lbfgsb_device_possible(batch->NP, kmax, batch_limit) || num_restarts > PCABO_INLAUNCH_MAXQ || maxiter < 1 ||
+      batch->max_q < 64 + 8 * ngroups || (size_t)(num_restarts + 2) * kmax > (size_t)batch->max_q * MD)
+    return 1;
+  std::vector<int> act;
+  for (int b = 0; b < B; ++b) {
+    const pcabo_ctx* c = batch->ctx[b];
+    if (!batch->active[b] || !c->have_gp) continue;
+    const double* bd = bounds + (size_t)b * 2 * MD;
+    for (int j = 0; j < c->k; ++j)
+      if (!std::isfinite(bd[j]) || !std::isfinite(bd[c->k + j]) || bd[j] > bd[c->k + j]) return 1;
+    act.push_back(b);
+  }
+  hipStream_t s = batch->stream;
+  for (int b : act) {
+    pcabo_ctx* c = batch->ctx[b];
+    if (c->rt_stale) { launch_rt_build(s, c->dR, c->n, c->NP, c->ld, c->dGram); c->rt_stale = false; }
+  }
+  auto fill_status = [&](const std::vector<int>& run_status) {
+    for (int b = 0; b < B; ++b) {
+      const pcabo_ctx* c = batch->ctx[b];
+      int st = run_status[b];
+      if (!batch->active[b]) st = PCABO_ERR_ARG; else if (!c->have_gp) st = PCABO_ERR_NOT_PD;
+      if (status) status[b] = st;
+    }
+  };
+  const size_t xq_doubles = (size_t)(num_restarts + 2) * kmax;
+  const double inv_ls = 1.0 / batch->lengthscale;
+  auto launch = [&](int nent, int mode) -> int {
+    BHIPCHK(hipMemcpyAsync(batch->dOptTab, batch->hOptTab, (size_t)nent * sizeof(unsigned), hipMemcpyHostToDevice, s));
+    BHIPCHK(hipMemcpy2DAsync(c0->dXq, batch->zs, c0->hXq, batch->hzs, xq_doubles * sizeof(double), B, hipMemcpyHostToDevice, s));
+    if (launch_lbfgsb_group(s, batch->dOptTab, nent, mode, num_restarts, maxiter, batch->n, batch->NP, c0->ld, c0->dXq, c0->dZnT,
+                            c0->dR, c0->dGram, c0->dAlpha, c0->dBounds4, c0->dYstats, c0->dBestF, c0->dK, inv_ls, maximize ? 1 : 0,
+                            acq, batch->kernel, c0->dGrad, c0->dVal, batch->zs) != 0)
+      return bset_err(batch, PCABO_ERR_HIP, "the device-resident optimiser could not be launched%s", "");
+    BHIPCHK(hipMemcpy2DAsync(c0->hVal, batch->hzs, c0->dVal, batch->zs, (size_t)(64 + 8 * ngroups) * sizeof(double), B, hipMemcpyDeviceToHost, s));
+    BHIPCHK(hipMemcpy2DAsync(c0->hGrad, batch->hzs, c0->dGrad, batch->zs, (size_t)num_restarts * kmax * sizeof(double), B, hipMemcpyDeviceToHost, s));
+    BHIPCHK(wait_stream(s));
+    BHIPCHK(hipGetLastError());
+    return PCABO_OK;
+  };
+  std::vector<int> run_status(B, PCABO_OK);
+  if (batch->dev_lbfgsb == 1) {
+    // ---- everything on the device
+    int nent = 0;
+    for (size_t blk = 0; blk < act.size(); blk += 8)          // both groups of a run on one XCD (work-groups go round the 8 XCDs)
+      for (int gi = 0; gi < ngroups; ++gi)
+        for (size_t r = blk; r < std::min(act.size(), blk + 8); ++r) {
+          const int q0 = gi * batch_limit, nq = std::min(batch_limit, num_restarts - q0);
+          batch->hOptTab[nent++] = ((unsigned)act[r] << 16) | ((unsigned)q0 << 8) | (unsigned)nq;
+        }
+    for (int b : act) {
+      pcabo_ctx* c = batch->ctx[b];
+      const int k = c->k;
+      memcpy(c->hXq, ics + (size_t)b * num_restarts * MD, (size_t)num_restarts * k * sizeof(double));
+      memcpy(c->hXq + (size_t)num_restarts * k, bounds + (size_t)b * 2 * MD, (size_t)2 * k * sizeof(double));
+    }
+    if (nent > 0) { const int rc = launch(nent, 1); if (rc != PCABO_OK) return rc; }
+    for (int b : act) {
+      const pcabo_ctx* c = batch->ctx[b];
+      const int k = c->k;
+      int any_failed = 0;
+      for (int gi = 0; gi < ngroups; ++gi) {
+        const double* o = c->hVal + 64 + 8 * gi;
+        if (info) { int* io = info + ((size_t)b * ngroups + gi) * 4; io[0] = (int)o[0]; io[1] = (int)o[1]; io[2] = (int)o[2]; io[3] = (int)o[3]; }
+        if ((int)o[2] == 2) any_failed = 1;
+        if ((int)o[4] != 0) run_status[b] = (int)o[4];
+        if ((int)o[7] != 0) run_status[b] = PCABO_ERR_TIMEOUT;       // evaluation cap (cannot happen within maxiter / maxls)
+      }
+      if (run_status[b] == PCABO_ERR_NAN) set_err(batch->ctx[b], PCABO_ERR_NAN, "NaN in acquisition gradient%s", "");
+      memcpy(cand + (size_t)b * num_restarts * MD, c->hGrad, (size_t)num_restarts * k * sizeof(double));
+      memcpy(vals + (size_t)b * num_restarts, c->hVal, (size_t)num_restarts * sizeof(double));
+      if (failed) failed[b] = any_failed;
+    }
+    for (int b = 0; b < B; ++b) if (failed && (!batch->active[b] || !batch->ctx[b]->have_gp)) failed[b] = 0;
+    fill_status(run_status);
+    return PCABO_OK;
+  }
+  // ---- the twin: host L-BFGS-B (csrc/lbfgsb.cpp), evaluations through mode 0 of the same kernel, one launch per round
+  std::vector<std::vector<RestartGroup>> groups(B);
+  for (int b : act) {
+    groups[b].resize(ngroups);
+    for (int gi = 0; gi < ngroups; ++gi) {
+      const int q0 = gi * batch_limit, nq = std::min(batch_limit, num_restarts - q0);
+      groups[b][gi].init(ics + (size_t)b * num_restarts * MD, bounds + (size_t)b * 2 * MD, q0, nq, batch->ctx[b]->k, maxiter);
+    }
+  }
+  struct Pending { int b, gi; };
+  std::vector<Pending> pend;
+  for (;;) {
+    pend.clear();
+    int nent = 0;
+    for (int b : act) {
+      if (run_status[b] != PCABO_OK) continue;
+      pcabo_ctx* c = batch->ctx[b];
+      for (int gi = 0; gi < ngroups; ++gi) {
+        RestartGroup& rg = groups[b][gi];
+        if (!rg.active) continue;
+        rg.advance();
+        if (!rg.active) continue;
+        memcpy(c->hXq + (size_t)rg.q0 * c->k, rg.x.data(), (size_t)rg.nq * c->k * sizeof(double));
+        batch->hOptTab[nent++] = ((unsigned)b << 16) | ((unsigned)rg.q0 << 8) | (unsigned)rg.nq;
+        pend.push_back({b, gi});
+      }
+    }
+    if (nent == 0) break;
+    const int rc = launch(nent, 0);
+    if (rc != PCABO_OK) return rc;
+    for (const Pending& pe : pend) {
+      pcabo_ctx* c = batch->ctx[pe.b];
+      if (!groups[pe.b][pe.gi].absorb(c->hVal, c->hGrad)) {
+        run_status[pe.b] = PCABO_ERR_NAN;
+        set_err(c, PCABO_ERR_NAN, "NaN in acquisition gradient%s", "");
+      }
+    }
+  }
+  {
+    int nent = 0;
+    std::vector<Pending> redo;
+    for (int b : act) {
+      if (run_status[b] != PCABO_OK) continue;
+      pcabo_ctx* c = batch->ctx[b];
+      const int k = c->k;
+      double* cb = cand + (size_t)b * num_restarts * MD;
+      for (int gi = 0; gi < ngroups; ++gi) {
+        RestartGroup& rg = groups[b][gi];
+        for (int t = 0; t < rg.nq * k; ++t) {
+          double v = rg.x[t];
+          v = v < rg.lo[t] ? rg.lo[t] : (v > rg.hi[t] ? rg.hi[t] : v);
+          cb[(size_t)rg.q0 * k + t] = v;
+        }
+        const bool reuse = rg.have_cache && (int)rg.vc.size() == rg.nq &&
+                           memcmp(cb + (size_t)rg.q0 * k, rg.xc.data(), (size_t)rg.nq * k * sizeof(double)) == 0;
+        if (reuse) { for (int j = 0; j < rg.nq; ++j) vals[(size_t)b * num_restarts + rg.q0 + j] = rg.vc[j]; }
+        else {
+          memcpy(c->hXq + (size_t)rg.q0 * k, cb + (size_t)rg.q0 * k, (size_t)rg.nq * k * sizeof(double));
+          batch->hOptTab[nent++] = ((unsigned)b << 16) | ((unsigned)rg.q0 << 8) | (unsigned)rg.nq;
+          redo.push_back({b, gi});
+        }
+      }
+    }
+    if (nent > 0) {
+      const int rc = launch(nent, 0);
+      if (rc != PCABO_OK) return rc;
+      for (const Pending& pe : redo) {
+        const RestartGroup& rg = groups[pe.b][pe.gi];
+        for (int j = 0; j < rg.nq; ++j) vals[(size_t)pe.b * num_restarts + rg.q0 + j] = batch->ctx[pe.b]->hVal[rg.q0 + j];
+      }
+    }
+  }
+  for (int b = 0; b < B; ++b) {
+    int any_failed = 0;
+    for (int gi = 0; gi < (int)groups[b].size(); ++gi) {
+      const RestartGroup& rg = groups[b][gi];
+      const int wf = rg.opt.warnflag();
+      if (info) { int* o = info + ((size_t)b * ngroups + gi) * 4; o[0] = rg.niter; o[1] = rg.nfev; o[2] = wf; o[3] = rg.opt.task(); }
+      if (wf == 2) any_failed = 1;
+    }
+    if (failed) failed[b] = any_failed;
+  }
+  fill_status(run_status);
   return PCABO_OK;
 }
 
@@ -1981,6 +2170,11 @@ int pcabo_batch_optimize_acqf(pcabo_batch* batch, const double* ics, int num_res
   const int ngroups = (num_restarts + batch_limit - 1) / batch_limit;
   int rc = batch_put_best_f(batch, best_f);
   if (rc != PCABO_OK) return rc;
+  if (batch->dev_lbfgsb) {
+    const int drc = batch_optimize_device(batch, ics, num_restarts, batch_limit, bounds, maxiter, maximize, acq, cand, vals, info,
+                                          failed, status);
+    if (drc != 1) return drc;                       // 1: not eligible (size, bounds) - the host-paced path below
+  }
   BHIPCHK(hipStreamSynchronize(batch->stream));
   pcabo_ctx* c0 = batch->ctx[0];
   AcqParams pg = make_params(c0, 0.0, maximize, acq, 1);
@@ -2140,6 +2334,53 @@ int pcabo_batch_optimize_acqf(pcabo_batch* batch, const double* ics, int num_res
     }
     if (failed) failed[b] = any_failed;
     if (status) status[b] = run_status[b];
+  }
+  return PCABO_OK;
+}
+
+// Value and gradient of the acquisition at q <= 32 points per run through the evaluation of the device-resident optimiser
+// (mode 0 of k_lbfgsb_group; PCABO_OPT_DEVICE_LBFGSB must be on so that the transposed root inverse exists).  Xq[B][q * max_d]
+// (run b's points packed with stride k_b), val[B][q], grad[B][q * max_d] (same packing).  Diagnostics / parity tests.
+int pcabo_batch_device_acq_eval(pcabo_batch* batch, const double* Xq, int q, const double* best_f, int maximize, int acq,
+                                double* val, double* grad) {
+  if (!batch) return PCABO_ERR_ARG;
+  if (!Xq || !best_f || !val || !grad || q < 1 || q > PCABO_INLAUNCH_MAXQ || (acq != PCABO_ACQ_LOG_EI && acq != PCABO_ACQ_PI))
+    return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_device_acq_eval: bad argument (q <= 32)%s", "");
+  if (!batch->have_gp || !batch->dev_lbfgsb)
+    return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_device_acq_eval: needs a conditioned GP and PCABO_OPT_DEVICE_LBFGSB%s", "");
+  BHIPCHK(hipSetDevice(batch->device));
+  const int B = batch->B, MD = batch->max_d, kmax = batch_max_k(batch);
+  if (!lbfgsb_device_possible(batch->NP, kmax, PCABO_GROUP_Q) || batch->max_q < 64)
+    return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_device_acq_eval: shape beyond the device optimiser (n <= 512, k <= 40)%s", "");
+  int rc = batch_put_best_f(batch, best_f);
+  if (rc != PCABO_OK) return rc;
+  pcabo_ctx* c0 = batch->ctx[0];
+  hipStream_t s = batch->stream;
+  int nent = 0;
+  for (int b = 0; b < B; ++b) {
+    pcabo_ctx* c = batch->ctx[b];
+    if (!c->have_gp) continue;
+    if (c->rt_stale) { launch_rt_build(s, c->dR, c->n, c->NP, c->ld, c->dGram); c->rt_stale = false; }
+    memcpy(c->hXq, Xq + (size_t)b * q * MD, (size_t)q * c->k * sizeof(double));
+    for (int q0 = 0; q0 < q; q0 += PCABO_GROUP_Q)
+      batch->hOptTab[nent++] = ((unsigned)b << 16) | ((unsigned)q0 << 8) | (unsigned)std::min(PCABO_GROUP_Q, q - q0);
+  }
+  if (nent == 0) return PCABO_OK;
+  BHIPCHK(hipMemcpyAsync(batch->dOptTab, batch->hOptTab, (size_t)nent * sizeof(unsigned), hipMemcpyHostToDevice, s));
+  BHIPCHK(hipMemcpy2DAsync(c0->dXq, batch->zs, c0->hXq, batch->hzs, (size_t)(q + 2) * kmax * sizeof(double), B, hipMemcpyHostToDevice, s));
+  if (launch_lbfgsb_group(s, batch->dOptTab, nent, 0, q, 1, batch->n, batch->NP, c0->ld, c0->dXq, c0->dZnT, c0->dR, c0->dGram,
+                          c0->dAlpha, c0->dBounds4, c0->dYstats, c0->dBestF, c0->dK, 1.0 / batch->lengthscale, maximize ? 1 : 0, acq,
+                          batch->kernel, c0->dGrad, c0->dVal, batch->zs) != 0)
+    return bset_err(batch, PCABO_ERR_HIP, "the device-resident optimiser could not be launched%s", "");
+  BHIPCHK(hipMemcpy2DAsync(c0->hVal, batch->hzs, c0->dVal, batch->zs, (size_t)q * sizeof(double), B, hipMemcpyDeviceToHost, s));
+  BHIPCHK(hipMemcpy2DAsync(c0->hGrad, batch->hzs, c0->dGrad, batch->zs, (size_t)q * kmax * sizeof(double), B, hipMemcpyDeviceToHost, s));
+  BHIPCHK(wait_stream(s));
+  BHIPCHK(hipGetLastError());
+  for (int b = 0; b < B; ++b) {
+    const pcabo_ctx* c = batch->ctx[b];
+    if (!c->have_gp) continue;
+    memcpy(val + (size_t)b * q, c->hVal, (size_t)q * sizeof(double));
+    memcpy(grad + (size_t)b * q * MD, c->hGrad, (size_t)q * c->k * sizeof(double));
   }
   return PCABO_OK;
 }

@@ -213,3 +213,13 @@ int acq_slabs(int NP);
 void launch_inverse_map(hipStream_t s, const double* z, const double* comps, const double* data_mean,
                         const double* pca_mean, int k, int d, double* x, const int* k_dev = nullptr, ZB zb = ZB(),
                         double* host_x = nullptr, HostMirror* hm = nullptr, unsigned long long seq = 0);   // host_x / hm: results + flag to pinned host
+// Device-resident L-BFGS-B of a batch's restart groups (kernels_lbfgsb.hip): RT = transposed root inverse (zeros above the
+// diagonal and beyond n), then one work-group per table entry (run << 16 | first query << 8 | count).  mode 1: optimise from the
+// initial conditions in Xq ([num_restarts x k | lower k | upper k] per run), candidates to out_x, values / counters to out_v;
+// mode 0: one value+gradient evaluation at the points in Xq.  Returns 0, or -1 when the launch could not be set up.
+void launch_rt_build(hipStream_t s, const double* R, int n, int NP, int ld, double* RT, ZB zb = ZB());
+bool lbfgsb_device_possible(int NP, int kmax, int batch_limit);
+int launch_lbfgsb_group(hipStream_t st, const unsigned* table, int entries, int mode, int num_restarts, int maxiter, int n, int NP,
+                        int ld, const double* Xq, const double* ZnT, const double* R, const double* RT, const double* alpha,
+                        const double* bounds4, const double* ystats, const double* bestf, const int* k_dev, double inv_ls,
+                        int maximize, int acq, int kernel, double* out_x, double* out_v, size_t zs);

@@ -16,7 +16,7 @@ ABI_VERSION = 1
 KERNEL_MATERN52, KERNEL_RBF = 0, 1
 ACQ_LOG_EI, ACQ_PI = 0, 1
 PTR_HOST, PTR_DEVICE = 0, 1
-OPT_RESIDENT, OPT_BESTF_F32, OPT_GROUP_ACQ = 0, 1, 2
+OPT_RESIDENT, OPT_BESTF_F32, OPT_GROUP_ACQ, OPT_DEVICE_LBFGSB = 0, 1, 2, 3
 PROFILE_GROUPS = ("wpca", "gram", "cholesky", "root_inverse_alpha", "acq_partial", "acq_large_batches")
 
 # Hardware queues.  A Batch drives the GPU from several worker threads on separate HIP streams (its gangs): the runtime's
@@ -52,7 +52,7 @@ EXPORTS = [
     "pcabo_get_profile", "pcabo_get_profile_calibration", "pcabo_reset_profile",
     "pcabo_batch_create", "pcabo_batch_destroy", "pcabo_batch_last_error", "pcabo_batch_ctx",
     "pcabo_batch_wpca_gp_condition_begin", "pcabo_batch_wpca_results", "pcabo_batch_acq_bounds",
-    "pcabo_batch_gp_condition_end_eval", "pcabo_batch_optimize_acqf", "pcabo_batch_inverse_map",
+    "pcabo_batch_gp_condition_end_eval", "pcabo_batch_optimize_acqf", "pcabo_batch_inverse_map", "pcabo_batch_device_acq_eval",
     "pcabo_batch_set_profiling", "pcabo_batch_get_profile", "pcabo_batch_set_active", "pcabo_batch_set_workers", "pcabo_batch_set_option",
     "pcabo_bbob_table_doubles", "pcabo_bbob_create", "pcabo_bbob_destroy", "pcabo_bbob_eval",
     "pcabo_comm_unique_id", "pcabo_comm_create", "pcabo_gather_best", "pcabo_comm_last_error", "pcabo_comm_destroy",
@@ -129,6 +129,7 @@ def _load() -> C.CDLL:
     lib.pcabo_batch_gp_condition_end_eval.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp]
     lib.pcabo_batch_optimize_acqf.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
     lib.pcabo_batch_inverse_map.argtypes = [vp, vp, vp]
+    lib.pcabo_batch_device_acq_eval.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp]
     lib.pcabo_batch_set_profiling.argtypes = [vp, C.c_int]
     lib.pcabo_batch_set_active.argtypes = [vp, vp]
     lib.pcabo_batch_get_profile.argtypes = [vp, vp]
@@ -376,7 +377,7 @@ class Batch:
     rows A-H of all runs, one scoring launch, shared acquisition launches for the L-BFGS-B rounds of all runs."""
 
     def __init__(self, B: int, max_n: int, max_d: int, max_q: int = 512, device: int = 0, workers: int = 0,
-                 group_acq: bool = True):
+                 group_acq: bool = True, device_lbfgsb: int = 0):
         self._h = C.c_void_p()
         rc = LIB.pcabo_batch_create(int(device), int(B), int(max_n), int(max_d), int(max_q), C.byref(self._h))
         if rc != 0:
@@ -393,6 +394,9 @@ class Batch:
             self.set_workers(workers)
         if not group_acq:            # L-BFGS-B rounds through the per-query kernels (a stand-alone context's default)
             self._chk(LIB.pcabo_batch_set_option(self._h, OPT_GROUP_ACQ, 0))
+        if device_lbfgsb:            # 1: every restart group's L-BFGS-B inside one launch; 2: its host-stepped twin (tests)
+            self._chk(LIB.pcabo_batch_set_option(self._h, OPT_DEVICE_LBFGSB, int(device_lbfgsb)))
+        self.device_lbfgsb = int(device_lbfgsb)
         advice = hw_queues_advice(min(B, int(workers) if workers else 8) + 2)      # gang streams + the batch's + the default stream
         if advice:
             import warnings
@@ -489,6 +493,18 @@ class Batch:
             k = int(self.k[b])
             out.append((cand[b, : nr * k].reshape(nr, k).copy(), vals[b].copy(), info[b].copy(), bool(failed[b])))
         return out, status
+
+    def device_acq_eval(self, xq_list, best_f, maximize=False, acq=ACQ_LOG_EI):
+        """Value and gradient at xq_list[b] (q x k_b, q <= 32) through the evaluation of the device-resident optimiser."""
+        B, MD = self.B, self.max_d
+        q = xq_list[0].shape[0]
+        xq = np.zeros((B, q * MD))
+        for b in range(B):
+            xq[b, : xq_list[b].size] = np.ascontiguousarray(xq_list[b], dtype=np.float64).ravel()
+        bf = _f64(best_f, (B,))
+        val, grad = np.zeros((B, q)), np.zeros((B, q * MD))
+        self._chk(LIB.pcabo_batch_device_acq_eval(self._h, _ptr(xq), int(q), _ptr(bf), int(bool(maximize)), int(acq), _ptr(val), _ptr(grad)))
+        return [val[b].copy() for b in range(B)], [grad[b, : q * int(self.k[b])].reshape(q, int(self.k[b])).copy() for b in range(B)]
 
     def set_profiling(self, on: bool) -> None:
         self._chk(LIB.pcabo_batch_set_profiling(self._h, int(bool(on))))

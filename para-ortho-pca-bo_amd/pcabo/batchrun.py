@@ -98,9 +98,13 @@ class BatchedPCABO:
         self._engines_ahead = {}           # run -> (generator state before the draw, engine), filled during the rounds
         # acq_kernel: "group" (default: the throughput kernel k_acq_group for the L-BFGS-B rounds; a run is bit-identical to
         # PCA_BO(acq_kernel="group")) or "latency" (the per-query kernels: bit-identical to PCA_BO's default)
-        if acq_kernel not in ("group", "latency"):
-            raise ValueError("acq_kernel must be 'group' or 'latency'")
-        self._group_acq = acq_kernel == "group"
+        # or "device" (every restart group's whole L-BFGS-B inside one kernel launch, csrc/kernels_lbfgsb.hip: no host round
+        # trips, no worker threads; an evaluation order of its own) / "device-twin" (the same evaluation kernel stepped by the
+        # host's L-BFGS-B, launch by launch: what "device" is compared with bit for bit)
+        if acq_kernel not in ("group", "latency", "device", "device-twin"):
+            raise ValueError("acq_kernel must be 'group', 'latency', 'device' or 'device-twin'")
+        self._group_acq = acq_kernel != "latency"
+        self._device_lbfgsb = {"device": 1, "device-twin": 2}.get(acq_kernel, 0)
 
     # ---- seeding + DoE (AbstractAlgorithm.py:310-328, AbstractBayesianOptimizer.py:142-176) --------------------------
     def start(self) -> None:
@@ -119,7 +123,7 @@ class BatchedPCABO:
             self._X[b, : self.n_DoE] = np.vstack(self.x_evals[b])
             self._F[b, : self.n_DoE] = self.f_evals[b]
         self._batch = _native.Batch(B, max_n=self.budget, max_d=d, max_q=max(self.raw_samples, 16), device=self.device,
-                                    workers=self._workers, group_acq=self._group_acq)
+                                    workers=self._workers, group_acq=self._group_acq, device_lbfgsb=self._device_lbfgsb)
         if self._device_objective:
             from .bbob_device import DeviceObjectives
             self._dev_obj = DeviceObjectives(self.problems, device=self.device, penalty=OOB_PENALTY)
@@ -393,7 +397,7 @@ def run_side_by_side(runners: Sequence["BatchedPCABO"], started: bool = False) -
 
 
 def bench_block(device: int, B: int, fid: int, dim: int, budget_factor: int = 10, doe_factor: float = 3.0,
-                sub_batches: int = 1, workers: int = 0) -> dict:
+                sub_batches: int = 1, workers: int = 0, acq_kernel: str = "group") -> dict:
     """Aggregate BO iterations / second of B runs (instances 0..B-1 of one BBOB function and dimension, seeds per
     ExperimentRunner.py:146) advancing together on one GPU - as one lock-step batch, or as `sub_batches` lock-step batches
     side by side (run_side_by_side); DoE and set-up untimed."""
@@ -404,7 +408,8 @@ def bench_block(device: int, B: int, fid: int, dim: int, budget_factor: int = 10
     for t in range(S):
         inst = list(range(t, B, S))
         subs.append(BatchedPCABO([BBOBProblem(fid, i, dim) for i in inst], [1000 * fid + 10 * dim + i for i in inst], budget, n_doe,
-                                 device=device, workers=workers or (workers_for(S) if S > 1 else 0), host_threads=max(1, 8 // S)))
+                                 device=device, workers=workers or (workers_for(S) if S > 1 else 0), host_threads=max(1, 8 // S),
+                                 acq_kernel=acq_kernel))
     for r in subs:
         r.start()
     torch.cuda.synchronize()

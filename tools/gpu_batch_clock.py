@@ -1,5 +1,5 @@
 """Aggregate rate of B runs advancing in lock-step (pcabo.batchrun) - diagnostic.
-usage: gpu_batch_clock.py B [dim] [fid] [sub_batches] [workers per batch, 0 = default]"""
+usage: gpu_batch_clock.py B [dim] [fid] [sub_batches] [workers per batch, 0 = default] [acq_kernel: group | latency | device]"""
 import json, os, sys
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # read by the HIP runtime at its first call: a Batch uses a stream per worker thread
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,7 +12,9 @@ dim = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 fid = int(sys.argv[3]) if len(sys.argv) > 3 else 15
 S = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 W = int(sys.argv[5]) if len(sys.argv) > 5 else 0
-out = batchrun.bench_block(0, B, fid, dim, sub_batches=S, workers=W)
+AK = sys.argv[6] if len(sys.argv) > 6 else "group"
+out = batchrun.bench_block(0, B, fid, dim, sub_batches=S, workers=W, acq_kernel=AK)
 out["workers"] = W
+out["acq_kernel"] = AK
 out.pop("best_f")
 print(json.dumps(out))

@@ -38,13 +38,35 @@
 #define LB_MAXEVAL 20000    // hard cap on the evaluations of one group (the host's limits stop it long before)
 
 #define LSYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+// In-kernel clocks of the timing build (make timing; tools/gpu_device_lbfgsb_phases.py): ticks (100 MHz) and calls per phase,
+// accumulated by work-group 0 (its thread 0 / lane 0 of wave 0)
+#ifdef PCABO_ACQ_TIMING
+__device__ unsigned long long g_lb_ticks[32], g_lb_calls[32];
+extern "C" int pcabo_debug_lb_ticks(unsigned long long* ticks32, unsigned long long* calls32, int reset) {
+  if (hipMemcpyFromSymbol(ticks32, HIP_SYMBOL(g_lb_ticks), sizeof(g_lb_ticks)) != hipSuccess) return -3;
+  if (hipMemcpyFromSymbol(calls32, HIP_SYMBOL(g_lb_calls), sizeof(g_lb_calls)) != hipSuccess) return -3;
+  if (reset) {
+    unsigned long long z[32] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_lb_ticks), z, sizeof(z)) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(g_lb_calls), z, sizeof(z)) != hipSuccess) return -3;
+  }
+  return 0;
+}
+#define LBT_BEGIN() unsigned long long lbt_t0_ = wall_clock64()
+#define LBT_NEXT(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); g_lb_ticks[i] += t_ - lbt_t0_; g_lb_calls[i] += 1; lbt_t0_ = t_; } } while (0)
+#else
+#define LBT_BEGIN()
+#define LBT_NEXT(i)
+#endif
 // LDS pointers carry their address space in the type: ds_read / ds_write whether or not a helper is inlined
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(3))) double ldsd;
 typedef __attribute__((address_space(3))) int ldsi;
+typedef const __attribute__((address_space(1))) double gcd;      // global memory, read only: global_load even behind a call
 #else
 typedef double ldsd;
 typedef int ldsi;
+typedef const double gcd;
 #endif
 
 // ---- persistent scalars of a group (LDS) ----------------------------------------------------------------------------
@@ -1040,8 +1062,7 @@ __device__ int lb_step(const LbLds L, int lane) {
     } else {
       if (lane == 0) { ISC(I_UPDATD) = 1; ISC(I_IUPDAT) = ISC(I_IUPDAT) + 1; }
       LSYNC();
-      lb_matupd(L, rr, dr, lane);
-      lb_formt(L, lane);
+      { LBT_BEGIN(); lb_matupd(L, rr, dr, lane); LBT_NEXT(6); lb_formt(L, lane); LBT_NEXT(7); }
       if (ISC(I_INFO) != 0) lb_reset_memory(L, lane);
     }
     need_iteration_start = true;
@@ -1050,14 +1071,14 @@ __device__ int lb_step(const LbLds L, int lane) {
     if (need_iteration_start) {
       need_iteration_start = false;
       sti0(&ISC(I_IWORD), -1, lane);
-      lb_cauchy(L, lane);
+      { LBT_BEGIN(); lb_cauchy(L, lane); LBT_NEXT(0); }
       if (ISC(I_INFO) != 0) { lb_reset_memory(L, lane); need_iteration_start = true; continue; }
-      lb_freev(L, lane);
+      { LBT_BEGIN(); lb_freev(L, lane); LBT_NEXT(1); }
       if (ISC(I_NFREE) != 0 && ISC(I_COL) != 0) {
-        if (ISC(I_WRK)) lb_formk(L, lane);
+        if (ISC(I_WRK)) { LBT_BEGIN(); lb_formk(L, lane); LBT_NEXT(2); }
         if (ISC(I_INFO) != 0) { lb_reset_memory(L, lane); need_iteration_start = true; continue; }
-        lb_cmprlb(L, lane);
-        if (ISC(I_INFO) == 0) lb_subsm(L, lane);
+        { LBT_BEGIN(); lb_cmprlb(L, lane); LBT_NEXT(3); }
+        if (ISC(I_INFO) == 0) { LBT_BEGIN(); lb_subsm(L, lane); LBT_NEXT(4); }
         if (ISC(I_INFO) != 0) { lb_reset_memory(L, lane); need_iteration_start = true; continue; }
       }
       for (int i = lane; i < n; i += 64) L.d()[i] = L.z()[i] - L.x()[i];
@@ -1065,7 +1086,7 @@ __device__ int lb_step(const LbLds L, int lane) {
       LSYNC();
     }
     if (resume_linesearch) { resume_linesearch = false; sti0(&ISC(I_PHASE), 2, lane); LSYNC(); }
-    lb_lnsrlb(L, lane);
+    { LBT_BEGIN(); lb_lnsrlb(L, lane); LBT_NEXT(5); }
     if (ISC(I_INFO) != 0 || ISC(I_IBACK) >= 20) {
       for (int i = lane; i < n; i += 64) { L.x()[i] = L.t()[i]; L.g()[i] = L.r()[i]; }
       if (lane == 0) SC(S_F) = SC(S_FOLD);
@@ -1131,7 +1152,7 @@ __device__ void lb_advance(const LbLds L, int maxiter, int lane) {
 // Evaluation: value and gradient of the acquisition at the group's nq points (all LB_THREADS threads)
 // =====================================================================================================================
 struct LbEval {
-  const double *ZnT, *R, *RT, *alpha, *nlo, *nhi;
+  gcd *ZnT, *R, *RT, *alpha, *nlo, *nhi;
   int n, k, NP, ld, H, S;
   double best_f, ym, ysd, inv_ls;
   int maximize, acq, kernel;
@@ -1191,44 +1212,45 @@ __device__ inline void lb_scalar_core(double vv, double mus, const LbEval& E, do
 
 // x in L.x() (nq * k) -> L.vals()[q] (acquisition values) and, with want_grad, L.g()[q * k + c] = -d value_q / d x_qc
 // (the gradient of the minimised objective -sum_q value_q).  Ends with a work-group barrier.
-__device__ __noinline__ void lb_eval(const LbLds L, const LbEval& E, int nq, bool want_grad) {
+// Every global load of a loop trip is issued before the first use (LB_UB of them in flight per thread, the next trip's while the
+// current one is consumed): one CU has to pull ~0.8 MB per triangular pass through ~1 us of L2 / Infinity Cache latency.
+#define LB_UB 16
+__device__ __noinline__ void lb_eval(const LbLds L, const LbEval E, int nq, bool want_grad) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int n = E.n, k = E.k, NP = E.NP, ld = E.ld, H = E.H, S = E.S;
   const int XS = LB_MAXK + 2;
+  LBT_BEGIN();
   for (int idx = tid; idx < LB_GQ * k; idx += LB_THREADS) {
     const int q = idx / k, c = idx - q * k, qq = q < nq ? q : 0;
     const double lo = E.nlo[c], hi = E.nhi[c];
     L.xn()[q * XS + c] = (L.x()[qq * k + c] - lo) / (hi - lo);
   }
   __syncthreads();
+  LBT_NEXT(8);
   // ---- kernel vectors: a thread per training point (the threads of pass 2's first group), all queries per pass over ZnT
   double cf[LB_GQ];
   const int hh = w / S, wsub = w - hh * S;
   const int jmine = 64 * (S - 1 - slab_of(wsub, S)) + lane;           // this thread's column in pass 2 (hh < H)
   if (hh == 0) {
-    const int j = jmine;
+    const int j = jmine, jj = j < n ? j : n - 1;
     double sq[LB_GQ];
 #pragma unroll
     for (int q = 0; q < LB_GQ; ++q) { sq[q] = 0.0; cf[q] = 0.0; }
     double ksv[LB_GQ] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    if (j < n) {
-      int c = 0;
-      for (; c + 4 <= k; c += 4) {
-        const double z0 = E.ZnT[(size_t)c * ld + j], z1 = E.ZnT[(size_t)(c + 1) * ld + j];
-        const double z2 = E.ZnT[(size_t)(c + 2) * ld + j], z3 = E.ZnT[(size_t)(c + 3) * ld + j];
+    constexpr int CB = 12;
+    for (int c0 = 0; c0 < k; c0 += CB) {
+      double z[CB];
 #pragma unroll
-        for (int q = 0; q < LB_GQ; ++q) {
-          double dd = L.xn()[q * XS + c] - z0; sq[q] = fma(dd, dd, sq[q]);
-          dd = L.xn()[q * XS + c + 1] - z1; sq[q] = fma(dd, dd, sq[q]);
-          dd = L.xn()[q * XS + c + 2] - z2; sq[q] = fma(dd, dd, sq[q]);
-          dd = L.xn()[q * XS + c + 3] - z3; sq[q] = fma(dd, dd, sq[q]);
+      for (int u = 0; u < CB; ++u) { const int cc = c0 + u < k ? c0 + u : k - 1; z[u] = (E.ZnT + (size_t)cc * ld)[jj]; }
+#pragma unroll
+      for (int u = 0; u < CB; ++u) {
+        if (c0 + u < k) {
+#pragma unroll
+          for (int q = 0; q < LB_GQ; ++q) { const double dd = L.xn()[q * XS + c0 + u] - z[u]; sq[q] = fma(dd, dd, sq[q]); }
         }
       }
-      for (; c < k; ++c) {
-        const double z0 = E.ZnT[(size_t)c * ld + j];
-#pragma unroll
-        for (int q = 0; q < LB_GQ; ++q) { const double dd = L.xn()[q * XS + c] - z0; sq[q] = fma(dd, dd, sq[q]); }
-      }
+    }
+    if (j < n) {
       const double s5 = 2.23606797749979, il2 = E.inv_ls * E.inv_ls;
 #pragma unroll
       for (int q = 0; q < LB_GQ; ++q) {
@@ -1248,6 +1270,7 @@ __device__ __noinline__ void lb_eval(const LbLds L, const LbEval& E, int nq, boo
     for (int q = 0; q < LB_GQ; ++q) L.ks()[j * LB_QS + q] = ksv[q];
   }
   __syncthreads();
+  LBT_NEXT(9);
   // ---- pass 1: v_q[i] = sum_j RT[j][i] ks_q[j], thread (row i, part hh of the columns)
   const int imine = 64 * slab_of(wsub, S) + lane;
   if (hh < H) {
@@ -1255,28 +1278,35 @@ __device__ __noinline__ void lb_eval(const LbLds L, const LbEval& E, int nq, boo
     const int jtot = n < 64 * (i / 64 + 1) ? n : 64 * (i / 64 + 1);
     const int J0 = (int)((long long)jtot * hh / H), J1 = (int)((long long)jtot * (hh + 1) / H);
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0;
-    const double* rp = E.RT + i;
-    int j = J0;
-    for (; j + 4 <= J1; j += 4) {
-      const double r0 = rp[(size_t)j * ld], r1 = rp[(size_t)(j + 1) * ld], r2 = rp[(size_t)(j + 2) * ld], r3 = rp[(size_t)(j + 3) * ld];
-      const ldsd* kp = L.ks() + j * LB_QS;
-      a0 = fma(r0, kp[0], a0); a1 = fma(r0, kp[1], a1); a2 = fma(r0, kp[2], a2); a3 = fma(r0, kp[3], a3); a4 = fma(r0, kp[4], a4);
-      kp += LB_QS;
-      a0 = fma(r1, kp[0], a0); a1 = fma(r1, kp[1], a1); a2 = fma(r1, kp[2], a2); a3 = fma(r1, kp[3], a3); a4 = fma(r1, kp[4], a4);
-      kp += LB_QS;
-      a0 = fma(r2, kp[0], a0); a1 = fma(r2, kp[1], a1); a2 = fma(r2, kp[2], a2); a3 = fma(r2, kp[3], a3); a4 = fma(r2, kp[4], a4);
-      kp += LB_QS;
-      a0 = fma(r3, kp[0], a0); a1 = fma(r3, kp[1], a1); a2 = fma(r3, kp[2], a2); a3 = fma(r3, kp[3], a3); a4 = fma(r3, kp[4], a4);
+    gcd* rp = E.RT;                       // (uniform row base + the lane's 32-bit offset: one address register for all loads)
+    double rc[LB_UB], rn[LB_UB];
+#pragma unroll
+    for (int u = 0; u < LB_UB; ++u) { rc[u] = 0.0; rn[u] = 0.0; }
+    if (J0 < J1) {
+#pragma unroll
+      for (int u = 0; u < LB_UB; ++u) { const int jj = J0 + u < J1 ? J0 + u : J1 - 1; rc[u] = (rp + (size_t)jj * ld)[i]; }
     }
-    for (; j < J1; ++j) {
-      const double r0 = rp[(size_t)j * ld];
-      const ldsd* kp = L.ks() + j * LB_QS;
-      a0 = fma(r0, kp[0], a0); a1 = fma(r0, kp[1], a1); a2 = fma(r0, kp[2], a2); a3 = fma(r0, kp[3], a3); a4 = fma(r0, kp[4], a4);
+    for (int j = J0; j < J1; j += LB_UB) {
+      if (j + LB_UB < J1) {
+#pragma unroll
+        for (int u = 0; u < LB_UB; ++u) { const int jj = j + LB_UB + u < J1 ? j + LB_UB + u : J1 - 1; rn[u] = (rp + (size_t)jj * ld)[i]; }
+      }
+#pragma unroll
+      for (int u = 0; u < LB_UB; ++u) {
+        if (j + u < J1) {
+          const ldsd* kp = L.ks() + (j + u) * LB_QS;
+          const double r0 = rc[u];
+          a0 = fma(r0, kp[0], a0); a1 = fma(r0, kp[1], a1); a2 = fma(r0, kp[2], a2); a3 = fma(r0, kp[3], a3); a4 = fma(r0, kp[4], a4);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < LB_UB; ++u) rc[u] = rn[u];
     }
     ldsd* dst = hh == 0 ? L.vb() + i * LB_QS : L.part() + ((size_t)(hh - 1) * NP + i) * LB_QS;
     dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = a3; dst[4] = a4;
   }
   __syncthreads();
+  LBT_NEXT(10);
   if (hh == 0) {
     const int i = imine;
     double v[LB_GQ];
@@ -1295,7 +1325,8 @@ __device__ __noinline__ void lb_eval(const LbLds L, const LbEval& E, int nq, boo
     }
   }
   __syncthreads();
-  // ---- scalar chains (lanes 0 .. nq - 1 of wave 0) beside pass 2 of the other waves
+  LBT_NEXT(11);
+  // ---- scalar chains (lanes 0 .. 4 of wave 0) beside pass 2 of the other waves
   if (tid < LB_GQ) {
     double vv = 0.0, mus = 0.0;
     for (int s = 0; s < S; ++s) { vv += L.red()[s * 10 + tid]; mus += L.red()[s * 10 + LB_GQ + tid]; }
@@ -1310,23 +1341,29 @@ __device__ __noinline__ void lb_eval(const LbLds L, const LbEval& E, int nq, boo
     const int j = jmine;
     const int ibeg = 64 * (j / 64), len = n > ibeg ? n - ibeg : 0;
     const int I0 = ibeg + (int)((long long)len * hh / H), I1 = ibeg + (int)((long long)len * (hh + 1) / H);
-    const double* rp = E.R + j;
-    int i = I0;
-    for (; i + 4 <= I1; i += 4) {
-      const double r0 = rp[(size_t)i * ld], r1 = rp[(size_t)(i + 1) * ld], r2 = rp[(size_t)(i + 2) * ld], r3 = rp[(size_t)(i + 3) * ld];
-      const ldsd* vp = L.vb() + i * LB_QS;
-      a0 = fma(r0, vp[0], a0); a1 = fma(r0, vp[1], a1); a2 = fma(r0, vp[2], a2); a3 = fma(r0, vp[3], a3); a4 = fma(r0, vp[4], a4);
-      vp += LB_QS;
-      a0 = fma(r1, vp[0], a0); a1 = fma(r1, vp[1], a1); a2 = fma(r1, vp[2], a2); a3 = fma(r1, vp[3], a3); a4 = fma(r1, vp[4], a4);
-      vp += LB_QS;
-      a0 = fma(r2, vp[0], a0); a1 = fma(r2, vp[1], a1); a2 = fma(r2, vp[2], a2); a3 = fma(r2, vp[3], a3); a4 = fma(r2, vp[4], a4);
-      vp += LB_QS;
-      a0 = fma(r3, vp[0], a0); a1 = fma(r3, vp[1], a1); a2 = fma(r3, vp[2], a2); a3 = fma(r3, vp[3], a3); a4 = fma(r3, vp[4], a4);
+    gcd* rp = E.R;
+    double rc[LB_UB], rn[LB_UB];
+#pragma unroll
+    for (int u = 0; u < LB_UB; ++u) { rc[u] = 0.0; rn[u] = 0.0; }
+    if (I0 < I1) {
+#pragma unroll
+      for (int u = 0; u < LB_UB; ++u) { const int ii = I0 + u < I1 ? I0 + u : I1 - 1; rc[u] = (rp + (size_t)ii * ld)[j]; }
     }
-    for (; i < I1; ++i) {
-      const double r0 = rp[(size_t)i * ld];
-      const ldsd* vp = L.vb() + i * LB_QS;
-      a0 = fma(r0, vp[0], a0); a1 = fma(r0, vp[1], a1); a2 = fma(r0, vp[2], a2); a3 = fma(r0, vp[3], a3); a4 = fma(r0, vp[4], a4);
+    for (int i = I0; i < I1; i += LB_UB) {
+      if (i + LB_UB < I1) {
+#pragma unroll
+        for (int u = 0; u < LB_UB; ++u) { const int ii = i + LB_UB + u < I1 ? i + LB_UB + u : I1 - 1; rn[u] = (rp + (size_t)ii * ld)[j]; }
+      }
+#pragma unroll
+      for (int u = 0; u < LB_UB; ++u) {
+        if (i + u < I1) {
+          const ldsd* vp = L.vb() + (i + u) * LB_QS;
+          const double r0 = rc[u];
+          a0 = fma(r0, vp[0], a0); a1 = fma(r0, vp[1], a1); a2 = fma(r0, vp[2], a2); a3 = fma(r0, vp[3], a3); a4 = fma(r0, vp[4], a4);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < LB_UB; ++u) rc[u] = rn[u];
     }
     if (hh > 0) {
       ldsd* dst = L.part() + ((size_t)(hh - 1) * NP + j) * LB_QS;
@@ -1334,6 +1371,7 @@ __device__ __noinline__ void lb_eval(const LbLds L, const LbEval& E, int nq, boo
     }
   }
   __syncthreads();
+  LBT_NEXT(12);
   if (hh == 0) {
     const int j = jmine;
     double wv[LB_GQ] = {a0, a1, a2, a3, a4};
@@ -1341,30 +1379,49 @@ __device__ __noinline__ void lb_eval(const LbLds L, const LbEval& E, int nq, boo
 #pragma unroll
       for (int q = 0; q < LB_GQ; ++q) wv[q] += L.part()[((size_t)(h2 - 1) * NP + j) * LB_QS + q];
     const double aj = j < n ? E.alpha[j] : 0.0;
-    // u_q[j] = c_mu (alpha_j cf) + c_sg (w cf): the point's weight in the contraction with (xn_c - zn_cj)
+    // u_q[j] = c_mu (alpha_j cf) + c_sg (w cf): the point's weight in the contraction with (xn_c - zn_cj); stored [q][j]
 #pragma unroll
-    for (int q = 0; q < LB_GQ; ++q) L.ks()[j * LB_QS + q] = fma(L.cq()[2 * q], aj * cf[q], L.cq()[2 * q + 1] * (wv[q] * cf[q]));
+    for (int q = 0; q < LB_GQ; ++q) L.ks()[q * NP + j] = fma(L.cq()[2 * q], aj * cf[q], L.cq()[2 * q + 1] * (wv[q] * cf[q]));
   }
   __syncthreads();
-  // ---- gradient: wave per component, lanes over the points
-  for (int c = w; c < k; c += LB_THREADS / 64) {
-    double acc[LB_GQ] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    double xq[LB_GQ];
+  LBT_NEXT(13);
+  // ---- gradient: wave per component (c = w, w + 16, w + 32), lanes over the points; all rows of ZnT a wave needs are loaded first
+  {
+    constexpr int CW = (LB_MAXK + 15) / 16, NB = LB_MAXNP / 64;
+    double z[CW][NB];
 #pragma unroll
-    for (int q = 0; q < LB_GQ; ++q) xq[q] = L.xn()[q * XS + c];
-    for (int j = lane; j < n; j += 64) {
-      const double z = E.ZnT[(size_t)c * ld + j];
+    for (int ci = 0; ci < CW; ++ci) {
+      const int c = w + 16 * ci, cc = c < k ? c : k - 1;
 #pragma unroll
-      for (int q = 0; q < LB_GQ; ++q) acc[q] = fma(L.ks()[j * LB_QS + q], xq[q] - z, acc[q]);
+      for (int bq = 0; bq < NB; ++bq) { const int j = lane + 64 * bq; z[ci][bq] = (E.ZnT + (size_t)cc * ld)[j < n ? j : n - 1]; }
     }
-    const double inv = E.nhi[c] - E.nlo[c];
 #pragma unroll
-    for (int q = 0; q < LB_GQ; ++q) {
-      const double s = wave_sum(acc[q]);
-      if (lane == 0 && q < nq) L.g()[q * k + c] = -(s / inv);
+    for (int ci = 0; ci < CW; ++ci) {
+      const int c = w + 16 * ci;
+      if (c < k) {
+        double acc[LB_GQ] = {0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int bq = 0; bq < NB; ++bq) {
+          const int j = lane + 64 * bq;
+          if (64 * bq < n) {
+#pragma unroll
+            for (int q = 0; q < LB_GQ; ++q) {
+              const double uq = j < n ? L.ks()[q * NP + j] : 0.0;
+              acc[q] = fma(uq, L.xn()[q * XS + c] - z[ci][bq], acc[q]);
+            }
+          }
+        }
+        const double inv = E.nhi[c] - E.nlo[c];
+#pragma unroll
+        for (int q = 0; q < LB_GQ; ++q) {
+          const double s = wave_sum(acc[q]);
+          if (lane == 0 && q < nq) L.g()[q * k + c] = -(s / inv);
+        }
+      }
     }
   }
   __syncthreads();
+  LBT_NEXT(14);
 }
 
 // =====================================================================================================================
@@ -1393,7 +1450,7 @@ __global__ __launch_bounds__(LB_THREADS) void k_lbfgsb_group(
   LbLds L;
   L.base = (ldsd*)s_dyn; L.n = nv; L.NP = NP;
   LbEval E;
-  E.ZnT = ZnT; E.R = R; E.RT = RT; E.alpha = alpha; E.nlo = bounds4; E.nhi = bounds4 + PCABO_MAXD;
+  E.ZnT = (gcd*)ZnT; E.R = (gcd*)R; E.RT = (gcd*)RT; E.alpha = (gcd*)alpha; E.nlo = (gcd*)bounds4; E.nhi = (gcd*)(bounds4 + PCABO_MAXD);
   E.n = n; E.k = k; E.NP = NP; E.ld = ld; E.H = H; E.S = NP / 64;
   E.best_f = *bestf; E.ym = ystats[0]; E.ysd = ystats[1]; E.inv_ls = inv_ls; E.maximize = maximize; E.acq = acq; E.kernel = kernel;
   // ---- initial state
@@ -1422,10 +1479,13 @@ __global__ __launch_bounds__(LB_THREADS) void k_lbfgsb_group(
   }
   // ---- the optimisation
   for (int guard = 0; guard < LB_MAXEVAL; ++guard) {
+    LBT_BEGIN();
     if (w == 0) lb_advance(L, maxiter, lane);
     __syncthreads();
+    LBT_NEXT(16);
     if (!ISC(I_ACTIVE)) break;
     lb_eval(L, E, nq, true);
+    LBT_NEXT(17);
     // RestartGroup::absorb: f = -(sum of the values, in order), NaN check of the gradient, cache
     if (w == 0) {
       bool nan = false;

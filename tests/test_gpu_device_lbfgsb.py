@@ -1,0 +1,143 @@
+"""Device-resident L-BFGS-B of the batched path (first option; csrc/kernels_lbfgsb.hip): every restart
+group's whole optimisation (botorch gen_candidates_scipy -> scipy L-BFGS-B, PCA_BO.py:607-614) inside ONE kernel launch.
+
+  * the device steps must be the host's (csrc/lbfgsb.cpp, pinned against scipy on the CPU): whole runs with the stepping on the
+    device equal, bit for bit, the same runs with the host stepping the same evaluation kernel launch by launch ("device-twin");
+  * the evaluation (a third summation order) against the oracle: value + gradient at teacher-forced states;
+  * runs in device mode replayed by the oracle with the thresholds of the host-paced batches.
+"""
+import numpy as np
+import pytest
+import torch
+
+import pcabo_oracle as O
+from pcabo.bbob import BBOBProblem
+from test_gpu_configs import _seed, _teacher_force
+from test_gpu_late_phase import _rel
+from test_gpu_parity import _check_replay, _replay_with_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(fid, insts, dim, budget, n_doe, acq_kernel, **kw):
+    from pcabo.batchrun import BatchedPCABO
+    r = BatchedPCABO([BBOBProblem(fid, i, dim) for i in insts], [_seed(fid, dim, i) for i in insts], budget, n_doe,
+                     acq_kernel=acq_kernel, **kw)
+    r.run()
+    return r
+
+
+@pytest.mark.parametrize("fid,dim,budget,n_doe,B", [(15, 10, 90, 30, 5), (17, 20, 250, 60, 4), (15, 40, 450, 120, 3)])
+def test_device_stepping_equals_host_stepping_bit_for_bit(native, fid, dim, budget, n_doe, B):
+    """Whole runs (full budgets at d = 20 / 40: n up to 249 / 449, every row-split of the evaluation from 8 parts at n <= 128
+    to 2 at n > 341): L-BFGS-B inside the kernel against lbfgsb.cpp on the host over the same evaluation kernel.  Every
+    evaluated point, every objective value and the optimiser's counters of every iteration must be identical - L-BFGS-B
+    amplifies a one-ulp difference by ~10 per five evaluations (tests/test_lbfgsb_divergence.py), so nothing short of the same
+    operations in the same order passes."""
+    torch.set_num_threads(4)
+    insts = list(range(B))
+    keep = lambda b, n: True
+    dev = _run(fid, insts, dim, budget, n_doe, "device", record_trace=True, trace_filter=keep)
+    twin = _run(fid, insts, dim, budget, n_doe, "device-twin", record_trace=True, trace_filter=keep)
+    assert dev.failed == twin.failed == [None] * B
+    rounds = 0
+    for b in range(B):
+        assert np.array_equal(np.vstack(dev.x_evals[b]), np.vstack(twin.x_evals[b])), (dim, b)
+        assert np.array_equal(np.array(dev.f_evals[b]), np.array(twin.f_evals[b])), (dim, b)
+    assert len(dev.trace) == len(twin.trace) == B * (budget - n_doe)
+    for td, tt in zip(dev.trace, twin.trace):
+        assert (td["b"], td["n"]) == (tt["b"], tt["n"])
+        assert np.array_equal(td["cands"], tt["cands"]) and np.array_equal(td["vals"], tt["vals"]), (td["b"], td["n"])
+        assert np.array_equal(td["info"], tt["info"]), (td["b"], td["n"], td["info"], tt["info"])
+        rounds += int(np.asarray(td["info"])[:, 1].sum())
+    print("[device = twin, f%d d=%d] %d runs x %d iterations, %d L-BFGS-B evaluations compared" % (fid, dim, B, budget - n_doe, rounds))
+
+
+@pytest.mark.parametrize("dim,budget,n_doe,states", [(20, 250, 60, (61, 130, 249)), (40, 450, 120, (121, 260, 449))])
+def test_device_evaluation_against_oracle(native, dim, budget, n_doe, states):
+    """Value and gradient of the device optimiser's evaluation (pass 1 over the transposed root inverse, pass 2 over the root
+    inverse, row splits of 8 .. 2 parts) at states of a device-mode run, against the oracle's torch-autograd log-EI; the
+    values the run itself reported for its end points against the oracle's surface."""
+    torch.set_num_threads(4)
+    fid, inst = 15, 1
+    r = _run(fid, [inst, inst + 1], dim, budget, n_doe, "device", record_trace=True, trace_filter=lambda b, n: b == 0 and n in states)
+    X, f = np.vstack(r.x_evals[0]), np.array(r.f_evals[0], dtype=float)
+    assert len(r.trace) == len(states)
+    worst = {"val": 0.0, "grad": 0.0, "run_vals": 0.0}
+    for tr in r.trace:
+        rec = _teacher_force(X, f, tr, BBOBProblem(fid, inst, dim), dim)
+        n, k = rec.n, rec.k
+        bt = native.Batch(1, max_n=budget, max_d=dim, max_q=512, device_lbfgsb=1)
+        bt.wpca_gp_condition_begin(rec.X[None], rec.ranks[None], rec.noise[None], np.asarray(rec.f, dtype=float)[None])
+        res = bt.wpca_results()
+        assert res[0]["k"] == k == tr["k"]
+        vraw, st = bt.gp_wait_eval([rec.trace.raw_X], [rec.best_f])
+        assert not st.any()
+        gp = O.ExactGP(rec.wpca.Z, rec.f, rec.norm_bounds)
+        acq = O.Acquisition(gp, rec.best_f, False)
+        Xs = np.vstack([rec.trace.ics, rec.trace.cands, rec.trace.raw_X[:12]])          # 32 queries
+        ov, og = acq.value_and_grad(Xs)
+        v, g = bt.device_acq_eval([Xs], [rec.best_f])
+        worst["val"] = max(worst["val"], float((np.abs(v[0] - ov) / np.maximum(1.0, np.abs(ov))).max()))
+        worst["grad"] = max(worst["grad"], _rel(g[0], og))
+        v7, g7 = bt.device_acq_eval([Xs[:7]], [rec.best_f])           # a point's numbers do not depend on its group
+        assert np.array_equal(v7[0], v[0][:7]) and np.array_equal(g7[0], g[0][:7])
+        vo = rec.acq(torch.from_numpy(np.ascontiguousarray(tr["cands"]))).detach().numpy()
+        worst["run_vals"] = max(worst["run_vals"], float((np.abs(vo - tr["vals"]) / np.maximum(1.0, np.abs(tr["vals"]))).max()))
+        del bt
+    print("[device evaluation vs oracle, d=%d] value %.2e gradient %.2e, the run's own end-point values %.2e" % (
+        dim, worst["val"], worst["grad"], worst["run_vals"]))
+    assert worst["val"] < 1e-8 and worst["grad"] < 1e-6 and worst["run_vals"] < 1e-8, worst
+
+
+def test_device_mode_batch_replayed_by_oracle(native):
+    """A 12-run device-mode batch of a configs[2] cell (f16, d = 20, full budget); two runs replayed by the oracle from
+    their own states: same k, same raw-sample picks, restart end points, counts, chosen candidate and objective value
+    (thresholds of the host-paced batches, tests/test_gpu_configs.py)."""
+    from pcabo.batchrun import BatchedPCABO
+    torch.set_num_threads(4)
+    fid, dim, B, every = 16, 20, 12, 24
+    budget, n_doe = 10 * dim + 50, 3 * dim
+    replayed = (0, 7)
+    r = BatchedPCABO([BBOBProblem(fid, i, dim) for i in range(B)], [_seed(fid, dim, i) for i in range(B)], budget, n_doe,
+                     record_trace=True, trace_filter=lambda b, n: b in replayed and (n - n_doe) % every == 2, acq_kernel="device")
+    r.run()
+    assert all(x is None for x in r.failed), r.failed
+    for b in range(B):
+        assert len(r.f_evals[b]) == budget and r.current_best[b] == min(r.f_evals[b])
+
+    class _View:
+        pass
+
+    for b in replayed:
+        v = _View()
+        v.x_evals, v.f_evals, v.maximization = r.x_evals[b], r.f_evals[b], False
+        v.trace = [t for t in r.trace if t["b"] == b]
+        st = _replay_with_oracle(v, lambda: BBOBProblem(fid, b, dim), dim)
+        _check_replay(st, min_iters=len(v.trace) - 1, late=True)
+
+
+def test_device_mode_falls_back_where_it_does_not_apply(native):
+    """k > 40 (d = 100 here) is beyond the device optimiser's LDS layout: the call takes the host-paced path and returns what
+    the batch returns without the option."""
+    rng = np.random.default_rng(5)
+    B, n, d, q = 2, 150, 50, 64
+    X = rng.uniform(-5, 5, (B, n, d))
+    y = rng.normal(size=(B, n)) * 50 + 300
+    ranks = np.argsort(np.argsort(y, axis=1), axis=1) + 1
+    outs = []
+    for dev in (0, 1):
+        bt = native.Batch(B, max_n=200, max_d=d, max_q=q, device_lbfgsb=dev)
+        bt.wpca_gp_condition_begin(X, ranks, None, y)
+        res = bt.wpca_results()
+        assert min(r["k"] for r in res) > 40
+        boxes = bt.acq_bounds()
+        raw = [boxes[b][0] + (boxes[b][1] - boxes[b][0]) * np.random.default_rng(b).uniform(size=(q, res[b]["k"])) for b in range(B)]
+        best = [float(y[b].min()) for b in range(B)]
+        vals, status = bt.gp_wait_eval(raw, best)
+        o, st = bt.optimize_acqf([raw[b][:10] for b in range(B)], boxes, best)
+        assert not st.any()
+        outs.append(o)
+        del bt
+    for b in range(B):
+        assert np.array_equal(outs[0][b][0], outs[1][b][0]) and np.array_equal(outs[0][b][2], outs[1][b][2])

@@ -93,7 +93,7 @@ enum {
   OFF_WN1 = OFF_WN + 4 * LB_M * LB_M, OFF_WA = OFF_WN1 + 4 * LB_M * LB_M, OFF_ACC = OFF_WA + 8 * LB_M, OFF_SC = OFF_ACC + 64,
   OFF_VC = OFF_SC + LB_EVEN(S_COUNT + 2), OFF_INTS = OFF_VC + 8,
   OFF_XN = OFF_INTS + LB_EVEN((4 * LB_NVP + I_COUNT + 2) / 2 + 2), OFF_RED = OFF_XN + LB_EVEN(LB_GQ * (LB_MAXK + 2)),
-  OFF_VALS = OFF_RED + 160, OFF_CQ = OFF_VALS + 8, OFF_KS = OFF_CQ + 16
+  OFF_VALS = OFF_RED + 160, OFF_CQ = OFF_VALS + 8, OFF_NLO = OFF_CQ + 16, OFF_NHI = OFF_NLO + LB_MAXK, OFF_KS = OFF_NHI + LB_MAXK
 };
 struct LbLds {
   ldsd* base;
@@ -132,6 +132,8 @@ struct LbLds {
   __device__ ldsd* red() const { return base + OFF_RED; }
   __device__ ldsd* vals() const { return base + OFF_VALS; }
   __device__ ldsd* cq() const { return base + OFF_CQ; }
+  __device__ ldsd* nlo() const { return base + OFF_NLO; }
+  __device__ ldsd* nhi() const { return base + OFF_NHI; }
   __device__ ldsd* ks() const { return base + OFF_KS; }
   __device__ ldsd* vb() const { return base + OFF_KS + LB_QS * NP; }
   __device__ ldsd* part() const { return base + OFF_KS + 2 * LB_QS * NP; }
@@ -156,21 +158,27 @@ __device__ inline void st0(ldsd* p, double v, int lane) { if (lane == 0) *p = v;
 __device__ inline void sti0(ldsi* p, int v, int lane) { if (lane == 0) *p = v; }
 __device__ inline unsigned long long lanes_below(int lane) { return lane == 0 ? 0ull : (~0ull >> (64 - lane)); }
 
-// ordered sum of an LDS array, every lane the same chain: s = (((s0 op a[0]) op a[1]) ...)
+// ordered sum of an LDS array, every lane the same chain: s = (((s0 op a[0]) op a[1]) ...); 16 loads per LDS round trip
 __device__ inline double chain_add(double s, const ldsd* a, int n) {
   int i = 0;
-  for (; i + 8 <= n; i += 8) {
-    const double a0 = a[i], a1 = a[i + 1], a2 = a[i + 2], a3 = a[i + 3], a4 = a[i + 4], a5 = a[i + 5], a6 = a[i + 6], a7 = a[i + 7];
-    s += a0; s += a1; s += a2; s += a3; s += a4; s += a5; s += a6; s += a7;
+  for (; i + 16 <= n; i += 16) {
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = a[i + u];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += v[u];
   }
   for (; i < n; ++i) s += a[i];
   return s;
 }
 __device__ inline double chain_sub(double s, const ldsd* a, int n) {
   int i = 0;
-  for (; i + 8 <= n; i += 8) {
-    const double a0 = a[i], a1 = a[i + 1], a2 = a[i + 2], a3 = a[i + 3], a4 = a[i + 4], a5 = a[i + 5], a6 = a[i + 6], a7 = a[i + 7];
-    s -= a0; s -= a1; s -= a2; s -= a3; s -= a4; s -= a5; s -= a6; s -= a7;
+  for (; i + 16 <= n; i += 16) {
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = a[i + u];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s -= v[u];
   }
   for (; i < n; ++i) s -= a[i];
   return s;
@@ -183,38 +191,35 @@ __device__ inline double wave_ddot(const LbLds L, const ldsd* a, const ldsd* b, 
   LSYNC();
   return s;
 }
-// ddot of two short LDS vectors (<= 2 LB_M), every lane the same chain
-__device__ inline double small_ddot(const ldsd* a, const ldsd* b, int n) {
+// ddot of two short LDS vectors (n <= 2 LB_M) in the host's order: lane j forms product j, every lane adds them in order
+__device__ inline double small_ddot(const ldsd* a, const ldsd* b, int n, int lane) {
+  const int j = lane < n ? lane : 0;
+  const double pr = a[j] * b[j];
   double s = 0.0;
-  for (int i = 0; i < n; ++i) s += a[i] * b[i];
+#pragma unroll
+  for (int u = 0; u < 2 * LB_M; ++u) if (u < n) s += bcast(pr, u);
   return s;
 }
 
-// "reduce over variables": lanes 0 .. 2 LB_M - 1 (physical columns of WY | WS) each run  acc += coef[t] * W(rows[t], column),
-// t in increasing order (lbfgsb.cpp: accum).  A second, independent set (rows2 / coef2 / count2) runs on lanes 32 .. 32 + 2 LB_M - 1.
-// Results in L.acc()[lane].
-__device__ inline void lb_accum2(const LbLds L, const ldsi* rows, const ldsd* coef, int count, const ldsi* rows2,
-                                 const ldsd* coef2, int count2, int lane) {
-  const int half = lane >> 5, c = (lane & 31) % (2 * LB_M);
+// "reduce over variables" (lbfgsb.cpp: accum): lanes 0 .. 2 LB_M - 1 (physical columns of WY | WS) each run
+// acc += coefA[t] * W(t, column) over ALL variables t = 0 .. n-1 in increasing order - a variable outside the host's index list
+// carries coefficient 0.0, which leaves every non-zero partial sum as it is (the host skips it); lanes 32 .. 32 + 2 LB_M - 1
+// run coefB over t = n-1 .. 0 (the host's list of active variables is in decreasing order).  Results in L.acc()[lane].
+__device__ inline void lb_accum(const LbLds L, const ldsd* coefA, const ldsd* coefB, int lane) {
+  const int n = L.n, half = lane >> 5, c = (lane & 31) % (2 * LB_M);
   const ldsd* col = c < LB_M ? L.wy() + c * LB_LDW : L.ws() + (c - LB_M) * LB_LDW;
-  const ldsi* rw = half ? rows2 : rows;
-  const ldsd* cf = half ? coef2 : coef;
-  const int cnt = half ? count2 : count;
-  const int cmax = count > count2 ? count : count2;
+  const bool down = half && coefB;
+  const ldsd* cf = down ? coefB : coefA;
   double a = 0.0;
-  int t = 0;
-  for (; t + 4 <= cmax; t += 4) {
-    double w0 = 0, w1 = 0, w2 = 0, w3 = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-    if (t + 3 < cnt) {
-      const int r0 = rw ? rw[t] : t, r1 = rw ? rw[t + 1] : t + 1, r2 = rw ? rw[t + 2] : t + 2, r3 = rw ? rw[t + 3] : t + 3;
-      w0 = col[r0]; w1 = col[r1]; w2 = col[r2]; w3 = col[r3];
-      c0 = cf[t]; c1 = cf[t + 1]; c2 = cf[t + 2]; c3 = cf[t + 3];
-      a += c0 * w0; a += c1 * w1; a += c2 * w2; a += c3 * w3;
-    } else {
-      for (int u = t; u < t + 4 && u < cnt; ++u) a += cf[u] * col[rw ? rw[u] : u];
-    }
+  int s = 0;
+  for (; s + 8 <= n; s += 8) {
+    double w[8], cc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int t = down ? n - 1 - (s + u) : s + u; w[u] = col[t]; cc[u] = cf[t]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a += cc[u] * w[u];
   }
-  for (; t < cmax; ++t) if (t < cnt) a += cf[t] * col[rw ? rw[t] : t];
+  for (; s < n; ++s) { const int t = down ? n - 1 - s : s; a += cf[t] * col[t]; }
   L.acc()[lane] = a;
   LSYNC();
 }
@@ -253,68 +258,106 @@ __device__ inline int lb_dpofa(ldsd* A, int lda, int nn, int lane) {
   return info;
 }
 
-// LINPACK dtrsl, upper-triangular T (LDS, leading dimension ldt), ONE right-hand side spread over the lanes (lane l holds b[l],
-// l < nn <= 2 LB_M).  job 11: T' x = b, job 1: T x = b.  Returns the solution in the same lanes.
-__device__ inline double lb_dtrsl_lanes(const ldsd* T, int ldt, int nn, double b, int job, int lane) {
-  const int l = lane < 2 * LB_M ? lane : 2 * LB_M - 1;
+__device__ inline int lb_trsl_zero_diag(double tdiag, int nn, int lane) {
+  const unsigned long long m = __ballot(lane < nn && tdiag == 0.0);
+  return m ? __ffsll((long long)m) : 0;
+}
+
+// LINPACK dtrsl with an upper-triangular T of order nn <= NN held in registers - lane l: tc[j] = T(j, l) (its column),
+// tr[j] = T(l, j) (its row), td = T(l, l) - and ONE right-hand side spread over the lanes (lane l holds b[l]).
+// job 11: T' x = b, job 1: T x = b; the host's operation order.  Returns the solution in the same lanes.
+template <int NN>
+__device__ inline double lb_dtrsl_regs(const double (&tc)[NN], const double (&tr)[NN], double td, int nn, double b, int job, int lane) {
   if (job == 11) {
     double s = 0.0;
-    for (int j = 0; j < nn; ++j) {
-      // lane j: b[0] / t[0] (no subtraction on the host), b[j] = (b[j] - ddot) / t[j][j] otherwise
-      const double cand = (j == 0) ? b / T[0] : (b - s) / T[j * ldt + j];
-      const double xj = bcast(cand, j);
-      if (lane == j) b = xj;
-      if (l > j && l < nn) s += T[l * ldt + j] * xj;
+#pragma unroll
+    for (int j = 0; j < NN; ++j) {
+      if (j < nn) {
+        const double tjj = bcast(td, j);
+        const double cand = (j == 0) ? b / tjj : (b - s) / tjj;       // (b[0] / t[0]: no subtraction on the host)
+        const double xj = bcast(cand, j);
+        if (lane == j) b = xj;
+        if (lane > j && lane < nn) s += tc[j] * xj;
+      }
     }
     return b;
   }
   // job 1: b[nn-1] /= T(nn-1, nn-1); for j = nn-2 .. 0: b[0..j] += -b[j+1] T(0..j, j+1); b[j] /= T(j, j)
   {
-    const double last = bcast(b, nn - 1) / T[(nn - 1) * ldt + nn - 1];
+    const double last = bcast(b, nn - 1) / bcast(td, nn - 1);
     if (lane == nn - 1) b = last;
   }
-  for (int j = nn - 2; j >= 0; --j) {
-    const double temp = -bcast(b, j + 1);
-    if (l <= j) b += temp * T[(j + 1) * ldt + l];
-    const double q = bcast(b, j) / T[j * ldt + j];
-    if (lane == j) b = q;
+#pragma unroll
+  for (int j = NN - 2; j >= 0; --j) {
+    if (j <= nn - 2) {
+      const double temp = -bcast(b, j + 1);
+      if (lane <= j) b += temp * tr[j + 1];
+      const double q = bcast(b, j) / bcast(td, j);
+      if (lane == j) b = q;
+    }
   }
   return b;
 }
 
-__device__ inline int lb_trsl_zero_diag(const ldsd* T, int ldt, int nn, int lane) {
-  const bool z = lane < nn && T[lane * ldt + lane] == 0.0;
-  const unsigned long long m = __ballot(z);
-  return m ? __ffsll((long long)m) : 0;
-}
-
 // p = M v with the middle matrix of the compact representation (lbfgsb.cpp: bmv).  v, p: LDS vectors of 2 col entries.
-// Returns info (0 ok).
-__device__ inline int lb_bmv(const LbLds L, const ldsd* v, ldsd* p, int lane) {
+// The 10 x 10 matrices come into registers in one LDS round trip (lane i: row i and column i of SY, row i and column i of the
+// factor T); everything after that is register arithmetic and broadcasts.  Returns info (0 ok).
+__device__ __noinline__ int lb_bmv(const LbLds L, const ldsd* v, ldsd* p, int lane) {
   const int col = ISC(I_COL);
   if (col == 0) return 0;
-  const int i = lane < LB_M ? lane : LB_M - 1;
+  const int i = lane < LB_M ? lane : LB_M - 1, ic = i < col ? i : 0;
+  double syr[LB_M], syc[LB_M], tc[LB_M], tr[LB_M];
+#pragma unroll
+  for (int k = 0; k < LB_M; ++k) { syr[k] = SY_(i, k); syc[k] = SY_(k, i); tc[k] = WT_(k, i); tr[k] = WT_(i, k); }
+  const double sydiag = SY_(i, i), tdiag = WT_(i, i);
+  const double vin1 = v[ic], vin2 = v[col + ic];
   // p2[i] = v[col + i] + sum_{k < i} SY(i, k) v[k] / SY(k, k)
   double sum = 0.0;
-  for (int k = 0; k + 1 < col; ++k) if (i > k && i < col) sum += SY_(i, k) * v[k] / SY_(k, k);
-  double p2 = (i == 0) ? v[col] : v[col + (i < col ? i : 0)] + sum;
-  int info = lb_trsl_zero_diag(L.wt(), LB_M, col, lane);
+#pragma unroll
+  for (int k = 0; k < LB_M - 1; ++k) {
+    if (k + 1 < col) {
+      const double vk = bcast(vin1, k), skk = bcast(sydiag, k);
+      if (i > k && i < col) sum += syr[k] * vk / skk;
+    }
+  }
+  double p2 = (i == 0) ? vin2 : vin2 + sum;
+  const int info = lb_trsl_zero_diag(tdiag, col, lane);
   if (info != 0) return info;
-  p2 = lb_dtrsl_lanes(L.wt(), LB_M, col, p2, 11, lane);
-  const double sq = sqrt(SY_(i < col ? i : 0, i < col ? i : 0));
-  double p1 = v[i < col ? i : 0] / sq;
-  p2 = lb_dtrsl_lanes(L.wt(), LB_M, col, p2, 1, lane);
+  p2 = lb_dtrsl_regs<LB_M>(tc, tr, tdiag, col, p2, 11, lane);
+  const double sq = sqrt(sydiag);
+  double p1 = vin1 / sq;
+  p2 = lb_dtrsl_regs<LB_M>(tc, tr, tdiag, col, p2, 1, lane);
   p1 = -p1 / sq;
   double s2 = 0.0;
-  for (int k = 1; k < col; ++k) {
-    const double pk = bcast(p2, k);
-    if (i < k) s2 += SY_(k, i) * pk / SY_(i, i);
+#pragma unroll
+  for (int k = 1; k < LB_M; ++k) {
+    if (k < col) {
+      const double pk = bcast(p2, k);
+      if (i < k) s2 += syc[k] * pk / sydiag;
+    }
   }
   p1 += s2;
   LSYNC();                       // every lane has read v (p may alias it)
   if (lane < col) { p[lane] = p1; p[col + lane] = p2; }
   LSYNC();
   return 0;
+}
+
+// The two triangular solves of the subspace minimisation (lbfgsb.cpp: subsm - dtrsl job 11, sign change of the first col
+// entries, dtrsl job 1) with the 2 col x 2 col factor K in registers.  b: lane l holds wv[l].  info through *info.
+__device__ __noinline__ double lb_subsm_solves(const LbLds L, double b, int* info, int lane) {
+  const int col = ISC(I_COL), col2 = 2 * col;
+  const int l = lane < 2 * LB_M ? lane : 2 * LB_M - 1;
+  double tc[2 * LB_M], tr[2 * LB_M];
+#pragma unroll
+  for (int j = 0; j < 2 * LB_M; ++j) { tc[j] = WN_(j, l); tr[j] = WN_(l, j); }
+  const double td = WN_(l, l);
+  *info = lb_trsl_zero_diag(td, col2, lane);
+  if (*info != 0) return b;
+  b = lb_dtrsl_regs<2 * LB_M>(tc, tr, td, col2, b, 11, lane);
+  if (lane < col) b = -b;
+  b = lb_dtrsl_regs<2 * LB_M>(tc, tr, td, col2, b, 1, lane);
+  return b;
 }
 
 __device__ inline double wave_max(double v) {
@@ -348,7 +391,7 @@ __device__ __noinline__ void lb_cauchy(const LbLds L, int lane) {
   ldsd* t = L.t(); ldsd* d = L.d(); ldsd* xcp = L.z();
   ldsi* iorder = L.indx2();
   if (SC(S_SBGNRM) <= 0.0) { for (int i = lane; i < n; i += 64) xcp[i] = L.x()[i]; LSYNC(); return; }
-  int nbreak = 0, nmove = 0;
+  int nbreak = 0;
   for (int base = 0; base < n; base += 64) {
     const int i = base + lane;
     double neggi = 0.0, tl = 0.0, tu = 0.0;
@@ -367,10 +410,6 @@ __device__ __noinline__ void lb_cauchy(const LbLds L, int lane) {
       d[i] = moving ? neggi : 0.0;
       L.prod()[i] = moving ? neggi * neggi : 0.0;
     }
-    const unsigned long long mm = __ballot(moving);
-    const int pos = nmove + __popcll(mm & lanes_below(lane));
-    if (moving) { L.rows()[pos] = i; L.coef()[pos] = neggi; }
-    nmove += __popcll(mm);
     const bool brk = moving && neggi != 0.0;
     const unsigned long long mb = __ballot(brk);
     const int pb = nbreak + __popcll(mb & lanes_below(lane));
@@ -380,7 +419,7 @@ __device__ __noinline__ void lb_cauchy(const LbLds L, int lane) {
   LSYNC();
   double f1 = chain_sub(0.0, L.prod(), n);         // f1 -= neggi^2 over the moving variables, in order (others subtract 0.0)
   if (col > 0) {
-    lb_accum2(L, L.rows(), L.coef(), nmove, nullptr, nullptr, 0, lane);
+    lb_accum(L, d, nullptr, lane);                   // d[i] = -g[i] for the moving variables, 0.0 for the others
     if (lane < col) {
       int pointr = head + lane; if (pointr >= LB_M) pointr -= LB_M;
       p[lane] = L.acc()[pointr];
@@ -396,7 +435,7 @@ __device__ __noinline__ void lb_cauchy(const LbLds L, int lane) {
   if (col > 0) {
     const int info = lb_bmv(L, p, v, lane);
     if (info != 0) { sti0(&ISC(I_INFO), info, lane); LSYNC(); return; }
-    f2 -= small_ddot(v, p, col2);
+    f2 -= small_ddot(v, p, col2, lane);
   }
   double dtm = -f1 / f2;
   double tsum = 0.0;
@@ -450,9 +489,9 @@ __device__ __noinline__ void lb_cauchy(const LbLds L, int lane) {
         LSYNC();
         const int info = lb_bmv(L, wbp, v, lane);
         if (info != 0) { sti0(&ISC(I_INFO), info, lane); LSYNC(); return; }
-        const double wmc = small_ddot(c, v, col2);
-        const double wmp = small_ddot(p, v, col2);
-        const double wmw = small_ddot(wbp, v, col2);
+        const double wmc = small_ddot(c, v, col2, lane);
+        const double wmp = small_ddot(p, v, col2, lane);
+        const double wmw = small_ddot(wbp, v, col2, lane);
         LSYNC();
         if (lane < col2) p[lane] -= dibp * wbp[lane];
         LSYNC();
@@ -516,10 +555,10 @@ __device__ __noinline__ void lb_freev(const LbLds L, int lane) {
 
 // LEL' factorisation of the indefinite subspace matrix (lbfgsb.cpp: formk)
 __device__ __noinline__ void lb_formk(const LbLds L, int lane) {
-  const int n = L.n, m = LB_M, col = ISC(I_COL), head = ISC(I_HEAD), nsub = ISC(I_NFREE);
+  const int n = L.n, m = LB_M, col = ISC(I_COL), head = ISC(I_HEAD);
   const int nenter = ISC(I_NENTER), ileave = ISC(I_ILEAVE);
   const double theta = SC(S_THETA);
-  const ldsi* ind = L.index(); const ldsi* indx2 = L.indx2();
+  const ldsi* indx2 = L.indx2();
   int upcl;
   if (ISC(I_UPDATD)) {
     if (ISC(I_IUPDAT) > m) {
@@ -550,9 +589,14 @@ __device__ __noinline__ void lb_formk(const LbLds L, int lane) {
     }
     const int ipntr = (head + col - 1) % m;
     const int iy = col - 1, is = m + col - 1;
-    for (int k = lane; k < n; k += 64) L.coef()[k] = k < nsub ? WY_(ind[k], ipntr) : WS_(ind[k], ipntr);
+    // free variables (increasing order) with WY(k, ipntr), active ones (the host's list runs downwards) with WS(k, ipntr)
+    for (int k = lane; k < n; k += 64) {
+      const bool fr = L.iwhere()[k] <= 0;
+      L.coef()[k] = fr ? WY_(k, ipntr) : 0.0;
+      L.prod()[k] = fr ? 0.0 : WS_(k, ipntr);
+    }
     LSYNC();
-    lb_accum2(L, ind, L.coef(), nsub, ind + nsub, L.coef() + nsub, n - nsub, lane);
+    lb_accum(L, L.coef(), L.prod(), lane);
     if (lane < col) {
       int jp = head + lane; if (jp >= m) jp -= m;
       WN1_(iy, lane) = L.acc()[jp];                 // t1
@@ -670,23 +714,22 @@ __device__ __noinline__ void lb_subsm(const LbLds L, int lane) {
   const ldsi* ind = L.index();
   ldsd* x = L.z(); ldsd* d = L.r(); ldsd* wv = L.wa();
   if (nsub <= 0) return;
-  lb_accum2(L, ind, d, nsub, nullptr, nullptr, 0, lane);
+  // full = d scattered to the variables' own places (zeros elsewhere; with every variable free it is d itself)
+  for (int k = lane; k < n; k += 64) L.full()[k] = 0.0;
+  LSYNC();
+  for (int i = lane; i < nsub; i += 64) L.full()[ind[i]] = d[i];
+  LSYNC();
+  lb_accum(L, L.full(), nullptr, lane);
   double b = 0.0;
   if (lane < col2) {
     const int i = lane < col ? lane : lane - col;
     int pointr = ISC(I_HEAD) + i; if (pointr >= m) pointr -= m;
     b = lane < col ? L.acc()[pointr] : theta * L.acc()[m + pointr];
   }
-  int info = lb_trsl_zero_diag(L.wn(), 2 * m, col2, lane);
+  int info = 0;
+  b = lb_subsm_solves(L, b, &info, lane);
   if (info != 0) { sti0(&ISC(I_INFO), info, lane); LSYNC(); return; }
-  b = lb_dtrsl_lanes(L.wn(), 2 * m, col2, b, 11, lane);
-  if (lane < col) b = -b;
-  b = lb_dtrsl_lanes(L.wn(), 2 * m, col2, b, 1, lane);
   if (lane < col2) wv[lane] = b;
-  // full = d scattered to the variables' own places (zeros elsewhere; with every variable free it is d itself)
-  for (int k = lane; k < n; k += 64) L.full()[k] = 0.0;
-  LSYNC();
-  for (int i = lane; i < nsub; i += 64) L.full()[ind[i]] = d[i];
   LSYNC();
   int pointr = ISC(I_HEAD);
   for (int jy = 0; jy < col; ++jy) {
@@ -981,7 +1024,7 @@ __device__ __noinline__ void lb_matupd(const LbLds L, double rr, double dr, int 
     for (int u = 0; u < 2; ++u) { if (dst[u] > 0) L.ss()[dst[u] - 1] = src[u]; else if (dst[u] < 0) L.sy()[-dst[u] - 1] = src[u]; }
   }
   LSYNC();
-  lb_accum2(L, nullptr, L.d(), n, nullptr, nullptr, 0, lane);
+  lb_accum(L, L.d(), nullptr, lane);
   if (lane < col - 1) {
     int pointr = head + lane; if (pointr >= m) pointr -= m;
     SY_(col - 1, lane) = L.acc()[pointr];
@@ -1222,7 +1265,7 @@ __device__ __noinline__ void lb_eval(const LbLds L, const LbEval E, int nq, bool
   LBT_BEGIN();
   for (int idx = tid; idx < LB_GQ * k; idx += LB_THREADS) {
     const int q = idx / k, c = idx - q * k, qq = q < nq ? q : 0;
-    const double lo = E.nlo[c], hi = E.nhi[c];
+    const double lo = L.nlo()[c], hi = L.nhi()[c];
     L.xn()[q * XS + c] = (L.x()[qq * k + c] - lo) / (hi - lo);
   }
   __syncthreads();
@@ -1370,6 +1413,16 @@ __device__ __noinline__ void lb_eval(const LbLds L, const LbEval E, int nq, bool
       dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = a3; dst[4] = a4;
     }
   }
+  // the rows of ZnT the gradient contraction of this wave needs (components w, w + 16, w + 32) leave now: they arrive while
+  // the barrier and the u phase pass
+  constexpr int CW = (LB_MAXK + 15) / 16, NB = LB_MAXNP / 64;
+  double z[CW][NB];
+#pragma unroll
+  for (int ci = 0; ci < CW; ++ci) {
+    const int c = w + 16 * ci, cc = c < k ? c : k - 1;
+#pragma unroll
+    for (int bq = 0; bq < NB; ++bq) { const int j = lane + 64 * bq; z[ci][bq] = (E.ZnT + (size_t)cc * ld)[j < n ? j : n - 1]; }
+  }
   __syncthreads();
   LBT_NEXT(12);
   if (hh == 0) {
@@ -1387,14 +1440,6 @@ __device__ __noinline__ void lb_eval(const LbLds L, const LbEval E, int nq, bool
   LBT_NEXT(13);
   // ---- gradient: wave per component (c = w, w + 16, w + 32), lanes over the points; all rows of ZnT a wave needs are loaded first
   {
-    constexpr int CW = (LB_MAXK + 15) / 16, NB = LB_MAXNP / 64;
-    double z[CW][NB];
-#pragma unroll
-    for (int ci = 0; ci < CW; ++ci) {
-      const int c = w + 16 * ci, cc = c < k ? c : k - 1;
-#pragma unroll
-      for (int bq = 0; bq < NB; ++bq) { const int j = lane + 64 * bq; z[ci][bq] = (E.ZnT + (size_t)cc * ld)[j < n ? j : n - 1]; }
-    }
 #pragma unroll
     for (int ci = 0; ci < CW; ++ci) {
       const int c = w + 16 * ci;
@@ -1411,7 +1456,7 @@ __device__ __noinline__ void lb_eval(const LbLds L, const LbEval E, int nq, bool
             }
           }
         }
-        const double inv = E.nhi[c] - E.nlo[c];
+        const double inv = L.nhi()[c] - L.nlo()[c];
 #pragma unroll
         for (int q = 0; q < LB_GQ; ++q) {
           const double s = wave_sum(acc[q]);
@@ -1466,6 +1511,7 @@ __global__ __launch_bounds__(LB_THREADS) void k_lbfgsb_group(
   for (int i = tid; i < LB_M * LB_M; i += LB_THREADS) { L.sy()[i] = 0.0; L.ss()[i] = 0.0; L.wt()[i] = 0.0; }
   for (int i = tid; i < 4 * LB_M * LB_M; i += LB_THREADS) { L.wn()[i] = 0.0; L.wn1()[i] = 0.0; }
   if (tid < 8 * LB_M) L.wa()[tid] = 0.0;
+  if (tid < k) { L.nlo()[tid] = bounds4[tid]; L.nhi()[tid] = bounds4[PCABO_MAXD + tid]; }
   if (tid < S_COUNT) L.sc()[tid] = 0.0;
   if (tid < I_COUNT) L.isc()[tid] = 0;
   __syncthreads();

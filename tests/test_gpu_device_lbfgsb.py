@@ -118,17 +118,17 @@ def test_device_mode_batch_replayed_by_oracle(native):
 
 
 def test_device_mode_falls_back_where_it_does_not_apply(native):
-    """k > 40 (d = 100 here) is beyond the device optimiser's LDS layout: the call takes the host-paced path and returns what
-    the batch returns without the option."""
+    """k > 40 is beyond the device optimiser's LDS layout: the call takes the host-paced path and returns what the batch
+    returns without the option."""
     rng = np.random.default_rng(5)
-    B, n, d, q = 2, 150, 50, 64
+    B, n, d, q = 2, 180, 60, 64
     X = rng.uniform(-5, 5, (B, n, d))
     y = rng.normal(size=(B, n)) * 50 + 300
     ranks = np.argsort(np.argsort(y, axis=1), axis=1) + 1
     outs = []
     for dev in (0, 1):
         bt = native.Batch(B, max_n=200, max_d=d, max_q=q, device_lbfgsb=dev)
-        bt.wpca_gp_condition_begin(X, ranks, None, y)
+        bt.wpca_gp_condition_begin(X, ranks, None, y, n_components=48)
         res = bt.wpca_results()
         assert min(r["k"] for r in res) > 40
         boxes = bt.acq_bounds()

@@ -378,6 +378,18 @@ def main():
             two = batchrun.bench_block(device, args.batch, FID, DIM, sub_batches=2)
             batch["side_by_side"] = {k: two[k] for k in ("sub_batches", "aggregate_bo_iterations_per_s", "seconds", "bo_iterations",
                                                           "host_phase_seconds", "retries", "failed_runs")}
+            # 4 x B runs in flight (configs[2] / [3] hold 270 / 600 runs): host-paced (four batches, a host thread and two gang
+            # workers each) against the device-resident optimiser (every restart group's L-BFGS-B inside one
+            # launch, csrc/kernels_lbfgsb.hip; four batches interleaved on ONE host thread, no worker threads)
+            keys = ("runs", "sub_batches", "aggregate_bo_iterations_per_s", "seconds", "bo_iterations", "host_phase_seconds",
+                    "retries", "failed_runs")
+            big = batchrun.bench_block(device, 4 * args.batch, FID, DIM, sub_batches=4)
+            dev = batchrun.bench_block(device, 4 * args.batch, FID, DIM, sub_batches=4, acq_kernel="device", schedule="interleaved")
+            batch["four_batches_host_paced"] = {k: big[k] for k in keys}
+            batch["four_batches_device_resident"] = {**{k: dev[k] for k in keys}, "host_thread_busy_seconds": dev["interleave"]["host_busy_seconds"],
+                                                     "note": "pcabo.batchrun.run_interleaved + acq_kernel='device' (PCABO_OPT_DEVICE_LBFGSB = 1); a run "
+                                                             "is bit-identical to the same run with the host's L-BFGS-B over the same evaluation "
+                                                             "kernel (tests/test_gpu_device_lbfgsb.py)"}
     if rank == 0 and size == 1 and not args.no_kchol_grid and not args.no_roofline:
         from pcabo import kchol_bench
         grid = kchol_bench.run(device, (1, 30), reps=3, big_batch=120)

@@ -69,7 +69,7 @@ int pcabo_last_error(pcabo_ctx* ctx, char* buf, int buflen);
  *   latency kernels; implies one launch per evaluation.  Same formulas, another summation order (~1e-15 relative), so a
  *   run is bit-reproducible within a mode, not across modes. */
 enum { PCABO_OPT_RESIDENT = 0, PCABO_OPT_BESTF_F32 = 1, PCABO_OPT_GROUP_ACQ = 2,
-       PCABO_OPT_DEVICE_LBFGSB = 3 /* batches only, see pcabo_batch_set_option */ };
+       PCABO_OPT_DEVICE_LBFGSB = 3, PCABO_OPT_LBFGSB_CUS = 4 /* batches only, see pcabo_batch_set_option */ };
 int pcabo_set_option(pcabo_ctx* ctx, int option, int value);
 
 /* Rows A-C (+D,J): rank-weighted PCA of the evaluated points.
@@ -240,7 +240,11 @@ int pcabo_batch_set_workers(pcabo_batch* batch, int workers);
  *   without a host round trip (csrc/kernels_lbfgsb.hip; needs n <= 512, k <= 40, batch_limit <= 5 and finite bounds - other
  *   calls take the host-paced path).  Its evaluation sums in an order of its own (a third arithmetic mode, ~1e-15 relative from
  *   the other two).  2 = the same evaluation kernel driven by the HOST's L-BFGS-B, one launch per round: slow, the reference
- *   the device stepping is compared with bit for bit (tests/test_gpu_device_lbfgsb.py). */
+ *   the device stepping is compared with bit for bit (tests/test_gpu_device_lbfgsb.py).
+ * PCABO_OPT_LBFGSB_CUS (default 0 = the whole chip): the launches of the device-resident optimiser go to a stream confined to the
+ *   first `value` compute units (hipExtStreamCreateWithCUMask).  Its work-groups hold a whole CU each for milliseconds; with
+ *   several batches of one process in flight the rest of the chip stays free for the short kernels of the others.  Results do
+ *   not depend on it. */
 int pcabo_batch_set_option(pcabo_batch* batch, int option, int value);
 int pcabo_batch_last_error(pcabo_batch* batch, char* buf, int buflen);
 pcabo_ctx* pcabo_batch_ctx(pcabo_batch* batch, int b);
@@ -265,6 +269,20 @@ int pcabo_batch_gp_condition_end_eval(pcabo_batch* batch, const double* Xq, int 
 int pcabo_batch_optimize_acqf(pcabo_batch* batch, const double* ics, int num_restarts, int batch_limit,
                               const double* bounds, int maxiter, const double* best_f, int maximize, int acq,
                               double* cand, double* vals, int* info, int* failed, int* status);
+/* The two waiting calls of an iteration in halves, for a caller that advances SEVERAL batches from one thread (the reference's
+ * outer loop over runs, ExperimentRunner.py:137-183, interleaved instead of threaded): _begin enqueues and returns, _end waits
+ * and collects, pcabo_batch_busy tells whether the batch's stream still has work (1) or a waiting call would return at once (0).
+ * pcabo_batch_optimize_acqf_begin needs PCABO_OPT_DEVICE_LBFGSB = 1 (the whole optimisation is one launch); it returns 1 -
+ * nothing enqueued - when the call does not qualify for it, and the caller then uses pcabo_batch_optimize_acqf.  The arrays
+ * handed to a _begin are read before it returns. */
+int pcabo_batch_busy(pcabo_batch* batch);
+int pcabo_batch_gp_condition_end_eval_begin(pcabo_batch* batch, const double* Xq, int q, const double* best_f, int maximize, int acq);
+int pcabo_batch_gp_condition_end_eval_end(pcabo_batch* batch, const double* Xq, int q, const double* best_f, int maximize,
+                                          int acq, double* val, int* status);
+int pcabo_batch_optimize_acqf_begin(pcabo_batch* batch, const double* ics, int num_restarts, int batch_limit,
+                                    const double* bounds, int maxiter, const double* best_f, int maximize, int acq);
+int pcabo_batch_optimize_acqf_end(pcabo_batch* batch, int num_restarts, int batch_limit, double* cand, double* vals, int* info,
+                                  int* failed, int* status);
 /* Park / unpark runs: active[B]; a parked run still goes through the lock-step launches of rows A-K but is skipped by
  * pcabo_batch_optimize_acqf (status PCABO_ERR_ARG).  For runs that failed the way the reference's would (botorch raises on a
  * NaN acquisition gradient, reached once the reference's unclipped out-of-box candidates have blown up the search box). */

@@ -95,7 +95,9 @@ class ExperimentRunner:
         # side_by_side: that many lock-step batches advance at once, one host thread each (pcabo.batchrun.run_side_by_side):
         # one batch's host-paced L-BFGS-B rounds overlap the other's launches and bookkeeping.  Same runs, same numbers.
         self.side_by_side = max(1, int(side_by_side))
-        self.batch_acq_kernel = batch_acq_kernel      # pcabo.batchrun.BatchedPCABO(acq_kernel=...)
+        # pcabo.batchrun.BatchedPCABO(acq_kernel=...): "group" (host-paced L-BFGS-B rounds, the default), "latency", or "device"
+        # (device-resident L-BFGS-B: pays from ~100 runs in flight, e.g. batched=30, side_by_side=4)
+        self.batch_acq_kernel = batch_acq_kernel
 
         self.triggers = [ALWAYS]
         self.logger_properties = [RAWYBEST]
@@ -157,7 +159,7 @@ class ExperimentRunner:
     def _run_pca_batched(self, logger, ebar) -> None:
         """This rank's PCA_BO runs, `self.batched` runs of one dimension at a time in lock-step (pcabo.batchrun),
         `self.side_by_side` such batches at once."""
-        from pcabo.batchrun import BatchedPCABO, run_side_by_side, workers_for
+        from pcabo.batchrun import BatchedPCABO, run_interleaved, run_side_by_side, workers_for
         from pcabo.bbob import BBOBProblem
         from pcabo.iohlog import LoggedProblem
         mine = self._my_runs()
@@ -181,7 +183,9 @@ class ExperimentRunner:
                                       host_threads=max(1, 8 // len(group)), acq_kernel=self.batch_acq_kernel)
                 jobs.append((dim, chunk, probs, n_doe, runner))
             start_time = time()
-            run_side_by_side([j[4] for j in jobs])
+            # "device": every batch's L-BFGS-B phase is one launch - one host thread interleaves the batches of the group
+            # (pcabo.batchrun.run_interleaved); otherwise a host thread per batch
+            (run_interleaved if self.batch_acq_kernel == "device" else run_side_by_side)([j[4] for j in jobs])
             elapsed = (time() - start_time) / sum(len(j[1]) for j in jobs)          # a run's share of its group of batches
             # the reference's three phase timers (PCA_BO.py:65), as a run's share of its batch's host clock: the
             # conditioning is enqueued together with the wPCA ("pca"), its wait falls into the optimiser's time as in

@@ -142,6 +142,10 @@ static inline size_t lb_lds_doubles(int NP, int H) { return (size_t)OFF_KS + (si
 
 #define SC(i) L.sc()[i]
 #define ISC(i) L.isc()[i]
+// The same scalars read as wave-uniform values (v_readfirstlane): what comes out of LDS is a per-lane value to the compiler -
+// branches and loop bounds on it would be lane-masked, a lane index for v_readlane would need a search loop
+#define ISR(i) __builtin_amdgcn_readfirstlane(L.isc()[i])
+#define SR(i) uni(L.sc()[i])
 #define WS_(i, p) L.ws()[(p) * LB_LDW + (i)]
 #define WY_(i, p) L.wy()[(p) * LB_LDW + (i)]
 #define SY_(i, j) L.sy()[(j) * LB_M + (i)]
@@ -151,6 +155,15 @@ static inline size_t lb_lds_doubles(int NP, int H) { return (size_t)OFF_KS + (si
 #define WN1_(i, j) L.wn1()[(j) * 2 * LB_M + (i)]
 
 __device__ inline int nxt(int p) { return p + 1 == LB_M ? 0 : p + 1; }
+__device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ inline double uni(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+__device__ inline gcd* uni(gcd* p) {
+  const unsigned long long a = (unsigned long long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+  return (gcd*)(((unsigned long long)hi << 32) | lo);
+}
 __device__ inline double bcast(double v, int lane) {      // value of `lane` (uniform index) in every lane
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
@@ -303,7 +316,7 @@ __device__ inline double lb_dtrsl_regs(const double (&tc)[NN], const double (&tr
 // The 10 x 10 matrices come into registers in one LDS round trip (lane i: row i and column i of SY, row i and column i of the
 // factor T); everything after that is register arithmetic and broadcasts.  Returns info (0 ok).
 __device__ __noinline__ int lb_bmv(const LbLds L, const ldsd* v, ldsd* p, int lane) {
-  const int col = ISC(I_COL);
+  const int col = ISR(I_COL);
   if (col == 0) return 0;
   const int i = lane < LB_M ? lane : LB_M - 1, ic = i < col ? i : 0;
   double syr[LB_M], syc[LB_M], tc[LB_M], tr[LB_M];
@@ -346,7 +359,7 @@ __device__ __noinline__ int lb_bmv(const LbLds L, const ldsd* v, ldsd* p, int la
 // The two triangular solves of the subspace minimisation (lbfgsb.cpp: subsm - dtrsl job 11, sign change of the first col
 // entries, dtrsl job 1) with the 2 col x 2 col factor K in registers.  b: lane l holds wv[l].  info through *info.
 __device__ __noinline__ double lb_subsm_solves(const LbLds L, double b, int* info, int lane) {
-  const int col = ISC(I_COL), col2 = 2 * col;
+  const int col = ISR(I_COL), col2 = 2 * col;
   const int l = lane < 2 * LB_M ? lane : 2 * LB_M - 1;
   double tc[2 * LB_M], tr[2 * LB_M];
 #pragma unroll
@@ -385,12 +398,12 @@ __device__ inline void lb_reset_memory(const LbLds L, int lane) {
 
 // Generalised Cauchy point (lbfgsb.cpp: cauchy, the branch for variables with both bounds)
 __device__ __noinline__ void lb_cauchy(const LbLds L, int lane) {
-  const int n = L.n, col = ISC(I_COL), head = ISC(I_HEAD), col2 = 2 * col;
-  const double theta = SC(S_THETA);
+  const int n = L.n, col = ISR(I_COL), head = ISR(I_HEAD), col2 = 2 * col;
+  const double theta = SR(S_THETA);
   ldsd* p = L.wa(); ldsd* c = L.wa() + 2 * LB_M; ldsd* wbp = L.wa() + 4 * LB_M; ldsd* v = L.wa() + 6 * LB_M;
   ldsd* t = L.t(); ldsd* d = L.d(); ldsd* xcp = L.z();
   ldsi* iorder = L.indx2();
-  if (SC(S_SBGNRM) <= 0.0) { for (int i = lane; i < n; i += 64) xcp[i] = L.x()[i]; LSYNC(); return; }
+  if (SR(S_SBGNRM) <= 0.0) { for (int i = lane; i < n; i += 64) xcp[i] = L.x()[i]; LSYNC(); return; }
   int nbreak = 0;
   for (int base = 0; base < n; base += 64) {
     const int i = base + lane;
@@ -516,7 +529,7 @@ __device__ __noinline__ void lb_cauchy(const LbLds L, int lane) {
 }
 
 __device__ __noinline__ void lb_freev(const LbLds L, int lane) {
-  const int n = L.n, nfree_old = ISC(I_NFREE), iter = ISC(I_ITER);
+  const int n = L.n, nfree_old = ISR(I_NFREE), iter = ISR(I_ITER);
   int nenter = 0, ileave = n;
   if (iter > 0) {
     for (int base = 0; base < nfree_old; base += 64) {
@@ -537,7 +550,7 @@ __device__ __noinline__ void lb_freev(const LbLds L, int lane) {
     }
   }
   LSYNC();
-  const int wrk = (ileave < n) || (nenter > 0) || ISC(I_UPDATD);
+  const int wrk = (ileave < n) || (nenter > 0) || ISR(I_UPDATD);
   int nfree = 0, iact = n;
   for (int base = 0; base < n; base += 64) {
     const int i = base + lane;
@@ -555,13 +568,13 @@ __device__ __noinline__ void lb_freev(const LbLds L, int lane) {
 
 // LEL' factorisation of the indefinite subspace matrix (lbfgsb.cpp: formk)
 __device__ __noinline__ void lb_formk(const LbLds L, int lane) {
-  const int n = L.n, m = LB_M, col = ISC(I_COL), head = ISC(I_HEAD);
-  const int nenter = ISC(I_NENTER), ileave = ISC(I_ILEAVE);
-  const double theta = SC(S_THETA);
+  const int n = L.n, m = LB_M, col = ISR(I_COL), head = ISR(I_HEAD);
+  const int nenter = ISR(I_NENTER), ileave = ISR(I_ILEAVE);
+  const double theta = SR(S_THETA);
   const ldsi* indx2 = L.indx2();
   int upcl;
-  if (ISC(I_UPDATD)) {
-    if (ISC(I_IUPDAT) > m) {
+  if (ISR(I_UPDATD)) {
+    if (ISR(I_IUPDAT) > m) {
       // shift the three blocks of WN1 one step up-left: every source is read before anything is written
       double src[3]; int dst[3];
       const int tri = m * (m - 1) / 2, tot = 2 * tri + (m - 1) * (m - 1);      // 171 elements: three per lane
@@ -691,13 +704,13 @@ __device__ __noinline__ void lb_formk(const LbLds L, int lane) {
 }
 
 __device__ __noinline__ void lb_cmprlb(const LbLds L, int lane) {
-  const int n = L.n, col = ISC(I_COL), nfree = ISC(I_NFREE);
-  const double theta = SC(S_THETA);
+  const int n = L.n, col = ISR(I_COL), nfree = ISR(I_NFREE);
+  const double theta = SR(S_THETA);
   for (int k = lane; k < n; k += 64) L.full()[k] = -theta * (L.z()[k] - L.x()[k]) - L.g()[k];
   LSYNC();
   const int info = lb_bmv(L, L.wa() + 2 * LB_M, L.wa(), lane);
   if (info != 0) { sti0(&ISC(I_INFO), -8, lane); LSYNC(); return; }
-  int pointr = ISC(I_HEAD);
+  int pointr = ISR(I_HEAD);
   for (int j = 0; j < col; ++j) {
     const double a1 = L.wa()[j], a2 = theta * L.wa()[col + j];
     for (int k = lane; k < n; k += 64) L.full()[k] += WY_(k, pointr) * a1 + WS_(k, pointr) * a2;
@@ -709,8 +722,8 @@ __device__ __noinline__ void lb_cmprlb(const LbLds L, int lane) {
 }
 
 __device__ __noinline__ void lb_subsm(const LbLds L, int lane) {
-  const int n = L.n, m = LB_M, col = ISC(I_COL), nsub = ISC(I_NFREE), col2 = 2 * col;
-  const double theta = SC(S_THETA);
+  const int n = L.n, m = LB_M, col = ISR(I_COL), nsub = ISR(I_NFREE), col2 = 2 * col;
+  const double theta = SR(S_THETA);
   const ldsi* ind = L.index();
   ldsd* x = L.z(); ldsd* d = L.r(); ldsd* wv = L.wa();
   if (nsub <= 0) return;
@@ -723,7 +736,7 @@ __device__ __noinline__ void lb_subsm(const LbLds L, int lane) {
   double b = 0.0;
   if (lane < col2) {
     const int i = lane < col ? lane : lane - col;
-    int pointr = ISC(I_HEAD) + i; if (pointr >= m) pointr -= m;
+    int pointr = ISR(I_HEAD) + i; if (pointr >= m) pointr -= m;
     b = lane < col ? L.acc()[pointr] : theta * L.acc()[m + pointr];
   }
   int info = 0;
@@ -731,7 +744,7 @@ __device__ __noinline__ void lb_subsm(const LbLds L, int lane) {
   if (info != 0) { sti0(&ISC(I_INFO), info, lane); LSYNC(); return; }
   if (lane < col2) wv[lane] = b;
   LSYNC();
-  int pointr = ISC(I_HEAD);
+  int pointr = ISR(I_HEAD);
   for (int jy = 0; jy < col; ++jy) {
     const double a1 = wv[jy], a2 = wv[col + jy];
     for (int k = lane; k < n; k += 64) L.full()[k] = L.full()[k] + WY_(k, pointr) * a1 / theta + WS_(k, pointr) * a2;
@@ -914,10 +927,10 @@ __device__ inline void lb_dcsrch(double f, double g, double* stp, double ftol, d
 }
 
 __device__ inline void ls_load(const LbLds L, LsState& s) {
-  s.task = ISC(LS_TASK); s.brackt = ISC(LS_BRACKT); s.stage = ISC(LS_STAGE);
-  s.ginit = SC(LS_GINIT); s.gtest = SC(LS_GTEST); s.gx = SC(LS_GX); s.gy = SC(LS_GY); s.finit = SC(LS_FINIT);
-  s.fx = SC(LS_FX); s.fy = SC(LS_FY); s.stx = SC(LS_STX); s.sty = SC(LS_STY); s.stmin = SC(LS_STMIN); s.stmax = SC(LS_STMAX);
-  s.width = SC(LS_WIDTH); s.width1 = SC(LS_WIDTH1);
+  s.task = ISR(LS_TASK); s.brackt = ISR(LS_BRACKT); s.stage = ISR(LS_STAGE);
+  s.ginit = SR(LS_GINIT); s.gtest = SR(LS_GTEST); s.gx = SR(LS_GX); s.gy = SR(LS_GY); s.finit = SR(LS_FINIT);
+  s.fx = SR(LS_FX); s.fy = SR(LS_FY); s.stx = SR(LS_STX); s.sty = SR(LS_STY); s.stmin = SR(LS_STMIN); s.stmax = SR(LS_STMAX);
+  s.width = SR(LS_WIDTH); s.width1 = SR(LS_WIDTH1);
 }
 __device__ inline void ls_store(const LbLds L, const LsState& s, int lane) {
   if (lane == 0) {
@@ -932,14 +945,14 @@ __device__ inline void ls_store(const LbLds L, const LsState& s, int lane) {
 __device__ __noinline__ void lb_lnsrlb(const LbLds L, int lane) {
   const int n = L.n;
   const double big = 1e10, ftol = 1e-3, gtol = 0.9, xtol = 0.1;
-  const double f = SC(S_F);
+  const double f = SR(S_F);
   LsState ls;
   double stp, stpmx, dnorm;
-  if (ISC(I_PHASE) != 2) {
+  if (ISR(I_PHASE) != 2) {
     const double dtd = wave_ddot(L, L.d(), L.d(), n, lane);
     dnorm = sqrt(dtd);
     stpmx = big;
-    if (ISC(I_ITER) == 0) stpmx = 1.0;
+    if (ISR(I_ITER) == 0) stpmx = 1.0;
     else {
       // the host's scan  "if (a1 stpmx < a2) stpmx = a2 / a1"  in order: stpmx only falls and the products are monotone in it,
       // so within a chunk of 64 the first lane whose test holds is the next one to change it; the others test again after it
@@ -974,10 +987,10 @@ __device__ __noinline__ void lb_lnsrlb(const LbLds L, int lane) {
     LSYNC();
   } else {
     ls_load(L, ls);
-    stp = SC(S_STP); stpmx = SC(S_STPMX); dnorm = SC(S_DNORM);
+    stp = SR(S_STP); stpmx = SR(S_STPMX); dnorm = SR(S_DNORM);
   }
   const double gd = wave_ddot(L, L.g(), L.d(), n, lane);
-  int ifun = ISC(I_IFUN);
+  int ifun = ISR(I_IFUN);
   LSYNC();
   if (lane == 0) SC(S_GD) = gd;
   if (ifun == 0) {
@@ -988,7 +1001,7 @@ __device__ __noinline__ void lb_lnsrlb(const LbLds L, int lane) {
   ls_store(L, ls, lane);
   if (lane == 0) SC(S_STP) = stp;
   if (ls.task != 2 && ls.task != 3) {
-    if (lane == 0) { ISC(I_TASK) = LBFGSB_FG; ISC(I_IFUN) = ifun + 1; ISC(I_NFGV) = ISC(I_NFGV) + 1; ISC(I_IBACK) = ifun; }
+    if (lane == 0) { ISC(I_TASK) = LBFGSB_FG; ISC(I_IFUN) = ifun + 1; ISC(I_NFGV) = ISR(I_NFGV) + 1; ISC(I_IBACK) = ifun; }
     if (stp == 1.0) { for (int i = lane; i < n; i += 64) L.x()[i] = L.z()[i]; }
     else { for (int i = lane; i < n; i += 64) L.x()[i] = stp * L.d()[i] + L.t()[i]; }
   } else {
@@ -998,8 +1011,8 @@ __device__ __noinline__ void lb_lnsrlb(const LbLds L, int lane) {
 }
 
 __device__ __noinline__ void lb_matupd(const LbLds L, double rr, double dr, int lane) {
-  const int n = L.n, m = LB_M, iupdat = ISC(I_IUPDAT);
-  int col = ISC(I_COL), head = ISC(I_HEAD), itail = ISC(I_ITAIL);
+  const int n = L.n, m = LB_M, iupdat = ISR(I_IUPDAT);
+  int col = ISR(I_COL), head = ISR(I_HEAD), itail = ISR(I_ITAIL);
   if (iupdat <= m) { col = iupdat; itail = (head + iupdat - 1) % m; }
   else { itail = nxt(itail); head = nxt(head); }
   for (int i = lane; i < n; i += 64) { WS_(i, itail) = L.d()[i]; WY_(i, itail) = L.r()[i]; }
@@ -1031,7 +1044,7 @@ __device__ __noinline__ void lb_matupd(const LbLds L, double rr, double dr, int 
     SS_(lane, col - 1) = L.acc()[m + pointr];
   }
   if (lane == 0) {
-    const double stp = SC(S_STP), dtd = SC(S_DTD);
+    const double stp = SR(S_STP), dtd = SR(S_DTD);
     SS_(col - 1, col - 1) = stp == 1.0 ? dtd : stp * stp * dtd;
     SY_(col - 1, col - 1) = dr;
     ISC(I_COL) = col; ISC(I_HEAD) = head; ISC(I_ITAIL) = itail; SC(S_THETA) = theta;
@@ -1040,8 +1053,8 @@ __device__ __noinline__ void lb_matupd(const LbLds L, double rr, double dr, int 
 }
 
 __device__ __noinline__ void lb_formt(const LbLds L, int lane) {
-  const int col = ISC(I_COL);
-  const double theta = SC(S_THETA);
+  const int col = ISR(I_COL);
+  const double theta = SR(S_THETA);
   for (int e = lane; e < col * (col + 1) / 2; e += 64) {
     int j = 0, ee = e;
     while (ee > j) { ee -= j + 1; ++j; }
@@ -1062,9 +1075,9 @@ __device__ __noinline__ void lb_formt(const LbLds L, int lane) {
 __device__ int lb_step(const LbLds L, int lane) {
   const int n = L.n;
   const double pgtol = 1e-5, factr = 1e7;
-  if (ISC(I_TASK) >= LBFGSB_CONV_PG) return ISC(I_TASK);
+  if (ISR(I_TASK) >= LBFGSB_CONV_PG) return ISR(I_TASK);
   bool need_iteration_start = false, resume_linesearch = false;
-  const int phase = ISC(I_PHASE);
+  const int phase = ISR(I_PHASE);
   if (phase == 0) {
     // (init: the caller has zeroed the state, clamped x into the box and classified the variables)
     if (lane == 0) { ISC(I_PHASE) = 1; ISC(I_TASK) = LBFGSB_FG; }
@@ -1074,23 +1087,23 @@ __device__ int lb_step(const LbLds L, int lane) {
   if (phase == 1) {
     sti0(&ISC(I_NFGV), 1, lane);
     lb_projgr(L, lane);
-    if (SC(S_SBGNRM) <= pgtol) { sti0(&ISC(I_TASK), LBFGSB_CONV_PG, lane); LSYNC(); return LBFGSB_CONV_PG; }
+    if (SR(S_SBGNRM) <= pgtol) { sti0(&ISC(I_TASK), LBFGSB_CONV_PG, lane); LSYNC(); return LBFGSB_CONV_PG; }
     need_iteration_start = true;
   } else if (phase == 2) {
     resume_linesearch = true;
   } else {
-    if (SC(S_SBGNRM) <= pgtol) { sti0(&ISC(I_TASK), LBFGSB_CONV_PG, lane); LSYNC(); return LBFGSB_CONV_PG; }
-    const double f = SC(S_F), fold = SC(S_FOLD);
+    if (SR(S_SBGNRM) <= pgtol) { sti0(&ISC(I_TASK), LBFGSB_CONV_PG, lane); LSYNC(); return LBFGSB_CONV_PG; }
+    const double f = SR(S_F), fold = SR(S_FOLD);
     const double ddum = fmax(fmax(fabs(fold), fabs(f)), 1.0);
     if ((fold - f) <= (factr * DBL_EPSILON) * ddum) {
-      if (lane == 0) { ISC(I_TASK) = LBFGSB_CONV_F; if (ISC(I_IBACK) >= 10) ISC(I_INFO) = -5; }
+      if (lane == 0) { ISC(I_TASK) = LBFGSB_CONV_F; if (ISR(I_IBACK) >= 10) ISC(I_INFO) = -5; }
       LSYNC();
       return LBFGSB_CONV_F;
     }
     for (int i = lane; i < n; i += 64) L.r()[i] = L.g()[i] - L.r()[i];
     LSYNC();
     const double rr = wave_ddot(L, L.r(), L.r(), n, lane);
-    const double stp = SC(S_STP), gd = SC(S_GD), gdold = SC(S_GDOLD);
+    const double stp = SR(S_STP), gd = SR(S_GD), gdold = SR(S_GDOLD);
     double dr, ddum2;
     if (stp == 1.0) { dr = gd - gdold; ddum2 = -gdold; }
     else {
@@ -1103,10 +1116,10 @@ __device__ int lb_step(const LbLds L, int lane) {
       sti0(&ISC(I_UPDATD), 0, lane);
       LSYNC();
     } else {
-      if (lane == 0) { ISC(I_UPDATD) = 1; ISC(I_IUPDAT) = ISC(I_IUPDAT) + 1; }
+      if (lane == 0) { ISC(I_UPDATD) = 1; ISC(I_IUPDAT) = ISR(I_IUPDAT) + 1; }
       LSYNC();
       { LBT_BEGIN(); lb_matupd(L, rr, dr, lane); LBT_NEXT(6); lb_formt(L, lane); LBT_NEXT(7); }
-      if (ISC(I_INFO) != 0) lb_reset_memory(L, lane);
+      if (ISR(I_INFO) != 0) lb_reset_memory(L, lane);
     }
     need_iteration_start = true;
   }
@@ -1115,14 +1128,14 @@ __device__ int lb_step(const LbLds L, int lane) {
       need_iteration_start = false;
       sti0(&ISC(I_IWORD), -1, lane);
       { LBT_BEGIN(); lb_cauchy(L, lane); LBT_NEXT(0); }
-      if (ISC(I_INFO) != 0) { lb_reset_memory(L, lane); need_iteration_start = true; continue; }
+      if (ISR(I_INFO) != 0) { lb_reset_memory(L, lane); need_iteration_start = true; continue; }
       { LBT_BEGIN(); lb_freev(L, lane); LBT_NEXT(1); }
-      if (ISC(I_NFREE) != 0 && ISC(I_COL) != 0) {
-        if (ISC(I_WRK)) { LBT_BEGIN(); lb_formk(L, lane); LBT_NEXT(2); }
-        if (ISC(I_INFO) != 0) { lb_reset_memory(L, lane); need_iteration_start = true; continue; }
+      if (ISR(I_NFREE) != 0 && ISR(I_COL) != 0) {
+        if (ISR(I_WRK)) { LBT_BEGIN(); lb_formk(L, lane); LBT_NEXT(2); }
+        if (ISR(I_INFO) != 0) { lb_reset_memory(L, lane); need_iteration_start = true; continue; }
         { LBT_BEGIN(); lb_cmprlb(L, lane); LBT_NEXT(3); }
-        if (ISC(I_INFO) == 0) { LBT_BEGIN(); lb_subsm(L, lane); LBT_NEXT(4); }
-        if (ISC(I_INFO) != 0) { lb_reset_memory(L, lane); need_iteration_start = true; continue; }
+        if (ISR(I_INFO) == 0) { LBT_BEGIN(); lb_subsm(L, lane); LBT_NEXT(4); }
+        if (ISR(I_INFO) != 0) { lb_reset_memory(L, lane); need_iteration_start = true; continue; }
       }
       for (int i = lane; i < n; i += 64) L.d()[i] = L.z()[i] - L.x()[i];
       sti0(&ISC(I_PHASE), 0, lane);
@@ -1130,13 +1143,13 @@ __device__ int lb_step(const LbLds L, int lane) {
     }
     if (resume_linesearch) { resume_linesearch = false; sti0(&ISC(I_PHASE), 2, lane); LSYNC(); }
     { LBT_BEGIN(); lb_lnsrlb(L, lane); LBT_NEXT(5); }
-    if (ISC(I_INFO) != 0 || ISC(I_IBACK) >= 20) {
+    if (ISR(I_INFO) != 0 || ISR(I_IBACK) >= 20) {
       for (int i = lane; i < n; i += 64) { L.x()[i] = L.t()[i]; L.g()[i] = L.r()[i]; }
-      if (lane == 0) SC(S_F) = SC(S_FOLD);
+      if (lane == 0) SC(S_F) = SR(S_FOLD);
       LSYNC();
-      if (ISC(I_COL) == 0) {
+      if (ISR(I_COL) == 0) {
         if (lane == 0) {
-          if (ISC(I_INFO) == 0) { ISC(I_INFO) = -9; ISC(I_NFGV) -= 1; ISC(I_IFUN) -= 1; ISC(I_IBACK) -= 1; }
+          if (ISR(I_INFO) == 0) { ISC(I_INFO) = -9; ISC(I_NFGV) -= 1; ISC(I_IFUN) -= 1; ISC(I_IBACK) -= 1; }
           ISC(I_TASK) = LBFGSB_ABNORMAL; ISC(I_ITER) += 1;
         }
         LSYNC();
@@ -1148,8 +1161,8 @@ __device__ int lb_step(const LbLds L, int lane) {
       need_iteration_start = true;
       continue;
     }
-    if (ISC(I_TASK) == LBFGSB_FG) { sti0(&ISC(I_PHASE), 2, lane); LSYNC(); return LBFGSB_FG; }
-    sti0(&ISC(I_ITER), ISC(I_ITER) + 1, lane);
+    if (ISR(I_TASK) == LBFGSB_FG) { sti0(&ISC(I_PHASE), 2, lane); LSYNC(); return LBFGSB_FG; }
+    sti0(&ISC(I_ITER), ISR(I_ITER) + 1, lane);
     LSYNC();
     lb_projgr(L, lane);
     if (lane == 0) { ISC(I_PHASE) = 3; ISC(I_TASK) = LBFGSB_NEW_X; }
@@ -1160,15 +1173,15 @@ __device__ int lb_step(const LbLds L, int lane) {
 
 // RestartGroup::advance (pcabo_api.hip): step until the group needs f, g at x (I_TASK == FG on return) or has stopped (I_ACTIVE == 0)
 __device__ void lb_advance(const LbLds L, int maxiter, int lane) {
-  while (ISC(I_ACTIVE)) {
+  while (ISR(I_ACTIVE)) {
     const int task = lb_step(L, lane);
     if (task == LBFGSB_FG) {
-      if (ISC(I_HAVE_CACHE)) {
+      if (ISR(I_HAVE_CACHE)) {
         bool diff = false;
         for (int i = lane; i < L.n; i += 64) diff = diff || (__double_as_longlong(L.x()[i]) != __double_as_longlong(L.xc()[i]));
         if (!__ballot(diff)) {
           for (int i = lane; i < L.n; i += 64) L.g()[i] = L.gc()[i];
-          st0(&SC(S_F), SC(S_FC), lane);
+          st0(&SC(S_F), SR(S_FC), lane);
           LSYNC();
           continue;
         }
@@ -1176,12 +1189,12 @@ __device__ void lb_advance(const LbLds L, int maxiter, int lane) {
       return;
     }
     if (task == LBFGSB_NEW_X) {
-      const int niter = ISC(I_NITER) + 1;
+      const int niter = ISR(I_NITER) + 1;
       LSYNC();
       if (lane == 0) {
         ISC(I_NITER) = niter;
         if (niter >= maxiter) ISC(I_TASK) = LBFGSB_STOP_ITER;
-        else if (ISC(I_NFEV) > 15000) ISC(I_TASK) = LBFGSB_STOP_FUN;
+        else if (ISR(I_NFEV) > 15000) ISC(I_TASK) = LBFGSB_STOP_FUN;
       }
       LSYNC();
       continue;
@@ -1258,8 +1271,17 @@ __device__ inline void lb_scalar_core(double vv, double mus, const LbEval& E, do
 // Every global load of a loop trip is issued before the first use (LB_UB of them in flight per thread, the next trip's while the
 // current one is consumed): one CU has to pull ~0.8 MB per triangular pass through ~1 us of L2 / Infinity Cache latency.
 #define LB_UB 16
-__device__ __noinline__ void lb_eval(const LbLds L, const LbEval E, int nq, bool want_grad) {
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+__device__ __noinline__ void lb_eval(const LbLds L_, const LbEval E_, int nq, bool want_grad) {
+  // (arguments of a function that is not inlined arrive in vector registers: made wave-uniform again here, so that loop bounds,
+  // row bases and LDS addresses of the broadcasts are scalar)
+  const int tid = threadIdx.x, lane = tid & 63, w = uni(tid >> 6);
+  LbLds L; L.base = (ldsd*)(unsigned)uni((int)(unsigned)(unsigned long long)L_.base); L.n = uni(L_.n); L.NP = uni(L_.NP);
+  LbEval E;
+  E.ZnT = uni(E_.ZnT); E.R = uni(E_.R); E.RT = uni(E_.RT); E.alpha = uni(E_.alpha); E.nlo = E_.nlo; E.nhi = E_.nhi;
+  E.n = uni(E_.n); E.k = uni(E_.k); E.NP = uni(E_.NP); E.ld = uni(E_.ld); E.H = uni(E_.H); E.S = uni(E_.S);
+  E.best_f = E_.best_f; E.ym = E_.ym; E.ysd = E_.ysd; E.inv_ls = uni(E_.inv_ls);
+  E.maximize = uni(E_.maximize); E.acq = uni(E_.acq); E.kernel = uni(E_.kernel);
+  nq = uni(nq);
   const int n = E.n, k = E.k, NP = E.NP, ld = E.ld, H = E.H, S = E.S;
   const int XS = LB_MAXK + 2;
   LBT_BEGIN();
@@ -1490,7 +1512,7 @@ __global__ __launch_bounds__(LB_THREADS) void k_lbfgsb_group(
   alpha = zrun(alpha, zs, run_); bounds4 = zrun(bounds4, zs, run_); ystats = zrun(ystats, zs, run_);
   bestf = zrun(bestf, zs, run_); k_dev = zrun(k_dev, zs, run_); out_x = zrun(out_x, zs, run_); out_v = zrun(out_v, zs, run_);
   const int k = *k_dev;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = uni(tid >> 6);
   const int nv = nq * k;
   LbLds L;
   L.base = (ldsd*)s_dyn; L.n = nv; L.NP = NP;
@@ -1529,7 +1551,7 @@ __global__ __launch_bounds__(LB_THREADS) void k_lbfgsb_group(
     if (w == 0) lb_advance(L, maxiter, lane);
     __syncthreads();
     LBT_NEXT(16);
-    if (!ISC(I_ACTIVE)) break;
+    if (!ISR(I_ACTIVE)) break;
     lb_eval(L, E, nq, true);
     LBT_NEXT(17);
     // RestartGroup::absorb: f = -(sum of the values, in order), NaN check of the gradient, cache
@@ -1547,11 +1569,11 @@ __global__ __launch_bounds__(LB_THREADS) void k_lbfgsb_group(
       }
     }
     __syncthreads();
-    if (!ISC(I_ACTIVE)) break;
+    if (!ISR(I_ACTIVE)) break;
   }
   __syncthreads();
   // ---- end points (clamped), their values: the last evaluation's if that was the point, one more evaluation otherwise
-  bool same = ISC(I_HAVE_CACHE) != 0;
+  bool same = ISR(I_HAVE_CACHE) != 0;
   for (int i = tid; i < nv; i += LB_THREADS) {
     double v = L.x()[i];
     v = v < L.lo()[i] ? L.lo()[i] : (v > L.hi()[i] ? L.hi()[i] : v);
@@ -1559,7 +1581,7 @@ __global__ __launch_bounds__(LB_THREADS) void k_lbfgsb_group(
     if (__double_as_longlong(v) != __double_as_longlong(L.xc()[i])) same = false;
   }
   const int all_same = __syncthreads_and(same ? 1 : 0);
-  const int status = ISC(I_STATUS);
+  const int status = ISR(I_STATUS);
   if (status == 0) {
     if (!all_same) lb_eval(L, E, nq, false);
     else { if (tid < nq) L.vals()[tid] = L.vc()[tid]; __syncthreads(); }
@@ -1567,11 +1589,11 @@ __global__ __launch_bounds__(LB_THREADS) void k_lbfgsb_group(
   }
   for (int i = tid; i < nv; i += LB_THREADS) out_x[(size_t)q0 * k + i] = L.x()[i];
   if (tid == 0) {
-    const int task = ISC(I_TASK);
+    const int task = ISR(I_TASK);
     const int wf = (task == LBFGSB_CONV_PG || task == LBFGSB_CONV_F) ? 0 : ((task == LBFGSB_STOP_ITER || task == LBFGSB_STOP_FUN) ? 1 : 2);
     double* o = out_v + 64 + 8 * gi;
-    o[0] = ISC(I_NITER); o[1] = ISC(I_NFEV); o[2] = wf; o[3] = task; o[4] = status; o[5] = ISC(I_EVALS); o[6] = ISC(I_TIES);
-    o[7] = ISC(I_ACTIVE) ? 1.0 : 0.0;                 // 1: stopped by the evaluation cap (cannot happen within the host's limits)
+    o[0] = ISR(I_NITER); o[1] = ISR(I_NFEV); o[2] = wf; o[3] = task; o[4] = status; o[5] = ISR(I_EVALS); o[6] = ISR(I_TIES);
+    o[7] = ISR(I_ACTIVE) ? 1.0 : 0.0;                 // 1: stopped by the evaluation cap (cannot happen within the host's limits)
   }
 }
 

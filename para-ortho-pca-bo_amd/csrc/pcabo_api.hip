@@ -1608,8 +1608,13 @@ struct pcabo_batch {
   int cnt_S = 0; bool cnt_dirty = true;
   bool prof = false; hipEvent_t pev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // phase marks of the last conditioning
   bool group_acq = true;                 // L-BFGS-B rounds through k_acq_group (pcabo_batch_set_option(PCABO_OPT_GROUP_ACQ, 0): the per-query kernels)
+  bool score_enqueued = false;           // pcabo_batch_gp_condition_end_eval_begin without its _end yet
+  bool opt_enqueued = false; int opt_restarts = 0, opt_limit = 0; std::vector<int> opt_act;   // pcabo_batch_optimize_acqf_begin without its _end yet
   int dev_lbfgsb = 0;                    // PCABO_OPT_DEVICE_LBFGSB: 1 device-resident L-BFGS-B, 2 its host-stepped twin
   unsigned *dOptTab = nullptr, *hOptTab = nullptr;   // launch table of the device-resident optimiser (B * 32 entries)
+  int opt_cus = 0;                       // PCABO_OPT_LBFGSB_CUS: > 0 = the optimiser's launches run on a stream confined to that many CUs
+  hipStream_t optStream = nullptr; int optStream_cus = 0;
+  hipEvent_t evOptIn = nullptr, evOptOut = nullptr;
   int G = 0;                             // gangs = worker threads of the L-BFGS-B phase
   std::vector<hipStream_t> gstream;
   GangPool pool;
@@ -1640,6 +1645,9 @@ static void batch_free(pcabo_batch* batch) {
   for (hipEvent_t e : batch->pev) if (e) (void)hipEventDestroy(e);
   if (batch->dSlab) (void)hipFree(batch->dSlab);
   if (batch->hSlab) (void)hipHostFree(batch->hSlab);
+  if (batch->optStream) { (void)hipStreamSynchronize(batch->optStream); (void)hipStreamDestroy(batch->optStream); }
+  if (batch->evOptIn) (void)hipEventDestroy(batch->evOptIn);
+  if (batch->evOptOut) (void)hipEventDestroy(batch->evOptOut);
   if (batch->dOptTab) (void)hipFree(batch->dOptTab);
   if (batch->hOptTab) (void)hipHostFree(batch->hOptTab);
   if (batch->stream) (void)hipStreamDestroy(batch->stream);
@@ -1733,6 +1741,11 @@ int pcabo_batch_set_workers(pcabo_batch* batch, int workers) {
 // is bit-identical to the same run in a stand-alone context with default options.  Not during a call on this batch.
 int pcabo_batch_set_option(pcabo_batch* batch, int option, int value) {
   if (!batch) return PCABO_ERR_ARG;
+  if (option == PCABO_OPT_LBFGSB_CUS) {
+    if (value < 0 || value > 1024) return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_set_option: PCABO_OPT_LBFGSB_CUS takes 0 .. 1024 (%s%d)", "", value);
+    batch->opt_cus = value;
+    return PCABO_OK;
+  }
   if (option == PCABO_OPT_DEVICE_LBFGSB) {
     if (value < 0 || value > 2) return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_set_option: PCABO_OPT_DEVICE_LBFGSB takes 0, 1 or 2 (%s%d)", "", value);
     batch->dev_lbfgsb = value;
@@ -1923,17 +1936,30 @@ static int batch_put_best_f(pcabo_batch* batch, const double* best_f) {
   return PCABO_OK;
 }
 
-int pcabo_batch_gp_condition_end_eval(pcabo_batch* batch, const double* Xq, int q, const double* best_f, int maximize,
-                                      int acq, double* val, int* status) {
+// The scoring of the raw samples in two halves: _begin packs the points, enqueues copy - scoring launch - copy back and
+// returns; _end waits for the stream and finishes (jitter retries of single runs included).  pcabo_batch_busy tells a caller
+// that drives several batches from one thread when _end (or any other waiting call) would return at once.
+int pcabo_batch_busy(pcabo_batch* batch) {
   if (!batch) return PCABO_ERR_ARG;
-  if (!Xq || !best_f || !val || q < 1 || q > batch->max_q || (acq != PCABO_ACQ_LOG_EI && acq != PCABO_ACQ_PI))
+  if (hipSetDevice(batch->device) != hipSuccess) return PCABO_ERR_HIP;
+  const hipError_t e = hipStreamQuery(batch->stream);
+  return e == hipErrorNotReady ? 1 : (e == hipSuccess ? 0 : PCABO_ERR_HIP);
+}
+
+static int batch_score_impl(pcabo_batch* batch, const double* Xq, int q, const double* best_f, int maximize,
+                            int acq, double* val, int* status, int phase /* 0 both, 1 begin, 2 end */) {
+  if (!batch) return PCABO_ERR_ARG;
+  if (!Xq || !best_f || (!val && phase != 1) || q < 1 || q > batch->max_q || (acq != PCABO_ACQ_LOG_EI && acq != PCABO_ACQ_PI))
     return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_gp_condition_end_eval: bad argument%s", "");
   if (!batch->gp_pending) return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_gp_condition_end_eval: no conditioning in flight%s", "");
+  if (phase == 2 && !batch->score_enqueued) return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_gp_condition_end_eval_end: no _begin before it%s", "");
+  if (phase != 2 && batch->score_enqueued) return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_gp_condition_end_eval: a scoring is already enqueued%s", "");
   if (batch->wpca_uncollected) { int rc = pcabo_batch_wpca_results(batch, nullptr, nullptr, nullptr, nullptr, nullptr); if (rc != PCABO_OK) return rc; }
   BHIPCHK(hipSetDevice(batch->device));
   hipStream_t s = batch->stream;
   const int B = batch->B, kmax = batch_max_k(batch);
   pcabo_ctx* c0 = batch->ctx[0];
+  if (phase != 2) {
   for (int b = 0; b < B; ++b)
     memcpy(batch->ctx[b]->hXq, Xq + (size_t)b * q * batch->max_d, (size_t)q * batch->ctx[b]->k * sizeof(double));
   BHIPCHK(hipMemcpy2DAsync(c0->dXq, batch->zs, c0->hXq, batch->hzs, (size_t)q * kmax * sizeof(double), B, hipMemcpyHostToDevice, s));
@@ -1949,8 +1975,13 @@ int pcabo_batch_gp_condition_end_eval(pcabo_batch* batch, const double* Xq, int 
                p, c0->dPartial, c0->dCounters, c0->dVal, c0->dGrad, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
                batch_ab(batch, 0, 0), B, 0);
   BHIPCHK(hipMemcpy2DAsync(c0->hVal, batch->hzs, c0->dVal, batch->zs, (size_t)q * sizeof(double), B, hipMemcpyDeviceToHost, s));
+  BHIPCHK(hipGetLastError());
+  batch->score_enqueued = true;
+  }
+  if (phase == 1) return PCABO_OK;
   BHIPCHK(wait_stream(s));
   BHIPCHK(hipGetLastError());
+  batch->score_enqueued = false;
   batch->gp_pending = false; batch->have_gp = true;
   int worst = PCABO_OK;
   for (int b = 0; b < B; ++b) {
@@ -1984,20 +2015,39 @@ int pcabo_batch_gp_condition_end_eval(pcabo_batch* batch, const double* Xq, int 
   return PCABO_OK;
 }
 
+int pcabo_batch_gp_condition_end_eval(pcabo_batch* batch, const double* Xq, int q, const double* best_f, int maximize,
+                                      int acq, double* val, int* status) {
+  return batch_score_impl(batch, Xq, q, best_f, maximize, acq, val, status, 0);
+}
+int pcabo_batch_gp_condition_end_eval_begin(pcabo_batch* batch, const double* Xq, int q, const double* best_f, int maximize, int acq) {
+  return batch_score_impl(batch, Xq, q, best_f, maximize, acq, nullptr, nullptr, 1);
+}
+int pcabo_batch_gp_condition_end_eval_end(pcabo_batch* batch, const double* Xq, int q, const double* best_f, int maximize,
+                                          int acq, double* val, int* status) {
+  return batch_score_impl(batch, Xq, q, best_f, maximize, acq, val, status, 2);
+}
+
 // pcabo_batch_optimize_acqf with PCABO_OPT_DEVICE_LBFGSB: every restart group's L-BFGS-B inside one launch of k_lbfgsb_group
 // (value 1), or the host's L-BFGS-B over the same kernel's evaluation-only mode, one launch per round (value 2: the twin the
 // device stepping is compared with).  Returns PCABO_OK / an error, or 1 when the call is not eligible (the caller then takes
 // the host-paced path).
 static int batch_optimize_device(pcabo_batch* batch, const double* ics, int num_restarts, int batch_limit, const double* bounds,
                                  int maxiter, int maximize, int acq, double* cand, double* vals, int* info, int* failed,
-                                 int* status) {
+                                 int* status, int phase = 0 /* 0 whole call, 1 enqueue only, 2 wait + collect */) {
   const int B = batch->B, MD = batch->max_d, kmax = batch_max_k(batch);
   const int ngroups = (num_restarts + batch_limit - 1) / batch_limit;
   pcabo_ctx* c0 = batch->ctx[0];
-  if (!lbfgsb_device_possible(batch->NP, kmax, batch_limit) || num_restarts > PCABO_INLAUNCH_MAXQ || maxiter < 1 ||
+  if (phase == 2) {
+    if (!batch->opt_enqueued || batch->opt_restarts != num_restarts || batch->opt_limit != batch_limit)
+      return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_optimize_acqf_end: no matching _begin before it%s", "");
+  } else if (batch->opt_enqueued) {
+    return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_optimize_acqf: an optimisation of this batch is already enqueued%s", "");
+  } else if (!lbfgsb_device_possible(batch->NP, kmax, batch_limit) || num_restarts > PCABO_INLAUNCH_MAXQ || maxiter < 1 ||
       batch->max_q < 64 + 8 * ngroups || (size_t)(num_restarts + 2) * kmax > (size_t)batch->max_q * MD)
     return 1;
   std::vector<int> act;
+  if (phase == 2) act = batch->opt_act;
+  else
   for (int b = 0; b < B; ++b) {
     const pcabo_ctx* c = batch->ctx[b];
     if (!batch->active[b] || !c->have_gp) continue;
@@ -2007,6 +2057,7 @@ static int batch_optimize_device(pcabo_batch* batch, const double* ics, int num_
     act.push_back(b);
   }
   hipStream_t s = batch->stream;
+  if (phase != 2)
   for (int b : act) {
     pcabo_ctx* c = batch->ctx[b];
     if (c->rt_stale) { launch_rt_build(s, c->dR, c->n, c->NP, c->ld, c->dGram); c->rt_stale = false; }
@@ -2021,15 +2072,46 @@ static int batch_optimize_device(pcabo_batch* batch, const double* ics, int num_
   };
   const size_t xq_doubles = (size_t)(num_restarts + 2) * kmax;
   const double inv_ls = 1.0 / batch->lengthscale;
-  auto launch = [&](int nent, int mode) -> int {
+  // PCABO_OPT_LBFGSB_CUS: the optimiser's work-groups take a whole CU each for milliseconds; confined to a part of the chip they
+  // leave the rest to the short kernels of the other batches of the process (conditioning, scoring)
+  hipStream_t ks = s;
+  if (batch->opt_cus > 0) {
+    if (batch->optStream && batch->optStream_cus != batch->opt_cus) {
+      (void)hipStreamSynchronize(batch->optStream); (void)hipStreamDestroy(batch->optStream); batch->optStream = nullptr;
+    }
+    if (!batch->optStream) {
+      hipDeviceProp_t prop;
+      BHIPCHK(hipGetDeviceProperties(&prop, batch->device));
+      const int total = prop.multiProcessorCount, words = (total + 31) / 32;
+      std::vector<uint32_t> mask((size_t)words, 0u);
+      for (int i = 0; i < std::min(batch->opt_cus, total); ++i) mask[i >> 5] |= 1u << (i & 31);
+      if (hipExtStreamCreateWithCUMask(&batch->optStream, (uint32_t)words, mask.data()) != hipSuccess) {
+        (void)hipGetLastError();
+        batch->optStream = nullptr;
+        return bset_err(batch, PCABO_ERR_HIP, "PCABO_OPT_LBFGSB_CUS: a stream with a CU mask could not be created (%s%d CUs)", "", batch->opt_cus);
+      }
+      batch->optStream_cus = batch->opt_cus;
+      if (!batch->evOptIn) { BHIPCHK(hipEventCreateWithFlags(&batch->evOptIn, hipEventDisableTiming)); BHIPCHK(hipEventCreateWithFlags(&batch->evOptOut, hipEventDisableTiming)); }
+    }
+    ks = batch->optStream;
+  }
+  auto enqueue = [&](int nent, int mode) -> int {
     BHIPCHK(hipMemcpyAsync(batch->dOptTab, batch->hOptTab, (size_t)nent * sizeof(unsigned), hipMemcpyHostToDevice, s));
     BHIPCHK(hipMemcpy2DAsync(c0->dXq, batch->zs, c0->hXq, batch->hzs, xq_doubles * sizeof(double), B, hipMemcpyHostToDevice, s));
-    if (launch_lbfgsb_group(s, batch->dOptTab, nent, mode, num_restarts, maxiter, batch->n, batch->NP, c0->ld, c0->dXq, c0->dZnT,
+    if (ks != s) { BHIPCHK(hipEventRecord(batch->evOptIn, s)); BHIPCHK(hipStreamWaitEvent(ks, batch->evOptIn, 0)); }
+    if (launch_lbfgsb_group(ks, batch->dOptTab, nent, mode, num_restarts, maxiter, batch->n, batch->NP, c0->ld, c0->dXq, c0->dZnT,
                             c0->dR, c0->dGram, c0->dAlpha, c0->dBounds4, c0->dYstats, c0->dBestF, c0->dK, inv_ls, maximize ? 1 : 0,
                             acq, batch->kernel, c0->dGrad, c0->dVal, batch->zs) != 0)
       return bset_err(batch, PCABO_ERR_HIP, "the device-resident optimiser could not be launched%s", "");
+    if (ks != s) { BHIPCHK(hipEventRecord(batch->evOptOut, ks)); BHIPCHK(hipStreamWaitEvent(s, batch->evOptOut, 0)); }
     BHIPCHK(hipMemcpy2DAsync(c0->hVal, batch->hzs, c0->dVal, batch->zs, (size_t)(64 + 8 * ngroups) * sizeof(double), B, hipMemcpyDeviceToHost, s));
     BHIPCHK(hipMemcpy2DAsync(c0->hGrad, batch->hzs, c0->dGrad, batch->zs, (size_t)num_restarts * kmax * sizeof(double), B, hipMemcpyDeviceToHost, s));
+    BHIPCHK(hipGetLastError());
+    return PCABO_OK;
+  };
+  auto launch = [&](int nent, int mode) -> int {
+    const int rc = enqueue(nent, mode);
+    if (rc != PCABO_OK) return rc;
     BHIPCHK(wait_stream(s));
     BHIPCHK(hipGetLastError());
     return PCABO_OK;
@@ -2038,6 +2120,7 @@ static int batch_optimize_device(pcabo_batch* batch, const double* ics, int num_
   if (batch->dev_lbfgsb == 1) {
     // ---- everything on the device
     int nent = 0;
+    if (phase != 2) {
     for (size_t blk = 0; blk < act.size(); blk += 8)          // both groups of a run on one XCD (work-groups go round the 8 XCDs)
       for (int gi = 0; gi < ngroups; ++gi)
         for (size_t r = blk; r < std::min(act.size(), blk + 8); ++r) {
@@ -2050,7 +2133,13 @@ static int batch_optimize_device(pcabo_batch* batch, const double* ics, int num_
       memcpy(c->hXq, ics + (size_t)b * num_restarts * MD, (size_t)num_restarts * k * sizeof(double));
       memcpy(c->hXq + (size_t)num_restarts * k, bounds + (size_t)b * 2 * MD, (size_t)2 * k * sizeof(double));
     }
-    if (nent > 0) { const int rc = launch(nent, 1); if (rc != PCABO_OK) return rc; }
+    if (nent > 0) { const int rc = enqueue(nent, 1); if (rc != PCABO_OK) return rc; }
+    batch->opt_act = act; batch->opt_restarts = num_restarts; batch->opt_limit = batch_limit; batch->opt_enqueued = true;
+    }
+    if (phase == 1) return PCABO_OK;
+    batch->opt_enqueued = false;
+    BHIPCHK(wait_stream(s));
+    BHIPCHK(hipGetLastError());
     for (int b : act) {
       const pcabo_ctx* c = batch->ctx[b];
       const int k = c->k;
@@ -2071,6 +2160,7 @@ static int batch_optimize_device(pcabo_batch* batch, const double* ics, int num_
     fill_status(run_status);
     return PCABO_OK;
   }
+  if (phase != 0) return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_optimize_acqf_begin / _end need PCABO_OPT_DEVICE_LBFGSB = 1%s", "");
   // ---- the twin: host L-BFGS-B (csrc/lbfgsb.cpp), evaluations through mode 0 of the same kernel, one launch per round
   std::vector<std::vector<RestartGroup>> groups(B);
   for (int b : act) {
@@ -2336,6 +2426,31 @@ int pcabo_batch_optimize_acqf(pcabo_batch* batch, const double* ics, int num_res
     if (status) status[b] = run_status[b];
   }
   return PCABO_OK;
+}
+
+// pcabo_batch_optimize_acqf in two halves for callers that drive several batches from one thread (PCABO_OPT_DEVICE_LBFGSB = 1
+// only: the whole optimisation is one launch, so _begin returns as soon as it is enqueued).  _begin returns PCABO_OK, an error,
+// or 1 when the call does not qualify for the device-resident optimiser - the caller then uses pcabo_batch_optimize_acqf.
+int pcabo_batch_optimize_acqf_begin(pcabo_batch* batch, const double* ics, int num_restarts, int batch_limit,
+                                    const double* bounds, int maxiter, const double* best_f, int maximize, int acq) {
+  if (!batch) return PCABO_ERR_ARG;
+  if (!ics || !bounds || !best_f || num_restarts < 1 || batch_limit < 1 || num_restarts > PCABO_INLAUNCH_MAXQ ||
+      (acq != PCABO_ACQ_LOG_EI && acq != PCABO_ACQ_PI))
+    return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_optimize_acqf_begin: bad argument (num_restarts <= 32)%s", "");
+  if (!batch->have_gp) return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_optimize_acqf_begin: no conditioned GP%s", "");
+  if (batch->dev_lbfgsb != 1) return 1;
+  BHIPCHK(hipSetDevice(batch->device));
+  const int rc = batch_put_best_f(batch, best_f);
+  if (rc != PCABO_OK) return rc;
+  return batch_optimize_device(batch, ics, num_restarts, batch_limit, bounds, maxiter, maximize, acq, nullptr, nullptr, nullptr,
+                               nullptr, nullptr, 1);
+}
+int pcabo_batch_optimize_acqf_end(pcabo_batch* batch, int num_restarts, int batch_limit, double* cand, double* vals, int* info,
+                                  int* failed, int* status) {
+  if (!batch || !cand || !vals) return PCABO_ERR_ARG;
+  BHIPCHK(hipSetDevice(batch->device));
+  return batch_optimize_device(batch, nullptr, num_restarts, batch_limit, nullptr, 1, 0, PCABO_ACQ_LOG_EI, cand, vals, info, failed,
+                               status, 2);
 }
 
 // Value and gradient of the acquisition at q <= 32 points per run through the evaluation of the device-resident optimiser

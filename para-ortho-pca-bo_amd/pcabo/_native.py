@@ -16,7 +16,7 @@ ABI_VERSION = 1
 KERNEL_MATERN52, KERNEL_RBF = 0, 1
 ACQ_LOG_EI, ACQ_PI = 0, 1
 PTR_HOST, PTR_DEVICE = 0, 1
-OPT_RESIDENT, OPT_BESTF_F32, OPT_GROUP_ACQ, OPT_DEVICE_LBFGSB = 0, 1, 2, 3
+OPT_RESIDENT, OPT_BESTF_F32, OPT_GROUP_ACQ, OPT_DEVICE_LBFGSB, OPT_LBFGSB_CUS = 0, 1, 2, 3, 4
 PROFILE_GROUPS = ("wpca", "gram", "cholesky", "root_inverse_alpha", "acq_partial", "acq_large_batches")
 
 # Hardware queues.  A Batch drives the GPU from several worker threads on separate HIP streams (its gangs): the runtime's
@@ -53,6 +53,8 @@ EXPORTS = [
     "pcabo_batch_create", "pcabo_batch_destroy", "pcabo_batch_last_error", "pcabo_batch_ctx",
     "pcabo_batch_wpca_gp_condition_begin", "pcabo_batch_wpca_results", "pcabo_batch_acq_bounds",
     "pcabo_batch_gp_condition_end_eval", "pcabo_batch_optimize_acqf", "pcabo_batch_inverse_map", "pcabo_batch_device_acq_eval",
+    "pcabo_batch_busy", "pcabo_batch_gp_condition_end_eval_begin", "pcabo_batch_gp_condition_end_eval_end",
+    "pcabo_batch_optimize_acqf_begin", "pcabo_batch_optimize_acqf_end",
     "pcabo_batch_set_profiling", "pcabo_batch_get_profile", "pcabo_batch_set_active", "pcabo_batch_set_workers", "pcabo_batch_set_option",
     "pcabo_bbob_table_doubles", "pcabo_bbob_create", "pcabo_bbob_destroy", "pcabo_bbob_eval",
     "pcabo_comm_unique_id", "pcabo_comm_create", "pcabo_gather_best", "pcabo_comm_last_error", "pcabo_comm_destroy",
@@ -130,6 +132,11 @@ def _load() -> C.CDLL:
     lib.pcabo_batch_optimize_acqf.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
     lib.pcabo_batch_inverse_map.argtypes = [vp, vp, vp]
     lib.pcabo_batch_device_acq_eval.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp]
+    lib.pcabo_batch_busy.argtypes = [vp]
+    lib.pcabo_batch_gp_condition_end_eval_begin.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int]
+    lib.pcabo_batch_gp_condition_end_eval_end.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp]
+    lib.pcabo_batch_optimize_acqf_begin.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int]
+    lib.pcabo_batch_optimize_acqf_end.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
     lib.pcabo_batch_set_profiling.argtypes = [vp, C.c_int]
     lib.pcabo_batch_set_active.argtypes = [vp, vp]
     lib.pcabo_batch_get_profile.argtypes = [vp, vp]
@@ -377,7 +384,7 @@ class Batch:
     rows A-H of all runs, one scoring launch, shared acquisition launches for the L-BFGS-B rounds of all runs."""
 
     def __init__(self, B: int, max_n: int, max_d: int, max_q: int = 512, device: int = 0, workers: int = 0,
-                 group_acq: bool = True, device_lbfgsb: int = 0):
+                 group_acq: bool = True, device_lbfgsb: int = 0, lbfgsb_cus: int = 0):
         self._h = C.c_void_p()
         rc = LIB.pcabo_batch_create(int(device), int(B), int(max_n), int(max_d), int(max_q), C.byref(self._h))
         if rc != 0:
@@ -397,6 +404,8 @@ class Batch:
         if device_lbfgsb:            # 1: every restart group's L-BFGS-B inside one launch; 2: its host-stepped twin (tests)
             self._chk(LIB.pcabo_batch_set_option(self._h, OPT_DEVICE_LBFGSB, int(device_lbfgsb)))
         self.device_lbfgsb = int(device_lbfgsb)
+        if lbfgsb_cus:               # the optimiser's launches confined to that many CUs (several batches of one process in flight)
+            self._chk(LIB.pcabo_batch_set_option(self._h, OPT_LBFGSB_CUS, int(lbfgsb_cus)))
         advice = hw_queues_advice(min(B, int(workers) if workers else 8) + 2)      # gang streams + the batch's + the default stream
         if advice:
             import warnings
@@ -471,6 +480,64 @@ class Batch:
         self._chk(LIB.pcabo_batch_gp_condition_end_eval(self._h, _ptr(buf), q, _ptr(bf), int(bool(maximize)), int(acq),
                                                         _ptr(val), _ptr(status)))
         return val, status
+
+    # ---- the two waiting calls in halves (one thread advancing several batches: pcabo.batchrun.run_interleaved) -------------
+    def busy(self) -> bool:
+        rc = LIB.pcabo_batch_busy(self._h)
+        if rc < 0:
+            raise PcaboError(rc, self._err())
+        return rc == 1
+
+    def gp_eval_begin(self, Xq_list, best_f, maximize=False, acq=ACQ_LOG_EI):
+        q = Xq_list[0].shape[0]
+        buf = np.zeros((self.B, q * self.max_d))
+        for b, xq in enumerate(Xq_list):
+            buf[b, : xq.size] = np.ascontiguousarray(xq, dtype=np.float64).ravel()
+        bf = _f64(best_f, (self.B,))
+        self._chk(LIB.pcabo_batch_gp_condition_end_eval_begin(self._h, _ptr(buf), q, _ptr(bf), int(bool(maximize)), int(acq)))
+        return (buf, q, bf, int(bool(maximize)), int(acq))
+
+    def gp_eval_end(self, token):
+        buf, q, bf, mx, acq = token
+        val = np.empty((self.B, q))
+        status = np.zeros(self.B, dtype=np.int32)
+        self._chk(LIB.pcabo_batch_gp_condition_end_eval_end(self._h, _ptr(buf), q, _ptr(bf), mx, acq, _ptr(val), _ptr(status)))
+        return val, status
+
+    def _pack_ics(self, ics_list, bounds_list):
+        B, MD = self.B, self.max_d
+        nr = ics_list[0].shape[0]
+        ics, bnd = np.zeros((B, nr * MD)), np.zeros((B, 2 * MD))
+        for b in range(B):
+            ics[b, : ics_list[b].size] = np.ascontiguousarray(ics_list[b], dtype=np.float64).ravel()
+            bnd[b, : bounds_list[b].size] = np.ascontiguousarray(bounds_list[b], dtype=np.float64).ravel()
+        return nr, ics, bnd
+
+    def optimize_begin(self, ics_list, bounds_list, best_f, maximize=False, acq=ACQ_LOG_EI, batch_limit=5, maxiter=200):
+        """Enqueue the device-resident optimisation; returns a token for optimize_end, or None when the call does not qualify
+        (the caller then uses optimize_acqf)."""
+        nr, ics, bnd = self._pack_ics(ics_list, bounds_list)
+        bf = _f64(best_f, (self.B,))
+        rc = LIB.pcabo_batch_optimize_acqf_begin(self._h, _ptr(ics), nr, int(batch_limit), _ptr(bnd), int(maxiter), _ptr(bf),
+                                                 int(bool(maximize)), int(acq))
+        if rc == 1:
+            return None
+        self._chk(rc)
+        return (nr, int(batch_limit))
+
+    def optimize_end(self, token):
+        nr, batch_limit = token
+        B, MD = self.B, self.max_d
+        ng = (nr + batch_limit - 1) // batch_limit
+        cand, vals = np.zeros((B, nr * MD)), np.zeros((B, nr))
+        info = np.zeros((B, ng, 4), dtype=np.int32)
+        failed, status = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
+        self._chk(LIB.pcabo_batch_optimize_acqf_end(self._h, nr, batch_limit, _ptr(cand), _ptr(vals), _ptr(info), _ptr(failed), _ptr(status)))
+        out = []
+        for b in range(B):
+            k = int(self.k[b])
+            out.append((cand[b, : nr * k].reshape(nr, k).copy(), vals[b].copy(), info[b].copy(), bool(failed[b])))
+        return out, status
 
     def optimize_acqf(self, ics_list, bounds_list, best_f, maximize=False, acq=ACQ_LOG_EI, batch_limit=5, maxiter=200):
         """ics_list[b]: num_restarts x k_b; bounds_list[b]: 2 x k_b.  Returns per run (cand, vals, info, failed) + status."""

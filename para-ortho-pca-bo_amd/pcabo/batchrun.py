@@ -39,7 +39,7 @@ class BatchedPCABO:
                  var_threshold: float = 0.95, acquisition_function: str = "expected_improvement",
                  maximization: bool = False, device: int = 0, num_restarts: int = 10, raw_samples: int = 512,
                  record_trace: bool = False, host_threads: int = 0, device_objective: bool = False, workers: int = 0,
-                 trace_filter=None, acq_kernel: str = "group"):
+                 trace_filter=None, acq_kernel: str = "group", lbfgsb_cus: int = 0):
         self.problems, self.seeds = list(problems), [int(s) for s in seeds]
         self.B = len(self.problems)
         assert self.B == len(self.seeds) and self.B >= 1
@@ -105,6 +105,7 @@ class BatchedPCABO:
             raise ValueError("acq_kernel must be 'group', 'latency', 'device' or 'device-twin'")
         self._group_acq = acq_kernel != "latency"
         self._device_lbfgsb = {"device": 1, "device-twin": 2}.get(acq_kernel, 0)
+        self._lbfgsb_cus = int(lbfgsb_cus)         # "device": the optimiser's launches confined to that many CUs (0: the whole chip)
 
     # ---- seeding + DoE (AbstractAlgorithm.py:310-328, AbstractBayesianOptimizer.py:142-176) --------------------------
     def start(self) -> None:
@@ -123,7 +124,8 @@ class BatchedPCABO:
             self._X[b, : self.n_DoE] = np.vstack(self.x_evals[b])
             self._F[b, : self.n_DoE] = self.f_evals[b]
         self._batch = _native.Batch(B, max_n=self.budget, max_d=d, max_q=max(self.raw_samples, 16), device=self.device,
-                                    workers=self._workers, group_acq=self._group_acq, device_lbfgsb=self._device_lbfgsb)
+                                    workers=self._workers, group_acq=self._group_acq, device_lbfgsb=self._device_lbfgsb,
+                                    lbfgsb_cus=self._lbfgsb_cus)
         if self._device_objective:
             from .bbob_device import DeviceObjectives
             self._dev_obj = DeviceObjectives(self.problems, device=self.device, penalty=OOB_PENALTY)
@@ -162,6 +164,13 @@ class BatchedPCABO:
 
     # ---- one lock-step BO iteration (PCA_BO.py:178-298 for every run) ------------------------------------------------
     def iteration(self) -> None:
+        for _ in self._iteration_steps():
+            pass                                  # (every wait then happens inside the library call that follows the yield)
+
+    def _iteration_steps(self):
+        """The iteration as a generator: it yields wherever the next library call would wait for the device, so that ONE host
+        thread can advance several batches (run_interleaved resumes a batch once its stream has drained).  Driven straight
+        through (iteration()) it is the blocking iteration: same calls, same order, same results."""
         B, d, n, bt = self.B, self.dimension, self.n, self._batch
         t0 = perf_counter()
         pre = {}
@@ -208,6 +217,7 @@ class BatchedPCABO:
                 engines[b] = _init.scrambled_sobol_engine(self.k_prev[b], self._tg[b])
         for b in range(B):                # (torch's small ops do not gain from the host threads: measured slower)
             guess(b)
+        yield "conditioning"
         res = bt.wpca_results()
         t2 = perf_counter()
         bounds = bt.acq_bounds()
@@ -227,7 +237,9 @@ class BatchedPCABO:
         for b in range(B):
             bt.ctx[b].match_best_f_dtype(best_f[b])
         t3 = perf_counter()
-        vals, status = bt.gp_wait_eval(raw, best_f, self.maximization, self.acq_code)
+        token = bt.gp_eval_begin(raw, best_f, self.maximization, self.acq_code)
+        yield "scoring"
+        vals, status = bt.gp_eval_end(token)
         for b in range(B):
             if self.failed[b] is None and (status[b] != 0 or not np.isfinite(vals[b]).all()):
                 self._park(b, n, "GP conditioning failed (K not positive definite)" if status[b] != 0
@@ -255,7 +267,13 @@ class BatchedPCABO:
             engines_job = self._pool.submit(build_engines)
         else:
             engines_job = None
-        outs, status = bt.optimize_acqf(ics, bounds, best_f, self.maximization, self.acq_code, batch_limit=5, maxiter=200)
+        token = bt.optimize_begin(ics, bounds, best_f, self.maximization, self.acq_code, batch_limit=5, maxiter=200) \
+            if self._device_lbfgsb == 1 else None
+        if token is not None:             # the device-resident optimiser: one launch, collected when it has drained
+            yield "optimize"
+            outs, status = bt.optimize_end(token)
+        else:
+            outs, status = bt.optimize_acqf(ics, bounds, best_f, self.maximization, self.acq_code, batch_limit=5, maxiter=200)
         if engines_job is not None:
             # botorch's retry below draws from a run's generator: a run that needs it takes its generator back first
             built = engines_job.result()
@@ -387,17 +405,80 @@ def run_side_by_side(runners: Sequence["BatchedPCABO"], started: bool = False) -
     if len(runners) == 1:
         drive(runners[0])
     else:
+        # A batch thread gives the interpreter lock away at every library call and needs it back right after: with the default
+        # switch interval (5 ms) each hand-back can wait that long for a thread that is in the middle of its bookkeeping - measured
+        # on 4 x 30 runs: the initial picks of a batch 3.5 s instead of 0.5 s.  PCABO_SWITCH_INTERVAL (seconds) overrides.
+        import os
+        import sys
+        old = sys.getswitchinterval()
+        sys.setswitchinterval(float(os.environ.get("PCABO_SWITCH_INTERVAL", "2e-4")))
         threads = [threading.Thread(target=drive, args=(r,), name=f"pcabo-batch-{i}") for i, r in enumerate(runners)]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
+        try:
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+        finally:
+            sys.setswitchinterval(old)
     if errors:
         raise errors[0]
 
 
+LAST_INTERLEAVE_STATS: dict = {}      # of the last run_interleaved call: how long the one host thread was busy, per segment
+
+
+def run_interleaved(runners: Sequence["BatchedPCABO"], started: bool = False) -> None:
+    """Advance several batches from ONE host thread: every batch is run as far as its next wait for the device
+    (_iteration_steps), then the next batch gets the interpreter; a batch is resumed once its stream has drained
+    (pcabo_batch_busy).  Made for acq_kernel = "device", where the long wait of an iteration - the L-BFGS-B phase - is a single
+    launch: the batches' host work (ranks, noise, Sobol engines, picks, bookkeeping) runs back to back without the threads'
+    fight for the interpreter lock, while up to len(runners) optimisation launches share the GPU.  Batches are independent, so
+    every run is bit-identical to the same run in any other grouping or schedule."""
+    if not started:
+        for r in runners:
+            r.start()
+    steps = {id(r): None for r in runners}
+    live = list(runners)
+    stats = LAST_INTERLEAVE_STATS
+    stats.clear()
+    stats.update({"host_busy_seconds": 0.0, "resumptions": 0, "segments": {}})
+    t_start = perf_counter()
+    try:
+        while live:
+            for r in list(live):
+                g = steps[id(r)]
+                if g is None:
+                    if r.n >= r.budget:
+                        live.remove(r)
+                        continue
+                    g = steps[id(r)] = r._iteration_steps()
+                elif r._batch.busy():
+                    continue
+                t0 = perf_counter()
+                try:
+                    where = next(g)
+                except StopIteration:
+                    steps[id(r)] = None
+                    where = "end"
+                dt = perf_counter() - t0
+                stats["host_busy_seconds"] += dt
+                stats["resumptions"] += 1
+                seg = stats["segments"].setdefault(where, [0.0, 0])
+                seg[0] += dt
+                seg[1] += 1
+        stats["wall_seconds"] = perf_counter() - t_start
+    finally:
+        for g in steps.values():
+            if g is not None:
+                g.close()
+        if not started:
+            for r in runners:
+                r.finish()
+
+
 def bench_block(device: int, B: int, fid: int, dim: int, budget_factor: int = 10, doe_factor: float = 3.0,
-                sub_batches: int = 1, workers: int = 0, acq_kernel: str = "group") -> dict:
+                sub_batches: int = 1, workers: int = 0, acq_kernel: str = "group", schedule: str = "threads",
+                lbfgsb_cus: int = 0) -> dict:
     """Aggregate BO iterations / second of B runs (instances 0..B-1 of one BBOB function and dimension, seeds per
     ExperimentRunner.py:146) advancing together on one GPU - as one lock-step batch, or as `sub_batches` lock-step batches
     side by side (run_side_by_side); DoE and set-up untimed."""
@@ -409,13 +490,32 @@ def bench_block(device: int, B: int, fid: int, dim: int, budget_factor: int = 10
         inst = list(range(t, B, S))
         subs.append(BatchedPCABO([BBOBProblem(fid, i, dim) for i in inst], [1000 * fid + 10 * dim + i for i in inst], budget, n_doe,
                                  device=device, workers=workers or (workers_for(S) if S > 1 else 0), host_threads=max(1, 8 // S),
-                                 acq_kernel=acq_kernel))
+                                 acq_kernel=acq_kernel, lbfgsb_cus=lbfgsb_cus))
     for r in subs:
         r.start()
     torch.cuda.synchronize()
     t0 = perf_counter()
     try:
-        run_side_by_side(subs, started=True)
+        if schedule.startswith("interleaved") and len(schedule) > len("interleaved"):
+            # "interleaved2", "interleaved3": that many host threads, each interleaving its share of the batches
+            import threading
+            T = max(1, min(int(schedule[len("interleaved"):]), S))
+            errs: List[BaseException] = []
+
+            def drive(part):
+                try:
+                    run_interleaved(part, started=True)
+                except BaseException as e:      # noqa: BLE001
+                    errs.append(e)
+            th = [threading.Thread(target=drive, args=(subs[t::T],)) for t in range(T)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            if errs:
+                raise errs[0]
+        else:
+            (run_interleaved if schedule == "interleaved" else run_side_by_side)(subs, started=True)
         torch.cuda.synchronize()
         dt = perf_counter() - t0
     finally:
@@ -427,7 +527,10 @@ def bench_block(device: int, B: int, fid: int, dim: int, budget_factor: int = 10
     for t, r in enumerate(subs):
         for j, i in enumerate(range(t, B, S)):
             best[i] = float(r.current_best[j])
-    return {"runs": B, "sub_batches": S, "function": fid, "dimension": dim, "budget": budget, "n_DoE": n_doe,
+    extra = {"interleave": {k: (v if not isinstance(v, dict) else {a: [round(b[0], 3), b[1]] for a, b in v.items()})
+                            for k, v in LAST_INTERLEAVE_STATS.items()}} if schedule == "interleaved" else {}
+    extra["schedule"] = schedule
+    return {**extra, "runs": B, "sub_batches": S, "function": fid, "dimension": dim, "budget": budget, "n_DoE": n_doe,
             "aggregate_bo_iterations_per_s": iters / dt, "seconds": dt, "bo_iterations": iters,
             "ms_per_lockstep_iteration": 1e3 * dt / (budget - n_doe), "host_phase_seconds": phases,
             "retries": sum(r.retries for r in subs), "failed_runs": sum(f is not None for r in subs for f in r.failed), "best_f": best,

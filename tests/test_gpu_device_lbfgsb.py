@@ -141,3 +141,26 @@ def test_device_mode_falls_back_where_it_does_not_apply(native):
         del bt
     for b in range(B):
         assert np.array_equal(outs[0][b][0], outs[1][b][0]) and np.array_equal(outs[0][b][2], outs[1][b][2])
+
+
+def test_interleaved_batches_equal_batches_run_alone(native):
+    """pcabo.batchrun.run_interleaved: three device-mode batches advanced from ONE host thread (begin / end halves of the
+    scoring and of the optimisation, pcabo_batch_busy) - every run must take, bit for bit, the path it takes in a batch that
+    runs alone with the blocking calls."""
+    from pcabo.batchrun import BatchedPCABO, run_interleaved
+    torch.set_num_threads(4)
+    fid, dim, budget, n_doe = 15, 10, 80, 30
+    groups = [[0, 1, 2], [3, 4], [5, 6, 7, 8]]
+
+    def make(insts):
+        return BatchedPCABO([BBOBProblem(fid, i, dim) for i in insts], [_seed(fid, dim, i) for i in insts], budget, n_doe,
+                            acq_kernel="device")
+    together = [make(g) for g in groups]
+    run_interleaved(together)
+    for g, rt in zip(groups, together):
+        alone = make(g)
+        alone.run()
+        for b in range(len(g)):
+            assert np.array_equal(np.vstack(rt.x_evals[b]), np.vstack(alone.x_evals[b])), (g, b)
+            assert np.array_equal(np.array(rt.f_evals[b]), np.array(alone.f_evals[b])), (g, b)
+            assert len(rt.f_evals[b]) == budget

@@ -1,7 +1,7 @@
 """Run one of BASELINE.json's multi-run configurations end to end on ONE GPU through the product's own runner
 (`ExperimentRunner(batched=30)`: the 30 instances of a (function, dimension) cell advance in lock-step) and print one
 JSON line: runs, BO iterations, wall seconds, aggregate BO iterations/s, per-dimension breakdown, IOHprofiler files written.
-    python tools/gpu_run_config.py 2 [batched] [side_by_side]     # configs[2]: f15/f16/f17 x d in {10, 20, 40} x 30 runs
+    python tools/gpu_run_config.py 2 [batched] [side_by_side] [acq_kernel]     # configs[2]: f15/f16/f17 x d in {10, 20, 40} x 30 runs
     python tools/gpu_run_config.py 3      # configs[3] on one GPU: f15-f24 x d in {20, 40} x 30 runs (the N = 1 point)"""
 import json, os, sys, tempfile, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # read by the HIP runtime at its first call: a Batch uses a stream per worker thread
@@ -12,6 +12,7 @@ from Algorithms import ExperimentRunner
 which = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 batched = int(sys.argv[2]) if len(sys.argv) > 2 else 30          # runs per lock-step batch
 side_by_side = int(sys.argv[3]) if len(sys.argv) > 3 else 2      # batches advancing at once
+acq_kernel = sys.argv[4] if len(sys.argv) > 4 else "group"       # "device": device-resident L-BFGS-B, the batches interleaved on one host thread
 fids, dims = ([15, 16, 17], [10, 20, 40]) if which == 2 else (list(range(15, 25)), [20, 40])
 torch.set_num_threads(4)
 root = tempfile.mkdtemp(prefix="pcabo_cfg%d_" % which)
@@ -19,7 +20,7 @@ per_dim = {}
 t_all = time.perf_counter()
 for dim in dims:                       # one runner call per dimension so that each gets its own clock
     er = ExperimentRunner(algorithms=["pca"], dimensions=[dim], problem_ids=fids, num_runs=30, root_dir=root,
-                          experiment_name=f"experiment-d{dim}", progress=False, batched=batched, side_by_side=side_by_side)
+                          experiment_name=f"experiment-d{dim}", progress=False, batched=batched, side_by_side=side_by_side, batch_acq_kernel=acq_kernel)
     t0 = time.perf_counter()
     er.run_experiment()
     dt = time.perf_counter() - t0
@@ -32,5 +33,5 @@ total = time.perf_counter() - t_all
 files = sum(len(f) for _, _, f in os.walk(root))
 its = sum(v["bo_iterations"] for v in per_dim.values())
 print(json.dumps({"config": f"BASELINE.json configs[{which}] on one MI355X: PCA_BO, functions {fids}, dimensions {dims}, 30 instances each, "
-                            f"ExperimentRunner(batched={batched}, side_by_side={side_by_side})", "runs": sum(v["runs"] for v in per_dim.values()), "bo_iterations": its,
+                            f"ExperimentRunner(batched={batched}, side_by_side={side_by_side}, batch_acq_kernel={acq_kernel!r})", "runs": sum(v["runs"] for v in per_dim.values()), "bo_iterations": its,
                   "seconds": total, "aggregate_bo_iterations_per_s": its / total, "per_dimension": per_dim, "files_written": files}))

@@ -283,6 +283,8 @@ int pcabo_batch_optimize_acqf_begin(pcabo_batch* batch, const double* ics, int n
                                     const double* bounds, int maxiter, const double* best_f, int maximize, int acq);
 int pcabo_batch_optimize_acqf_end(pcabo_batch* batch, int num_restarts, int batch_limit, double* cand, double* vals, int* info,
                                   int* failed, int* status);
+int pcabo_batch_inverse_map_begin(pcabo_batch* batch, const double* z);
+int pcabo_batch_inverse_map_end(pcabo_batch* batch, double* x);
 /* Park / unpark runs: active[B]; a parked run still goes through the lock-step launches of rows A-K but is skipped by
  * pcabo_batch_optimize_acqf (status PCABO_ERR_ARG).  For runs that failed the way the reference's would (botorch raises on a
  * NaN acquisition gradient, reached once the reference's unclipped out-of-box candidates have blown up the search box). */

@@ -1275,7 +1275,7 @@ __device__ __noinline__ void lb_eval(const LbLds L_, const LbEval E_, int nq, bo
   // (arguments of a function that is not inlined arrive in vector registers: made wave-uniform again here, so that loop bounds,
   // row bases and LDS addresses of the broadcasts are scalar)
   const int tid = threadIdx.x, lane = tid & 63, w = uni(tid >> 6);
-  LbLds L; L.base = (ldsd*)(unsigned)uni((int)(unsigned)(unsigned long long)L_.base); L.n = uni(L_.n); L.NP = uni(L_.NP);
+  LbLds L; L.base = (ldsd*)(__UINTPTR_TYPE__)(unsigned)uni((int)(unsigned)(__UINTPTR_TYPE__)L_.base); L.n = uni(L_.n); L.NP = uni(L_.NP);
   LbEval E;
   E.ZnT = uni(E_.ZnT); E.R = uni(E_.R); E.RT = uni(E_.RT); E.alpha = uni(E_.alpha); E.nlo = E_.nlo; E.nhi = E_.nhi;
   E.n = uni(E_.n); E.k = uni(E_.k); E.NP = uni(E_.NP); E.ld = uni(E_.ld); E.H = uni(E_.H); E.S = uni(E_.S);

@@ -1609,6 +1609,7 @@ struct pcabo_batch {
   bool prof = false; hipEvent_t pev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // phase marks of the last conditioning
   bool group_acq = true;                 // L-BFGS-B rounds through k_acq_group (pcabo_batch_set_option(PCABO_OPT_GROUP_ACQ, 0): the per-query kernels)
   bool score_enqueued = false;           // pcabo_batch_gp_condition_end_eval_begin without its _end yet
+  bool imap_enqueued = false;            // pcabo_batch_inverse_map_begin without its _end yet
   bool opt_enqueued = false; int opt_restarts = 0, opt_limit = 0; std::vector<int> opt_act;   // pcabo_batch_optimize_acqf_begin without its _end yet
   int dev_lbfgsb = 0;                    // PCABO_OPT_DEVICE_LBFGSB: 1 device-resident L-BFGS-B, 2 its host-stepped twin
   unsigned *dOptTab = nullptr, *hOptTab = nullptr;   // launch table of the device-resident optimiser (B * 32 entries)
@@ -2500,22 +2501,32 @@ int pcabo_batch_device_acq_eval(pcabo_batch* batch, const double* Xq, int q, con
   return PCABO_OK;
 }
 
-int pcabo_batch_inverse_map(pcabo_batch* batch, const double* z, double* x) {
-  if (!batch || !z || !x) return PCABO_ERR_ARG;
+static int batch_inverse_map_impl(pcabo_batch* batch, const double* z, double* x, int phase /* 0 whole call, 1 enqueue, 2 wait + collect */) {
+  if (!batch || (!z && phase != 2) || (!x && phase != 1)) return PCABO_ERR_ARG;
   if (batch->n == 0 || batch->wpca_uncollected) return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_inverse_map: no weighted PCA collected%s", "");
+  if (phase == 2 && !batch->imap_enqueued) return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_inverse_map_end: no _begin before it%s", "");
   BHIPCHK(hipSetDevice(batch->device));
   hipStream_t s = batch->stream;
   pcabo_ctx* c0 = batch->ctx[0];
   const int B = batch->B, MD = batch->max_d, d = batch->d;
-  for (int b = 0; b < B; ++b) memcpy(batch->ctx[b]->hXq, z + (size_t)b * MD, (size_t)batch->ctx[b]->k * sizeof(double));
-  BHIPCHK(hipMemcpy2DAsync(c0->dZq, batch->zs, c0->hXq, batch->hzs, (size_t)MD * sizeof(double), B, hipMemcpyHostToDevice, s));
-  launch_inverse_map(s, c0->dZq, c0->dComps, c0->dDataMean, c0->dPcaMean, 0, d, c0->dXout, c0->dK, batch_zb(batch));
-  BHIPCHK(hipMemcpy2DAsync(c0->hSmall, batch->hzs, c0->dXout, batch->zs, (size_t)d * sizeof(double), B, hipMemcpyDeviceToHost, s));
+  if (phase != 2) {
+    for (int b = 0; b < B; ++b) memcpy(batch->ctx[b]->hXq, z + (size_t)b * MD, (size_t)batch->ctx[b]->k * sizeof(double));
+    BHIPCHK(hipMemcpy2DAsync(c0->dZq, batch->zs, c0->hXq, batch->hzs, (size_t)MD * sizeof(double), B, hipMemcpyHostToDevice, s));
+    launch_inverse_map(s, c0->dZq, c0->dComps, c0->dDataMean, c0->dPcaMean, 0, d, c0->dXout, c0->dK, batch_zb(batch));
+    BHIPCHK(hipMemcpy2DAsync(c0->hSmall, batch->hzs, c0->dXout, batch->zs, (size_t)d * sizeof(double), B, hipMemcpyDeviceToHost, s));
+    BHIPCHK(hipGetLastError());
+    batch->imap_enqueued = true;
+  }
+  if (phase == 1) return PCABO_OK;
+  batch->imap_enqueued = false;
   BHIPCHK(wait_stream(s));
   BHIPCHK(hipGetLastError());
   for (int b = 0; b < B; ++b) memcpy(x + (size_t)b * d, batch->ctx[b]->hSmall, (size_t)d * sizeof(double));
   return PCABO_OK;
 }
+int pcabo_batch_inverse_map(pcabo_batch* batch, const double* z, double* x) { return batch_inverse_map_impl(batch, z, x, 0); }
+int pcabo_batch_inverse_map_begin(pcabo_batch* batch, const double* z) { return batch_inverse_map_impl(batch, z, nullptr, 1); }
+int pcabo_batch_inverse_map_end(pcabo_batch* batch, double* x) { return batch_inverse_map_impl(batch, nullptr, x, 2); }
 
 }  // extern "C"
 

@@ -54,7 +54,7 @@ EXPORTS = [
     "pcabo_batch_wpca_gp_condition_begin", "pcabo_batch_wpca_results", "pcabo_batch_acq_bounds",
     "pcabo_batch_gp_condition_end_eval", "pcabo_batch_optimize_acqf", "pcabo_batch_inverse_map", "pcabo_batch_device_acq_eval",
     "pcabo_batch_busy", "pcabo_batch_gp_condition_end_eval_begin", "pcabo_batch_gp_condition_end_eval_end",
-    "pcabo_batch_optimize_acqf_begin", "pcabo_batch_optimize_acqf_end",
+    "pcabo_batch_optimize_acqf_begin", "pcabo_batch_optimize_acqf_end", "pcabo_batch_inverse_map_begin", "pcabo_batch_inverse_map_end",
     "pcabo_batch_set_profiling", "pcabo_batch_get_profile", "pcabo_batch_set_active", "pcabo_batch_set_workers", "pcabo_batch_set_option",
     "pcabo_bbob_table_doubles", "pcabo_bbob_create", "pcabo_bbob_destroy", "pcabo_bbob_eval",
     "pcabo_comm_unique_id", "pcabo_comm_create", "pcabo_gather_best", "pcabo_comm_last_error", "pcabo_comm_destroy",
@@ -137,6 +137,8 @@ def _load() -> C.CDLL:
     lib.pcabo_batch_gp_condition_end_eval_end.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp]
     lib.pcabo_batch_optimize_acqf_begin.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int]
     lib.pcabo_batch_optimize_acqf_end.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+    lib.pcabo_batch_inverse_map_begin.argtypes = [vp, vp]
+    lib.pcabo_batch_inverse_map_end.argtypes = [vp, vp]
     lib.pcabo_batch_set_profiling.argtypes = [vp, C.c_int]
     lib.pcabo_batch_set_active.argtypes = [vp, vp]
     lib.pcabo_batch_get_profile.argtypes = [vp, vp]
@@ -593,6 +595,17 @@ class Batch:
             z[b, : zb.size] = np.asarray(zb, dtype=np.float64).ravel()
         x = np.empty((self.B, self.d))
         self._chk(LIB.pcabo_batch_inverse_map(self._h, _ptr(z), _ptr(x)))
+        return x
+
+    def inverse_map_begin(self, z_list) -> None:
+        z = np.zeros((self.B, self.max_d))
+        for b, zb in enumerate(z_list):
+            z[b, : zb.size] = np.asarray(zb, dtype=np.float64).ravel()
+        self._chk(LIB.pcabo_batch_inverse_map_begin(self._h, _ptr(z)))
+
+    def inverse_map_end(self):
+        x = np.empty((self.B, self.d))
+        self._chk(LIB.pcabo_batch_inverse_map_end(self._h, _ptr(x)))
         return x
 
 

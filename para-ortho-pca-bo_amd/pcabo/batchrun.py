@@ -315,7 +315,9 @@ class BatchedPCABO:
                                    "cands": cand.copy(), "vals": v.copy(), "info": info.copy(), "chosen": best,
                                    "retried": retried, **pre[b]})
         self.lbfgsb_info.append(infos)
-        X_new = bt.inverse_map(z_new)
+        bt.inverse_map_begin(z_new)
+        yield "inverse map"
+        X_new = bt.inverse_map_end()
         f_dev = None
         if self._dev_obj is not None and not self.maximization:
             f_dev, raw_dev, oob_dev = self._dev_obj.evaluate(X_new)

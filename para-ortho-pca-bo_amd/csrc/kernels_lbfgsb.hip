@@ -1271,6 +1271,14 @@ __device__ inline void lb_scalar_core(double vv, double mus, const LbEval& E, do
 // Every global load of a loop trip is issued before the first use (LB_UB of them in flight per thread, the next trip's while the
 // current one is consumed): one CU has to pull ~0.8 MB per triangular pass through ~1 us of L2 / Infinity Cache latency.
 #define LB_UB 16
+// element `lane8 / 8` of a row whose base is wave-uniform: (scalar base) + (32-bit lane offset) - global_load with an SGPR base, no
+// vector address arithmetic per load
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(1))) char gcc_;
+#else
+typedef const char gcc_;
+#endif
+__device__ inline double ld_row(gcd* row, unsigned lane8) { return *(gcd*)((gcc_*)row + lane8); }
 __device__ __noinline__ void lb_eval(const LbLds L_, const LbEval E_, int nq, bool want_grad) {
   // (arguments of a function that is not inlined arrive in vector registers: made wave-uniform again here, so that loop bounds,
   // row bases and LDS addresses of the broadcasts are scalar)
@@ -1295,18 +1303,31 @@ __device__ __noinline__ void lb_eval(const LbLds L_, const LbEval E_, int nq, bo
   // ---- kernel vectors: a thread per training point (the threads of pass 2's first group), all queries per pass over ZnT
   double cf[LB_GQ];
   const int hh = w / S, wsub = w - hh * S;
-  const int jmine = 64 * (S - 1 - slab_of(wsub, S)) + lane;           // this thread's column in pass 2 (hh < H)
+  const int cbu = S - 1 - slab_of(wsub, S), sbu = slab_of(wsub, S);   // wave-uniform: this wave's column block (pass 2) / row slab (pass 1)
+  const int jmine = 64 * cbu + lane;                                  // this thread's column in pass 2 (hh < H)
   if (hh == 0) {
     const int j = jmine, jj = j < n ? j : n - 1;
+    const unsigned j8 = (unsigned)jj * 8u;
     double sq[LB_GQ];
 #pragma unroll
     for (int q = 0; q < LB_GQ; ++q) { sq[q] = 0.0; cf[q] = 0.0; }
     double ksv[LB_GQ] = {0.0, 0.0, 0.0, 0.0, 0.0};
     constexpr int CB = 12;
-    for (int c0 = 0; c0 < k; c0 += CB) {
+    int c0 = 0;
+    for (; c0 + CB <= k; c0 += CB) {              // whole chunks: CB loads in flight, no guards
       double z[CB];
 #pragma unroll
-      for (int u = 0; u < CB; ++u) { const int cc = c0 + u < k ? c0 + u : k - 1; z[u] = (E.ZnT + (size_t)cc * ld)[jj]; }
+      for (int u = 0; u < CB; ++u) z[u] = ld_row(E.ZnT + (size_t)(c0 + u) * ld, j8);
+#pragma unroll
+      for (int u = 0; u < CB; ++u) {
+#pragma unroll
+        for (int q = 0; q < LB_GQ; ++q) { const double dd = L.xn()[q * XS + c0 + u] - z[u]; sq[q] = fma(dd, dd, sq[q]); }
+      }
+    }
+    {
+      double z[CB];
+#pragma unroll
+      for (int u = 0; u < CB; ++u) { const int cc = c0 + u < k ? c0 + u : k - 1; z[u] = ld_row(E.ZnT + (size_t)cc * ld, j8); }
 #pragma unroll
       for (int u = 0; u < CB; ++u) {
         if (c0 + u < k) {
@@ -1337,35 +1358,30 @@ __device__ __noinline__ void lb_eval(const LbLds L_, const LbEval E_, int nq, bo
   __syncthreads();
   LBT_NEXT(9);
   // ---- pass 1: v_q[i] = sum_j RT[j][i] ks_q[j], thread (row i, part hh of the columns)
-  const int imine = 64 * slab_of(wsub, S) + lane;
+  const int imine = 64 * sbu + lane;
   if (hh < H) {
     const int i = imine;
-    const int jtot = n < 64 * (i / 64 + 1) ? n : 64 * (i / 64 + 1);
+    const int jtot = n < 64 * (sbu + 1) ? n : 64 * (sbu + 1);
     const int J0 = (int)((long long)jtot * hh / H), J1 = (int)((long long)jtot * (hh + 1) / H);
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0;
-    gcd* rp = E.RT;                       // (uniform row base + the lane's 32-bit offset: one address register for all loads)
-    double rc[LB_UB], rn[LB_UB];
+    gcd* rp = E.RT + 64 * sbu;            // (wave-uniform row base + the lane's 32-bit offset: no address arithmetic per load)
+    const unsigned l8 = (unsigned)lane * 8u;
+    int j = J0;
+    for (; j + LB_UB <= J1; j += LB_UB) {          // whole trips: LB_UB loads in flight, no guards (the other waves of the SIMD cover the wait)
+      double rc[LB_UB];
 #pragma unroll
-    for (int u = 0; u < LB_UB; ++u) { rc[u] = 0.0; rn[u] = 0.0; }
-    if (J0 < J1) {
-#pragma unroll
-      for (int u = 0; u < LB_UB; ++u) { const int jj = J0 + u < J1 ? J0 + u : J1 - 1; rc[u] = (rp + (size_t)jj * ld)[i]; }
-    }
-    for (int j = J0; j < J1; j += LB_UB) {
-      if (j + LB_UB < J1) {
-#pragma unroll
-        for (int u = 0; u < LB_UB; ++u) { const int jj = j + LB_UB + u < J1 ? j + LB_UB + u : J1 - 1; rn[u] = (rp + (size_t)jj * ld)[i]; }
-      }
+      for (int u = 0; u < LB_UB; ++u) rc[u] = ld_row(rp + (size_t)(j + u) * ld, l8);
 #pragma unroll
       for (int u = 0; u < LB_UB; ++u) {
-        if (j + u < J1) {
-          const ldsd* kp = L.ks() + (j + u) * LB_QS;
-          const double r0 = rc[u];
-          a0 = fma(r0, kp[0], a0); a1 = fma(r0, kp[1], a1); a2 = fma(r0, kp[2], a2); a3 = fma(r0, kp[3], a3); a4 = fma(r0, kp[4], a4);
-        }
+        const ldsd* kp = L.ks() + (j + u) * LB_QS;
+        const double r0 = rc[u];
+        a0 = fma(r0, kp[0], a0); a1 = fma(r0, kp[1], a1); a2 = fma(r0, kp[2], a2); a3 = fma(r0, kp[3], a3); a4 = fma(r0, kp[4], a4);
       }
-#pragma unroll
-      for (int u = 0; u < LB_UB; ++u) rc[u] = rn[u];
+    }
+    for (; j < J1; ++j) {
+      const double r0 = ld_row(rp + (size_t)j * ld, l8);
+      const ldsd* kp = L.ks() + j * LB_QS;
+      a0 = fma(r0, kp[0], a0); a1 = fma(r0, kp[1], a1); a2 = fma(r0, kp[2], a2); a3 = fma(r0, kp[3], a3); a4 = fma(r0, kp[4], a4);
     }
     ldsd* dst = hh == 0 ? L.vb() + i * LB_QS : L.part() + ((size_t)(hh - 1) * NP + i) * LB_QS;
     dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = a3; dst[4] = a4;
@@ -1404,31 +1420,26 @@ __device__ __noinline__ void lb_eval(const LbLds L_, const LbEval E_, int nq, bo
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0;
   if (hh < H) {
     const int j = jmine;
-    const int ibeg = 64 * (j / 64), len = n > ibeg ? n - ibeg : 0;
+    const int ibeg = 64 * cbu, len = n > ibeg ? n - ibeg : 0;
     const int I0 = ibeg + (int)((long long)len * hh / H), I1 = ibeg + (int)((long long)len * (hh + 1) / H);
-    gcd* rp = E.R;
-    double rc[LB_UB], rn[LB_UB];
+    gcd* rp = E.R + ibeg;
+    const unsigned l8 = (unsigned)lane * 8u;
+    int i = I0;
+    for (; i + LB_UB <= I1; i += LB_UB) {
+      double rc[LB_UB];
 #pragma unroll
-    for (int u = 0; u < LB_UB; ++u) { rc[u] = 0.0; rn[u] = 0.0; }
-    if (I0 < I1) {
-#pragma unroll
-      for (int u = 0; u < LB_UB; ++u) { const int ii = I0 + u < I1 ? I0 + u : I1 - 1; rc[u] = (rp + (size_t)ii * ld)[j]; }
-    }
-    for (int i = I0; i < I1; i += LB_UB) {
-      if (i + LB_UB < I1) {
-#pragma unroll
-        for (int u = 0; u < LB_UB; ++u) { const int ii = i + LB_UB + u < I1 ? i + LB_UB + u : I1 - 1; rn[u] = (rp + (size_t)ii * ld)[j]; }
-      }
+      for (int u = 0; u < LB_UB; ++u) rc[u] = ld_row(rp + (size_t)(i + u) * ld, l8);
 #pragma unroll
       for (int u = 0; u < LB_UB; ++u) {
-        if (i + u < I1) {
-          const ldsd* vp = L.vb() + (i + u) * LB_QS;
-          const double r0 = rc[u];
-          a0 = fma(r0, vp[0], a0); a1 = fma(r0, vp[1], a1); a2 = fma(r0, vp[2], a2); a3 = fma(r0, vp[3], a3); a4 = fma(r0, vp[4], a4);
-        }
+        const ldsd* vp = L.vb() + (i + u) * LB_QS;
+        const double r0 = rc[u];
+        a0 = fma(r0, vp[0], a0); a1 = fma(r0, vp[1], a1); a2 = fma(r0, vp[2], a2); a3 = fma(r0, vp[3], a3); a4 = fma(r0, vp[4], a4);
       }
-#pragma unroll
-      for (int u = 0; u < LB_UB; ++u) rc[u] = rn[u];
+    }
+    for (; i < I1; ++i) {
+      const double r0 = ld_row(rp + (size_t)i * ld, l8);
+      const ldsd* vp = L.vb() + i * LB_QS;
+      a0 = fma(r0, vp[0], a0); a1 = fma(r0, vp[1], a1); a2 = fma(r0, vp[2], a2); a3 = fma(r0, vp[3], a3); a4 = fma(r0, vp[4], a4);
     }
     if (hh > 0) {
       ldsd* dst = L.part() + ((size_t)(hh - 1) * NP + j) * LB_QS;
@@ -1443,7 +1454,7 @@ __device__ __noinline__ void lb_eval(const LbLds L_, const LbEval E_, int nq, bo
   for (int ci = 0; ci < CW; ++ci) {
     const int c = w + 16 * ci, cc = c < k ? c : k - 1;
 #pragma unroll
-    for (int bq = 0; bq < NB; ++bq) { const int j = lane + 64 * bq; z[ci][bq] = (E.ZnT + (size_t)cc * ld)[j < n ? j : n - 1]; }
+    for (int bq = 0; bq < NB; ++bq) { const int j = lane + 64 * bq; z[ci][bq] = ld_row(E.ZnT + (size_t)cc * ld, (unsigned)(j < n ? j : n - 1) * 8u); }
   }
   __syncthreads();
   LBT_NEXT(12);

@@ -407,21 +407,13 @@ def run_side_by_side(runners: Sequence["BatchedPCABO"], started: bool = False) -
     if len(runners) == 1:
         drive(runners[0])
     else:
-        # A batch thread gives the interpreter lock away at every library call and needs it back right after: with the default
-        # switch interval (5 ms) each hand-back can wait that long for a thread that is in the middle of its bookkeeping - measured
-        # on 4 x 30 runs: the initial picks of a batch 3.5 s instead of 0.5 s.  PCABO_SWITCH_INTERVAL (seconds) overrides.
-        import os
-        import sys
-        old = sys.getswitchinterval()
-        sys.setswitchinterval(float(os.environ.get("PCABO_SWITCH_INTERVAL", "2e-4")))
+        # (the interpreter's switch interval makes no difference here - 5 ms, 0.2 ms, 0.02 ms measured on 4 x 30 runs: what the
+        # threads wait for is each other's bookkeeping, see run_interleaved)
         threads = [threading.Thread(target=drive, args=(r,), name=f"pcabo-batch-{i}") for i, r in enumerate(runners)]
-        try:
-            for t in threads:
-                t.start()
-            for t in threads:
-                t.join()
-        finally:
-            sys.setswitchinterval(old)
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
     if errors:
         raise errors[0]
 

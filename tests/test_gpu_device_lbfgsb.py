@@ -164,3 +164,39 @@ def test_interleaved_batches_equal_batches_run_alone(native):
             assert np.array_equal(np.vstack(rt.x_evals[b]), np.vstack(alone.x_evals[b])), (g, b)
             assert np.array_equal(np.array(rt.f_evals[b]), np.array(alone.f_evals[b])), (g, b)
             assert len(rt.f_evals[b]) == budget
+
+
+def test_device_mode_blown_up_run_and_parked_run(native):
+    """The reference's unclipped candidates blow the search box of f21 / instance 25 at d = 40 up to |x| ~ 1e55
+    (tests/test_gpu_configs.py::test_blown_up_run_follows_the_oracle_to_the_end): the device-resident optimiser must carry such a
+    state like the host does - same path as the host-stepped twin, bit for bit, nothing parked; and a run parked by the caller
+    must not disturb the other runs of a device-mode batch."""
+    from pcabo.batchrun import BatchedPCABO
+    torch.set_num_threads(4)
+    fid, inst, dim, budget, n_doe = 21, 25, 40, 450, 120
+    runs = {}
+    for mode in ("device", "device-twin"):
+        r = BatchedPCABO([BBOBProblem(fid, inst, dim), BBOBProblem(15, 0, dim)], [_seed(fid, dim, inst), _seed(15, dim, 0)],
+                         budget, n_doe, acq_kernel=mode)
+        r.run()
+        assert r.failed == [None, None]
+        runs[mode] = r
+    X = np.vstack(runs["device"].x_evals[0])
+    assert np.abs(X).max() > 1e40 and np.isfinite(X).all()
+    for b in range(2):
+        assert np.array_equal(np.vstack(runs["device"].x_evals[b]), np.vstack(runs["device-twin"].x_evals[b])), b
+        assert np.array_equal(np.array(runs["device"].f_evals[b]), np.array(runs["device-twin"].f_evals[b])), b
+    # a parked run: the others take the path they take without it
+    insts = [0, 1, 2]
+    seeds = [15100 + i for i in insts]
+    r = BatchedPCABO([BBOBProblem(15, i, 10) for i in insts], seeds, 60, 30, acq_kernel="device")
+    r.start()
+    for it in range(30):
+        if it == 7:
+            r._park(1, r.n, "parked by the test")
+        r.iteration()
+    r.finish()
+    alone = BatchedPCABO([BBOBProblem(15, i, 10) for i in (0, 2)], [seeds[0], seeds[2]], 60, 30, acq_kernel="device")
+    alone.run()
+    for b, a in ((0, 0), (2, 1)):
+        assert np.array_equal(np.vstack(r.x_evals[b]), np.vstack(alone.x_evals[a])), b

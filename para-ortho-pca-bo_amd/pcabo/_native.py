@@ -492,7 +492,9 @@ class Batch:
 
     def gp_eval_begin(self, Xq_list, best_f, maximize=False, acq=ACQ_LOG_EI):
         q = Xq_list[0].shape[0]
-        buf = np.zeros((self.B, q * self.max_d))
+        buf = getattr(self, "_raw_buf", None)        # (only the first q * k_b entries of a row are read: no need to clear 5 MB per call)
+        if buf is None or buf.shape != (self.B, q * self.max_d):
+            buf = self._raw_buf = np.zeros((self.B, q * self.max_d))
         for b, xq in enumerate(Xq_list):
             buf[b, : xq.size] = np.ascontiguousarray(xq, dtype=np.float64).ravel()
         bf = _f64(best_f, (self.B,))

@@ -30,6 +30,17 @@ NOISE = 0.006737946999085467         # exp(-5)
 OOB_PENALTY = 1000
 
 
+class _Share:
+    """One run's part of a pool job that returns {run: value} (looks like the future of that part)."""
+    __slots__ = ("job", "key")
+
+    def __init__(self, job, key):
+        self.job, self.key = job, key
+
+    def result(self):
+        return self.job.result()[self.key]
+
+
 class BatchedPCABO:
     """`problems[b]`: ioh-like objects (`.bounds.lb/.ub`, `.meta_data.n_variables`, callable) of ONE dimension;
     `seeds[b]`: the run's seed (ExperimentRunner.py:146).  After `run()`: `x_evals[b]`, `f_evals[b]`, `current_best[b]`,
@@ -129,13 +140,13 @@ class BatchedPCABO:
         if self._device_objective:
             from .bbob_device import DeviceObjectives
             self._dev_obj = DeviceObjectives(self.problems, device=self.device, penalty=OOB_PENALTY)
-        if self._host_threads > 1:
-            from concurrent.futures import ThreadPoolExecutor
-            self._pool = ThreadPoolExecutor(max_workers=self._host_threads)
+        # (a pool of ONE thread still pays: next iteration's noise blocks and Sobol engines are made beside the L-BFGS-B phase)
+        from concurrent.futures import ThreadPoolExecutor
+        self._pool = ThreadPoolExecutor(max_workers=max(1, self._host_threads))
 
     def _each(self, fn):
         """fn(b) for every run, on the host threads."""
-        if self._pool is None:
+        if self._pool is None or self._host_threads <= 1:
             return [fn(b) for b in range(self.B)]
         return list(self._pool.map(fn, range(self.B)))
 
@@ -181,16 +192,15 @@ class BatchedPCABO:
                               "best_f": self.current_best[b]}
         self._pre_states = pre            # (kept on the object: still there when a run stops in this iteration)
         F = np.ascontiguousarray(self._F[:, :n])      # B x n (a parked run: its finite stand-in, see _park)
-        ranks = np.empty((B, n), dtype=np.int64)
+        # ranks as the reference forms them per run (PCA_BO.py:330-333; the penalty value repeats, so how numpy's unstable sort
+        # orders ties matters): argsort along the rows of the B x n array sorts every row with the routine a 1-D array gets - the
+        # same permutation, ties included (checked on 6 000 rows with repeated values; the bit-for-bit tests compare whole runs)
+        ranks = np.argsort(np.argsort(-F if self.maximization else F, axis=1), axis=1).astype(np.int64) + 1
         noise = np.empty((B, n, d))
 
         ahead, self._noise_ahead = self._noise_ahead, {}
 
         def prep(b):
-            # per run, on a 1-D array exactly as the reference does it (PCA_BO.py:330-333): the penalty value repeats, and
-            # how numpy's unstable sort orders ties must be what the run sees alone
-            fb = F[b].copy()
-            ranks[b] = np.argsort(np.argsort(-fb if self.maximization else fb)) + 1
             fut = ahead.get(b)
             if fut is not None:
                 nz = fut.result()
@@ -199,7 +209,11 @@ class BatchedPCABO:
                 noise[b] = nz
             else:
                 noise[b] = self._rs[b].normal(0, 1e-8, size=(n, d))                   # PCA_BO.py:376, the run's own stream
-        self._each(prep)
+        if len(ahead) == B:                        # all drawn ahead: nothing left that a pool thread would do faster
+            for b in range(B):
+                prep(b)
+        else:
+            self._each(prep)
         t1 = perf_counter()
         bt.wpca_gp_condition_begin(self._X[:, :n], ranks, noise, F, maximize=self.maximization,
                                    var_threshold=self.var_threshold, n_components=self.n_components,
@@ -248,14 +262,27 @@ class BatchedPCABO:
                 vals[b] = np.linspace(0.0, 1.0, vals.shape[1])          # anything finite: the pick below is discarded
         t4 = perf_counter()
         pick = _init.initialize_q_batch if self.acq_code == _native.ACQ_LOG_EI else _init.initialize_q_batch_nonneg
-        idx = [pick(vals[b], self.num_restarts, generator=self._tg[b]) if self.failed[b] is None
-               else np.arange(self.num_restarts) for b in range(B)]
+        if self.acq_code == _native.ACQ_LOG_EI:   # all runs' Boltzmann weights at once, a run's own generator for its draw
+            idx = _init.initialize_q_batch_rows(vals, self.num_restarts, self._tg,
+                                                skip=[b for b in range(B) if self.failed[b] is not None])
+        else:
+            idx = [pick(vals[b], self.num_restarts, generator=self._tg[b]) if self.failed[b] is None
+                   else np.arange(self.num_restarts) for b in range(B)]
         ics = [raw[b][idx[b]] for b in range(B)]
         t5 = perf_counter()
         if self._pool is not None and not self.record_trace and n + 1 < self.budget:
-            for b in range(B):
-                if self.failed[b] is None:
-                    self._noise_ahead[b] = self._pool.submit(self._rs[b].normal, 0, 1e-8, (n + 1, d))
+            # one task per pool thread, each drawing the blocks of its share of the runs (a submit per run cost the host thread
+            # 0.7 ms per iteration at 30 runs); every run's block comes from its own stream, so the grouping changes nothing
+            alive = [b for b in range(B) if self.failed[b] is None]
+            T = max(1, min(self._host_threads, len(alive)))
+            for t in range(T):
+                mine = alive[t::T]
+
+                def draw_many(mine=mine, shape=(n + 1, d)):
+                    return {b: self._rs[b].normal(0, 1e-8, shape) for b in mine}
+                job = self._pool.submit(draw_many)
+                for b in mine:
+                    self._noise_ahead[b] = _Share(job, b)
             live = [b for b in range(B) if self.failed[b] is None and self.k_prev[b]]
 
             def build_engines():

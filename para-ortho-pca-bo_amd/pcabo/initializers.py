@@ -97,6 +97,48 @@ def initialize_q_batch(acq_vals: np.ndarray, n: int, eta: float = INIT_ETA, gene
     return idcs
 
 
+def initialize_q_batch_rows(acq_vals: np.ndarray, n: int, generators, eta: float = INIT_ETA, skip=None):
+    """initialize_q_batch for every row of acq_vals (B x n_samples, one run per row, its own generator): the statistics that are
+    bit-identical row-wise and on the 2-D tensor (mean, arg-max, the element-wise weights) are formed for all rows at once, the
+    standard deviation - torch's 2-D reduction rounds it differently - and the multinomial draw per row.  Returns what B calls
+    of initialize_q_batch return (rows listed in `skip` get arange(n) without touching their generator)."""
+    v = torch.from_numpy(np.ascontiguousarray(acq_vals, dtype=np.float64))
+    B, n_samples = v.shape
+    skip = set(skip or ())
+    if n > n_samples:
+        raise RuntimeError(f"n ({n}) cannot be larger than the number of provided samples ({n_samples})")
+    if n == n_samples:
+        return [np.arange(n) for _ in range(B)]
+    std = torch.stack([v[b].std(dim=0) for b in range(B)])
+    mean = v.mean(dim=1)
+    max_idx = torch.max(v, dim=1)[1]
+    safe = torch.where(std == 0.0, torch.ones_like(std), std)
+    weights = torch.exp(eta * ((v - mean[:, None]) / safe[:, None]))
+    check = eta * (n_samples - 1) / math.sqrt(n_samples) >= 700.0
+    out = []
+    for b in range(B):
+        if b in skip:
+            out.append(np.arange(n))
+            continue
+        if float(std[b]) == 0.0:
+            warnings.warn("All acquisition values for raw samples points are the same. "
+                          "Choosing initial conditions at random.", RuntimeWarning)
+            out.append(torch.randperm(n=n_samples, generator=generators[b])[:n].numpy())
+            continue
+        w = weights[b]
+        if check:
+            eta_z = eta * ((v[b] - mean[b]) / std[b])
+            while bool(torch.isinf(w).any()):
+                eta_z = eta_z * 0.5
+                w = torch.exp(eta_z)
+        idcs = torch.multinomial(w, n, generator=generators[b]).numpy()
+        mi = int(max_idx[b])
+        if mi not in idcs:
+            idcs[-1] = mi
+        out.append(idcs)
+    return out
+
+
 def initialize_q_batch_nonneg(acq_vals: np.ndarray, n: int, eta: float = 1.0, alpha: float = 1e-4,
                               generator=None) -> np.ndarray:
     """Variant botorch uses for non-negative acquisitions (probability of improvement)."""

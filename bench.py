@@ -385,11 +385,14 @@ def main():
                     "retries", "failed_runs")
             big = batchrun.bench_block(device, 4 * args.batch, FID, DIM, sub_batches=4)
             dev = batchrun.bench_block(device, 4 * args.batch, FID, DIM, sub_batches=4, acq_kernel="device", schedule="interleaved")
+            dev2 = batchrun.bench_block(device, 8 * args.batch, FID, DIM, sub_batches=4, acq_kernel="device", schedule="interleaved")
             batch["four_batches_host_paced"] = {k: big[k] for k in keys}
             batch["four_batches_device_resident"] = {**{k: dev[k] for k in keys}, "host_thread_busy_seconds": dev["interleave"]["host_busy_seconds"],
                                                      "note": "pcabo.batchrun.run_interleaved + acq_kernel='device' (PCABO_OPT_DEVICE_LBFGSB = 1); a run "
                                                              "is bit-identical to the same run with the host's L-BFGS-B over the same evaluation "
                                                              "kernel (tests/test_gpu_device_lbfgsb.py)"}
+            batch["four_double_batches_device_resident"] = {**{k: dev2[k] for k in keys},
+                                                            "host_thread_busy_seconds": dev2["interleave"]["host_busy_seconds"]}
     if rank == 0 and size == 1 and not args.no_kchol_grid and not args.no_roofline:
         from pcabo import kchol_bench
         grid = kchol_bench.run(device, (1, 30), reps=3, big_batch=120)

@@ -30,6 +30,9 @@ def parse_arguments():
     # not in the reference: PCA_BO runs of one dimension advance in lock-step, `--batched` at a time (0: one run after the other)
     p.add_argument("--batched", type=int, default=0, help="PCA_BO runs per lock-step batch (same runs, same numbers)")
     p.add_argument("--side_by_side", type=int, default=2, help="lock-step batches advancing at once (one host thread each)")
+    p.add_argument("--batch_acq_kernel", default="group", choices=["group", "latency", "device"],
+                   help="'device': every restart group's L-BFGS-B inside one kernel launch, the batches interleaved on one host "
+                        "thread - for many runs per GPU (e.g. --batched 75 --side_by_side 4)")
     return p.parse_args()
 
 
@@ -42,7 +45,7 @@ def main():
         algorithms=a.algorithms, dimensions=a.dimensions, problem_ids=a.problems, num_runs=a.runs,
         budget_factor=a.budget_factor, doe_factor=a.doe_factor, root_dir=os.getcwd(), experiment_name=a.experiment_dir,
         acquisition_function=a.acquisition, pca_components=0, var_threshold=a.var_threshold, verbose=a.verbose,
-        progress=(rank == 0), batched=a.batched, side_by_side=a.side_by_side)
+        progress=(rank == 0), batched=a.batched, side_by_side=a.side_by_side, batch_acq_kernel=a.batch_acq_kernel)
     t0 = time.time()
     experiment.run_experiment()
     dt = time.time() - t0

@@ -95,8 +95,9 @@ class ExperimentRunner:
         # side_by_side: that many lock-step batches advance at once, one host thread each (pcabo.batchrun.run_side_by_side):
         # one batch's host-paced L-BFGS-B rounds overlap the other's launches and bookkeeping.  Same runs, same numbers.
         self.side_by_side = max(1, int(side_by_side))
-        # pcabo.batchrun.BatchedPCABO(acq_kernel=...): "group" (host-paced L-BFGS-B rounds, the default), "latency", or "device"
-        # (device-resident L-BFGS-B: pays from ~100 runs in flight, e.g. batched=30, side_by_side=4)
+        # pcabo.batchrun.BatchedPCABO(acq_kernel=...): "group" (host-paced L-BFGS-B rounds, the default), "latency", "device"
+        # (device-resident L-BFGS-B: pays from ~100 runs in flight, e.g. batched=75, side_by_side=4) or "auto" (per dimension:
+        # "device" in four large batches when this rank has >= 100 runs of it and d <= 40, "group" otherwise)
         self.batch_acq_kernel = batch_acq_kernel
 
         self.triggers = [ALWAYS]
@@ -163,29 +164,41 @@ class ExperimentRunner:
         from pcabo.bbob import BBOBProblem
         from pcabo.iohlog import LoggedProblem
         mine = self._my_runs()
-        chunks = []
+        groups = []                          # lists of (dim, runs of one batch, kernel): the batches of a list advance together
         for dim in sorted({r[1] for r in mine}, key=self.dimensions.index):
+            cell = [r for r in mine if r[1] == dim]
+            kernel = self.batch_acq_kernel
+            if kernel == "auto":
+                # many runs of one dimension on this GPU: the optimiser on the device, FOUR large batches interleaved on one host
+                # thread (measured best: bigger batches win, more than four at once do not - DESIGN.md 8b); few runs: host-paced
+                kernel = "device" if len(cell) >= 100 and dim <= 40 else "group"
+                if kernel == "device":
+                    per = -(-len(cell) // (4 * -(-len(cell) // 480)))          # <= 120 runs per batch, a multiple of four batches
+                    parts = [cell[i:i + per] for i in range(0, len(cell), per)]
+                    groups += [[(dim, part, kernel) for part in parts[i:i + 4]] for i in range(0, len(parts), 4)]
+                    continue
             # the runs of a dimension are divided EVENLY over a multiple of `side_by_side` batches of about `batched` runs
             # (a lone last batch would advance with nothing beside it; larger batches amortise the rounds of the slowest
             # restart better: 90 runs with batched=30, side_by_side=2 go as 2 x 45 rather than 30 + 30 | 30)
-            cell = [r for r in mine if r[1] == dim]
-            chunks += [(dim, part) for part in split_evenly(cell, self.batched, self.side_by_side)]
-        for i in range(0, len(chunks), self.side_by_side):
-            group = chunks[i:i + self.side_by_side]
+            parts = split_evenly(cell, self.batched, self.side_by_side)
+            groups += [[(dim, part, kernel) for part in parts[i:i + self.side_by_side]]
+                       for i in range(0, len(parts), self.side_by_side)]
+        for group in groups:
             jobs = []
-            for dim, chunk in group:
+            for dim, chunk, kernel in group:
                 probs = [BBOBProblem(pid, inst, dim) for pid, _, inst in chunk]
                 budget, n_doe = self.budget_factor * dim + 50, int(self.doe_factor * dim)
                 seeds = [1000 * pid + 10 * dim + inst for pid, _, inst in chunk]
                 runner = BatchedPCABO(probs, seeds, budget, n_doe, n_components=self.pca_components or 0,
                                       var_threshold=self.var_threshold, acquisition_function=self.acquisition_function,
                                       device=self.device, workers=workers_for(len(group)) if len(group) > 1 else 0,
-                                      host_threads=max(1, 8 // len(group)), acq_kernel=self.batch_acq_kernel)
+                                      host_threads=max(1, 8 // len(group)), acq_kernel=kernel)
                 jobs.append((dim, chunk, probs, n_doe, runner))
+            kernel = group[0][2]
             start_time = time()
             # "device": every batch's L-BFGS-B phase is one launch - one host thread interleaves the batches of the group
             # (pcabo.batchrun.run_interleaved); otherwise a host thread per batch
-            (run_interleaved if self.batch_acq_kernel == "device" else run_side_by_side)([j[4] for j in jobs])
+            (run_interleaved if kernel == "device" else run_side_by_side)([j[4] for j in jobs])
             elapsed = (time() - start_time) / sum(len(j[1]) for j in jobs)          # a run's share of its group of batches
             # the reference's three phase timers (PCA_BO.py:65), as a run's share of its batch's host clock: the
             # conditioning is enqueued together with the wPCA ("pca"), its wait falls into the optimiser's time as in

@@ -30,7 +30,7 @@ def parse_arguments():
     # not in the reference: PCA_BO runs of one dimension advance in lock-step, `--batched` at a time (0: one run after the other)
     p.add_argument("--batched", type=int, default=0, help="PCA_BO runs per lock-step batch (same runs, same numbers)")
     p.add_argument("--side_by_side", type=int, default=2, help="lock-step batches advancing at once (one host thread each)")
-    p.add_argument("--batch_acq_kernel", default="group", choices=["group", "latency", "device"],
+    p.add_argument("--batch_acq_kernel", default="group", choices=["group", "latency", "device", "auto"],
                    help="'device': every restart group's L-BFGS-B inside one kernel launch, the batches interleaved on one host "
                         "thread - for many runs per GPU (e.g. --batched 75 --side_by_side 4)")
     return p.parse_args()

@@ -200,3 +200,23 @@ def test_device_mode_blown_up_run_and_parked_run(native):
     alone.run()
     for b, a in ((0, 0), (2, 1)):
         assert np.array_equal(np.vstack(r.x_evals[b]), np.vstack(alone.x_evals[a])), b
+
+
+def test_experiment_runner_in_device_mode(native, tmp_path):
+    """ExperimentRunner(batch_acq_kernel="device"): the reference's runner surface over device-mode batches interleaved on one
+    host thread; the results and the IOHprofiler files do not depend on how the runs are grouped into batches."""
+    import os
+    from Algorithms import ExperimentRunner
+    outs = []
+    for tag, batched, sbs in (("a", 3, 2), ("b", 6, 1)):
+        root = tmp_path / tag
+        er = ExperimentRunner(algorithms=["pca"], dimensions=[5], problem_ids=[15, 20], num_runs=3, budget_factor=5, doe_factor=2.0,
+                              root_dir=str(root), experiment_name="experiment", progress=False, batched=batched, side_by_side=sbs,
+                              batch_acq_kernel="device")
+        er.run_experiment()
+        assert len(er.results) == 6 and not er.failed_runs
+        outs.append((root, sorted((r["problem_id"], r["instance"], r["best"]) for r in er.results)))
+    assert outs[0][1] == outs[1][1]
+    for fid, name in ((15, "RastriginRotated"), (20, "Schwefel")):
+        rel = os.path.join("pca-experiment", f"data_f{fid}_{name}", f"IOHprofiler_f{fid}_DIM5.dat")
+        assert open(os.path.join(outs[0][0], rel)).read() == open(os.path.join(outs[1][0], rel)).read()

@@ -220,3 +220,16 @@ def test_experiment_runner_in_device_mode(native, tmp_path):
     for fid, name in ((15, "RastriginRotated"), (20, "Schwefel")):
         rel = os.path.join("pca-experiment", f"data_f{fid}_{name}", f"IOHprofiler_f{fid}_DIM5.dat")
         assert open(os.path.join(outs[0][0], rel)).read() == open(os.path.join(outs[1][0], rel)).read()
+
+
+def test_device_stepping_with_probability_of_improvement(native):
+    """The other acquisition of the reference's surface (PCA_BO.py:653-677: "probability_of_improvement") through the device-resident
+    optimiser: same bits as the host-stepped twin (PI's gradient has no sigma term of its own: another branch of the scalar chain)."""
+    torch.set_num_threads(4)
+    fid, dim, budget, n_doe, B = 15, 10, 70, 30, 3
+    dev = _run(fid, list(range(B)), dim, budget, n_doe, "device", acquisition_function="probability_of_improvement")
+    twin = _run(fid, list(range(B)), dim, budget, n_doe, "device-twin", acquisition_function="probability_of_improvement")
+    for b in range(B):
+        assert np.array_equal(np.vstack(dev.x_evals[b]), np.vstack(twin.x_evals[b])), b
+        assert np.array_equal(np.array(dev.f_evals[b]), np.array(twin.f_evals[b])), b
+        assert len(dev.f_evals[b]) == budget

@@ -251,6 +251,9 @@ pcabo_ctx* pcabo_batch_ctx(pcabo_batch* batch, int b);
 
 /* Rows A-H of all runs as one enqueue (pcabo_wpca_gp_condition_begin for B runs).  X[B][n*d], ranks[B][n], noise[B][n*d] or
  * NULL, y[B][n].  Returns after the enqueue; pcabo_batch_wpca_results waits for the wPCA part only. */
+/* Doubles between the blocks of two runs in the X / noise / y arrays handed to pcabo_batch_wpca_gp_condition_begin (0 = dense,
+ * the default: n*d, n*d, n).  A driver that keeps X as [B][budget][d] passes budget*d and saves a dense copy per iteration. */
+int pcabo_batch_set_input_strides(pcabo_batch* batch, size_t x_stride, size_t noise_stride, size_t y_stride);
 int pcabo_batch_wpca_gp_condition_begin(pcabo_batch* batch, const double* X, const int64_t* ranks, const double* noise,
                                         const double* y, int n, int d, int maximize, double var_threshold,
                                         int n_components, double lengthscale, double gp_noise, int kernel);

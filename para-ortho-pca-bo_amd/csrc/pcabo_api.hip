@@ -1608,6 +1608,7 @@ struct pcabo_batch {
   int cnt_S = 0; bool cnt_dirty = true;
   bool prof = false; hipEvent_t pev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // phase marks of the last conditioning
   bool group_acq = true;                 // L-BFGS-B rounds through k_acq_group (pcabo_batch_set_option(PCABO_OPT_GROUP_ACQ, 0): the per-query kernels)
+  size_t in_stride_x = 0, in_stride_noise = 0, in_stride_y = 0;   // pcabo_batch_set_input_strides (doubles between two runs' blocks; 0: dense)
   bool score_enqueued = false;           // pcabo_batch_gp_condition_end_eval_begin without its _end yet
   bool imap_enqueued = false;            // pcabo_batch_inverse_map_begin without its _end yet
   bool opt_enqueued = false; int opt_restarts = 0, opt_limit = 0; std::vector<int> opt_act;   // pcabo_batch_optimize_acqf_begin without its _end yet
@@ -1795,6 +1796,15 @@ pcabo_ctx* pcabo_batch_ctx(pcabo_batch* batch, int b) {
   return batch->ctx[b];
 }
 
+// X, noise and y of pcabo_batch_wpca_gp_condition_begin as they lie in the caller's own arrays: doubles between the blocks of two
+// runs (0 = dense, the default).  A driver that keeps X as [B][budget][d] and y as [B][budget] hands the first n rows of every run
+// over without building a dense copy per iteration.
+int pcabo_batch_set_input_strides(pcabo_batch* batch, size_t x_stride, size_t noise_stride, size_t y_stride) {
+  if (!batch) return PCABO_ERR_ARG;
+  batch->in_stride_x = x_stride; batch->in_stride_noise = noise_stride; batch->in_stride_y = y_stride;
+  return PCABO_OK;
+}
+
 int pcabo_batch_wpca_gp_condition_begin(pcabo_batch* batch, const double* X, const int64_t* ranks, const double* noise,
                                         const double* y, int n, int d, int maximize, double var_threshold,
                                         int n_components, double lengthscale, double gp_noise, int kernel) {
@@ -1810,12 +1820,16 @@ int pcabo_batch_wpca_gp_condition_begin(pcabo_batch* batch, const double* X, con
   const size_t nd = (size_t)n * d;
   // pack [X | noise | ranks | y] of every run into its pinned block; ONE strided copy carries all runs
   const size_t off_noise = nd, off_r = noise ? 2 * nd : nd, off_y = off_r + n, total = off_y + n;
+  const size_t sx = batch->in_stride_x ? batch->in_stride_x : nd, sn = batch->in_stride_noise ? batch->in_stride_noise : nd;
+  const size_t sy = batch->in_stride_y ? batch->in_stride_y : (size_t)n;
+  if (sx < nd || sn < nd || sy < (size_t)n)
+    return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_wpca_gp_condition_begin: an input stride is smaller than a run's block%s", "");
   for (int b = 0; b < B; ++b) {
     double* h = batch->ctx[b]->hIn;
-    memcpy(h, X + (size_t)b * nd, nd * sizeof(double));
-    if (noise) memcpy(h + off_noise, noise + (size_t)b * nd, nd * sizeof(double));
+    memcpy(h, X + (size_t)b * sx, nd * sizeof(double));
+    if (noise) memcpy(h + off_noise, noise + (size_t)b * sn, nd * sizeof(double));
     memcpy(h + off_r, ranks + (size_t)b * n, (size_t)n * 8);
-    memcpy(h + off_y, y + (size_t)b * n, (size_t)n * sizeof(double));
+    memcpy(h + off_y, y + (size_t)b * sy, (size_t)n * sizeof(double));
   }
   BHIPCHK(hipMemcpy2DAsync(c0->dIn, batch->zs, c0->hIn, batch->hzs, total * sizeof(double), B, hipMemcpyHostToDevice, s));
   const double* inX = c0->dIn;

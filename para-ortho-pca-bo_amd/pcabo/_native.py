@@ -55,6 +55,7 @@ EXPORTS = [
     "pcabo_batch_gp_condition_end_eval", "pcabo_batch_optimize_acqf", "pcabo_batch_inverse_map", "pcabo_batch_device_acq_eval",
     "pcabo_batch_busy", "pcabo_batch_gp_condition_end_eval_begin", "pcabo_batch_gp_condition_end_eval_end",
     "pcabo_batch_optimize_acqf_begin", "pcabo_batch_optimize_acqf_end", "pcabo_batch_inverse_map_begin", "pcabo_batch_inverse_map_end",
+    "pcabo_batch_set_input_strides",
     "pcabo_batch_set_profiling", "pcabo_batch_get_profile", "pcabo_batch_set_active", "pcabo_batch_set_workers", "pcabo_batch_set_option",
     "pcabo_bbob_table_doubles", "pcabo_bbob_create", "pcabo_bbob_destroy", "pcabo_bbob_eval",
     "pcabo_comm_unique_id", "pcabo_comm_create", "pcabo_gather_best", "pcabo_comm_last_error", "pcabo_comm_destroy",
@@ -138,6 +139,7 @@ def _load() -> C.CDLL:
     lib.pcabo_batch_optimize_acqf_begin.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int]
     lib.pcabo_batch_optimize_acqf_end.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
     lib.pcabo_batch_inverse_map_begin.argtypes = [vp, vp]
+    lib.pcabo_batch_set_input_strides.argtypes = [vp, C.c_size_t, C.c_size_t, C.c_size_t]
     lib.pcabo_batch_inverse_map_end.argtypes = [vp, vp]
     lib.pcabo_batch_set_profiling.argtypes = [vp, C.c_int]
     lib.pcabo_batch_set_active.argtypes = [vp, vp]
@@ -444,12 +446,29 @@ class Batch:
     def wpca_gp_condition_begin(self, X, ranks, noise, y, maximize=False, var_threshold=0.95, n_components=0,
                                 lengthscale=0.6931471805599453, gp_noise=0.006737946999085467, kernel=KERNEL_MATERN52):
         """X[B,n,d], ranks[B,n] (int64), noise[B,n,d] or None, y[B,n]: enqueue rows A-H of every run."""
-        X = _f64(X)
+        X = np.asarray(X, dtype=np.float64)
         B, n, d = X.shape
         assert B == self.B
         ranks = np.ascontiguousarray(ranks, dtype=np.int64).reshape(B, n)
-        nz = None if noise is None else _f64(noise, (B, n, d))
-        y = _f64(y, (B, n))
+        y = np.asarray(y, dtype=np.float64).reshape(B, n)
+
+        def block(a, row):          # the runs' blocks as they lie in the caller's array: a stride instead of a dense copy
+            if a is None:
+                return None, 0
+            a = np.asarray(a, dtype=np.float64)
+            item = a.itemsize
+            inner_ok = all(a.strides[i] == item * int(np.prod(a.shape[i + 1:])) for i in range(1, a.ndim))
+            if a.dtype == np.float64 and inner_ok and a.strides[0] % item == 0 and a.strides[0] // item >= row:
+                return a, a.strides[0] // item
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            return a, row
+        X, sx = block(X, n * d)
+        nz, sn = block(noise, n * d)
+        y, sy = block(y, n)
+        strides = (0 if sx == n * d else sx, 0 if sn == n * d else sn, 0 if sy == n else sy)
+        if strides != getattr(self, "_in_strides", (0, 0, 0)):
+            self._chk(LIB.pcabo_batch_set_input_strides(self._h, *strides))
+            self._in_strides = strides
         self._chk(LIB.pcabo_batch_wpca_gp_condition_begin(self._h, _ptr(X), _ptr(ranks), _ptr(nz), _ptr(y), n, d,
                                                           int(bool(maximize)), float(var_threshold), int(n_components),
                                                           float(lengthscale), float(gp_noise), int(kernel)))
@@ -492,13 +511,22 @@ class Batch:
             raise PcaboError(rc, self._err())
         return rc == 1
 
+    def raw_row_buffer(self, q: int) -> np.ndarray:
+        """The (B, q * max_d) buffer gp_eval_begin packs the runs' points into: a caller that writes run b's q x k_b points into
+        `buf[b, :q*k_b].reshape(q, k_b)` itself (and passes those views) saves the copy."""
+        buf = getattr(self, "_raw_buf", None)
+        if buf is None or buf.shape != (self.B, q * self.max_d):
+            buf = self._raw_buf = np.zeros((self.B, q * self.max_d))
+        return buf
+
     def gp_eval_begin(self, Xq_list, best_f, maximize=False, acq=ACQ_LOG_EI):
         q = Xq_list[0].shape[0]
         buf = getattr(self, "_raw_buf", None)        # (only the first q * k_b entries of a row are read: no need to clear 5 MB per call)
         if buf is None or buf.shape != (self.B, q * self.max_d):
             buf = self._raw_buf = np.zeros((self.B, q * self.max_d))
         for b, xq in enumerate(Xq_list):
-            buf[b, : xq.size] = np.ascontiguousarray(xq, dtype=np.float64).ravel()
+            if not (isinstance(xq, np.ndarray) and xq.base is buf):       # (raw_row_buffer: the caller drew straight into the row)
+                buf[b, : xq.size] = np.ascontiguousarray(xq, dtype=np.float64).ravel()
         bf = _f64(best_f, (self.B,))
         self._chk(LIB.pcabo_batch_gp_condition_end_eval_begin(self._h, _ptr(buf), q, _ptr(bf), int(bool(maximize)), int(acq)))
         return (buf, q, bf, int(bool(maximize)), int(acq))
@@ -621,12 +649,15 @@ def sobol_scramble(state: np.ndarray, ltm: np.ndarray) -> None:
         raise PcaboError(rc, "pcabo_sobol_scramble: bad argument")
 
 
-def sobol_draw(state: np.ndarray, shift: np.ndarray, n: int, lo=None, rng=None) -> np.ndarray:
+def sobol_draw(state: np.ndarray, shift: np.ndarray, n: int, lo=None, rng=None, out=None) -> np.ndarray:
     """n points of a fresh scrambled engine ((k, 30) int64 state after `sobol_scramble`, (k,) int64 shift), optionally mapped
     into the box lo + rng * u - bit-identical to torch's SobolEngine.draw + botorch's scaling (pcabo_sobol_draw)."""
     assert state.dtype == np.int64 and shift.dtype == np.int64 and state.flags.c_contiguous and shift.flags.c_contiguous
     k = int(state.shape[0])
-    out = np.empty((int(n), k))
+    if out is None:
+        out = np.empty((int(n), k))
+    else:
+        assert out.shape == (int(n), k) and out.dtype == np.float64 and out.flags.c_contiguous
     if lo is not None:
         lo, rng = np.ascontiguousarray(lo, dtype=np.float64), np.ascontiguousarray(rng, dtype=np.float64)
     rc = LIB.pcabo_sobol_draw(_ptr(state), _ptr(shift), k, int(n), _ptr(lo), _ptr(rng), _ptr(out))

@@ -101,6 +101,7 @@ class BatchedPCABO:
         # per-run streams - nothing else draws from them after the DoE - 1.5 ms less in front of every lock-step iteration.
         # Off while per-iteration generator states are recorded (they must be the states BEFORE the draw).
         self._noise_ahead = {}
+        self._noise_next = None            # (B, n + 1, d) block the pool threads fill for the next iteration
         # likewise the scrambled Sobol engines of the next iteration (torch's two randint draws per run, 0.06 ms each and
         # serial under the interpreter lock): built by one pool thread with THIS iteration's k as the guess while the main
         # thread sits in pcabo_batch_optimize_acqf (which releases the lock).  The draws leave each run's torch generator
@@ -150,8 +151,17 @@ class BatchedPCABO:
             return [fn(b) for b in range(self.B)]
         return list(self._pool.map(fn, range(self.B)))
 
-    def _assign_new_best(self, b: int) -> None:
+    def _assign_new_best(self, b: int, appended: bool = False) -> None:
+        """AbstractBayesianOptimizer.assign_new_best (:196-208): best = min / max of f_evals, its index searched from the previous
+        best index.  `appended`: only the last value is new - the same result without walking the list (a strictly better value
+        is the new best at the last index; anything else leaves both as they are)."""
         f = self.f_evals[b]
+        if appended and len(f) > 1:
+            new, cur = f[-1], self.current_best[b]
+            if (new > cur) if self.maximization else (new < cur):
+                self.current_best[b] = new
+                self.current_best_index[b] = len(f) - 1
+            return
         self.current_best[b] = max(f) if self.maximization else min(f)
         self.current_best_index[b] = f.index(self.current_best[b], self.current_best_index[b])
 
@@ -196,9 +206,11 @@ class BatchedPCABO:
         # orders ties matters): argsort along the rows of the B x n array sorts every row with the routine a 1-D array gets - the
         # same permutation, ties included (checked on 6 000 rows with repeated values; the bit-for-bit tests compare whole runs)
         ranks = np.argsort(np.argsort(-F if self.maximization else F, axis=1), axis=1).astype(np.int64) + 1
-        noise = np.empty((B, n, d))
-
         ahead, self._noise_ahead = self._noise_ahead, {}
+        # (all blocks drawn ahead: the pool threads have written them into _noise_next themselves - no copy on this thread)
+        noise = self._noise_next if (len(ahead) == B and self._noise_next is not None and self._noise_next.shape == (B, n, d)) \
+            else np.empty((B, n, d))
+        self._noise_next = None
 
         def prep(b):
             fut = ahead.get(b)
@@ -206,7 +218,8 @@ class BatchedPCABO:
                 nz = fut.result()
                 if nz.shape != (n, d):
                     raise RuntimeError("noise drawn ahead is out of step with the run")
-                noise[b] = nz
+                if nz.base is not noise:
+                    noise[b] = nz
             else:
                 noise[b] = self._rs[b].normal(0, 1e-8, size=(n, d))                   # PCA_BO.py:376, the run's own stream
         if len(ahead) == B:                        # all drawn ahead: nothing left that a pool thread would do faster
@@ -215,7 +228,7 @@ class BatchedPCABO:
         else:
             self._each(prep)
         t1 = perf_counter()
-        bt.wpca_gp_condition_begin(self._X[:, :n], ranks, noise, F, maximize=self.maximization,
+        bt.wpca_gp_condition_begin(self._X[:, :n], ranks, noise, self._F[:, :n], maximize=self.maximization,
                                    var_threshold=self.var_threshold, n_components=self.n_components,
                                    lengthscale=LENGTHSCALE, gp_noise=NOISE)
         # while the device runs the eigen-decompositions: the scrambled Sobol engines, with last iteration's k
@@ -236,6 +249,7 @@ class BatchedPCABO:
         t2 = perf_counter()
         bounds = bt.acq_bounds()
         raw = [None] * B
+        rawbuf = bt.raw_row_buffer(self.raw_samples)      # the runs' raw samples are drawn straight into the rows the scoring packs
 
         def draw(b):
             if engines[b] is not None and res[b]["k"] != self.k_prev[b]:
@@ -244,7 +258,9 @@ class BatchedPCABO:
             if engines[b] is None:
                 engines[b] = _init.scrambled_sobol_engine(res[b]["k"], self._tg[b])
             self.k_prev[b] = res[b]["k"]
-            raw[b] = _init.draw_sobol(bounds[b], self.raw_samples, engines[b])
+            kb = res[b]["k"]
+            raw[b] = _init.draw_sobol(bounds[b], self.raw_samples, engines[b],
+                                      out=rawbuf[b, : self.raw_samples * kb].reshape(self.raw_samples, kb))
         for b in range(B):
             draw(b)
         best_f = [self.current_best[b] for b in range(B)]
@@ -274,12 +290,19 @@ class BatchedPCABO:
             # one task per pool thread, each drawing the blocks of its share of the runs (a submit per run cost the host thread
             # 0.7 ms per iteration at 30 runs); every run's block comes from its own stream, so the grouping changes nothing
             alive = [b for b in range(B) if self.failed[b] is None]
+            nxt = self._noise_next = np.empty((B, n + 1, d)) if len(alive) == B else None
+            if nxt is None:
+                nxt = np.empty((B, n + 1, d))
             T = max(1, min(self._host_threads, len(alive)))
             for t in range(T):
                 mine = alive[t::T]
 
-                def draw_many(mine=mine, shape=(n + 1, d)):
-                    return {b: self._rs[b].normal(0, 1e-8, shape) for b in mine}
+                def draw_many(mine=mine, shape=(n + 1, d), dest=nxt):
+                    out = {}
+                    for b in mine:
+                        dest[b] = self._rs[b].normal(0, 1e-8, shape)
+                        out[b] = dest[b]
+                    return out
                 job = self._pool.submit(draw_many)
                 for b in mine:
                     self._noise_ahead[b] = _Share(job, b)
@@ -363,7 +386,7 @@ class BatchedPCABO:
                 self.f_evals[b].append(new_f)
                 self._X[b, n] = new_x
                 self._F[b, n] = new_f
-                self._assign_new_best(b)
+                self._assign_new_best(b, appended=True)
                 continue
             outside = not np.all(new_x >= self.bounds[b][:, 0]) or not np.all(new_x <= self.bounds[b][:, 1])
             # out-of-box candidates are not evaluated; they cost budget and a fixed penalty (PCA_BO.py:260-263)
@@ -372,7 +395,7 @@ class BatchedPCABO:
             self.f_evals[b].append(new_f)
             self._X[b, n] = new_x
             self._F[b, n] = new_f
-            self._assign_new_best(b)
+            self._assign_new_best(b, appended=True)
         t7 = perf_counter()
         tm = self.timing
         tm["host_prep"] += t1 - t0

@@ -58,14 +58,14 @@ def scrambled_sobol_engine(k: int, generator=None) -> ScrambledSobol:
     return ScrambledSobol(k, state, shift)
 
 
-def draw_sobol(bounds: np.ndarray, n: int, engine=None) -> np.ndarray:
+def draw_sobol(bounds: np.ndarray, n: int, engine=None, out=None) -> np.ndarray:
     """botorch `draw_sobol_samples(bounds, n, q=1, seed=None)` -> n x k points inside `bounds` (2 x k).
     `engine`: a fresh engine from `scrambled_sobol_engine(k)` built earlier (same RNG consumption, earlier in time)."""
     from . import _native
     k = bounds.shape[1]
     if engine is None:
         engine = scrambled_sobol_engine(k)
-    return _native.sobol_draw(engine.state, engine.shift, n, bounds[0], bounds[1] - bounds[0])
+    return _native.sobol_draw(engine.state, engine.shift, n, bounds[0], bounds[1] - bounds[0], out=out)
 
 
 @torch.inference_mode()

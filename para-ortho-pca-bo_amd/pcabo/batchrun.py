@@ -522,7 +522,7 @@ def run_interleaved(runners: Sequence["BatchedPCABO"], started: bool = False) ->
 
 def bench_block(device: int, B: int, fid: int, dim: int, budget_factor: int = 10, doe_factor: float = 3.0,
                 sub_batches: int = 1, workers: int = 0, acq_kernel: str = "group", schedule: str = "threads",
-                lbfgsb_cus: int = 0) -> dict:
+                lbfgsb_cus: int = 0, device_objective: bool = False) -> dict:
     """Aggregate BO iterations / second of B runs (instances 0..B-1 of one BBOB function and dimension, seeds per
     ExperimentRunner.py:146) advancing together on one GPU - as one lock-step batch, or as `sub_batches` lock-step batches
     side by side (run_side_by_side); DoE and set-up untimed."""
@@ -534,7 +534,7 @@ def bench_block(device: int, B: int, fid: int, dim: int, budget_factor: int = 10
         inst = list(range(t, B, S))
         subs.append(BatchedPCABO([BBOBProblem(fid, i, dim) for i in inst], [1000 * fid + 10 * dim + i for i in inst], budget, n_doe,
                                  device=device, workers=workers or (workers_for(S) if S > 1 else 0), host_threads=max(1, 8 // S),
-                                 acq_kernel=acq_kernel, lbfgsb_cus=lbfgsb_cus))
+                                 acq_kernel=acq_kernel, lbfgsb_cus=lbfgsb_cus, device_objective=device_objective))
     for r in subs:
         r.start()
     torch.cuda.synchronize()
@@ -574,6 +574,7 @@ def bench_block(device: int, B: int, fid: int, dim: int, budget_factor: int = 10
     extra = {"interleave": {k: (v if not isinstance(v, dict) else {a: [round(b[0], 3), b[1]] for a, b in v.items()})
                             for k, v in LAST_INTERLEAVE_STATS.items()}} if schedule == "interleaved" else {}
     extra["schedule"] = schedule
+    extra["device_objective"] = bool(device_objective)
     return {**extra, "runs": B, "sub_batches": S, "function": fid, "dimension": dim, "budget": budget, "n_DoE": n_doe,
             "aggregate_bo_iterations_per_s": iters / dt, "seconds": dt, "bo_iterations": iters,
             "ms_per_lockstep_iteration": 1e3 * dt / (budget - n_doe), "host_phase_seconds": phases,

@@ -26,8 +26,7 @@
 #include <cfloat>
 #include <cmath>
 #include <mutex>
-
-#define PCABO_ERR_NAN_CODE (-4)      // PCABO_ERR_NAN of include/pcabo.h
+#include "../../include/pcabo.h"      // PCABO_ERR_NAN
 
 #define LB_M 10
 #define LB_THREADS 1024
@@ -1570,7 +1569,7 @@ __global__ __launch_bounds__(LB_THREADS) void k_lbfgsb_group(
       bool nan = false;
       for (int i = lane; i < nv; i += 64) { const double gv = L.g()[i]; nan = nan || (gv != gv); }
       if (__ballot(nan)) {
-        if (lane == 0) { ISC(I_STATUS) = PCABO_ERR_NAN_CODE; ISC(I_ACTIVE) = 0; }
+        if (lane == 0) { ISC(I_STATUS) = PCABO_ERR_NAN; ISC(I_ACTIVE) = 0; }
       } else {
         double fs = 0.0;
         for (int q = 0; q < nq; ++q) fs += L.vals()[q];

@@ -257,6 +257,12 @@ int pcabo_batch_set_input_strides(pcabo_batch* batch, size_t x_stride, size_t no
 int pcabo_batch_wpca_gp_condition_begin(pcabo_batch* batch, const double* X, const int64_t* ranks, const double* noise,
                                         const double* y, int n, int d, int maximize, double var_threshold,
                                         int n_components, double lengthscale, double gp_noise, int kernel);
+/* Rows D-H of all runs without the weighted PCA (pcabo_gp_condition_begin for B runs): the reference's Vanilla_BO conditions its
+ * GP on the raw d-dimensional points with Normalize switched off (Vanilla_BO.py:166-196) - the caller passes identity bounds.
+ * Z[B][n*k], y[B][n] (strides: pcabo_batch_set_input_strides), norm_bounds[2*k] (lo[k], hi[k], the same for every run) or NULL
+ * (bounds from the data, as for PCA_BO).  Continue with pcabo_batch_gp_condition_end_eval / pcabo_batch_optimize_acqf. */
+int pcabo_batch_gp_condition_begin(pcabo_batch* batch, const double* Z, const double* y, int n, int k, const double* norm_bounds,
+                                   double lengthscale, double gp_noise, int kernel);
 /* data_mean[B][d], pca_mean[B][d], comps[B][d*d] (the first min(n,d)*d entries of each block), evr[B][d], k[B]; any may be NULL */
 int pcabo_batch_wpca_results(pcabo_batch* batch, double* data_mean, double* pca_mean, double* comps, double* evr, int* k);
 /* Row J for every run: bounds[B][2*max_d], run b's block holds lo[k_b] then hi[k_b]. */

@@ -157,10 +157,11 @@ class ExperimentRunner:
         for pid, dim, inst in mine:
             yield LoggedProblem(BBOBProblem(pid, inst, dim), logger)
 
-    def _run_pca_batched(self, logger, ebar) -> None:
-        """This rank's PCA_BO runs, `self.batched` runs of one dimension at a time in lock-step (pcabo.batchrun),
-        `self.side_by_side` such batches at once."""
-        from pcabo.batchrun import BatchedPCABO, run_interleaved, run_side_by_side, workers_for
+    def _run_batched(self, logger, ebar, algorithm: str = "pca") -> None:
+        """This rank's runs of one algorithm, `self.batched` runs of one dimension at a time in lock-step (pcabo.batchrun:
+        BatchedPCABO / BatchedVanillaBO), `self.side_by_side` such batches at once."""
+        from pcabo.batchrun import BatchedPCABO, BatchedVanillaBO, run_interleaved, run_side_by_side, workers_for
+        Driver = BatchedVanillaBO if algorithm == "vanilla" else BatchedPCABO
         from pcabo.bbob import BBOBProblem
         from pcabo.iohlog import LoggedProblem
         mine = self._my_runs()
@@ -189,7 +190,7 @@ class ExperimentRunner:
                 probs = [BBOBProblem(pid, inst, dim) for pid, _, inst in chunk]
                 budget, n_doe = self.budget_factor * dim + 50, int(self.doe_factor * dim)
                 seeds = [1000 * pid + 10 * dim + inst for pid, _, inst in chunk]
-                runner = BatchedPCABO(probs, seeds, budget, n_doe, n_components=self.pca_components or 0,
+                runner = Driver(probs, seeds, budget, n_doe, n_components=self.pca_components or 0,
                                       var_threshold=self.var_threshold, acquisition_function=self.acquisition_function,
                                       device=self.device, workers=workers_for(len(group)) if len(group) > 1 else 0,
                                       host_threads=max(1, 8 // len(group)), acq_kernel=kernel)
@@ -206,6 +207,8 @@ class ExperimentRunner:
             shares = {id(j[4]): {"pca": (j[4].timing["host_prep"] + j[4].timing["pca"]) / len(j[1]), "SingleTaskGP": 0.0,
                                  "optimize_acqf": (j[4].timing["wait_score"] + j[4].timing["init_pick"] +
                                                    j[4].timing["lbfgsb"]) / len(j[1])} for j in jobs}
+            if algorithm == "vanilla":       # Vanilla_BO.TIME_PROFILES: the enqueue of the conditioning is its "SingleTaskGP"
+                shares = {key: {"SingleTaskGP": v["pca"], "optimize_acqf": v["optimize_acqf"]} for key, v in shares.items()}
             for dim, chunk, probs, n_doe, runner in jobs:
                 for b, (pid, _, inst) in enumerate(chunk):
                     replay = LoggedProblem(BBOBProblem(pid, inst, dim), logger)     # the run's rows, in its own order
@@ -215,7 +218,7 @@ class ExperimentRunner:
                     for name, seconds in shares[id(runner)].items():
                         logger.set_run_attribute(f"{name}_time", seconds)
                     done = len(runner.f_evals[b]) - n_doe
-                    self.results.append({"algorithm": "pca", "problem_id": pid, "dim": dim, "instance": inst,
+                    self.results.append({"algorithm": algorithm, "problem_id": pid, "dim": dim, "instance": inst,
                                          "best": min(runner.f_evals[b]), "time": elapsed, "iterations": done,
                                          **shares[id(runner)]})
                     if runner.failed[b] is not None:
@@ -255,13 +258,13 @@ class ExperimentRunner:
                     logger.add_run_attribute(f"{time_profile}_time", 0.0)
                 logger.add_run_attribute("time", 0.0)
 
-                if algorithm == "pca" and self.batched > 1 and HAVE_IOH:     # pragma: no cover
+                if self.batched > 1 and HAVE_IOH:     # pragma: no cover
                     import warnings
                     warnings.warn("batched > 1 is ignored while `ioh` is installed: the lock-step driver evaluates the in-repo "
                                   "BBOB problems (pcabo.bbob) and replays a run's rows into the logger afterwards; the runs "
                                   "go one at a time through ioh's own suite and Analyzer instead.", RuntimeWarning)
-                if algorithm == "pca" and self.batched > 1 and not HAVE_IOH:
-                    self._run_pca_batched(logger, ebar)
+                if self.batched > 1 and not HAVE_IOH:
+                    self._run_batched(logger, ebar, algorithm)
                     logger.close()
                     continue
                 for problem in self._problems(logger):

@@ -1888,6 +1888,72 @@ int pcabo_batch_wpca_gp_condition_begin(pcabo_batch* batch, const double* X, con
   return PCABO_OK;
 }
 
+// Rows D-H for every run WITHOUT the weighted PCA: the GPs live on the given points (pcabo_gp_condition_begin for B runs; the
+// reference's Vanilla_BO, Vanilla_BO.py:166-196, conditions on the raw d-dimensional points with Normalize switched off - the
+// caller passes identity bounds).  Z[B][n*k] and y[B][n] (strides: pcabo_batch_set_input_strides), norm_bounds[2*k] for all runs
+// (lo[k], hi[k]) or NULL (bounds from the data as for PCA_BO).  Finish with pcabo_batch_gp_condition_end_eval.
+int pcabo_batch_gp_condition_begin(pcabo_batch* batch, const double* Z, const double* y, int n, int k, const double* norm_bounds,
+                                   double lengthscale, double gp_noise, int kernel) {
+  if (!batch) return PCABO_ERR_ARG;
+  pcabo_ctx* c0 = batch->ctx[0];
+  if (!Z || !y || n < 2 || n > batch->max_n || k < 1 || k > batch->max_d || !gp_args_ok(c0, n, lengthscale, gp_noise, kernel))
+    return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_gp_condition_begin: bad argument or size beyond the batch's capacity%s", "");
+  if (batch->gp_pending) return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_gp_condition_begin: a conditioning is in flight%s", "");
+  BHIPCHK(hipSetDevice(batch->device));
+  hipStream_t s = batch->stream;
+  const int B = batch->B;
+  const size_t nk = (size_t)n * k, off_y = nk, total = nk + n;
+  const size_t sx = batch->in_stride_x ? batch->in_stride_x : nk, sy = batch->in_stride_y ? batch->in_stride_y : (size_t)n;
+  if (sx < nk || sy < (size_t)n)
+    return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_gp_condition_begin: an input stride is smaller than a run's block%s", "");
+  for (int b = 0; b < B; ++b) {
+    pcabo_ctx* c = batch->ctx[b];
+    memcpy(c->hIn, Z + (size_t)b * sx, nk * sizeof(double));
+    memcpy(c->hIn + off_y, y + (size_t)b * sy, (size_t)n * sizeof(double));
+    c->hm->k = k;
+    if (norm_bounds) memcpy(c->hSmall, norm_bounds, (size_t)2 * k * sizeof(double));
+  }
+  BHIPCHK(hipMemcpy2DAsync(c0->dIn, batch->zs, c0->hIn, batch->hzs, total * sizeof(double), B, hipMemcpyHostToDevice, s));
+  BHIPCHK(hipMemcpy2DAsync(c0->dK, batch->zs, &c0->hm->k, batch->hzs, sizeof(int), B, hipMemcpyHostToDevice, s));
+  if (norm_bounds)
+    BHIPCHK(hipMemcpy2DAsync(c0->dUserNB, batch->zs, c0->hSmall, batch->hzs, (size_t)2 * k * sizeof(double), B, hipMemcpyHostToDevice, s));
+  const double* inZ = c0->dIn;
+  const double* inY = c0->dIn + off_y;
+  const ZB zb = batch_zb(batch);
+  auto mark = [&](int i) { if (batch->prof) (void)hipEventRecord(batch->pev[i], s); };
+  mark(0);
+  const int NP = round_up(n, PCABO_BS);
+  if (acq_slabs(NP) != batch->cnt_S || batch->cnt_dirty) {
+    BHIPCHK(hipMemset2DAsync(c0->dCounters, batch->zs, 0, (PCABO_CNT_DONE + 1) * sizeof(unsigned int), B, s));
+    batch->cnt_S = acq_slabs(NP); batch->cnt_dirty = false;
+  }
+  mark(1);
+  launch_zstats(s, inZ, inY, n, -1, norm_bounds ? c0->dUserNB : nullptr, c0->dBounds4, c0->dZnMean, c0->dYstats, c0->dYs, c0->hm, c0->dK, zb);
+  BHIPCHK(hipEventRecord(batch->evBounds, s));
+  BHIPCHK(hipEventRecord(batch->evPca, s));
+  launch_znorm(s, inZ, n, -1, NP, 0, c0->ld, c0->dBounds4, c0->dZnMean, 1.0 / lengthscale, c0->dZnT, c0->dAT, c0->dNrm, c0->dK, zb);
+  launch_gram(s, c0->dAT, c0->dNrm, n, NP, 0, c0->ld, gp_noise, kernel, nullptr, c0->dK, c0->dL, c0->dInfo, zb);
+  mark(2);
+  launch_cholesky(s, c0->dL, NP, c0->ld, c0->dInfo, c0->dDiag, zb);
+  mark(3);
+  launch_trinv(s, c0->dL, NP, c0->ld, c0->dR, zb);
+  launch_alpha(s, c0->dR, c0->dYs, n, NP, c0->ld, c0->dTmp, c0->dAlpha, zb);
+  mark(4);
+  if (batch->dev_lbfgsb) launch_rt_build(s, c0->dR, n, NP, c0->ld, c0->dGram, zb);
+  BHIPCHK(hipMemcpy2DAsync((void*)&c0->hm->chol_info, batch->hzs, c0->dInfo, batch->zs, sizeof(int), B, hipMemcpyDeviceToHost, s));
+  BHIPCHK(hipGetLastError());
+  batch->n = n; batch->d = k; batch->NP = NP;
+  batch->lengthscale = lengthscale; batch->noise = gp_noise; batch->kernel = kernel;
+  batch->wpca_uncollected = false; batch->gp_pending = true; batch->have_gp = false;
+  for (int b = 0; b < B; ++b) {
+    pcabo_ctx* c = batch->ctx[b];
+    c->n = n; c->d = k; c->k = k; c->KP = round_up(k, 4); c->NP = NP; c->lengthscale = lengthscale; c->noise = gp_noise; c->kernel = kernel;
+    c->have_gp = false; c->have_wpca = false; c->gp_pending = false; c->wpca_uncollected = false;
+    c->cnt_S = batch->cnt_S; c->cnt_dirty = false;
+  }
+  return PCABO_OK;
+}
+
 int pcabo_batch_wpca_results(pcabo_batch* batch, double* data_mean, double* pca_mean, double* comps, double* evr, int* k) {
   if (!batch) return PCABO_ERR_ARG;
   if (!batch->wpca_uncollected && batch->n == 0) return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_wpca_results: nothing enqueued%s", "");

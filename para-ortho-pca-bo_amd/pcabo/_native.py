@@ -55,7 +55,7 @@ EXPORTS = [
     "pcabo_batch_gp_condition_end_eval", "pcabo_batch_optimize_acqf", "pcabo_batch_inverse_map", "pcabo_batch_device_acq_eval",
     "pcabo_batch_busy", "pcabo_batch_gp_condition_end_eval_begin", "pcabo_batch_gp_condition_end_eval_end",
     "pcabo_batch_optimize_acqf_begin", "pcabo_batch_optimize_acqf_end", "pcabo_batch_inverse_map_begin", "pcabo_batch_inverse_map_end",
-    "pcabo_batch_set_input_strides",
+    "pcabo_batch_set_input_strides", "pcabo_batch_gp_condition_begin",
     "pcabo_batch_set_profiling", "pcabo_batch_get_profile", "pcabo_batch_set_active", "pcabo_batch_set_workers", "pcabo_batch_set_option",
     "pcabo_bbob_table_doubles", "pcabo_bbob_create", "pcabo_bbob_destroy", "pcabo_bbob_eval",
     "pcabo_comm_unique_id", "pcabo_comm_create", "pcabo_gather_best", "pcabo_comm_last_error", "pcabo_comm_destroy",
@@ -140,6 +140,7 @@ def _load() -> C.CDLL:
     lib.pcabo_batch_optimize_acqf_end.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
     lib.pcabo_batch_inverse_map_begin.argtypes = [vp, vp]
     lib.pcabo_batch_set_input_strides.argtypes = [vp, C.c_size_t, C.c_size_t, C.c_size_t]
+    lib.pcabo_batch_gp_condition_begin.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_double, C.c_double, C.c_int]
     lib.pcabo_batch_inverse_map_end.argtypes = [vp, vp]
     lib.pcabo_batch_set_profiling.argtypes = [vp, C.c_int]
     lib.pcabo_batch_set_active.argtypes = [vp, vp]
@@ -473,6 +474,35 @@ class Batch:
                                                           int(bool(maximize)), float(var_threshold), int(n_components),
                                                           float(lengthscale), float(gp_noise), int(kernel)))
         self.n, self.d = n, d
+
+    def gp_condition_begin(self, Z, y, norm_bounds=None, lengthscale=0.6931471805599453, gp_noise=0.006737946999085467,
+                           kernel=KERNEL_MATERN52):
+        """Z[B,n,k], y[B,n]: rows D-H of every run on the given points, no weighted PCA (Vanilla_BO); norm_bounds (2, k) for all
+        runs or None.  Finish with gp_wait_eval / gp_eval_begin + gp_eval_end."""
+        Z = np.asarray(Z, dtype=np.float64)
+        B, n, k = Z.shape
+        assert B == self.B
+        y = np.asarray(y, dtype=np.float64).reshape(B, n)
+
+        def block(a, row):
+            item = a.itemsize
+            inner_ok = all(a.strides[i] == item * int(np.prod(a.shape[i + 1:])) for i in range(1, a.ndim))
+            if inner_ok and a.strides[0] % item == 0 and a.strides[0] // item >= row:
+                return a, a.strides[0] // item
+            return np.ascontiguousarray(a), row
+        Z, sx = block(Z, n * k)
+        y, sy = block(y, n)
+        strides = (0 if sx == n * k else sx, 0, 0 if sy == n else sy)
+        if strides != getattr(self, "_in_strides", (0, 0, 0)):
+            self._chk(LIB.pcabo_batch_set_input_strides(self._h, *strides))
+            self._in_strides = strides
+        nb = None if norm_bounds is None else _f64(norm_bounds, (2, k))
+        self._chk(LIB.pcabo_batch_gp_condition_begin(self._h, _ptr(Z), _ptr(y), n, k, _ptr(nb), float(lengthscale), float(gp_noise),
+                                                     int(kernel)))
+        self.n, self.d = n, k
+        self.k = np.full(B, k, dtype=np.int32)
+        for c in self.ctx:
+            c.n, c.d, c.k = n, k, k
 
     def wpca_results(self):
         B, n, d = self.B, self.n, self.d

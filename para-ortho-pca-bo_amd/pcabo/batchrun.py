@@ -427,6 +427,138 @@ class BatchedPCABO:
             self.finish()
 
 
+class BatchedVanillaBO(BatchedPCABO):
+    """B runs of the reference's Vanilla_BO (Vanilla_BO.py:39-301) in lock-step: the PCA_BO loop without the PCA - the exact GP
+    on the raw d-dimensional points (Normalize switched off: identity bounds, Vanilla_BO.py:188-194), the acquisition optimised
+    inside the problem's box (:206-213), every candidate evaluated (no out-of-box rule).  Same device calls as BatchedPCABO minus
+    rows A-C (pcabo_batch_gp_condition_begin); every run has its own torch.Generator seeded like the reference's global one and
+    takes, bit for bit, the path `Algorithms.Vanilla_BO` takes alone with the same evaluation kernels."""
+
+    def start(self) -> None:
+        super().start()
+        d = self.dimension
+        self._identity = np.vstack([np.zeros(d), np.ones(d)])
+        self._boxes = [np.ascontiguousarray(self.bounds[b].T, dtype=np.float64) for b in range(self.B)]     # 2 x d each
+        self.k_prev = [d] * self.B
+
+    def _iteration_steps(self):
+        B, d, n, bt = self.B, self.dimension, self.n, self._batch
+        t0 = perf_counter()
+        pre = {}
+        if self.record_trace:
+            for b in range(B):
+                if self.failed[b] is None and (self._trace_filter is None or self._trace_filter(b, n)):
+                    pre[b] = {"numpy_state": self._rs[b].get_state(), "torch_state": self._tg[b].get_state().clone(),
+                              "best_f": self.current_best[b]}
+        self._pre_states = pre
+        t1 = perf_counter()
+        bt.gp_condition_begin(self._X[:, :n], self._F[:, :n], norm_bounds=self._identity, lengthscale=LENGTHSCALE, gp_noise=NOISE)
+        # the scrambled Sobol engines (dimension d, always): built during the last iteration's optimiser phase, or now - while the
+        # device conditions the GPs
+        built, self._engines_ahead = self._engines_ahead, {}
+        bounds = self._boxes
+        raw = [None] * B
+        rawbuf = bt.raw_row_buffer(self.raw_samples)
+        for b in range(B):
+            engine = built[b][1] if b in built else _init.scrambled_sobol_engine(d, self._tg[b])
+            raw[b] = _init.draw_sobol(bounds[b], self.raw_samples, engine,
+                                      out=rawbuf[b, : self.raw_samples * d].reshape(self.raw_samples, d))
+        best_f = [self.current_best[b] for b in range(B)]
+        for b in range(B):
+            bt.ctx[b].match_best_f_dtype(best_f[b])
+        t3 = t2 = perf_counter()
+        token = bt.gp_eval_begin(raw, best_f, self.maximization, self.acq_code)
+        yield "scoring"
+        vals, status = bt.gp_eval_end(token)
+        for b in range(B):
+            if self.failed[b] is None and (status[b] != 0 or not np.isfinite(vals[b]).all()):
+                self._park(b, n, "GP conditioning failed (K not positive definite)" if status[b] != 0
+                           else "non-finite acquisition values on the raw samples")
+            if self.failed[b] is not None:
+                vals[b] = np.linspace(0.0, 1.0, vals.shape[1])
+        t4 = perf_counter()
+        pick = _init.initialize_q_batch if self.acq_code == _native.ACQ_LOG_EI else _init.initialize_q_batch_nonneg
+        if self.acq_code == _native.ACQ_LOG_EI:
+            idx = _init.initialize_q_batch_rows(vals, self.num_restarts, self._tg,
+                                                skip=[b for b in range(B) if self.failed[b] is not None])
+        else:
+            idx = [pick(vals[b], self.num_restarts, generator=self._tg[b]) if self.failed[b] is None
+                   else np.arange(self.num_restarts) for b in range(B)]
+        ics = [raw[b][idx[b]] for b in range(B)]
+        t5 = perf_counter()
+        engines_job = None
+        if self._pool is not None and not self.record_trace and n + 1 < self.budget:
+            live = [b for b in range(B) if self.failed[b] is None]
+
+            def build_engines():
+                out = {}
+                for b in live:
+                    st = self._tg[b].get_state()
+                    out[b] = (st, _init.scrambled_sobol_engine(d, self._tg[b]))
+                return out
+            engines_job = self._pool.submit(build_engines)
+        token = bt.optimize_begin(ics, bounds, best_f, self.maximization, self.acq_code, batch_limit=5, maxiter=200) \
+            if self._device_lbfgsb == 1 else None
+        if token is not None:
+            yield "optimize"
+            outs, status = bt.optimize_end(token)
+        else:
+            outs, status = bt.optimize_acqf(ics, bounds, best_f, self.maximization, self.acq_code, batch_limit=5, maxiter=200)
+        if engines_job is not None:
+            built = engines_job.result()
+            for b in list(built):
+                if status[b] != 0 or outs[b][3]:          # botorch's retry draws from the run's generator first
+                    self._tg[b].set_state(built[b][0])
+                    del built[b]
+            self._engines_ahead = built
+        for b in range(B):
+            if self.failed[b] is None and status[b] != 0:
+                self._park(b, n, "NaN in the acquisition gradient (botorch raises here)" if status[b] == -4
+                           else f"acquisition optimisation failed (status {int(status[b])})")
+        t6 = perf_counter()
+        infos = []
+        for b in range(B):
+            cand, v, info, failed = outs[b]
+            infos.append(info)
+            if self.failed[b] is not None:
+                continue
+            retried = False
+            if failed:
+                warnings.warn("Optimization failed in `gen_candidates_scipy`; trying again with a new set of "
+                              "initial conditions.", RuntimeWarning)
+                self.retries += 1
+                retried = True
+                c = bt.ctx[b]
+                raw_b = _init.draw_sobol(bounds[b], self.raw_samples, _init.scrambled_sobol_engine(d, self._tg[b]))
+                vals_b = c.acq_eval(raw_b, best_f[b], self.maximization, self.acq_code, grad=False)
+                ics_b = raw_b[pick(vals_b, self.num_restarts, generator=self._tg[b])]
+                cand, v, info, failed = c.optimize_acqf(ics_b, bounds[b], best_f[b], self.maximization, self.acq_code,
+                                                        batch_limit=5, maxiter=200)
+                ics[b] = ics_b
+                infos[-1] = info
+            best = int(np.argmax(v))
+            if b in pre:
+                self.trace.append({"b": b, "n": n, "k": d, "ic_idx": np.asarray(idx[b]).copy(), "ics": ics[b].copy(),
+                                   "cands": cand.copy(), "vals": v.copy(), "info": info.copy(), "chosen": best,
+                                   "retried": retried, **pre[b]})
+            new_x = np.asarray(cand[best], dtype=np.float64).ravel().copy()
+            new_f = self.problems[b](new_x)                # (Vanilla_BO.py:221-232: the candidate lies in the box and is evaluated)
+            self.x_evals[b].append(new_x)
+            self.f_evals[b].append(new_f)
+            self._X[b, n] = new_x
+            self._F[b, n] = new_f
+            self._assign_new_best(b, appended=True)
+        self.lbfgsb_info.append(infos)
+        t7 = perf_counter()
+        tm = self.timing
+        tm["host_prep"] += t1 - t0
+        tm["pca"] += t2 - t1
+        tm["wait_score"] += t4 - t3
+        tm["init_pick"] += t5 - t4
+        tm["lbfgsb"] += t6 - t5
+        tm["tail"] += t7 - t6
+
+
 def workers_for(side_by_side: int) -> int:
     """Gang threads per batch when `side_by_side` batches of this process advance at once: the workers spin, and a GPU of
     a shared node comes with ~16 cores - 8 for one batch, 4 each for two, never fewer than 2."""

@@ -275,3 +275,110 @@ def test_rccl_gather_best_through_the_c_abi(native):
         comm.close()
     with pytest.raises(native.PcaboError):
         native.Comm(uid, world=2, rank=5, device=0)
+
+
+def test_strided_inputs_and_call_halves(native):
+    """pcabo_batch_set_input_strides: X / y handed over as the first n rows of [B][budget][d] / [B][budget] arrays give the state
+    the dense arrays give, bit for bit; the begin / end halves of the waiting calls give what the blocking calls give, and an _end
+    without its _begin is refused (PCABO_ERR_ARG) instead of waiting for nothing."""
+    rng = np.random.default_rng(8)
+    B, n, budget, d, q = 3, 90, 140, 9, 512
+    Xfull = rng.uniform(-5, 5, (B, budget, d))
+    yfull = rng.normal(size=(B, budget)) * 40 + 100
+    ranks = np.argsort(np.argsort(yfull[:, :n], axis=1), axis=1) + 1
+    noise = rng.normal(0, 1e-8, (B, n, d))
+    outs = []
+    for strided in (False, True):
+        bt = native.Batch(B, max_n=budget, max_d=d, max_q=q, device_lbfgsb=1)
+        X = Xfull[:, :n] if strided else np.ascontiguousarray(Xfull[:, :n])
+        y = yfull[:, :n] if strided else np.ascontiguousarray(yfull[:, :n])
+        bt.wpca_gp_condition_begin(X, ranks, noise, y)
+        res = bt.wpca_results()
+        boxes = bt.acq_bounds()
+        raw = [boxes[b][0] + (boxes[b][1] - boxes[b][0]) * np.random.default_rng(b).uniform(size=(q, res[b]["k"])) for b in range(B)]
+        best = [float(y[b].min()) for b in range(B)]
+        if strided:                       # the halves
+            with pytest.raises(native.PcaboError):
+                bt.gp_eval_end((np.zeros((B, q * d)), q, np.zeros(B), 0, native.ACQ_LOG_EI))
+            tok = bt.gp_eval_begin(raw, best)
+            while bt.busy():
+                pass
+            vals, status = bt.gp_eval_end(tok)
+            with pytest.raises(native.PcaboError):
+                bt.optimize_end((10, 5))
+            tok = bt.optimize_begin([raw[b][:10] for b in range(B)], boxes, best)
+            assert tok is not None
+            o, st = bt.optimize_end(tok)
+            z = [o[b][0][int(np.argmax(o[b][1]))] for b in range(B)]
+            with pytest.raises(native.PcaboError):
+                bt.inverse_map_end()
+            bt.inverse_map_begin(z)
+            x = bt.inverse_map_end()
+        else:
+            vals, status = bt.gp_wait_eval(raw, best)
+            o, st = bt.optimize_acqf([raw[b][:10] for b in range(B)], boxes, best)
+            z = [o[b][0][int(np.argmax(o[b][1]))] for b in range(B)]
+            x = bt.inverse_map(z)
+        assert not status.any() and not st.any()
+        outs.append((res, boxes, vals, o, x, [bt.ctx[b].gp_state() for b in range(B)]))
+        bt.close()
+    (r0, b0, v0, o0, x0, s0), (r1, b1, v1, o1, x1, s1) = outs
+    assert np.array_equal(v0, v1) and np.array_equal(x0, x1)
+    for b in range(B):
+        assert r0[b]["k"] == r1[b]["k"] and np.array_equal(r0[b]["components"], r1[b]["components"])
+        assert np.array_equal(b0[b], b1[b])
+        for key in ("L", "R", "alpha"):
+            assert np.array_equal(s0[b][key], s1[b][key]), (b, key)
+        assert np.array_equal(o0[b][0], o1[b][0]) and np.array_equal(o0[b][1], o1[b][1]) and np.array_equal(o0[b][2], o1[b][2])
+
+
+def _single_vanilla(fid, inst, dim, budget, n_doe, seed):
+    from Algorithms import Vanilla_BO
+    opt = Vanilla_BO(budget=budget, n_DoE=n_doe, random_seed=seed, maximization=False)
+    opt(BBOBProblem(fid, inst, dim))
+    return np.vstack(opt.x_evals), np.array(opt.f_evals)
+
+
+@pytest.mark.parametrize("fid,dim,budget,n_doe,B", [(15, 10, 70, 30, 4), (20, 5, 75, 10, 5)])
+def test_batched_vanilla_runs_equal_single_runs_bit_for_bit(native, fid, dim, budget, n_doe, B):
+    """BatchedVanillaBO (pcabo_batch_gp_condition_begin: rows D-H of B runs on the raw points, no PCA) against the reference-surface
+    class Algorithms.Vanilla_BO run by run: same DoE, same raw samples and picks from the run's own generator, same candidates -
+    bit for bit with the per-query kernels on both sides; and the device-resident optimiser against its host-stepped twin."""
+    from pcabo.batchrun import BatchedVanillaBO
+    torch.set_num_threads(4)
+    insts = list(range(B))
+    seeds = [1000 * fid + 10 * dim + i for i in insts]
+    r = BatchedVanillaBO([BBOBProblem(fid, i, dim) for i in insts], seeds, budget, n_doe, acq_kernel="latency")
+    r.run()
+    for b, i in enumerate(insts):
+        X, f = _single_vanilla(fid, i, dim, budget, n_doe, seeds[b])
+        assert np.array_equal(np.vstack(r.x_evals[b]), X), (fid, b)
+        assert np.array_equal(np.array(r.f_evals[b]), f), (fid, b)
+    runs = {}
+    for mode in ("device", "device-twin"):
+        runs[mode] = BatchedVanillaBO([BBOBProblem(fid, i, dim) for i in insts], seeds, budget, n_doe, acq_kernel=mode)
+        runs[mode].run()
+    for b in range(B):
+        assert np.array_equal(np.vstack(runs["device"].x_evals[b]), np.vstack(runs["device-twin"].x_evals[b])), (fid, b)
+        assert len(runs["device"].f_evals[b]) == budget
+
+
+def test_experiment_runner_batches_vanilla_too(native, tmp_path):
+    """main.py's default experiment runs both algorithms: with `batched` the Vanilla_BO runs advance in lock-step as well and
+    the IOHprofiler files are the ones the serial runs write."""
+    import os
+    from Algorithms import ExperimentRunner
+    outs = []
+    for tag, batched in (("serial", 0), ("batched", 3)):
+        root = tmp_path / tag
+        er = ExperimentRunner(algorithms=["vanilla"], dimensions=[5], problem_ids=[15, 20], num_runs=3, budget_factor=5,
+                              doe_factor=2.0, root_dir=str(root), experiment_name="experiment", progress=False, batched=batched,
+                              batch_acq_kernel="latency")
+        er.run_experiment()
+        assert len(er.results) == 6
+        outs.append((root, sorted((r["problem_id"], r["instance"], r["best"]) for r in er.results)))
+    assert outs[0][1] == outs[1][1]
+    for fid, name in ((15, "RastriginRotated"), (20, "Schwefel")):
+        rel = os.path.join("vanilla-experiment", f"data_f{fid}_{name}", f"IOHprofiler_f{fid}_DIM5.dat")
+        a, b = open(os.path.join(outs[0][0], rel)).read(), open(os.path.join(outs[1][0], rel)).read()
+        assert a == b

@@ -654,7 +654,7 @@ def run_interleaved(runners: Sequence["BatchedPCABO"], started: bool = False) ->
 
 def bench_block(device: int, B: int, fid: int, dim: int, budget_factor: int = 10, doe_factor: float = 3.0,
                 sub_batches: int = 1, workers: int = 0, acq_kernel: str = "group", schedule: str = "threads",
-                lbfgsb_cus: int = 0, device_objective: bool = False) -> dict:
+                lbfgsb_cus: int = 0, device_objective: bool = False, algorithm: str = "pca") -> dict:
     """Aggregate BO iterations / second of B runs (instances 0..B-1 of one BBOB function and dimension, seeds per
     ExperimentRunner.py:146) advancing together on one GPU - as one lock-step batch, or as `sub_batches` lock-step batches
     side by side (run_side_by_side); DoE and set-up untimed."""
@@ -664,7 +664,8 @@ def bench_block(device: int, B: int, fid: int, dim: int, budget_factor: int = 10
     subs = []
     for t in range(S):
         inst = list(range(t, B, S))
-        subs.append(BatchedPCABO([BBOBProblem(fid, i, dim) for i in inst], [1000 * fid + 10 * dim + i for i in inst], budget, n_doe,
+        subs.append((BatchedVanillaBO if algorithm == "vanilla" else BatchedPCABO)(
+            [BBOBProblem(fid, i, dim) for i in inst], [1000 * fid + 10 * dim + i for i in inst], budget, n_doe,
                                  device=device, workers=workers or (workers_for(S) if S > 1 else 0), host_threads=max(1, 8 // S),
                                  acq_kernel=acq_kernel, lbfgsb_cus=lbfgsb_cus, device_objective=device_objective))
     for r in subs:
@@ -707,6 +708,7 @@ def bench_block(device: int, B: int, fid: int, dim: int, budget_factor: int = 10
                             for k, v in LAST_INTERLEAVE_STATS.items()}} if schedule == "interleaved" else {}
     extra["schedule"] = schedule
     extra["device_objective"] = bool(device_objective)
+    extra["algorithm"] = algorithm
     return {**extra, "runs": B, "sub_batches": S, "function": fid, "dimension": dim, "budget": budget, "n_DoE": n_doe,
             "aggregate_bo_iterations_per_s": iters / dt, "seconds": dt, "bo_iterations": iters,
             "ms_per_lockstep_iteration": 1e3 * dt / (budget - n_doe), "host_phase_seconds": phases,

@@ -184,6 +184,18 @@ class ExperimentRunner:
             parts = split_evenly(cell, self.batched, self.side_by_side)
             groups += [[(dim, part, kernel) for part in parts[i:i + self.side_by_side]]
                        for i in range(0, len(parts), self.side_by_side)]
+        import torch
+        saved_threads = torch.get_num_threads()      # (see BatchedPCABO.start: the loop's small tensor operations and torch's
+        if saved_threads > 4:                        # intra-op pool at the machine's core count do not get along)
+            torch.set_num_threads(4)
+        try:
+            self._run_batch_groups(groups, Driver, algorithm, logger, ebar, run_interleaved, run_side_by_side, workers_for,
+                                   BBOBProblem, LoggedProblem)
+        finally:
+            torch.set_num_threads(saved_threads)
+
+    def _run_batch_groups(self, groups, Driver, algorithm, logger, ebar, run_interleaved, run_side_by_side, workers_for,
+                          BBOBProblem, LoggedProblem) -> None:
         for group in groups:
             jobs = []
             for dim, chunk, kernel in group:

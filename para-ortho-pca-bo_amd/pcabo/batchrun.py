@@ -50,7 +50,7 @@ class BatchedPCABO:
                  var_threshold: float = 0.95, acquisition_function: str = "expected_improvement",
                  maximization: bool = False, device: int = 0, num_restarts: int = 10, raw_samples: int = 512,
                  record_trace: bool = False, host_threads: int = 0, device_objective: bool = False, workers: int = 0,
-                 trace_filter=None, acq_kernel: str = "group", lbfgsb_cus: int = 0):
+                 trace_filter=None, acq_kernel: str = "group", lbfgsb_cus: int = 0, torch_threads: Optional[int] = 4):
         self.problems, self.seeds = list(problems), [int(s) for s in seeds]
         self.B = len(self.problems)
         assert self.B == len(self.seeds) and self.B >= 1
@@ -100,6 +100,7 @@ class BatchedPCABO:
         # the host threads while the L-BFGS-B rounds of this iteration run inside the library: same numbers from the same
         # per-run streams - nothing else draws from them after the DoE - 1.5 ms less in front of every lock-step iteration.
         # Off while per-iteration generator states are recorded (they must be the states BEFORE the draw).
+        self._torch_threads, self._saved_torch_threads = torch_threads, None
         self._noise_ahead = {}
         self._noise_next = None            # (B, n + 1, d) block the pool threads fill for the next iteration
         # likewise the scrambled Sobol engines of the next iteration (torch's two randint draws per run, 0.06 ms each and
@@ -122,6 +123,12 @@ class BatchedPCABO:
     # ---- seeding + DoE (AbstractAlgorithm.py:310-328, AbstractBayesianOptimizer.py:142-176) --------------------------
     def start(self) -> None:
         B, d = self.B, self.dimension
+        # torch's intra-op pool at the machine's core count turns the loop's small tensor operations (std, exp, multinomial on 512
+        # values) into a fight between spinning OpenMP workers and the batches' own threads: main.py's default experiment ran at
+        # 704 it/s instead of ~3 000 until this was capped (Algorithms.PCA_BO does the same for a single run)
+        if self._torch_threads is not None and torch.get_num_threads() > int(self._torch_threads):
+            self._saved_torch_threads = torch.get_num_threads()
+            torch.set_num_threads(int(self._torch_threads))
         self._rs = [np.random.RandomState(s) for s in self.seeds]
         self._tg = [torch.Generator().manual_seed(s) for s in self.seeds]
         self._X = np.empty((B, self.budget, d))
@@ -406,6 +413,9 @@ class BatchedPCABO:
         tm["tail"] += t7 - t6
 
     def finish(self) -> None:
+        if getattr(self, "_saved_torch_threads", None) is not None:
+            torch.set_num_threads(self._saved_torch_threads)
+            self._saved_torch_threads = None
         if self._pool is not None:
             self._pool.shutdown()
             self._pool = None

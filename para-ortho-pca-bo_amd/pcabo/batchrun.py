@@ -50,7 +50,8 @@ class BatchedPCABO:
                  var_threshold: float = 0.95, acquisition_function: str = "expected_improvement",
                  maximization: bool = False, device: int = 0, num_restarts: int = 10, raw_samples: int = 512,
                  record_trace: bool = False, host_threads: int = 0, device_objective: bool = False, workers: int = 0,
-                 trace_filter=None, acq_kernel: str = "group", lbfgsb_cus: int = 0, torch_threads: Optional[int] = 4):
+                 trace_filter=None, acq_kernel: str = "group", lbfgsb_cus: int = 0, torch_threads: Optional[int] = 4,
+                 gc_freeze: bool = True):
         self.problems, self.seeds = list(problems), [int(s) for s in seeds]
         self.B = len(self.problems)
         assert self.B == len(self.seeds) and self.B >= 1
@@ -101,6 +102,7 @@ class BatchedPCABO:
         # per-run streams - nothing else draws from them after the DoE - 1.5 ms less in front of every lock-step iteration.
         # Off while per-iteration generator states are recorded (they must be the states BEFORE the draw).
         self._torch_threads, self._saved_torch_threads = torch_threads, None
+        self._gc_freeze, self._gc_entered = bool(gc_freeze), False
         self._noise_ahead = {}
         self._noise_next = None            # (B, n + 1, d) block the pool threads fill for the next iteration
         # likewise the scrambled Sobol engines of the next iteration (torch's two randint draws per run, 0.06 ms each and
@@ -129,6 +131,10 @@ class BatchedPCABO:
         if self._torch_threads is not None and torch.get_num_threads() > int(self._torch_threads):
             self._saved_torch_threads = torch.get_num_threads()
             torch.set_num_threads(int(self._torch_threads))
+        if self._gc_freeze and not self._gc_entered:       # pcabo/gcguard.py: the collector's full passes stay out of the loop
+            from . import gcguard
+            gcguard.enter()
+            self._gc_entered = True
         self._rs = [np.random.RandomState(s) for s in self.seeds]
         self._tg = [torch.Generator().manual_seed(s) for s in self.seeds]
         self._X = np.empty((B, self.budget, d))
@@ -416,6 +422,10 @@ class BatchedPCABO:
         if getattr(self, "_saved_torch_threads", None) is not None:
             torch.set_num_threads(self._saved_torch_threads)
             self._saved_torch_threads = None
+        if getattr(self, "_gc_entered", False):
+            from . import gcguard
+            gcguard.leave()
+            self._gc_entered = False
         if self._pool is not None:
             self._pool.shutdown()
             self._pool = None

@@ -393,6 +393,16 @@ def main():
                                                              "kernel (tests/test_gpu_device_lbfgsb.py)"}
             batch["four_double_batches_device_resident"] = {**{k: dev2[k] for k in keys},
                                                             "host_thread_busy_seconds": dev2["interleave"]["host_busy_seconds"]}
+            # what the device-resident optimiser's evaluations move, algorithmically, against the chip's HBM peak: evaluations the
+            # optimisers report x bytes of one evaluation at that iteration's (n, k), over the wall time of the whole block (all
+            # phases of the iterations, not the kernel alone - an aggregate, beside `roofline` of the single run's kernel)
+            batch["roofline_device_lbfgsb"] = {
+                "kernel": "k_lbfgsb_group (4 x %d runs in flight)" % (2 * args.batch), "bound": "hbm", "peak": 8000.0, "unit": "GB/s",
+                "achieved": dev2["lbfgsb_algorithmic_bytes"] / dev2["seconds"] / 1e9,
+                "frac": dev2["lbfgsb_algorithmic_bytes"] / dev2["seconds"] / 1e9 / 8000.0,
+                "group_evaluations": dev2["lbfgsb_group_evaluations"], "algorithmic_bytes": dev2["lbfgsb_algorithmic_bytes"],
+                "note": "one CU streams ~32 GB/s per work-group whatever the cache level (profiles/r03/device_lbfgsb_phases_n449_30runs.txt, "
+                        "DESIGN.md 8b); the traffic is served by L2 / Infinity Cache (profiles/r03/pmc_device_lbfgsb.json)"}
     if rank == 0 and size == 1 and not args.no_kchol_grid and not args.no_roofline:
         from pcabo import kchol_bench
         grid = kchol_bench.run(device, (1, 30), reps=3, big_batch=120)

@@ -72,6 +72,7 @@ class BatchedPCABO:
         self.current_best_index = [0] * self.B
         self.k_prev = [0] * self.B
         self.lbfgsb_info = []
+        self.k_hist = []                   # reduced dimension of every run, per iteration (BatchedVanillaBO: always d)
         self.retries = 0
         # failed[b]: None, or (n at failure, message).  The reference's run dies with an exception when botorch meets a NaN
         # acquisition gradient (reached by the reference's own dynamics: candidates outside the box are penalised but kept,
@@ -259,6 +260,7 @@ class BatchedPCABO:
             guess(b)
         yield "conditioning"
         res = bt.wpca_results()
+        self.k_hist.append(np.array([r["k"] for r in res], dtype=np.int32))
         t2 = perf_counter()
         bounds = bt.acq_bounds()
         raw = [None] * B
@@ -729,6 +731,20 @@ def bench_block(device: int, B: int, fid: int, dim: int, budget_factor: int = 10
     extra["schedule"] = schedule
     extra["device_objective"] = bool(device_objective)
     extra["algorithm"] = algorithm
+    # algorithmic bytes of the L-BFGS-B evaluations (SURVEY.md 8d per-unit figures: one value+gradient evaluation of a restart
+    # group reads the triangles of R and of its transpose, the normalised points twice and alpha): evaluations the optimisers
+    # report x bytes at that iteration's (n, k)
+    ev_bytes, evals = 0.0, 0
+    for r in subs:
+        for it, infos in enumerate(r.lbfgsb_info):
+            n_it = n_doe + it
+            for b, info in enumerate(infos):
+                kb = int(r.k_hist[it][b]) if it < len(r.k_hist) else dim
+                nf = int(np.asarray(info)[:, 1].sum())
+                evals += nf
+                ev_bytes += nf * (2 * 4.0 * n_it * (n_it + 1) + 2 * 8.0 * n_it * kb + 8.0 * n_it)
+    extra["lbfgsb_group_evaluations"] = evals
+    extra["lbfgsb_algorithmic_bytes"] = ev_bytes
     return {**extra, "runs": B, "sub_batches": S, "function": fid, "dimension": dim, "budget": budget, "n_DoE": n_doe,
             "aggregate_bo_iterations_per_s": iters / dt, "seconds": dt, "bo_iterations": iters,
             "ms_per_lockstep_iteration": 1e3 * dt / (budget - n_doe), "host_phase_seconds": phases,

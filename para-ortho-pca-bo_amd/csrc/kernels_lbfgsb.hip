@@ -1267,9 +1267,8 @@ __device__ inline void lb_scalar_core(double vv, double mus, const LbEval& E, do
 
 // x in L.x() (nq * k) -> L.vals()[q] (acquisition values) and, with want_grad, L.g()[q * k + c] = -d value_q / d x_qc
 // (the gradient of the minimised objective -sum_q value_q).  Ends with a work-group barrier.
-// Every global load of a loop trip is issued before the first use (LB_UB of them in flight per thread, the next trip's while the
-// current one is consumed): one CU has to pull ~0.8 MB per triangular pass through ~1 us of L2 / Infinity Cache latency.
-#define LB_UB 16
+// Every global load of a loop trip is issued before the first use: one CU has to pull ~0.8 MB per triangular pass through ~1 us
+// of L2 / Infinity Cache latency.
 // element `lane8 / 8` of a row whose base is wave-uniform: (scalar base) + (32-bit lane offset) - global_load with an SGPR base, no
 // vector address arithmetic per load
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1278,6 +1277,17 @@ typedef const __attribute__((address_space(1))) char gcc_;
 typedef const char gcc_;
 #endif
 __device__ inline double ld_row(gcd* row, unsigned lane8) { return *(gcd*)((gcc_*)row + lane8); }
+// the same with 16 bytes per lane (two neighbouring elements of the row): a wave's load instruction costs the CU's address path
+// ~11 ns whether a lane takes 8 or 16 bytes (profiles/r03/device_lbfgsb_pass_experiments.txt), so the triangular passes move two
+// rows (columns) of the matrix per instruction - lanes 0 .. 31 the even one, lanes 32 .. 63 the odd one
+typedef double lb_d2 __attribute__((ext_vector_type(2)));
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(1))) lb_d2 gcd2;
+#else
+typedef const lb_d2 gcd2;
+#endif
+__device__ inline lb_d2 ld_row2(gcd* row, unsigned off) { return *(gcd2*)((gcc_*)row + off); }
+#define LB_UB2 8            // 16-byte loads in flight per thread and trip (a trip covers 2 LB_UB2 rows or columns)
 __device__ __noinline__ void lb_eval(const LbLds L_, const LbEval E_, int nq, bool want_grad) {
   // (arguments of a function that is not inlined arrive in vector registers: made wave-uniform again here, so that loop bounds,
   // row bases and LDS addresses of the broadcasts are scalar)
@@ -1303,7 +1313,9 @@ __device__ __noinline__ void lb_eval(const LbLds L_, const LbEval E_, int nq, bo
   double cf[LB_GQ];
   const int hh = w / S, wsub = w - hh * S;
   const int cbu = S - 1 - slab_of(wsub, S), sbu = slab_of(wsub, S);   // wave-uniform: this wave's column block (pass 2) / row slab (pass 1)
-  const int jmine = 64 * cbu + lane;                                  // this thread's column in pass 2 (hh < H)
+  const int half = lane >> 5, l32 = lane & 31;
+  const int jmine = 64 * cbu + 2 * l32 + half;    // the column this thread finishes in pass 2 (hh < H): lanes 0 .. 31 the even ones
+  const unsigned off2 = (unsigned)half * (unsigned)ld * 8u + (unsigned)l32 * 16u;   // (row + half, elements 2 l32 and 2 l32 + 1)
   if (hh == 0) {
     const int j = jmine, jj = j < n ? j : n - 1;
     const unsigned j8 = (unsigned)jj * 8u;
@@ -1356,34 +1368,50 @@ __device__ __noinline__ void lb_eval(const LbLds L_, const LbEval E_, int nq, bo
   }
   __syncthreads();
   LBT_NEXT(9);
-  // ---- pass 1: v_q[i] = sum_j RT[j][i] ks_q[j], thread (row i, part hh of the columns)
-  const int imine = 64 * sbu + lane;
+  // ---- pass 1: v_q[i] = sum_j RT[j][i] ks_q[j].  A thread holds rows 2 l32 and 2 l32 + 1 of the wave's slab and takes every second
+  // column of part hh (its half-wave's parity); the two half-waves' sums meet at the end: (even columns) + (odd columns)
+  const int imine = 64 * sbu + 2 * l32 + half;
   if (hh < H) {
-    const int i = imine;
     const int jtot = n < 64 * (sbu + 1) ? n : 64 * (sbu + 1);
     const int J0 = (int)((long long)jtot * hh / H), J1 = (int)((long long)jtot * (hh + 1) / H);
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0;
-    gcd* rp = E.RT + 64 * sbu;            // (wave-uniform row base + the lane's 32-bit offset: no address arithmetic per load)
-    const unsigned l8 = (unsigned)lane * 8u;
+    double p0[LB_GQ] = {0.0, 0.0, 0.0, 0.0, 0.0}, p1[LB_GQ] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    gcd* rp = E.RT + 64 * sbu;            // (wave-uniform base + the lane's 32-bit offset: no address arithmetic per load)
     int j = J0;
-    for (; j + LB_UB <= J1; j += LB_UB) {          // whole trips: LB_UB loads in flight, no guards (the other waves of the SIMD cover the wait)
-      double rc[LB_UB];
+    for (; j + 2 * LB_UB2 <= J1; j += 2 * LB_UB2) {     // whole trips: LB_UB2 loads in flight, no guards (the other waves cover the wait)
+      lb_d2 rc[LB_UB2];
 #pragma unroll
-      for (int u = 0; u < LB_UB; ++u) rc[u] = ld_row(rp + (size_t)(j + u) * ld, l8);
+      for (int u = 0; u < LB_UB2; ++u) rc[u] = ld_row2(rp + (size_t)(j + 2 * u) * ld, off2);
 #pragma unroll
-      for (int u = 0; u < LB_UB; ++u) {
-        const ldsd* kp = L.ks() + (j + u) * LB_QS;
-        const double r0 = rc[u];
-        a0 = fma(r0, kp[0], a0); a1 = fma(r0, kp[1], a1); a2 = fma(r0, kp[2], a2); a3 = fma(r0, kp[3], a3); a4 = fma(r0, kp[4], a4);
+      for (int u = 0; u < LB_UB2; ++u) {
+        const ldsd* kp = L.ks() + (j + 2 * u + half) * LB_QS;
+#pragma unroll
+        for (int q = 0; q < LB_GQ; ++q) { const double kq = kp[q]; p0[q] = fma(rc[u].x, kq, p0[q]); p1[q] = fma(rc[u].y, kq, p1[q]); }
       }
     }
-    for (; j < J1; ++j) {
-      const double r0 = ld_row(rp + (size_t)j * ld, l8);
-      const ldsd* kp = L.ks() + j * LB_QS;
-      a0 = fma(r0, kp[0], a0); a1 = fma(r0, kp[1], a1); a2 = fma(r0, kp[2], a2); a3 = fma(r0, kp[3], a3); a4 = fma(r0, kp[4], a4);
+    if (j < J1) {                                       // the ragged end: one trip, every load issued before the first use
+      lb_d2 rc[LB_UB2];
+#pragma unroll
+      for (int u = 0; u < LB_UB2; ++u) {
+        const int jc = j + 2 * u + half, jl = jc < J1 ? jc : J1 - 1;
+        rc[u] = ld_row2(rp + (size_t)jl * ld, (unsigned)l32 * 16u);
+      }
+#pragma unroll
+      for (int u = 0; u < LB_UB2; ++u) {
+        const int jc = j + 2 * u + half;
+        if (jc < J1) {
+          const ldsd* kp = L.ks() + jc * LB_QS;
+#pragma unroll
+          for (int q = 0; q < LB_GQ; ++q) { const double kq = kp[q]; p0[q] = fma(rc[u].x, kq, p0[q]); p1[q] = fma(rc[u].y, kq, p1[q]); }
+        }
+      }
     }
-    ldsd* dst = hh == 0 ? L.vb() + i * LB_QS : L.part() + ((size_t)(hh - 1) * NP + i) * LB_QS;
-    dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = a3; dst[4] = a4;
+    // lanes 0 .. 31 finish row 2 l32 (their own even-column sum + the partner's odd-column sum), lanes 32 .. 63 row 2 l32 + 1
+    ldsd* dst = hh == 0 ? L.vb() + imine * LB_QS : L.part() + ((size_t)(hh - 1) * NP + imine) * LB_QS;
+#pragma unroll
+    for (int q = 0; q < LB_GQ; ++q) {
+      const double got = __shfl_xor(half ? p0[q] : p1[q], 32, 64);
+      dst[q] = half ? got + p1[q] : p0[q] + got;
+    }
   }
   __syncthreads();
   LBT_NEXT(10);
@@ -1415,35 +1443,55 @@ __device__ __noinline__ void lb_eval(const LbLds L_, const LbEval E_, int nq, bo
     L.vals()[tid] = value; L.cq()[2 * tid] = cmu; L.cq()[2 * tid + 1] = csg;
   }
   if (!want_grad) { __syncthreads(); return; }
-  // ---- pass 2: w_q[j] = sum_{i >= j} R[i][j] v_q[i], thread (column j, part hh of the rows)
+  // ---- pass 2: w_q[j] = sum_{i >= j} R[i][j] v_q[i].  A thread holds columns 2 l32 and 2 l32 + 1 of the wave's block and takes every
+  // second row of part hh; the half-waves meet as in pass 1: (even rows) + (odd rows), the thread keeps column jmine
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0;
   if (hh < H) {
-    const int j = jmine;
     const int ibeg = 64 * cbu, len = n > ibeg ? n - ibeg : 0;
     const int I0 = ibeg + (int)((long long)len * hh / H), I1 = ibeg + (int)((long long)len * (hh + 1) / H);
+    double p0[LB_GQ] = {0.0, 0.0, 0.0, 0.0, 0.0}, p1[LB_GQ] = {0.0, 0.0, 0.0, 0.0, 0.0};
     gcd* rp = E.R + ibeg;
-    const unsigned l8 = (unsigned)lane * 8u;
     int i = I0;
-    for (; i + LB_UB <= I1; i += LB_UB) {
-      double rc[LB_UB];
+    for (; i + 2 * LB_UB2 <= I1; i += 2 * LB_UB2) {
+      lb_d2 rc[LB_UB2];
 #pragma unroll
-      for (int u = 0; u < LB_UB; ++u) rc[u] = ld_row(rp + (size_t)(i + u) * ld, l8);
+      for (int u = 0; u < LB_UB2; ++u) rc[u] = ld_row2(rp + (size_t)(i + 2 * u) * ld, off2);
 #pragma unroll
-      for (int u = 0; u < LB_UB; ++u) {
-        const ldsd* vp = L.vb() + (i + u) * LB_QS;
-        const double r0 = rc[u];
-        a0 = fma(r0, vp[0], a0); a1 = fma(r0, vp[1], a1); a2 = fma(r0, vp[2], a2); a3 = fma(r0, vp[3], a3); a4 = fma(r0, vp[4], a4);
+      for (int u = 0; u < LB_UB2; ++u) {
+        const ldsd* vp = L.vb() + (i + 2 * u + half) * LB_QS;
+#pragma unroll
+        for (int q = 0; q < LB_GQ; ++q) { const double vq = vp[q]; p0[q] = fma(rc[u].x, vq, p0[q]); p1[q] = fma(rc[u].y, vq, p1[q]); }
       }
     }
-    for (; i < I1; ++i) {
-      const double r0 = ld_row(rp + (size_t)i * ld, l8);
-      const ldsd* vp = L.vb() + i * LB_QS;
-      a0 = fma(r0, vp[0], a0); a1 = fma(r0, vp[1], a1); a2 = fma(r0, vp[2], a2); a3 = fma(r0, vp[3], a3); a4 = fma(r0, vp[4], a4);
+    if (i < I1) {
+      lb_d2 rc[LB_UB2];
+#pragma unroll
+      for (int u = 0; u < LB_UB2; ++u) {
+        const int ic = i + 2 * u + half, il = ic < I1 ? ic : I1 - 1;
+        rc[u] = ld_row2(rp + (size_t)il * ld, (unsigned)l32 * 16u);
+      }
+#pragma unroll
+      for (int u = 0; u < LB_UB2; ++u) {
+        const int ic = i + 2 * u + half;
+        if (ic < I1) {
+          const ldsd* vp = L.vb() + ic * LB_QS;
+#pragma unroll
+          for (int q = 0; q < LB_GQ; ++q) { const double vq = vp[q]; p0[q] = fma(rc[u].x, vq, p0[q]); p1[q] = fma(rc[u].y, vq, p1[q]); }
+        }
+      }
+    }
+    double fin[LB_GQ];
+#pragma unroll
+    for (int q = 0; q < LB_GQ; ++q) {
+      const double got = __shfl_xor(half ? p0[q] : p1[q], 32, 64);
+      fin[q] = half ? got + p1[q] : p0[q] + got;
     }
     if (hh > 0) {
-      ldsd* dst = L.part() + ((size_t)(hh - 1) * NP + j) * LB_QS;
-      dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = a3; dst[4] = a4;
+      ldsd* dst = L.part() + ((size_t)(hh - 1) * NP + jmine) * LB_QS;
+#pragma unroll
+      for (int q = 0; q < LB_GQ; ++q) dst[q] = fin[q];
     }
+    a0 = fin[0]; a1 = fin[1]; a2 = fin[2]; a3 = fin[3]; a4 = fin[4];
   }
   // the rows of ZnT the gradient contraction of this wave needs (components w, w + 16, w + 32) leave now: they arrive while
   // the barrier and the u phase pass

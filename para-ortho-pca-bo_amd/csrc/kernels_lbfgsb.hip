@@ -92,7 +92,7 @@ enum {
   OFF_WN1 = OFF_WN + 4 * LB_M * LB_M, OFF_WA = OFF_WN1 + 4 * LB_M * LB_M, OFF_ACC = OFF_WA + 8 * LB_M, OFF_SC = OFF_ACC + 64,
   OFF_VC = OFF_SC + LB_EVEN(S_COUNT + 2), OFF_INTS = OFF_VC + 8,
   OFF_XN = OFF_INTS + LB_EVEN((4 * LB_NVP + I_COUNT + 2) / 2 + 2), OFF_RED = OFF_XN + LB_EVEN(LB_GQ * (LB_MAXK + 2)),
-  OFF_VALS = OFF_RED + 160, OFF_CQ = OFF_VALS + 8, OFF_NLO = OFF_CQ + 16, OFF_NHI = OFF_NLO + LB_MAXK, OFF_KS = OFF_NHI + LB_MAXK
+  OFF_VALS = OFF_RED + 160, OFF_CQ = OFF_VALS + 8, OFF_NLO = OFF_CQ + 16, OFF_NHI = OFF_NLO + LB_MAXK, OFF_EV = OFF_NHI + LB_MAXK, OFF_KS = OFF_EV + 16
 };
 struct LbLds {
   ldsd* base;
@@ -133,6 +133,7 @@ struct LbLds {
   __device__ ldsd* cq() const { return base + OFF_CQ; }
   __device__ ldsd* nlo() const { return base + OFF_NLO; }
   __device__ ldsd* nhi() const { return base + OFF_NHI; }
+  __device__ ldsd* ev() const { return base + OFF_EV; }
   __device__ ldsd* ks() const { return base + OFF_KS; }
   __device__ ldsd* vb() const { return base + OFF_KS + LB_QS * NP; }
   __device__ ldsd* part() const { return base + OFF_KS + 2 * LB_QS * NP; }
@@ -1288,16 +1289,38 @@ typedef const lb_d2 gcd2;
 #endif
 __device__ inline lb_d2 ld_row2(gcd* row, unsigned off) { return *(gcd2*)((gcc_*)row + off); }
 #define LB_UB2 8            // 16-byte loads in flight per thread and trip (a trip covers 2 LB_UB2 rows or columns)
-__device__ __noinline__ void lb_eval(const LbLds L_, const LbEval E_, int nq, bool want_grad) {
+// The evaluation's arguments live in LDS (written once by the kernel): a by-value struct of this size would travel through scratch
+// memory at every call, a round trip to memory before the first useful instruction.
+__device__ inline unsigned long long lds_u64(const ldsd* p) {
+  const double v = *p;
+  return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(v)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(__double2loint(v));
+}
+__device__ inline void lb_store_eval_args(const LbLds L, const LbEval& E) {       // one thread
+  ldsd* e = L.ev();
+  e[0] = __longlong_as_double((long long)(unsigned long long)E.ZnT); e[1] = __longlong_as_double((long long)(unsigned long long)E.R);
+  e[2] = __longlong_as_double((long long)(unsigned long long)E.RT); e[3] = __longlong_as_double((long long)(unsigned long long)E.alpha);
+  e[4] = __hiloint2double(E.n, E.k); e[5] = __hiloint2double(E.NP, E.ld); e[6] = __hiloint2double(E.H, E.S);
+  e[7] = __hiloint2double(E.maximize, E.acq); e[8] = __hiloint2double(E.kernel, 0);
+  e[9] = E.best_f; e[10] = E.ym; e[11] = E.ysd; e[12] = E.inv_ls;
+}
+__device__ __noinline__ void lb_eval(const LbLds L_, int nq, bool want_grad) {
   // (arguments of a function that is not inlined arrive in vector registers: made wave-uniform again here, so that loop bounds,
   // row bases and LDS addresses of the broadcasts are scalar)
   const int tid = threadIdx.x, lane = tid & 63, w = uni(tid >> 6);
   LbLds L; L.base = (ldsd*)(__UINTPTR_TYPE__)(unsigned)uni((int)(unsigned)(__UINTPTR_TYPE__)L_.base); L.n = uni(L_.n); L.NP = uni(L_.NP);
   LbEval E;
-  E.ZnT = uni(E_.ZnT); E.R = uni(E_.R); E.RT = uni(E_.RT); E.alpha = uni(E_.alpha); E.nlo = E_.nlo; E.nhi = E_.nhi;
-  E.n = uni(E_.n); E.k = uni(E_.k); E.NP = uni(E_.NP); E.ld = uni(E_.ld); E.H = uni(E_.H); E.S = uni(E_.S);
-  E.best_f = E_.best_f; E.ym = E_.ym; E.ysd = E_.ysd; E.inv_ls = uni(E_.inv_ls);
-  E.maximize = uni(E_.maximize); E.acq = uni(E_.acq); E.kernel = uni(E_.kernel);
+  {
+    const ldsd* e = L.ev();
+    E.ZnT = (gcd*)lds_u64(e); E.R = (gcd*)lds_u64(e + 1); E.RT = (gcd*)lds_u64(e + 2); E.alpha = (gcd*)lds_u64(e + 3);
+    E.nlo = nullptr; E.nhi = nullptr;
+    unsigned long long v;
+    v = lds_u64(e + 4); E.n = (int)(v >> 32); E.k = (int)(unsigned)v;
+    v = lds_u64(e + 5); E.NP = (int)(v >> 32); E.ld = (int)(unsigned)v;
+    v = lds_u64(e + 6); E.H = (int)(v >> 32); E.S = (int)(unsigned)v;
+    v = lds_u64(e + 7); E.maximize = (int)(v >> 32); E.acq = (int)(unsigned)v;
+    v = lds_u64(e + 8); E.kernel = (int)(v >> 32);
+    E.best_f = e[9]; E.ym = e[10]; E.ysd = e[11]; E.inv_ls = uni(e[12]);
+  }
   nq = uni(nq);
   const int n = E.n, k = E.k, NP = E.NP, ld = E.ld, H = E.H, S = E.S;
   const int XS = LB_MAXK + 2;
@@ -1317,35 +1340,52 @@ __device__ __noinline__ void lb_eval(const LbLds L_, const LbEval E_, int nq, bo
   const int jmine = 64 * cbu + 2 * l32 + half;    // the column this thread finishes in pass 2 (hh < H): lanes 0 .. 31 the even ones
   const unsigned off2 = (unsigned)half * (unsigned)ld * 8u + (unsigned)l32 * 16u;   // (row + half, elements 2 l32 and 2 l32 + 1)
   if (hh == 0) {
-    const int j = jmine, jj = j < n ? j : n - 1;
-    const unsigned j8 = (unsigned)jj * 8u;
-    double sq[LB_GQ];
+    // 16-byte loads here too: a thread takes points 2 l32 and 2 l32 + 1 of the wave's block and every second component (its
+    // half-wave's parity); (even components) + (odd components) meet in the lane that keeps the point
+    const int j = jmine;
+    double s0[LB_GQ] = {0.0, 0.0, 0.0, 0.0, 0.0}, s1[LB_GQ] = {0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int q = 0; q < LB_GQ; ++q) { sq[q] = 0.0; cf[q] = 0.0; }
+    for (int q = 0; q < LB_GQ; ++q) cf[q] = 0.0;
     double ksv[LB_GQ] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    constexpr int CB = 12;
+    constexpr int CB = 6;
+    gcd* zp = E.ZnT + 64 * cbu;
     int c0 = 0;
-    for (; c0 + CB <= k; c0 += CB) {              // whole chunks: CB loads in flight, no guards
-      double z[CB];
+    for (; c0 + 2 * CB <= k; c0 += 2 * CB) {              // whole chunks: CB loads in flight, no guards
+      lb_d2 z[CB];
 #pragma unroll
-      for (int u = 0; u < CB; ++u) z[u] = ld_row(E.ZnT + (size_t)(c0 + u) * ld, j8);
-#pragma unroll
-      for (int u = 0; u < CB; ++u) {
-#pragma unroll
-        for (int q = 0; q < LB_GQ; ++q) { const double dd = L.xn()[q * XS + c0 + u] - z[u]; sq[q] = fma(dd, dd, sq[q]); }
-      }
-    }
-    {
-      double z[CB];
-#pragma unroll
-      for (int u = 0; u < CB; ++u) { const int cc = c0 + u < k ? c0 + u : k - 1; z[u] = ld_row(E.ZnT + (size_t)cc * ld, j8); }
+      for (int u = 0; u < CB; ++u) z[u] = ld_row2(zp + (size_t)(c0 + 2 * u) * ld, off2);
 #pragma unroll
       for (int u = 0; u < CB; ++u) {
-        if (c0 + u < k) {
+        const ldsd* xp = L.xn() + c0 + 2 * u + half;
 #pragma unroll
-          for (int q = 0; q < LB_GQ; ++q) { const double dd = L.xn()[q * XS + c0 + u] - z[u]; sq[q] = fma(dd, dd, sq[q]); }
+        for (int q = 0; q < LB_GQ; ++q) {
+          const double xv = xp[q * XS], d0 = xv - z[u].x, d1 = xv - z[u].y;
+          s0[q] = fma(d0, d0, s0[q]); s1[q] = fma(d1, d1, s1[q]);
         }
       }
+    }
+    if (c0 < k) {
+      lb_d2 z[CB];
+#pragma unroll
+      for (int u = 0; u < CB; ++u) { const int c = c0 + 2 * u + half, cl = c < k ? c : k - 1; z[u] = ld_row2(zp + (size_t)cl * ld, (unsigned)l32 * 16u); }
+#pragma unroll
+      for (int u = 0; u < CB; ++u) {
+        const int c = c0 + 2 * u + half;
+        if (c < k) {
+          const ldsd* xp = L.xn() + c;
+#pragma unroll
+          for (int q = 0; q < LB_GQ; ++q) {
+            const double xv = xp[q * XS], d0 = xv - z[u].x, d1 = xv - z[u].y;
+            s0[q] = fma(d0, d0, s0[q]); s1[q] = fma(d1, d1, s1[q]);
+          }
+        }
+      }
+    }
+    double sq[LB_GQ];
+#pragma unroll
+    for (int q = 0; q < LB_GQ; ++q) {
+      const double got = __shfl_xor(half ? s0[q] : s1[q], 32, 64);
+      sq[q] = half ? got + s1[q] : s0[q] + got;
     }
     if (j < n) {
       const double s5 = 2.23606797749979, il2 = E.inv_ls * E.inv_ls;
@@ -1495,13 +1535,16 @@ __device__ __noinline__ void lb_eval(const LbLds L_, const LbEval E_, int nq, bo
   }
   // the rows of ZnT the gradient contraction of this wave needs (components w, w + 16, w + 32) leave now: they arrive while
   // the barrier and the u phase pass
-  constexpr int CW = (LB_MAXK + 15) / 16, NB = LB_MAXNP / 64;
-  double z[CW][NB];
+  constexpr int CW = (LB_MAXK + 15) / 16, NB = LB_MAXNP / 128;          // (a lane takes points 128 bq + 2 lane and + 1)
+  lb_d2 z[CW][NB];
 #pragma unroll
   for (int ci = 0; ci < CW; ++ci) {
     const int c = w + 16 * ci, cc = c < k ? c : k - 1;
 #pragma unroll
-    for (int bq = 0; bq < NB; ++bq) { const int j = lane + 64 * bq; z[ci][bq] = ld_row(E.ZnT + (size_t)cc * ld, (unsigned)(j < n ? j : n - 1) * 8u); }
+    for (int bq = 0; bq < NB; ++bq) {
+      const int j = 2 * lane + 128 * bq;
+      z[ci][bq] = ld_row2(E.ZnT + (size_t)cc * ld, (unsigned)(j < NP ? j : 0) * 8u);
+    }
   }
   __syncthreads();
   LBT_NEXT(12);
@@ -1518,8 +1561,13 @@ __device__ __noinline__ void lb_eval(const LbLds L_, const LbEval E_, int nq, bo
   }
   __syncthreads();
   LBT_NEXT(13);
-  // ---- gradient: wave per component (c = w, w + 16, w + 32), lanes over the points; all rows of ZnT a wave needs are loaded first
+  // ---- gradient: wave per component (c = w, w + 16, w + 32), lanes over pairs of points; all rows of ZnT a wave needs were loaded above
   {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(3))) lb_d2 ldsd2;
+#else
+    typedef const lb_d2 ldsd2;
+#endif
 #pragma unroll
     for (int ci = 0; ci < CW; ++ci) {
       const int c = w + 16 * ci;
@@ -1527,12 +1575,15 @@ __device__ __noinline__ void lb_eval(const LbLds L_, const LbEval E_, int nq, bo
         double acc[LB_GQ] = {0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int bq = 0; bq < NB; ++bq) {
-          const int j = lane + 64 * bq;
-          if (64 * bq < n) {
+          const int j = 2 * lane + 128 * bq;
+          if (128 * bq < n) {
+            const double z0 = j < n ? z[ci][bq].x : 0.0, z1 = j + 1 < n ? z[ci][bq].y : 0.0;
 #pragma unroll
             for (int q = 0; q < LB_GQ; ++q) {
-              const double uq = j < n ? L.ks()[q * NP + j] : 0.0;
-              acc[q] = fma(uq, L.xn()[q * XS + c] - z[ci][bq], acc[q]);
+              const lb_d2 uq = j < NP ? *(ldsd2*)(L.ks() + q * NP + j) : lb_d2{0.0, 0.0};
+              const double xv = L.xn()[q * XS + c];
+              acc[q] = fma(j < n ? uq.x : 0.0, xv - z0, acc[q]);
+              acc[q] = fma(j + 1 < n ? uq.y : 0.0, xv - z1, acc[q]);
             }
           }
         }
@@ -1595,10 +1646,10 @@ __global__ __launch_bounds__(LB_THREADS) void k_lbfgsb_group(
   if (tid < S_COUNT) L.sc()[tid] = 0.0;
   if (tid < I_COUNT) L.isc()[tid] = 0;
   __syncthreads();
-  if (tid == 0) { SC(S_THETA) = 1.0; ISC(I_NFREE) = nv; ISC(I_ACTIVE) = 1; ISC(I_TASK) = LBFGSB_START; }
+  if (tid == 0) { SC(S_THETA) = 1.0; ISC(I_NFREE) = nv; ISC(I_ACTIVE) = 1; ISC(I_TASK) = LBFGSB_START; lb_store_eval_args(L, E); }
   __syncthreads();
   if (mode == 0) {
-    lb_eval(L, E, nq, true);
+    lb_eval(L, nq, true);
     if (tid < nq) out_v[q0 + tid] = L.vals()[tid];
     for (int i = tid; i < nv; i += LB_THREADS) out_x[(size_t)q0 * k + i] = -L.g()[i];      // the acquisition's own gradient
     return;
@@ -1610,7 +1661,7 @@ __global__ __launch_bounds__(LB_THREADS) void k_lbfgsb_group(
     __syncthreads();
     LBT_NEXT(16);
     if (!ISR(I_ACTIVE)) break;
-    lb_eval(L, E, nq, true);
+    lb_eval(L, nq, true);
     LBT_NEXT(17);
     // RestartGroup::absorb: f = -(sum of the values, in order), NaN check of the gradient, cache
     if (w == 0) {
@@ -1641,7 +1692,7 @@ __global__ __launch_bounds__(LB_THREADS) void k_lbfgsb_group(
   const int all_same = __syncthreads_and(same ? 1 : 0);
   const int status = ISR(I_STATUS);
   if (status == 0) {
-    if (!all_same) lb_eval(L, E, nq, false);
+    if (!all_same) lb_eval(L, nq, false);
     else { if (tid < nq) L.vals()[tid] = L.vc()[tid]; __syncthreads(); }
     if (tid < nq) out_v[q0 + tid] = L.vals()[tid];
   }

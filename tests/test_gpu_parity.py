@@ -387,8 +387,10 @@ def _check_replay(st, min_iters, frac=0.9, late=False):
     assert np.mean(st["count_equal"]) >= frac_cnt
     if st["dx"]:
         # a single restart left short of its optimum (joint stopping rule) can move the chosen point by ~1e-2:
-        # allowed for 1 in 20 iterations (measured: 1 of 40)
-        assert q(st["dx"], 0.5) < (1e-5 if late else 1e-7) and np.mean(np.array(st["dx"]) < 1e-2) >= 0.95 and max(st["dx"]) < 0.5
+        # allowed for 1 in 20 iterations (measured: 1 of 40), and for one iteration of a short replay (a replay of 5 iterations
+        # cannot tell 1 in 20 from 1 in 5: which restart branches differently changes with the rounding of the evaluation kernel)
+        far = int(np.sum(np.array(st["dx"]) >= 1e-2))
+        assert q(st["dx"], 0.5) < (1e-5 if late else 1e-7) and far <= max(1, len(st["dx"]) // 20) and max(st["dx"]) < 0.5
         assert np.mean(np.array(st["dx"]) < 1e-5) >= frac_x
         assert q(st["df"], 0.5) < 1e-9 and np.mean(np.array(st["df"]) < 1e-5) >= frac_x
     assert st["ties"] <= max(2, st["iters"] // 2)

@@ -573,6 +573,7 @@ __device__ __noinline__ void lb_formk(const LbLds L, int lane) {
   const double theta = SR(S_THETA);
   const ldsi* indx2 = L.indx2();
   int upcl;
+  LBT_BEGIN();
   if (ISR(I_UPDATD)) {
     if (ISR(I_IUPDAT) > m) {
       // shift the three blocks of WN1 one step up-left: every source is read before anything is written
@@ -609,7 +610,9 @@ __device__ __noinline__ void lb_formk(const LbLds L, int lane) {
       L.prod()[k] = fr ? 0.0 : WS_(k, ipntr);
     }
     LSYNC();
+    LBT_NEXT(18);
     lb_accum(L, L.coef(), L.prod(), lane);
+    LBT_NEXT(19);
     if (lane < col) {
       int jp = head + lane; if (jp >= m) jp -= m;
       WN1_(iy, lane) = L.acc()[jp];                 // t1
@@ -623,6 +626,7 @@ __device__ __noinline__ void lb_formk(const LbLds L, int lane) {
   } else {
     upcl = col;
   }
+  LBT_NEXT(20);
   // corrections for the variables that entered / left the free set
   {
     const int npair = upcl * (upcl + 1) / 2;
@@ -650,6 +654,7 @@ __device__ __noinline__ void lb_formk(const LbLds L, int lane) {
     }
     LSYNC();
   }
+  LBT_NEXT(21);
   // upper triangle of WN
   for (int e = lane; e < col * col; e += 64) {
     const int iy = e / col, jy = e % col, is = col + iy, is1 = m + iy, js = col + jy, js1 = m + jy;
@@ -662,7 +667,9 @@ __device__ __noinline__ void lb_formk(const LbLds L, int lane) {
     WN_(jy, is) = jy < iy ? -WN1_(is1, jy) : WN1_(is1, jy);
   }
   LSYNC();
+  LBT_NEXT(22);
   int info = lb_dpofa(L.wn(), 2 * m, col, lane);
+  LBT_NEXT(23);
   if (info != 0) { sti0(&ISC(I_INFO), -1, lane); LSYNC(); return; }
   // the col right-hand sides WN(0:col, js), js = col .. 2 col - 1: a system per lane (job 11, the host's order)
   {
@@ -690,6 +697,7 @@ __device__ __noinline__ void lb_formk(const LbLds L, int lane) {
     }
     LSYNC();
   }
+  LBT_NEXT(24);
   for (int e = lane; e < col * (col + 1) / 2; e += 64) {
     int a = 0, ee = e;
     while (ee > a) { ee -= a + 1; ++a; }           // pair (ee <= a)
@@ -699,7 +707,9 @@ __device__ __noinline__ void lb_formk(const LbLds L, int lane) {
     WN_(is, js) += s;
   }
   LSYNC();
+  LBT_NEXT(25);
   info = lb_dpofa(&WN_(col, col), 2 * m, col, lane);
+  LBT_NEXT(26);
   if (info != 0) { sti0(&ISC(I_INFO), -2, lane); LSYNC(); }
 }
 
@@ -727,12 +737,15 @@ __device__ __noinline__ void lb_subsm(const LbLds L, int lane) {
   const ldsi* ind = L.index();
   ldsd* x = L.z(); ldsd* d = L.r(); ldsd* wv = L.wa();
   if (nsub <= 0) return;
+  LBT_BEGIN();
   // full = d scattered to the variables' own places (zeros elsewhere; with every variable free it is d itself)
   for (int k = lane; k < n; k += 64) L.full()[k] = 0.0;
   LSYNC();
   for (int i = lane; i < nsub; i += 64) L.full()[ind[i]] = d[i];
   LSYNC();
+  LBT_NEXT(27);
   lb_accum(L, L.full(), nullptr, lane);
+  LBT_NEXT(28);
   double b = 0.0;
   if (lane < col2) {
     const int i = lane < col ? lane : lane - col;
@@ -742,6 +755,7 @@ __device__ __noinline__ void lb_subsm(const LbLds L, int lane) {
   int info = 0;
   b = lb_subsm_solves(L, b, &info, lane);
   if (info != 0) { sti0(&ISC(I_INFO), info, lane); LSYNC(); return; }
+  LBT_NEXT(29);
   if (lane < col2) wv[lane] = b;
   LSYNC();
   int pointr = ISR(I_HEAD);
@@ -751,6 +765,7 @@ __device__ __noinline__ void lb_subsm(const LbLds L, int lane) {
     pointr = nxt(pointr);
   }
   LSYNC();
+  LBT_NEXT(30);
   const double inv_theta = 1.0 / theta;
   for (int i = lane; i < nsub; i += 64) d[i] = L.full()[ind[i]] * inv_theta;
   for (int i = lane; i < n; i += 64) L.xp()[i] = x[i];
@@ -767,6 +782,7 @@ __device__ __noinline__ void lb_subsm(const LbLds L, int lane) {
   const int iword = __ballot(hit) ? 1 : 0;
   sti0(&ISC(I_IWORD), iword, lane);
   LSYNC();
+  LBT_NEXT(31);
   if (iword == 0) return;
   for (int i = lane; i < n; i += 64) L.prod()[i] = (x[i] - L.x()[i]) * L.g()[i];
   LSYNC();

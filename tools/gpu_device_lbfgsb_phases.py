@@ -27,7 +27,10 @@ vals, status = bt.gp_wait_eval(raw, best)
 ics = [raw[b][np.argsort(-vals[b])[:10]] for b in range(B)]
 names = {0: "cauchy", 1: "freev", 2: "formk", 3: "cmprlb", 4: "subsm", 5: "lnsrlb", 6: "matupd", 7: "formt",
          8: "eval: xn", 9: "eval: ks", 10: "eval: pass 1", 11: "eval: combine v", 12: "eval: scalar + pass 2", 13: "eval: u",
-         14: "eval: contraction", 16: "step (advance, all of it)", 17: "evaluation (all of it)"}
+         14: "eval: contraction", 16: "step (advance, all of it)", 17: "evaluation (all of it)",
+         18: "formk: shift + fill", 19: "formk: accum", 20: "formk: new column", 21: "formk: corrections", 22: "formk: assemble WN",
+         23: "formk: dpofa 1", 24: "formk: solves", 25: "formk: products", 26: "formk: dpofa 2",
+         27: "subsm: scatter", 28: "subsm: accum", 29: "subsm: solves", 30: "subsm: update full", 31: "subsm: project"}
 have = hasattr(N.LIB, "pcabo_debug_lb_ticks")
 for rep in range(3):
     if have:

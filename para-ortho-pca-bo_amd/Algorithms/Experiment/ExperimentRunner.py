@@ -51,6 +51,14 @@ class _NoBar:
     def close(self): pass
 
 
+def device_batch_plan(n_runs: int):
+    """Batches for the device-resident optimiser: (runs per batch, batches advancing at once) - up to four batches of at least
+    30 runs at a time, none larger than 120 runs (45 -> 1 x 45; 90 -> 3 x 30; 600 -> 8 x 75, four at a time)."""
+    nb = min(4, max(1, n_runs // 30))
+    rounds = -(-n_runs // (120 * nb))
+    return -(-n_runs // (nb * rounds)), nb
+
+
 def split_evenly(cell, batched: int, side_by_side: int):
     """Divide the runs of one dimension over lock-step batches of AT MOST `batched` runs each, as evenly as possible and in
     order; the number of batches is rounded up to a multiple of `side_by_side` so that no batch advances with nothing
@@ -96,8 +104,8 @@ class ExperimentRunner:
         # one batch's host-paced L-BFGS-B rounds overlap the other's launches and bookkeeping.  Same runs, same numbers.
         self.side_by_side = max(1, int(side_by_side))
         # pcabo.batchrun.BatchedPCABO(acq_kernel=...): "group" (host-paced L-BFGS-B rounds, the default), "latency", "device"
-        # (device-resident L-BFGS-B: pays from ~100 runs in flight, e.g. batched=75, side_by_side=4) or "auto" (per dimension:
-        # "device" in four large batches when this rank has >= 100 runs of it and d <= 40, "group" otherwise)
+        # (device-resident L-BFGS-B: pays from ~40 runs in flight, e.g. batched=75, side_by_side=4) or "auto" (per dimension:
+        # "device" in up to four batches when this rank has >= 40 runs of it and d <= 40, "group" otherwise)
         self.batch_acq_kernel = batch_acq_kernel
 
         self.triggers = [ALWAYS]
@@ -170,13 +178,14 @@ class ExperimentRunner:
             cell = [r for r in mine if r[1] == dim]
             kernel = self.batch_acq_kernel
             if kernel == "auto":
-                # many runs of one dimension on this GPU: the optimiser on the device, FOUR large batches interleaved on one host
-                # thread (measured best: bigger batches win, more than four at once do not - DESIGN.md 8b); few runs: host-paced
-                kernel = "device" if len(cell) >= 100 and dim <= 40 else "group"
+                # 40 runs or more of one dimension on this GPU: the optimiser on the device, up to FOUR batches of >= 30 runs interleaved
+                # on one host thread (measured, DESIGN.md 8b: 45 runs 1 932 it/s against 1 818 host-paced, 60 runs 2 490 / 2 033, 90 runs
+                # 3 172 / 2 256; bigger batches win, more than four at once do not); fewer runs: host-paced
+                kernel = "device" if len(cell) >= 40 and dim <= 40 else "group"
                 if kernel == "device":
-                    per = -(-len(cell) // (4 * -(-len(cell) // 480)))          # <= 120 runs per batch, a multiple of four batches
+                    per, nb = device_batch_plan(len(cell))
                     parts = [cell[i:i + per] for i in range(0, len(cell), per)]
-                    groups += [[(dim, part, kernel) for part in parts[i:i + 4]] for i in range(0, len(parts), 4)]
+                    groups += [[(dim, part, kernel) for part in parts[i:i + nb]] for i in range(0, len(parts), nb)]
                     continue
             # the runs of a dimension are divided EVENLY over a multiple of `side_by_side` batches of about `batched` runs
             # (a lone last batch would advance with nothing beside it; larger batches amortise the rounds of the slowest

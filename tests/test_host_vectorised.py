@@ -56,3 +56,14 @@ def test_row_wise_argsort_gives_the_ranks_of_the_1d_calls():
             for b in range(F.shape[0]):
                 fb = (sign * F[b]).copy()
                 assert np.array_equal(np.argsort(np.argsort(fb)) + 1, r2[b]), (t, b)
+
+
+def test_device_batch_plan_covers_every_run_in_bounded_batches():
+    """ExperimentRunner's "auto" mode: up to four batches of >= 30 runs at a time, none above 120 runs, nothing left over."""
+    from Algorithms.Experiment.ExperimentRunner import device_batch_plan
+    assert device_batch_plan(45) == (45, 1) and device_batch_plan(90) == (30, 3) and device_batch_plan(600) == (75, 4)
+    for n in range(40, 1500, 7):
+        per, nb = device_batch_plan(n)
+        parts = [min(per, n - i) for i in range(0, n, per)]
+        assert sum(parts) == n and max(parts) <= 120 and 1 <= nb <= 4
+        assert min(parts) >= min(30, n) // 2          # (the last batch may be short, never a sliver)

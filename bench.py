@@ -386,6 +386,11 @@ def main():
             big = batchrun.bench_block(device, 4 * args.batch, FID, DIM, sub_batches=4)
             dev = batchrun.bench_block(device, 4 * args.batch, FID, DIM, sub_batches=4, acq_kernel="device", schedule="interleaved")
             dev2 = batchrun.bench_block(device, 8 * args.batch, FID, DIM, sub_batches=4, acq_kernel="device", schedule="interleaved")
+            # the device-resident optimiser at 30 and 60 runs as well (one batch / two batches of B runs on one host thread)
+            dev30 = batchrun.bench_block(device, args.batch, FID, DIM, acq_kernel="device", schedule="interleaved")
+            dev60 = batchrun.bench_block(device, 2 * args.batch, FID, DIM, sub_batches=2, acq_kernel="device", schedule="interleaved")
+            batch["one_batch_device_resident"] = {k: dev30[k] for k in keys}
+            batch["two_batches_device_resident"] = {k: dev60[k] for k in keys}
             batch["four_batches_host_paced"] = {k: big[k] for k in keys}
             batch["four_batches_device_resident"] = {**{k: dev[k] for k in keys}, "host_thread_busy_seconds": dev["interleave"]["host_busy_seconds"],
                                                      "note": "pcabo.batchrun.run_interleaved + acq_kernel='device' (PCABO_OPT_DEVICE_LBFGSB = 1); a run "

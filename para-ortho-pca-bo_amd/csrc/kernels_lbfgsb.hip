@@ -16,10 +16,11 @@
 //    divide and square root), so that fed the same f / g values the device takes the host's iterates bit for bit
 //    (tests/test_gpu_device_lbfgsb.py compares the two through the evaluation-only mode of the same kernel).
 //  * The evaluation (rows I of SURVEY.md 8a for the group's points: kernel vectors, v = R ks, |v|^2, mu, log-EI / PI chain,
-//    w = R' v, gradient contraction) is thread-per-output with coalesced reads and no cross-lane reduction in the two
-//    triangular passes: pass 1 reads the TRANSPOSED root inverse RT (built once per conditioning by k_rt_build), pass 2 reads
-//    R itself; the rows / columns of a pass are split over 1024 / NP thread groups whose partial sums are added in a fixed
-//    order.  Same formulas as k_acq_group / k_acq_fast, another (fixed) summation order: a third arithmetic mode, selected
+//    w = R' v, gradient contraction) is thread-per-output with coalesced reads in the two triangular passes: pass 1 reads
+//    the TRANSPOSED root inverse RT (built once per conditioning by k_rt_build), pass 2 reads R itself; a thread loads 16
+//    bytes (two neighbouring outputs) and the half-waves split the summation index by parity - one exchange per query
+//    joins them (a CU issues a wave's load instruction every ~11 ns whatever its width: lb_eval); the rows / columns of a
+//    pass are split over 1024 / NP thread groups whose partial sums are added in a fixed order.  Same formulas as k_acq_group / k_acq_fast, another (fixed) summation order: a third arithmetic mode, selected
 //    per batch (PCABO_OPT_DEVICE_LBFGSB), never mixed within a run.
 #include "pcabo_internal.h"
 #include "lbfgsb.h"

@@ -81,6 +81,12 @@ enum { I_COL, I_HEAD, I_ITAIL, I_ITER, I_IUPDAT, I_UPDATD, I_WRK, I_NFREE, I_ILE
 // largest group, LB_GQ * LB_MAXK variables), the evaluation's three NP-sized arrays last.  The struct is three words and
 // travels by value.
 #define LB_NVCAP (LB_GQ * LB_MAXK)
+// work plan of the two triangular passes (lb_build_plan): per pass and wave [count, 2 x (unit, lo, hi, dest)], then per unit
+// [first extra slot, extra slots]
+#define LB_WAVES (LB_THREADS / 64)
+#define LB_PLAN_WAVE 9
+#define LB_PLAN_PASS (LB_WAVES * LB_PLAN_WAVE + 2 * (LB_MAXNP / 64))
+#define LB_PLAN_INTS (2 * LB_PLAN_PASS)
 #define LB_LDW (LB_NVCAP | 1)
 #define LB_NVP ((LB_NVCAP + 3) & ~1)
 #define LB_EVEN(x) (((x) + 1) & ~1)
@@ -93,7 +99,8 @@ enum {
   OFF_WN1 = OFF_WN + 4 * LB_M * LB_M, OFF_WA = OFF_WN1 + 4 * LB_M * LB_M, OFF_ACC = OFF_WA + 8 * LB_M, OFF_SC = OFF_ACC + 64,
   OFF_VC = OFF_SC + LB_EVEN(S_COUNT + 2), OFF_INTS = OFF_VC + 8,
   OFF_XN = OFF_INTS + LB_EVEN((4 * LB_NVP + I_COUNT + 2) / 2 + 2), OFF_RED = OFF_XN + LB_EVEN(LB_GQ * (LB_MAXK + 2)),
-  OFF_VALS = OFF_RED + 160, OFF_CQ = OFF_VALS + 8, OFF_NLO = OFF_CQ + 16, OFF_NHI = OFF_NLO + LB_MAXK, OFF_EV = OFF_NHI + LB_MAXK, OFF_KS = OFF_EV + 16
+  OFF_VALS = OFF_RED + 80, OFF_CQ = OFF_VALS + 8, OFF_NLO = OFF_CQ + 16, OFF_NHI = OFF_NLO + LB_MAXK, OFF_EV = OFF_NHI + LB_MAXK,
+  OFF_PLAN = OFF_EV + 16, OFF_KS = OFF_PLAN + LB_PLAN_INTS / 2
 };
 struct LbLds {
   ldsd* base;
@@ -135,11 +142,14 @@ struct LbLds {
   __device__ ldsd* nlo() const { return base + OFF_NLO; }
   __device__ ldsd* nhi() const { return base + OFF_NHI; }
   __device__ ldsd* ev() const { return base + OFF_EV; }
+  __device__ ldsi* plan() const { return (ldsi*)(base + OFF_PLAN); }
   __device__ ldsd* ks() const { return base + OFF_KS; }
   __device__ ldsd* vb() const { return base + OFF_KS + LB_QS * NP; }
-  __device__ ldsd* part() const { return base + OFF_KS + 2 * LB_QS * NP; }
+  __device__ ldsd* slots() const { return base + OFF_KS + 2 * LB_QS * NP; }       // partial sums of a pass: [slot][64][LB_GQ]
 };
-static inline size_t lb_lds_doubles(int NP, int H) { return (size_t)OFF_KS + (size_t)(2 + (H > 1 ? H - 1 : 1)) * LB_QS * NP; }
+// the triangular passes' partial slots: at most (waves + two-slab pairs - slabs) segments do not start their slab (lb_build_plan)
+static inline int lb_max_slots(int NP) { const int S = NP / 64; return 16 + S / 2 - S; }
+static inline size_t lb_lds_doubles(int NP) { return (size_t)OFF_KS + (size_t)2 * LB_QS * NP + (size_t)lb_max_slots(NP) * 64 * LB_GQ; }
 
 #define SC(i) L.sc()[i]
 #define ISC(i) L.isc()[i]
@@ -1224,14 +1234,75 @@ __device__ void lb_advance(const LbLds L, int maxiter, int lane) {
 // =====================================================================================================================
 // Evaluation: value and gradient of the acquisition at the group's nq points (all LB_THREADS threads)
 // =====================================================================================================================
+// The triangular passes, balanced.  Unit u of pass 1 is the 64-row slab u of RT' (columns 0 .. min(n, 64 (u + 1)) - 1), unit u of
+// pass 2 the 64-column block u of R (rows 64 u .. n - 1): work 1 : 2 : ... : S.  A slab per wave (split in equal parts) leaves the
+// pass waiting for the longest wave - a chain of load round trips that the CU's load rate does not explain (16.4 us against
+// 12.3).  Here the units are folded into pairs (largest with smallest), the 16 waves are dealt out to the pairs in proportion
+// to their work, and the waves of a pair cut its columns (rows) into equal ranges: a wave gets one or two segments
+// (unit, lo, hi).  The segment that starts a unit writes the unit's sums where the next phase reads them (dest -1), the others
+// go to numbered partial slots that the next phase adds in ascending order - a fixed order for a given (n, NP).
+// One thread, once per kernel (n and NP are the launch's).
+__device__ inline void lb_build_plan(const LbLds L, int n, int S) {
+  ldsi* plan = L.plan();
+  for (int i = 0; i < LB_PLAN_INTS; ++i) plan[i] = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    ldsi* pw = plan + pass * LB_PLAN_PASS;
+    ldsi* pu = pw + LB_WAVES * LB_PLAN_WAVE;
+    int lo[8], hi[8], order[8];
+    for (int u = 0; u < S; ++u) {
+      if (pass == 0) { lo[u] = 0; hi[u] = n < 64 * (u + 1) ? n : 64 * (u + 1); }
+      else { lo[u] = 64 * u; hi[u] = n > 64 * u ? n : 64 * u; }
+    }
+    for (int t = 0; t < S; ++t) {                     // pass 1: S-1, 0, S-2, 1 ...; pass 2 (largest unit first): 0, S-1, 1, S-2 ...
+      const int a = t / 2, big = pass == 0 ? S - 1 - a : a, small = pass == 0 ? a : S - 1 - a;
+      order[t] = (t & 1) ? small : big;
+    }
+    const int P = (S + 1) / 2;
+    long long total = 0;
+    for (int u = 0; u < S; ++u) total += hi[u] - lo[u];
+    int waves_left = LB_WAVES, slot = 0, wave = 0;
+    long long work_left = total;
+    for (int p = 0; p < P; ++p) {
+      const int ua = order[2 * p], ub = 2 * p + 1 < S ? order[2 * p + 1] : -1;
+      const int wa = hi[ua] - lo[ua], wb = ub >= 0 ? hi[ub] - lo[ub] : 0, work = wa + wb;
+      int wp;
+      if (p == P - 1) wp = waves_left;
+      else {
+        wp = work_left > 0 ? (int)(((long long)work * waves_left + work_left / 2) / work_left) : 1;
+        const int keep = P - 1 - p;                   // a wave at least for every pair still to come
+        if (wp > waves_left - keep) wp = waves_left - keep;
+        if (wp < 1) wp = 1;
+      }
+      waves_left -= wp; work_left -= work;
+      int chunk = (work + wp - 1) / wp;
+      chunk = (chunk + 1) & ~1;                         // (pairs of columns / rows: both half-waves busy)
+      if (chunk < 2) chunk = 2;
+      for (int t = 0; t < wp; ++t, ++wave) {
+        const int r0 = t * chunk < work ? t * chunk : work, r1 = (t + 1) * chunk < work ? (t + 1) * chunk : work;
+        ldsi* e = pw + wave * LB_PLAN_WAVE;
+        int cnt = 0;
+        for (int g = 0; g < 2; ++g) {                   // the range's part in unit a ([0, wa) of the pair), then in unit b
+          const int u = g == 0 ? ua : ub, base = g == 0 ? 0 : wa, len = g == 0 ? wa : wb;
+          if (u < 0) continue;
+          const int a0 = r0 > base ? r0 - base : 0, a1 = (r1 - base) < len ? r1 - base : len;
+          if (a1 <= a0) continue;
+          int dest = -1;
+          if (a0 > 0) { dest = slot++; if (pu[2 * u + 1] == 0) pu[2 * u] = dest; pu[2 * u + 1] += 1; }
+          e[1 + 4 * cnt] = u; e[2 + 4 * cnt] = lo[u] + a0; e[3 + 4 * cnt] = lo[u] + a1; e[4 + 4 * cnt] = dest;
+          ++cnt;
+        }
+        e[0] = cnt;
+      }
+    }
+  }
+}
+
 struct LbEval {
   gcd *ZnT, *R, *RT, *alpha, *nlo, *nhi;
-  int n, k, NP, ld, H, S;
+  int n, k, NP, ld, S;
   double best_f, ym, ysd, inv_ls;
   int maximize, acq, kernel;
 };
-
-__device__ inline int slab_of(int w, int S) { return (S & 1) ? w : (w < S / 2 ? w : S - 1 - (w - S / 2)); }
 
 __device__ inline void lb_log_ei_helper(double u, double* h, double* dh) {
   const double inv_sqrt2 = 0.7071067811865476, inv_sqrt_2pi = 0.3989422804014327, log2pi = 1.8378770664093453;
@@ -1316,7 +1387,7 @@ __device__ inline void lb_store_eval_args(const LbLds L, const LbEval& E) {     
   ldsd* e = L.ev();
   e[0] = __longlong_as_double((long long)(unsigned long long)E.ZnT); e[1] = __longlong_as_double((long long)(unsigned long long)E.R);
   e[2] = __longlong_as_double((long long)(unsigned long long)E.RT); e[3] = __longlong_as_double((long long)(unsigned long long)E.alpha);
-  e[4] = __hiloint2double(E.n, E.k); e[5] = __hiloint2double(E.NP, E.ld); e[6] = __hiloint2double(E.H, E.S);
+  e[4] = __hiloint2double(E.n, E.k); e[5] = __hiloint2double(E.NP, E.ld); e[6] = __hiloint2double(0, E.S);
   e[7] = __hiloint2double(E.maximize, E.acq); e[8] = __hiloint2double(E.kernel, 0);
   e[9] = E.best_f; e[10] = E.ym; e[11] = E.ysd; e[12] = E.inv_ls;
 }
@@ -1333,13 +1404,13 @@ __device__ __noinline__ void lb_eval(const LbLds L_, int nq, bool want_grad) {
     unsigned long long v;
     v = lds_u64(e + 4); E.n = (int)(v >> 32); E.k = (int)(unsigned)v;
     v = lds_u64(e + 5); E.NP = (int)(v >> 32); E.ld = (int)(unsigned)v;
-    v = lds_u64(e + 6); E.H = (int)(v >> 32); E.S = (int)(unsigned)v;
+    v = lds_u64(e + 6); E.S = (int)(unsigned)v;
     v = lds_u64(e + 7); E.maximize = (int)(v >> 32); E.acq = (int)(unsigned)v;
     v = lds_u64(e + 8); E.kernel = (int)(v >> 32);
     E.best_f = e[9]; E.ym = e[10]; E.ysd = e[11]; E.inv_ls = uni(e[12]);
   }
   nq = uni(nq);
-  const int n = E.n, k = E.k, NP = E.NP, ld = E.ld, H = E.H, S = E.S;
+  const int n = E.n, k = E.k, NP = E.NP, ld = E.ld, S = E.S;
   const int XS = LB_MAXK + 2;
   LBT_BEGIN();
   for (int idx = tid; idx < LB_GQ * k; idx += LB_THREADS) {
@@ -1351,12 +1422,13 @@ __device__ __noinline__ void lb_eval(const LbLds L_, int nq, bool want_grad) {
   LBT_NEXT(8);
   // ---- kernel vectors: a thread per training point (the threads of pass 2's first group), all queries per pass over ZnT
   double cf[LB_GQ];
-  const int hh = w / S, wsub = w - hh * S;
-  const int cbu = S - 1 - slab_of(wsub, S), sbu = slab_of(wsub, S);   // wave-uniform: this wave's column block (pass 2) / row slab (pass 1)
+  // waves 0 .. S-1 own the points of block w (kernel vectors, |v|^2 / mu, the weights u); the triangular passes follow the plan
+  const bool owner = w < S;
+  const int cbu = w;
   const int half = lane >> 5, l32 = lane & 31;
-  const int jmine = 64 * cbu + 2 * l32 + half;    // the column this thread finishes in pass 2 (hh < H): lanes 0 .. 31 the even ones
+  const int jmine = 64 * cbu + 2 * l32 + half;    // the point this thread owns (owner waves): lanes 0 .. 31 the even ones
   const unsigned off2 = (unsigned)half * (unsigned)ld * 8u + (unsigned)l32 * 16u;   // (row + half, elements 2 l32 and 2 l32 + 1)
-  if (hh == 0) {
+  if (owner) {
     // 16-byte loads here too: a thread takes points 2 l32 and 2 l32 + 1 of the wave's block and every second component (its
     // half-wave's parity); (even components) + (odd components) meet in the lane that keeps the point
     const int j = jmine;
@@ -1425,68 +1497,73 @@ __device__ __noinline__ void lb_eval(const LbLds L_, int nq, bool want_grad) {
   }
   __syncthreads();
   LBT_NEXT(9);
-  // ---- pass 1: v_q[i] = sum_j RT[j][i] ks_q[j].  A thread holds rows 2 l32 and 2 l32 + 1 of the wave's slab and takes every second
-  // column of part hh (its half-wave's parity); the two half-waves' sums meet at the end: (even columns) + (odd columns)
-  const int imine = 64 * sbu + 2 * l32 + half;
-  if (hh < H) {
-    const int jtot = n < 64 * (sbu + 1) ? n : 64 * (sbu + 1);
-    const int J0 = (int)((long long)jtot * hh / H), J1 = (int)((long long)jtot * (hh + 1) / H);
-    double p0[LB_GQ] = {0.0, 0.0, 0.0, 0.0, 0.0}, p1[LB_GQ] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    gcd* rp = E.RT + 64 * sbu;            // (wave-uniform base + the lane's 32-bit offset: no address arithmetic per load)
-    int j = J0;
-    for (; j + 2 * LB_UB2 <= J1; j += 2 * LB_UB2) {     // whole trips: LB_UB2 loads in flight, no guards (the other waves cover the wait)
-      lb_d2 rc[LB_UB2];
+  // ---- pass 1: v_q[i] = sum_j RT[j][i] ks_q[j].  A thread holds rows 2 l32 and 2 l32 + 1 of the segment's slab and takes every second
+  // column of the segment (its half-wave's parity); the two half-waves' sums meet at the end: (even columns) + (odd columns)
+  {
+    const ldsi* pl = L.plan() + w * LB_PLAN_WAVE;
+    const int nseg = uni(pl[0]);
+    for (int g = 0; g < nseg; ++g) {
+      const int unit = uni(pl[1 + 4 * g]), J0 = uni(pl[2 + 4 * g]), J1 = uni(pl[3 + 4 * g]), dest = uni(pl[4 + 4 * g]);
+      double p0[LB_GQ] = {0.0, 0.0, 0.0, 0.0, 0.0}, p1[LB_GQ] = {0.0, 0.0, 0.0, 0.0, 0.0};
+      gcd* rp = E.RT + 64 * unit;            // (wave-uniform base + the lane's 32-bit offset: no address arithmetic per load)
+      int j = J0;
+      for (; j + 2 * LB_UB2 <= J1; j += 2 * LB_UB2) {     // whole trips: LB_UB2 loads in flight, no guards (the other waves cover the wait)
+        lb_d2 rc[LB_UB2];
 #pragma unroll
-      for (int u = 0; u < LB_UB2; ++u) rc[u] = ld_row2(rp + (size_t)(j + 2 * u) * ld, off2);
+        for (int u = 0; u < LB_UB2; ++u) rc[u] = ld_row2(rp + (size_t)(j + 2 * u) * ld, off2);
 #pragma unroll
-      for (int u = 0; u < LB_UB2; ++u) {
-        const ldsd* kp = L.ks() + (j + 2 * u + half) * LB_QS;
-#pragma unroll
-        for (int q = 0; q < LB_GQ; ++q) { const double kq = kp[q]; p0[q] = fma(rc[u].x, kq, p0[q]); p1[q] = fma(rc[u].y, kq, p1[q]); }
-      }
-    }
-    if (j < J1) {                                       // the ragged end: one trip, every load issued before the first use
-      lb_d2 rc[LB_UB2];
-#pragma unroll
-      for (int u = 0; u < LB_UB2; ++u) {
-        const int jc = j + 2 * u + half, jl = jc < J1 ? jc : J1 - 1;
-        rc[u] = ld_row2(rp + (size_t)jl * ld, (unsigned)l32 * 16u);
-      }
-#pragma unroll
-      for (int u = 0; u < LB_UB2; ++u) {
-        const int jc = j + 2 * u + half;
-        if (jc < J1) {
-          const ldsd* kp = L.ks() + jc * LB_QS;
+        for (int u = 0; u < LB_UB2; ++u) {
+          const ldsd* kp = L.ks() + (j + 2 * u + half) * LB_QS;
 #pragma unroll
           for (int q = 0; q < LB_GQ; ++q) { const double kq = kp[q]; p0[q] = fma(rc[u].x, kq, p0[q]); p1[q] = fma(rc[u].y, kq, p1[q]); }
         }
       }
-    }
-    // lanes 0 .. 31 finish row 2 l32 (their own even-column sum + the partner's odd-column sum), lanes 32 .. 63 row 2 l32 + 1
-    ldsd* dst = hh == 0 ? L.vb() + imine * LB_QS : L.part() + ((size_t)(hh - 1) * NP + imine) * LB_QS;
+      if (j < J1) {                                       // the ragged end: one trip, every load issued before the first use
+        lb_d2 rc[LB_UB2];
 #pragma unroll
-    for (int q = 0; q < LB_GQ; ++q) {
-      const double got = __shfl_xor(half ? p0[q] : p1[q], 32, 64);
-      dst[q] = half ? got + p1[q] : p0[q] + got;
+        for (int u = 0; u < LB_UB2; ++u) {
+          const int jc = j + 2 * u + half, jl = jc < J1 ? jc : J1 - 1;
+          rc[u] = ld_row2(rp + (size_t)jl * ld, (unsigned)l32 * 16u);
+        }
+#pragma unroll
+        for (int u = 0; u < LB_UB2; ++u) {
+          const int jc = j + 2 * u + half;
+          if (jc < J1) {
+            const ldsd* kp = L.ks() + jc * LB_QS;
+#pragma unroll
+            for (int q = 0; q < LB_GQ; ++q) { const double kq = kp[q]; p0[q] = fma(rc[u].x, kq, p0[q]); p1[q] = fma(rc[u].y, kq, p1[q]); }
+          }
+        }
+      }
+      // lanes 0 .. 31 finish row 2 l32 (their own even-column sum + the partner's odd-column sum), lanes 32 .. 63 row 2 l32 + 1
+      const int rin = 2 * l32 + half;
+      ldsd* dst = dest < 0 ? L.vb() + (64 * unit + rin) * LB_QS : L.slots() + ((size_t)dest * 64 + rin) * LB_GQ;
+#pragma unroll
+      for (int q = 0; q < LB_GQ; ++q) {
+        const double got = __shfl_xor(half ? p0[q] : p1[q], 32, 64);
+        dst[q] = half ? got + p1[q] : p0[q] + got;
+      }
     }
   }
   __syncthreads();
   LBT_NEXT(10);
-  if (hh == 0) {
-    const int i = imine;
+  if (owner) {
+    const int i = 64 * w + lane;
+    const ldsi* pu = L.plan() + LB_WAVES * LB_PLAN_WAVE + 2 * w;
+    const int first = uni(pu[0]), extra = uni(pu[1]);
     double v[LB_GQ];
 #pragma unroll
     for (int q = 0; q < LB_GQ; ++q) v[q] = L.vb()[i * LB_QS + q];
-    for (int h2 = 1; h2 < H; ++h2)
+    for (int t = 0; t < extra; ++t)
 #pragma unroll
-      for (int q = 0; q < LB_GQ; ++q) v[q] += L.part()[((size_t)(h2 - 1) * NP + i) * LB_QS + q];
+      for (int q = 0; q < LB_GQ; ++q) v[q] += L.slots()[((size_t)(first + t) * 64 + lane) * LB_GQ + q];
     const double ai = i < n ? E.alpha[i] : 0.0;
 #pragma unroll
     for (int q = 0; q < LB_GQ; ++q) {
       L.vb()[i * LB_QS + q] = v[q];
       const double vv = wave_sum(v[q] * v[q]);
       const double mu = wave_sum(ai * L.ks()[i * LB_QS + q]);
-      if (lane == 0) { L.red()[wsub * 10 + q] = vv; L.red()[wsub * 10 + LB_GQ + q] = mu; }
+      if (lane == 0) { L.red()[w * 10 + q] = vv; L.red()[w * 10 + LB_GQ + q] = mu; }
     }
   }
   __syncthreads();
@@ -1500,55 +1577,53 @@ __device__ __noinline__ void lb_eval(const LbLds L_, int nq, bool want_grad) {
     L.vals()[tid] = value; L.cq()[2 * tid] = cmu; L.cq()[2 * tid + 1] = csg;
   }
   if (!want_grad) { __syncthreads(); return; }
-  // ---- pass 2: w_q[j] = sum_{i >= j} R[i][j] v_q[i].  A thread holds columns 2 l32 and 2 l32 + 1 of the wave's block and takes every
-  // second row of part hh; the half-waves meet as in pass 1: (even rows) + (odd rows), the thread keeps column jmine
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0;
-  if (hh < H) {
-    const int ibeg = 64 * cbu, len = n > ibeg ? n - ibeg : 0;
-    const int I0 = ibeg + (int)((long long)len * hh / H), I1 = ibeg + (int)((long long)len * (hh + 1) / H);
-    double p0[LB_GQ] = {0.0, 0.0, 0.0, 0.0, 0.0}, p1[LB_GQ] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    gcd* rp = E.R + ibeg;
-    int i = I0;
-    for (; i + 2 * LB_UB2 <= I1; i += 2 * LB_UB2) {
-      lb_d2 rc[LB_UB2];
+  // ---- pass 2: w_q[j] = sum_{i >= j} R[i][j] v_q[i].  A thread holds columns 2 l32 and 2 l32 + 1 of the segment's block and takes
+  // every second row of the segment; the half-waves meet as in pass 1: (even rows) + (odd rows).  The block's first segment
+  // leaves its sums where the kernel vectors were (they are no longer needed), the others in the partial slots
+  {
+    const ldsi* pl = L.plan() + LB_PLAN_PASS + w * LB_PLAN_WAVE;
+    const int nseg = uni(pl[0]);
+    for (int g = 0; g < nseg; ++g) {
+      const int unit = uni(pl[1 + 4 * g]), I0 = uni(pl[2 + 4 * g]), I1 = uni(pl[3 + 4 * g]), dest = uni(pl[4 + 4 * g]);
+      double p0[LB_GQ] = {0.0, 0.0, 0.0, 0.0, 0.0}, p1[LB_GQ] = {0.0, 0.0, 0.0, 0.0, 0.0};
+      gcd* rp = E.R + 64 * unit;
+      int i = I0;
+      for (; i + 2 * LB_UB2 <= I1; i += 2 * LB_UB2) {
+        lb_d2 rc[LB_UB2];
 #pragma unroll
-      for (int u = 0; u < LB_UB2; ++u) rc[u] = ld_row2(rp + (size_t)(i + 2 * u) * ld, off2);
+        for (int u = 0; u < LB_UB2; ++u) rc[u] = ld_row2(rp + (size_t)(i + 2 * u) * ld, off2);
 #pragma unroll
-      for (int u = 0; u < LB_UB2; ++u) {
-        const ldsd* vp = L.vb() + (i + 2 * u + half) * LB_QS;
-#pragma unroll
-        for (int q = 0; q < LB_GQ; ++q) { const double vq = vp[q]; p0[q] = fma(rc[u].x, vq, p0[q]); p1[q] = fma(rc[u].y, vq, p1[q]); }
-      }
-    }
-    if (i < I1) {
-      lb_d2 rc[LB_UB2];
-#pragma unroll
-      for (int u = 0; u < LB_UB2; ++u) {
-        const int ic = i + 2 * u + half, il = ic < I1 ? ic : I1 - 1;
-        rc[u] = ld_row2(rp + (size_t)il * ld, (unsigned)l32 * 16u);
-      }
-#pragma unroll
-      for (int u = 0; u < LB_UB2; ++u) {
-        const int ic = i + 2 * u + half;
-        if (ic < I1) {
-          const ldsd* vp = L.vb() + ic * LB_QS;
+        for (int u = 0; u < LB_UB2; ++u) {
+          const ldsd* vp = L.vb() + (i + 2 * u + half) * LB_QS;
 #pragma unroll
           for (int q = 0; q < LB_GQ; ++q) { const double vq = vp[q]; p0[q] = fma(rc[u].x, vq, p0[q]); p1[q] = fma(rc[u].y, vq, p1[q]); }
         }
       }
-    }
-    double fin[LB_GQ];
+      if (i < I1) {
+        lb_d2 rc[LB_UB2];
 #pragma unroll
-    for (int q = 0; q < LB_GQ; ++q) {
-      const double got = __shfl_xor(half ? p0[q] : p1[q], 32, 64);
-      fin[q] = half ? got + p1[q] : p0[q] + got;
-    }
-    if (hh > 0) {
-      ldsd* dst = L.part() + ((size_t)(hh - 1) * NP + jmine) * LB_QS;
+        for (int u = 0; u < LB_UB2; ++u) {
+          const int ic = i + 2 * u + half, il = ic < I1 ? ic : I1 - 1;
+          rc[u] = ld_row2(rp + (size_t)il * ld, (unsigned)l32 * 16u);
+        }
 #pragma unroll
-      for (int q = 0; q < LB_GQ; ++q) dst[q] = fin[q];
+        for (int u = 0; u < LB_UB2; ++u) {
+          const int ic = i + 2 * u + half;
+          if (ic < I1) {
+            const ldsd* vp = L.vb() + ic * LB_QS;
+#pragma unroll
+            for (int q = 0; q < LB_GQ; ++q) { const double vq = vp[q]; p0[q] = fma(rc[u].x, vq, p0[q]); p1[q] = fma(rc[u].y, vq, p1[q]); }
+          }
+        }
+      }
+      const int cin = 2 * l32 + half;
+      ldsd* dst = dest < 0 ? L.ks() + (64 * unit + cin) * LB_QS : L.slots() + ((size_t)dest * 64 + cin) * LB_GQ;
+#pragma unroll
+      for (int q = 0; q < LB_GQ; ++q) {
+        const double got = __shfl_xor(half ? p0[q] : p1[q], 32, 64);
+        dst[q] = half ? got + p1[q] : p0[q] + got;
+      }
     }
-    a0 = fin[0]; a1 = fin[1]; a2 = fin[2]; a3 = fin[3]; a4 = fin[4];
   }
   // the rows of ZnT the gradient contraction of this wave needs (components w, w + 16, w + 32) leave now: they arrive while
   // the barrier and the u phase pass
@@ -1565,16 +1640,21 @@ __device__ __noinline__ void lb_eval(const LbLds L_, int nq, bool want_grad) {
   }
   __syncthreads();
   LBT_NEXT(12);
-  if (hh == 0) {
+  if (owner) {
     const int j = jmine;
-    double wv[LB_GQ] = {a0, a1, a2, a3, a4};
-    for (int h2 = 1; h2 < H; ++h2)
+    const ldsi* pu = L.plan() + LB_PLAN_PASS + LB_WAVES * LB_PLAN_WAVE + 2 * w;
+    const int first = uni(pu[0]), extra = uni(pu[1]);
+    double wv[LB_GQ];
 #pragma unroll
-      for (int q = 0; q < LB_GQ; ++q) wv[q] += L.part()[((size_t)(h2 - 1) * NP + j) * LB_QS + q];
+    for (int q = 0; q < LB_GQ; ++q) wv[q] = L.ks()[j * LB_QS + q];
+    for (int t = 0; t < extra; ++t)
+#pragma unroll
+      for (int q = 0; q < LB_GQ; ++q) wv[q] += L.slots()[((size_t)(first + t) * 64 + (j - 64 * w)) * LB_GQ + q];
     const double aj = j < n ? E.alpha[j] : 0.0;
-    // u_q[j] = c_mu (alpha_j cf) + c_sg (w cf): the point's weight in the contraction with (xn_c - zn_cj); stored [q][j]
+    // u_q[j] = c_mu (alpha_j cf) + c_sg (w cf): the point's weight in the contraction with (xn_c - zn_cj); stored [q][j] where v
+    // was (pass 2 is over)
 #pragma unroll
-    for (int q = 0; q < LB_GQ; ++q) L.ks()[q * NP + j] = fma(L.cq()[2 * q], aj * cf[q], L.cq()[2 * q + 1] * (wv[q] * cf[q]));
+    for (int q = 0; q < LB_GQ; ++q) L.vb()[q * NP + j] = fma(L.cq()[2 * q], aj * cf[q], L.cq()[2 * q + 1] * (wv[q] * cf[q]));
   }
   __syncthreads();
   LBT_NEXT(13);
@@ -1597,7 +1677,7 @@ __device__ __noinline__ void lb_eval(const LbLds L_, int nq, bool want_grad) {
             const double z0 = j < n ? z[ci][bq].x : 0.0, z1 = j + 1 < n ? z[ci][bq].y : 0.0;
 #pragma unroll
             for (int q = 0; q < LB_GQ; ++q) {
-              const lb_d2 uq = j < NP ? *(ldsd2*)(L.ks() + q * NP + j) : lb_d2{0.0, 0.0};
+              const lb_d2 uq = j < NP ? *(ldsd2*)(L.vb() + q * NP + j) : lb_d2{0.0, 0.0};
               const double xv = L.xn()[q * XS + c];
               acc[q] = fma(j < n ? uq.x : 0.0, xv - z0, acc[q]);
               acc[q] = fma(j + 1 < n ? uq.y : 0.0, xv - z1, acc[q]);
@@ -1625,7 +1705,7 @@ __device__ __noinline__ void lb_eval(const LbLds L_, int nq, bool want_grad) {
 // out_v = [values (num_restarts) ... | 64 + 8 gi: niter, nfev, warnflag, task, status, evaluations, ties].
 // =====================================================================================================================
 __global__ __launch_bounds__(LB_THREADS) void k_lbfgsb_group(
-    const unsigned* __restrict__ table, int mode, int num_restarts, int maxiter, int n, int NP, int ld, int H,
+    const unsigned* __restrict__ table, int mode, int num_restarts, int maxiter, int n, int NP, int ld,
     const double* __restrict__ Xq, const double* __restrict__ ZnT, const double* __restrict__ R, const double* __restrict__ RT,
     const double* __restrict__ alpha, const double* __restrict__ bounds4, const double* __restrict__ ystats,
     const double* __restrict__ bestf, const int* __restrict__ k_dev, double inv_ls, int maximize, int acq, int kernel,
@@ -1644,7 +1724,7 @@ __global__ __launch_bounds__(LB_THREADS) void k_lbfgsb_group(
   L.base = (ldsd*)s_dyn; L.n = nv; L.NP = NP;
   LbEval E;
   E.ZnT = (gcd*)ZnT; E.R = (gcd*)R; E.RT = (gcd*)RT; E.alpha = (gcd*)alpha; E.nlo = (gcd*)bounds4; E.nhi = (gcd*)(bounds4 + PCABO_MAXD);
-  E.n = n; E.k = k; E.NP = NP; E.ld = ld; E.H = H; E.S = NP / 64;
+  E.n = n; E.k = k; E.NP = NP; E.ld = ld; E.S = NP / 64;
   E.best_f = *bestf; E.ym = ystats[0]; E.ysd = ystats[1]; E.inv_ls = inv_ls; E.maximize = maximize; E.acq = acq; E.kernel = kernel;
   // ---- initial state
   for (int i = tid; i < nv; i += LB_THREADS) {
@@ -1664,6 +1744,7 @@ __global__ __launch_bounds__(LB_THREADS) void k_lbfgsb_group(
   if (tid < I_COUNT) L.isc()[tid] = 0;
   __syncthreads();
   if (tid == 0) { SC(S_THETA) = 1.0; ISC(I_NFREE) = nv; ISC(I_ACTIVE) = 1; ISC(I_TASK) = LBFGSB_START; lb_store_eval_args(L, E); }
+  if (tid == 64) lb_build_plan(L, n, NP / 64);        // (a thread of another wave: beside the line above)
   __syncthreads();
   if (mode == 0) {
     lb_eval(L, nq, true);
@@ -1750,14 +1831,12 @@ bool lbfgsb_device_possible(int NP, int kmax, int batch_limit) {
   return NP <= LB_MAXNP && kmax <= LB_MAXK && batch_limit <= LB_GQ && NP >= 64;
 }
 
-static int lb_parts(int NP) { int H = LB_THREADS / NP; return H < 1 ? 1 : (H > 8 ? 8 : H); }
 
 int launch_lbfgsb_group(hipStream_t st, const unsigned* table, int entries, int mode, int num_restarts, int maxiter, int n, int NP,
                         int ld, const double* Xq, const double* ZnT, const double* R, const double* RT, const double* alpha,
                         const double* bounds4, const double* ystats, const double* bestf, const int* k_dev, double inv_ls,
                         int maximize, int acq, int kernel, double* out_x, double* out_v, size_t zs) {
-  const int H = lb_parts(NP);
-  const size_t lds = lb_lds_doubles(NP, H) * sizeof(double);
+  const size_t lds = lb_lds_doubles(NP) * sizeof(double);
   if (lds > 150 * 1024) return -1;
   {
     static std::mutex attr_mu;
@@ -1770,7 +1849,7 @@ int launch_lbfgsb_group(hipStream_t st, const unsigned* table, int entries, int 
       attr_done[dev] = true;
     }
   }
-  hipLaunchKernelGGL(k_lbfgsb_group, dim3(entries), dim3(LB_THREADS), lds, st, table, mode, num_restarts, maxiter, n, NP, ld, H, Xq,
+  hipLaunchKernelGGL(k_lbfgsb_group, dim3(entries), dim3(LB_THREADS), lds, st, table, mode, num_restarts, maxiter, n, NP, ld, Xq,
                      ZnT, R, RT, alpha, bounds4, ystats, bestf, k_dev, inv_ls, maximize, acq, kernel, out_x, out_v, zs);
   return 0;
 }

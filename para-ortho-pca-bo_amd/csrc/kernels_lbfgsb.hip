@@ -1685,11 +1685,10 @@ __device__ __noinline__ void lb_eval(const LbLds L_, int nq, bool want_grad) {
           }
         }
         const double inv = L.nhi()[c] - L.nlo()[c];
+        double mine = 0.0;                           // lane q keeps query q's sum: ONE division for the five
 #pragma unroll
-        for (int q = 0; q < LB_GQ; ++q) {
-          const double s = wave_sum(acc[q]);
-          if (lane == 0 && q < nq) L.g()[q * k + c] = -(s / inv);
-        }
+        for (int q = 0; q < LB_GQ; ++q) { const double s = wave_sum(acc[q]); if (lane == q) mine = s; }
+        if (lane < nq) L.g()[lane * k + c] = -(mine / inv);
       }
     }
   }

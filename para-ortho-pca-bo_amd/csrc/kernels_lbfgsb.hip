@@ -19,8 +19,8 @@
 //    w = R' v, gradient contraction) is thread-per-output with coalesced reads in the two triangular passes: pass 1 reads
 //    the TRANSPOSED root inverse RT (built once per conditioning by k_rt_build), pass 2 reads R itself; a thread loads 16
 //    bytes (two neighbouring outputs) and the half-waves split the summation index by parity - one exchange per query
-//    joins them (a CU issues a wave's load instruction every ~11 ns whatever its width: lb_eval); the rows / columns of a
-//    pass are split over 1024 / NP thread groups whose partial sums are added in a fixed order.  Same formulas as k_acq_group / k_acq_fast, another (fixed) summation order: a third arithmetic mode, selected
+//    joins them (a CU issues a wave's load instruction every ~11 ns whatever its width: lb_eval); the work of a pass is
+//    dealt out to the 16 waves by a plan built once per launch (lb_build_plan) whose partial sums are added in a fixed order.  Same formulas as k_acq_group / k_acq_fast, another (fixed) summation order: a third arithmetic mode, selected
 //    per batch (PCABO_OPT_DEVICE_LBFGSB), never mixed within a run.
 #include "pcabo_internal.h"
 #include "lbfgsb.h"

@@ -56,7 +56,7 @@ def test_device_stepping_equals_host_stepping_bit_for_bit(native, fid, dim, budg
 @pytest.mark.parametrize("dim,budget,n_doe,states", [(20, 250, 60, (61, 130, 249)), (40, 450, 120, (121, 260, 449))])
 def test_device_evaluation_against_oracle(native, dim, budget, n_doe, states):
     """Value and gradient of the device optimiser's evaluation (pass 1 over the transposed root inverse, pass 2 over the root
-    inverse, row splits of 8 .. 2 parts) at states of a device-mode run, against the oracle's torch-autograd log-EI; the
+    inverse, work plans of 1 .. 8 slabs) at states of a device-mode run, against the oracle's torch-autograd log-EI; the
     values the run itself reported for its end points against the oracle's surface."""
     torch.set_num_threads(4)
     fid, inst = 15, 1

@@ -53,7 +53,7 @@ def test_device_stepping_equals_host_stepping_bit_for_bit(native, fid, dim, budg
     print("[device = twin, f%d d=%d] %d runs x %d iterations, %d L-BFGS-B evaluations compared" % (fid, dim, B, budget - n_doe, rounds))
 
 
-@pytest.mark.parametrize("dim,budget,n_doe,states", [(20, 250, 60, (61, 130, 249)), (40, 450, 120, (121, 260, 449))])
+@pytest.mark.parametrize("dim,budget,n_doe,states", [(20, 250, 60, (61, 130, 249)), (40, 450, 120, (121, 260, 350, 420, 449))])
 def test_device_evaluation_against_oracle(native, dim, budget, n_doe, states):
     """Value and gradient of the device optimiser's evaluation (pass 1 over the transposed root inverse, pass 2 over the root
     inverse, work plans of 1 .. 8 slabs) at states of a device-mode run, against the oracle's torch-autograd log-EI; the

@@ -75,7 +75,7 @@ enum { S_THETA, S_FOLD, S_DNORM, S_GD, S_STPMX, S_SBGNRM, S_STP, S_GDOLD, S_DTD,
        S_COUNT };
 enum { I_COL, I_HEAD, I_ITAIL, I_ITER, I_IUPDAT, I_UPDATD, I_WRK, I_NFREE, I_ILEAVE, I_NENTER, I_INFO, I_IFUN, I_IBACK,
        I_NFGV, I_IWORD, I_TASK, I_PHASE, LS_TASK, LS_BRACKT, LS_STAGE, I_NITER, I_NFEV, I_HAVE_CACHE, I_ACTIVE, I_STATUS,
-       I_TIES, I_EVALS, I_COUNT };
+       I_TIES, I_EVALS, I_HCMD, I_HDONE, I_HPEND, I_INFO2, I_COUNT };
 
 // LDS layout of a group: every array at a compile-time offset from the dynamic block (the optimiser's arrays are sized for the
 // largest group, LB_GQ * LB_MAXK variables), the evaluation's three NP-sized arrays last.  The struct is three words and
@@ -407,6 +407,36 @@ __device__ inline void lb_reset_memory(const LbLds L, int lane) {
   LSYNC();
 }
 
+// ---- the helper wave -------------------------------------------------------------------------------------------------
+// Two routines of an iteration do not depend on what wave 0 does next: formt (the factor T of the middle matrix: the Cauchy
+// search needs it only at its first product with that matrix) and cmprlb (the reduced gradient: it needs the Cauchy point, not
+// the factor that formk builds meanwhile).  Wave 1 runs them while wave 0 goes on: a command word in LDS (sequence number | op),
+// an answer word, both sides sleeping between polls; every wait is bounded.  The routines and their data are what they were -
+// the results are bit for bit those of one wave doing everything in turn.
+#define LB_OP_END 1
+#define LB_OP_FORMT 2
+#define LB_OP_CMPRLB 3
+__device__ inline int lds_peek(ldsi* p) { return __builtin_amdgcn_readfirstlane(*(volatile ldsi*)p); }
+__device__ inline void lb_help_post(const LbLds L, int op, int lane) {          // wave 0; its LDS writes so far are visible first
+  LSYNC();
+  if (lane == 0) { const int c = (*(volatile ldsi*)&ISC(I_HCMD) & ~15) + 16; *(volatile ldsi*)&ISC(I_HCMD) = c | op; }
+  LSYNC();
+}
+__device__ inline void lb_help_wait(const LbLds L, int lane) {                  // wave 0: the helper has answered the last command
+  const int want = lds_peek(&ISC(I_HCMD));
+  bool ok = false;
+  for (int spin = 0; spin < (1 << 21); ++spin) {
+    if (lds_peek(&ISC(I_HDONE)) == want) { ok = true; break; }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  if (!ok && lane == 0) { ISC(I_STATUS) = PCABO_ERR_HIP; ISC(I_INFO) = -99; }   // (cannot happen: the helper's loop is bounded too)
+  LSYNC();
+}
+// wave 0, wherever the factor T is needed (or its failure has to be known): a formt handed to the helper is awaited once
+__device__ inline void lb_await_formt(const LbLds L, int lane) {
+  if (ISR(I_HPEND)) { lb_help_wait(L, lane); sti0(&ISC(I_HPEND), 0, lane); LSYNC(); }
+}
+
 // Generalised Cauchy point (lbfgsb.cpp: cauchy, the branch for variables with both bounds)
 __device__ __noinline__ void lb_cauchy(const LbLds L, int lane) {
   const int n = L.n, col = ISR(I_COL), head = ISR(I_HEAD), col2 = 2 * col;
@@ -457,6 +487,8 @@ __device__ __noinline__ void lb_cauchy(const LbLds L, int lane) {
   double f2 = -theta * f1;
   const double f2_org = f2;
   if (col > 0) {
+    lb_await_formt(L, lane);                        // T comes from the helper wave (lb_step)
+    if (ISR(I_INFO) != 0) return;                   // formt failed: the caller resets the memory and starts the iteration again
     const int info = lb_bmv(L, p, v, lane);
     if (info != 0) { sti0(&ISC(I_INFO), info, lane); LSYNC(); return; }
     f2 -= small_ddot(v, p, col2, lane);
@@ -724,13 +756,13 @@ __device__ __noinline__ void lb_formk(const LbLds L, int lane) {
   if (info != 0) { sti0(&ISC(I_INFO), -2, lane); LSYNC(); }
 }
 
-__device__ __noinline__ void lb_cmprlb(const LbLds L, int lane) {
+__device__ __noinline__ void lb_cmprlb(const LbLds L, int lane, int info_word) {
   const int n = L.n, col = ISR(I_COL), nfree = ISR(I_NFREE);
   const double theta = SR(S_THETA);
   for (int k = lane; k < n; k += 64) L.full()[k] = -theta * (L.z()[k] - L.x()[k]) - L.g()[k];
   LSYNC();
   const int info = lb_bmv(L, L.wa() + 2 * LB_M, L.wa(), lane);
-  if (info != 0) { sti0(&ISC(I_INFO), -8, lane); LSYNC(); return; }
+  if (info != 0) { sti0(&ISC(info_word), -8, lane); LSYNC(); return; }
   int pointr = ISR(I_HEAD);
   for (int j = 0; j < col; ++j) {
     const double a1 = L.wa()[j], a2 = theta * L.wa()[col + j];
@@ -1145,8 +1177,12 @@ __device__ int lb_step(const LbLds L, int lane) {
     } else {
       if (lane == 0) { ISC(I_UPDATD) = 1; ISC(I_IUPDAT) = ISR(I_IUPDAT) + 1; }
       LSYNC();
-      { LBT_BEGIN(); lb_matupd(L, rr, dr, lane); LBT_NEXT(6); lb_formt(L, lane); LBT_NEXT(7); }
-      if (ISR(I_INFO) != 0) lb_reset_memory(L, lane);
+      // formt goes to the helper wave; the Cauchy search below waits for it where it first needs T.  (If it fails the search
+      // returns with the failure set and the memory is reset there - the host resets it here and searches with an empty
+      // memory: the same state either way, the search's first part depends on x, g and the bounds only)
+      { LBT_BEGIN(); lb_matupd(L, rr, dr, lane); LBT_NEXT(6); }
+      sti0(&ISC(I_HPEND), 1, lane);
+      lb_help_post(L, LB_OP_FORMT, lane);
     }
     need_iteration_start = true;
   }
@@ -1155,12 +1191,18 @@ __device__ int lb_step(const LbLds L, int lane) {
       need_iteration_start = false;
       sti0(&ISC(I_IWORD), -1, lane);
       { LBT_BEGIN(); lb_cauchy(L, lane); LBT_NEXT(0); }
+      lb_await_formt(L, lane);                          // (a search that returned before it needed T)
       if (ISR(I_INFO) != 0) { lb_reset_memory(L, lane); need_iteration_start = true; continue; }
       { LBT_BEGIN(); lb_freev(L, lane); LBT_NEXT(1); }
       if (ISR(I_NFREE) != 0 && ISR(I_COL) != 0) {
+        // cmprlb on the helper wave beside formk (it reads the Cauchy point and T, formk the index sets: disjoint data); its
+        // failure comes back in a word of its own and counts only if formk did not fail first, as on the host
+        sti0(&ISC(I_INFO2), 0, lane);
+        lb_help_post(L, LB_OP_CMPRLB, lane);
         if (ISR(I_WRK)) { LBT_BEGIN(); lb_formk(L, lane); LBT_NEXT(2); }
+        { LBT_BEGIN(); lb_help_wait(L, lane); LBT_NEXT(3); }
         if (ISR(I_INFO) != 0) { lb_reset_memory(L, lane); need_iteration_start = true; continue; }
-        { LBT_BEGIN(); lb_cmprlb(L, lane); LBT_NEXT(3); }
+        if (ISR(I_INFO2) != 0) { sti0(&ISC(I_INFO), ISR(I_INFO2), lane); LSYNC(); }
         if (ISR(I_INFO) == 0) { LBT_BEGIN(); lb_subsm(L, lane); LBT_NEXT(4); }
         if (ISR(I_INFO) != 0) { lb_reset_memory(L, lane); need_iteration_start = true; continue; }
       }
@@ -1195,6 +1237,22 @@ __device__ int lb_step(const LbLds L, int lane) {
     if (lane == 0) { ISC(I_PHASE) = 3; ISC(I_TASK) = LBFGSB_NEW_X; }
     LSYNC();
     return LBFGSB_NEW_X;
+  }
+}
+
+// wave 1 while wave 0 advances: serves commands until LB_OP_END (bounded polling)
+__device__ void lb_helper(const LbLds L, int lane, int& last) {
+  for (int spin = 0; spin < (1 << 22); ++spin) {
+    const int c = lds_peek(&ISC(I_HCMD));
+    if (c == last) { __builtin_amdgcn_s_sleep(2); continue; }
+    last = c;
+    const int op = c & 15;
+    if (op == LB_OP_END) return;
+    if (op == LB_OP_FORMT) lb_formt(L, lane);
+    else if (op == LB_OP_CMPRLB) lb_cmprlb(L, lane, I_INFO2);
+    LSYNC();
+    if (lane == 0) *(volatile ldsi*)&ISC(I_HDONE) = c;
+    LSYNC();
   }
 }
 
@@ -1752,9 +1810,11 @@ __global__ __launch_bounds__(LB_THREADS) void k_lbfgsb_group(
     return;
   }
   // ---- the optimisation
+  int helper_seen = 0;                                  // (wave 1: the last command it has served)
   for (int guard = 0; guard < LB_MAXEVAL; ++guard) {
     LBT_BEGIN();
-    if (w == 0) lb_advance(L, maxiter, lane);
+    if (w == 0) { lb_advance(L, maxiter, lane); lb_help_post(L, LB_OP_END, lane); }
+    else if (w == 1) lb_helper(L, lane, helper_seen);
     __syncthreads();
     LBT_NEXT(16);
     if (!ISR(I_ACTIVE)) break;

@@ -96,7 +96,7 @@ enum {
   OFF_D = OFF_R + LB_NVP, OFF_T = OFF_D + LB_NVP, OFF_XP = OFF_T + LB_NVP, OFF_FULL = OFF_XP + LB_NVP, OFF_COEF = OFF_FULL + LB_NVP,
   OFF_XC = OFF_COEF + LB_NVP, OFF_GC = OFF_XC + LB_NVP, OFF_PROD = OFF_GC + LB_NVP,
   OFF_SY = OFF_PROD + LB_NVP, OFF_SS = OFF_SY + LB_M * LB_M, OFF_WT = OFF_SS + LB_M * LB_M, OFF_WN = OFF_WT + LB_M * LB_M,
-  OFF_WN1 = OFF_WN + 4 * LB_M * LB_M, OFF_WA = OFF_WN1 + 4 * LB_M * LB_M, OFF_ACC = OFF_WA + 8 * LB_M, OFF_SC = OFF_ACC + 64,
+  OFF_WN1 = OFF_WN + 4 * LB_M * LB_M, OFF_WA = OFF_WN1 + 4 * LB_M * LB_M, OFF_ACC = OFF_WA + 8 * LB_M, OFF_ACC2 = OFF_ACC + 64, OFF_SC = OFF_ACC2 + 64,
   OFF_VC = OFF_SC + LB_EVEN(S_COUNT + 2), OFF_INTS = OFF_VC + 8,
   OFF_XN = OFF_INTS + LB_EVEN((4 * LB_NVP + I_COUNT + 2) / 2 + 2), OFF_RED = OFF_XN + LB_EVEN(LB_GQ * (LB_MAXK + 2)),
   OFF_VALS = OFF_RED + 80, OFF_CQ = OFF_VALS + 8, OFF_NLO = OFF_CQ + 16, OFF_NHI = OFF_NLO + LB_MAXK, OFF_EV = OFF_NHI + LB_MAXK,
@@ -128,6 +128,7 @@ struct LbLds {
   __device__ ldsd* wn1() const { return base + OFF_WN1; }
   __device__ ldsd* wa() const { return base + OFF_WA; }
   __device__ ldsd* acc() const { return base + OFF_ACC; }
+  __device__ ldsd* acc2() const { return base + OFF_ACC2; }      // the helper wave's accumulations
   __device__ ldsd* sc() const { return base + OFF_SC; }
   __device__ ldsd* vc() const { return base + OFF_VC; }
   __device__ ldsi* index() const { return (ldsi*)(base + OFF_INTS); }
@@ -229,7 +230,7 @@ __device__ inline double small_ddot(const ldsd* a, const ldsd* b, int n, int lan
 // acc += coefA[t] * W(t, column) over ALL variables t = 0 .. n-1 in increasing order - a variable outside the host's index list
 // carries coefficient 0.0, which leaves every non-zero partial sum as it is (the host skips it); lanes 32 .. 32 + 2 LB_M - 1
 // run coefB over t = n-1 .. 0 (the host's list of active variables is in decreasing order).  Results in L.acc()[lane].
-__device__ inline void lb_accum(const LbLds L, const ldsd* coefA, const ldsd* coefB, int lane) {
+__device__ inline void lb_accum(const LbLds L, const ldsd* coefA, const ldsd* coefB, int lane, ldsd* out) {
   const int n = L.n, half = lane >> 5, c = (lane & 31) % (2 * LB_M);
   const ldsd* col = c < LB_M ? L.wy() + c * LB_LDW : L.ws() + (c - LB_M) * LB_LDW;
   const bool down = half && coefB;
@@ -244,7 +245,7 @@ __device__ inline void lb_accum(const LbLds L, const ldsd* coefA, const ldsd* co
     for (int u = 0; u < 8; ++u) a += cc[u] * w[u];
   }
   for (; s < n; ++s) { const int t = down ? n - 1 - s : s; a += cf[t] * col[t]; }
-  L.acc()[lane] = a;
+  out[lane] = a;
   LSYNC();
 }
 
@@ -473,7 +474,7 @@ __device__ __noinline__ void lb_cauchy(const LbLds L, int lane) {
   LSYNC();
   double f1 = chain_sub(0.0, L.prod(), n);         // f1 -= neggi^2 over the moving variables, in order (others subtract 0.0)
   if (col > 0) {
-    lb_accum(L, d, nullptr, lane);                   // d[i] = -g[i] for the moving variables, 0.0 for the others
+    lb_accum(L, d, nullptr, lane, L.acc());                   // d[i] = -g[i] for the moving variables, 0.0 for the others
     if (lane < col) {
       int pointr = head + lane; if (pointr >= LB_M) pointr -= LB_M;
       p[lane] = L.acc()[pointr];
@@ -654,7 +655,7 @@ __device__ __noinline__ void lb_formk(const LbLds L, int lane) {
     }
     LSYNC();
     LBT_NEXT(18);
-    lb_accum(L, L.coef(), L.prod(), lane);
+    lb_accum(L, L.coef(), L.prod(), lane, L.acc());
     LBT_NEXT(19);
     if (lane < col) {
       int jp = head + lane; if (jp >= m) jp -= m;
@@ -774,6 +775,19 @@ __device__ __noinline__ void lb_cmprlb(const LbLds L, int lane, int info_word) {
   LSYNC();
 }
 
+// the first part of subsm: it needs the reduced gradient (cmprlb), not formk's factor - the helper wave runs it beside formk
+__device__ inline void lb_subsm_head(const LbLds L, int lane) {
+  const int n = L.n, nsub = ISR(I_NFREE);
+  const ldsi* ind = L.index();
+  const ldsd* d = L.r();
+  // full = d scattered to the variables' own places (zeros elsewhere; with every variable free it is d itself)
+  for (int k = lane; k < n; k += 64) L.full()[k] = 0.0;
+  LSYNC();
+  for (int i = lane; i < nsub; i += 64) L.full()[ind[i]] = d[i];
+  LSYNC();
+  lb_accum(L, L.full(), nullptr, lane, L.acc2());
+}
+
 __device__ __noinline__ void lb_subsm(const LbLds L, int lane) {
   const int n = L.n, m = LB_M, col = ISR(I_COL), nsub = ISR(I_NFREE), col2 = 2 * col;
   const double theta = SR(S_THETA);
@@ -781,19 +795,14 @@ __device__ __noinline__ void lb_subsm(const LbLds L, int lane) {
   ldsd* x = L.z(); ldsd* d = L.r(); ldsd* wv = L.wa();
   if (nsub <= 0) return;
   LBT_BEGIN();
-  // full = d scattered to the variables' own places (zeros elsewhere; with every variable free it is d itself)
-  for (int k = lane; k < n; k += 64) L.full()[k] = 0.0;
-  LSYNC();
-  for (int i = lane; i < nsub; i += 64) L.full()[ind[i]] = d[i];
-  LSYNC();
+  // (full = d scattered to the variables' own places and W' full: lb_subsm_head, run by the helper wave right after cmprlb)
   LBT_NEXT(27);
-  lb_accum(L, L.full(), nullptr, lane);
   LBT_NEXT(28);
   double b = 0.0;
   if (lane < col2) {
     const int i = lane < col ? lane : lane - col;
     int pointr = ISR(I_HEAD) + i; if (pointr >= m) pointr -= m;
-    b = lane < col ? L.acc()[pointr] : theta * L.acc()[m + pointr];
+    b = lane < col ? L.acc2()[pointr] : theta * L.acc2()[m + pointr];
   }
   int info = 0;
   b = lb_subsm_solves(L, b, &info, lane);
@@ -1096,7 +1105,7 @@ __device__ __noinline__ void lb_matupd(const LbLds L, double rr, double dr, int 
     for (int u = 0; u < 2; ++u) { if (dst[u] > 0) L.ss()[dst[u] - 1] = src[u]; else if (dst[u] < 0) L.sy()[-dst[u] - 1] = src[u]; }
   }
   LSYNC();
-  lb_accum(L, L.d(), nullptr, lane);
+  lb_accum(L, L.d(), nullptr, lane, L.acc());
   if (lane < col - 1) {
     int pointr = head + lane; if (pointr >= m) pointr -= m;
     SY_(col - 1, lane) = L.acc()[pointr];
@@ -1249,7 +1258,7 @@ __device__ void lb_helper(const LbLds L, int lane, int& last) {
     const int op = c & 15;
     if (op == LB_OP_END) return;
     if (op == LB_OP_FORMT) lb_formt(L, lane);
-    else if (op == LB_OP_CMPRLB) lb_cmprlb(L, lane, I_INFO2);
+    else if (op == LB_OP_CMPRLB) { lb_cmprlb(L, lane, I_INFO2); if (ISR(I_INFO2) == 0 && ISR(I_NFREE) > 0) lb_subsm_head(L, lane); }
     LSYNC();
     if (lane == 0) *(volatile ldsi*)&ISC(I_HDONE) = c;
     LSYNC();

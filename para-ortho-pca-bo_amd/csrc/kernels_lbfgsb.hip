@@ -70,7 +70,7 @@ typedef const double gcd;
 #endif
 
 // ---- persistent scalars of a group (LDS) ----------------------------------------------------------------------------
-enum { S_THETA, S_FOLD, S_DNORM, S_GD, S_STPMX, S_SBGNRM, S_STP, S_GDOLD, S_DTD, S_F, S_FC,
+enum { S_THETA, S_FOLD, S_DNORM, S_GD, S_STPMX, S_SBGNRM, S_STP, S_GDOLD, S_DTD, S_F, S_FC, S_DR,
        LS_GINIT, LS_GTEST, LS_GX, LS_GY, LS_FINIT, LS_FX, LS_FY, LS_STX, LS_STY, LS_STMIN, LS_STMAX, LS_WIDTH, LS_WIDTH1,
        S_COUNT };
 enum { I_COL, I_HEAD, I_ITAIL, I_ITER, I_IUPDAT, I_UPDATD, I_WRK, I_NFREE, I_ILEAVE, I_NENTER, I_INFO, I_IFUN, I_IBACK,
@@ -1078,13 +1078,22 @@ __device__ __noinline__ void lb_lnsrlb(const LbLds L, int lane) {
   LSYNC();
 }
 
-__device__ __noinline__ void lb_matupd(const LbLds L, double rr, double dr, int lane) {
+// lbfgsb.cpp: matupd, in two parts.  Part A (wave 0): the new columns of WS / WY, theta and the ring's pointers - what the Cauchy
+// search reads first.  Part B (the helper wave, followed by formt): the new row of SY and column of SS - the step s_k is read from
+// the WS column part A has just written (the search overwrites d) - after the shift of the old entries, in the host's order.
+__device__ inline void lb_matupd_a(const LbLds L, double rr, double dr, int lane) {
   const int n = L.n, m = LB_M, iupdat = ISR(I_IUPDAT);
   int col = ISR(I_COL), head = ISR(I_HEAD), itail = ISR(I_ITAIL);
   if (iupdat <= m) { col = iupdat; itail = (head + iupdat - 1) % m; }
   else { itail = nxt(itail); head = nxt(head); }
   for (int i = lane; i < n; i += 64) { WS_(i, itail) = L.d()[i]; WY_(i, itail) = L.r()[i]; }
   const double theta = rr / dr;
+  if (lane == 0) { ISC(I_COL) = col; ISC(I_HEAD) = head; ISC(I_ITAIL) = itail; SC(S_THETA) = theta; SC(S_DR) = dr; }
+  LSYNC();
+}
+__device__ __noinline__ void lb_matupd_b(const LbLds L, int lane) {
+  const int m = LB_M, iupdat = ISR(I_IUPDAT);
+  const int col = ISR(I_COL), head = ISR(I_HEAD), itail = ISR(I_ITAIL);          // (part A's values)
   if (iupdat > m) {
     double src[2]; int dst[2];
     const int tri = (col - 1) * col / 2;               // 45 + 45 elements: two per lane
@@ -1105,17 +1114,16 @@ __device__ __noinline__ void lb_matupd(const LbLds L, double rr, double dr, int 
     for (int u = 0; u < 2; ++u) { if (dst[u] > 0) L.ss()[dst[u] - 1] = src[u]; else if (dst[u] < 0) L.sy()[-dst[u] - 1] = src[u]; }
   }
   LSYNC();
-  lb_accum(L, L.d(), nullptr, lane, L.acc());
+  lb_accum(L, &WS_(0, itail), nullptr, lane, L.acc2());
   if (lane < col - 1) {
     int pointr = head + lane; if (pointr >= m) pointr -= m;
-    SY_(col - 1, lane) = L.acc()[pointr];
-    SS_(lane, col - 1) = L.acc()[m + pointr];
+    SY_(col - 1, lane) = L.acc2()[pointr];
+    SS_(lane, col - 1) = L.acc2()[m + pointr];
   }
   if (lane == 0) {
     const double stp = SR(S_STP), dtd = SR(S_DTD);
     SS_(col - 1, col - 1) = stp == 1.0 ? dtd : stp * stp * dtd;
-    SY_(col - 1, col - 1) = dr;
-    ISC(I_COL) = col; ISC(I_HEAD) = head; ISC(I_ITAIL) = itail; SC(S_THETA) = theta;
+    SY_(col - 1, col - 1) = SR(S_DR);
   }
   LSYNC();
 }
@@ -1189,9 +1197,9 @@ __device__ int lb_step(const LbLds L, int lane) {
       // formt goes to the helper wave; the Cauchy search below waits for it where it first needs T.  (If it fails the search
       // returns with the failure set and the memory is reset there - the host resets it here and searches with an empty
       // memory: the same state either way, the search's first part depends on x, g and the bounds only)
-      { LBT_BEGIN(); lb_matupd(L, rr, dr, lane); LBT_NEXT(6); }
+      { LBT_BEGIN(); lb_matupd_a(L, rr, dr, lane); LBT_NEXT(6); }
       sti0(&ISC(I_HPEND), 1, lane);
-      lb_help_post(L, LB_OP_FORMT, lane);
+      lb_help_post(L, LB_OP_FORMT, lane);               // (the rest of matupd, then formt)
     }
     need_iteration_start = true;
   }
@@ -1257,7 +1265,7 @@ __device__ void lb_helper(const LbLds L, int lane, int& last) {
     last = c;
     const int op = c & 15;
     if (op == LB_OP_END) return;
-    if (op == LB_OP_FORMT) lb_formt(L, lane);
+    if (op == LB_OP_FORMT) { lb_matupd_b(L, lane); lb_formt(L, lane); }
     else if (op == LB_OP_CMPRLB) { lb_cmprlb(L, lane, I_INFO2); if (ISR(I_INFO2) == 0 && ISR(I_NFREE) > 0) lb_subsm_head(L, lane); }
     LSYNC();
     if (lane == 0) *(volatile ldsi*)&ISC(I_HDONE) = c;

@@ -104,8 +104,8 @@ class ExperimentRunner:
         # one batch's host-paced L-BFGS-B rounds overlap the other's launches and bookkeeping.  Same runs, same numbers.
         self.side_by_side = max(1, int(side_by_side))
         # pcabo.batchrun.BatchedPCABO(acq_kernel=...): "group" (host-paced L-BFGS-B rounds, the default), "latency", "device"
-        # (device-resident L-BFGS-B: pays from ~40 runs in flight, e.g. batched=75, side_by_side=4) or "auto" (per dimension:
-        # "device" in up to four batches when this rank has >= 40 runs of it and 20 <= d <= 40, "group" otherwise)
+        # (device-resident L-BFGS-B: pays from ~30 runs in flight, e.g. batched=75, side_by_side=4) or "auto" (per dimension:
+        # "device" in up to four batches when this rank has >= 30 runs of it and 20 <= d <= 40, "group" otherwise)
         self.batch_acq_kernel = batch_acq_kernel
 
         self.triggers = [ALWAYS]
@@ -178,11 +178,11 @@ class ExperimentRunner:
             cell = [r for r in mine if r[1] == dim]
             kernel = self.batch_acq_kernel
             if kernel == "auto":
-                # 40 runs or more of one dimension (20 <= d <= 40) on this GPU: the optimiser on the device, up to FOUR batches of >= 30
-                # runs interleaved on one host thread (measured at d = 40, DESIGN.md 8b: 45 runs 1 932 it/s against 1 818 host-paced, 60
-                # runs 2 490 / 2 033, 90 runs 3 172 / 2 256; bigger batches win, more than four at once do not); fewer runs, or small
-                # problems whose rounds the host paces faster than one wave steps them (d = 10: 2.1 s against 2.0 for 90 runs): host-paced
-                kernel = "device" if len(cell) >= 40 and 20 <= dim <= 40 else "group"
+                # 30 runs or more of one dimension (20 <= d <= 40) on this GPU: the optimiser on the device, up to FOUR batches of >= 30
+                # runs interleaved on one host thread (measured, DESIGN.md 8b: 30 runs 1 602 it/s against 1 345 host-paced at d = 40,
+                # 2 061 / 1 797 at d = 20; 60 runs 2 854 / 2 033, 120 runs 4 148 / 2 625; bigger batches win, more than four at once do
+                # not); fewer runs, or small problems whose rounds the host paces faster than one wave steps them (d = 10): host-paced
+                kernel = "device" if len(cell) >= 30 and 20 <= dim <= 40 else "group"
                 if kernel == "device":
                     per, nb = device_batch_plan(len(cell))
                     parts = [cell[i:i + per] for i in range(0, len(cell), per)]

@@ -33,7 +33,7 @@ def parse_arguments():
     p.add_argument("--batch_acq_kernel", default="group", choices=["group", "latency", "device", "auto"],
                    help="'device': every restart group's L-BFGS-B inside one kernel launch, the batches interleaved on one host "
                         "thread - for many runs per GPU (e.g. --batched 75 --side_by_side 4); 'auto': 'device' for a dimension "
-                        "20 <= d <= 40 with 40 or more runs on this GPU, 'group' otherwise")
+                        "20 <= d <= 40 with 30 or more runs on this GPU, 'group' otherwise")
     return p.parse_args()
 
 

@@ -3,7 +3,7 @@
 // /root/reference/Algorithms/BayesianOptimization/PCA_BO.py:607-614).
 //
 // One work-group of 1024 threads per restart group (<= 5 joint query points, <= 200 variables) runs the whole
-// optimisation without the host: evaluate (all 16 waves) -> L-BFGS-B step (wave 0) -> next point, until the group has
+// optimisation without the host: evaluate (all 16 waves) -> L-BFGS-B step (wave 0, wave 1 helping) -> next point, until the group has
 // converged or reached its limits.  No work-group waits for another one, nothing polls: a plain kernel whose every loop is
 // bounded (maxiter iterations of <= 20 line-search evaluations, a hard cap on evaluations on top).
 //
@@ -14,7 +14,9 @@
 //    triangular solves) keep a column or a right-hand side per lane and broadcast pivots with v_readlane.  Every number goes
 //    through the same operations in the same order as on the host (this file is compiled with -ffp-contract=off; IEEE
 //    divide and square root), so that fed the same f / g values the device takes the host's iterates bit for bit
-//    (tests/test_gpu_device_lbfgsb.py compares the two through the evaluation-only mode of the same kernel).
+//    (tests/test_gpu_device_lbfgsb.py compares the two through the evaluation-only mode of the same kernel).  Wave 1 helps:
+//    it runs the routines whose results wave 0 does not need at once (second half of matupd + formt beside the head of the
+//    Cauchy search, cmprlb + the head of subsm beside formk) - same routines, same data, handed over through two LDS words.
 //  * The evaluation (rows I of SURVEY.md 8a for the group's points: kernel vectors, v = R ks, |v|^2, mu, log-EI / PI chain,
 //    w = R' v, gradient contraction) is thread-per-output with coalesced reads in the two triangular passes: pass 1 reads
 //    the TRANSPOSED root inverse RT (built once per conditioning by k_rt_build), pass 2 reads R itself; a thread loads 16

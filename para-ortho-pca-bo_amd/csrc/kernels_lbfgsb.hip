@@ -211,13 +211,14 @@ __device__ inline double chain_sub(double s, const ldsd* a, int n) {
   return s;
 }
 // ddot of two LDS vectors in the host's order (products rounded, then added from 0.0): lanes form the products, every lane the chain
-__device__ inline double wave_ddot(const LbLds L, const ldsd* a, const ldsd* b, int n, int lane) {
-  for (int i = lane; i < n; i += 64) L.prod()[i] = a[i] * b[i];
+__device__ inline double wave_ddot_in(ldsd* buf, const ldsd* a, const ldsd* b, int n, int lane) {
+  for (int i = lane; i < n; i += 64) buf[i] = a[i] * b[i];
   LSYNC();
-  const double s = chain_add(0.0, L.prod(), n);
+  const double s = chain_add(0.0, buf, n);
   LSYNC();
   return s;
 }
+__device__ inline double wave_ddot(const LbLds L, const ldsd* a, const ldsd* b, int n, int lane) { return wave_ddot_in(L.prod(), a, b, n, lane); }
 // ddot of two short LDS vectors (n <= 2 LB_M) in the host's order: lane j forms product j, every lane adds them in order
 __device__ inline double small_ddot(const ldsd* a, const ldsd* b, int n, int lane) {
   const int j = lane < n ? lane : 0;
@@ -419,6 +420,7 @@ __device__ inline void lb_reset_memory(const LbLds L, int lane) {
 #define LB_OP_END 1
 #define LB_OP_FORMT 2
 #define LB_OP_CMPRLB 3
+#define LB_OP_DTD 4
 __device__ inline int lds_peek(ldsi* p) { return __builtin_amdgcn_readfirstlane(*(volatile ldsi*)p); }
 __device__ inline void lb_help_post(const LbLds L, int op, int lane) {          // wave 0; its LDS writes so far are visible first
   LSYNC();
@@ -1017,10 +1019,11 @@ __device__ __noinline__ void lb_lnsrlb(const LbLds L, int lane) {
   const double big = 1e10, ftol = 1e-3, gtol = 0.9, xtol = 0.1;
   const double f = SR(S_F);
   LsState ls;
-  double stp, stpmx, dnorm;
-  if (ISR(I_PHASE) != 2) {
-    const double dtd = wave_ddot(L, L.d(), L.d(), n, lane);
-    dnorm = sqrt(dtd);
+  double stp, stpmx;
+  const bool first_call = ISR(I_PHASE) != 2;
+  if (first_call) {
+    // d'd is not needed before the next matupd: the helper wave forms it (its own product buffer) while this wave goes on
+    lb_help_post(L, LB_OP_DTD, lane);
     stpmx = big;
     if (ISR(I_ITER) == 0) stpmx = 1.0;
     else {
@@ -1051,15 +1054,16 @@ __device__ __noinline__ void lb_lnsrlb(const LbLds L, int lane) {
     }
     stp = 1.0;                                        // (boxed: never min(1 / dnorm, stpmx))
     for (int i = lane; i < n; i += 64) { L.t()[i] = L.x()[i]; L.r()[i] = L.g()[i]; }
-    if (lane == 0) { SC(S_DTD) = dtd; SC(S_DNORM) = dnorm; SC(S_STPMX) = stpmx; SC(S_FOLD) = f; ISC(I_IFUN) = 0; ISC(I_IBACK) = 0; }
+    if (lane == 0) { SC(S_STPMX) = stpmx; SC(S_FOLD) = f; ISC(I_IFUN) = 0; ISC(I_IBACK) = 0; }
     ls.task = 0; ls.brackt = 0; ls.stage = 1;
     ls.ginit = ls.gtest = ls.gx = ls.gy = ls.finit = ls.fx = ls.fy = ls.stx = ls.sty = ls.stmin = ls.stmax = ls.width = ls.width1 = 0.0;
     LSYNC();
   } else {
     ls_load(L, ls);
-    stp = SR(S_STP); stpmx = SR(S_STPMX); dnorm = SR(S_DNORM);
+    stp = SR(S_STP); stpmx = SR(S_STPMX);
   }
   const double gd = wave_ddot(L, L.g(), L.d(), n, lane);
+  if (first_call) lb_help_wait(L, lane);              // (the helper's chain ran beside this one)
   int ifun = ISR(I_IFUN);
   LSYNC();
   if (lane == 0) SC(S_GD) = gd;
@@ -1268,6 +1272,10 @@ __device__ void lb_helper(const LbLds L, int lane, int& last) {
     const int op = c & 15;
     if (op == LB_OP_END) return;
     if (op == LB_OP_FORMT) { lb_matupd_b(L, lane); lb_formt(L, lane); }
+    else if (op == LB_OP_DTD) {
+      const double dtd = wave_ddot_in(L.coef(), L.d(), L.d(), L.n, lane);
+      if (lane == 0) { SC(S_DTD) = dtd; SC(S_DNORM) = sqrt(dtd); }
+    }
     else if (op == LB_OP_CMPRLB) { lb_cmprlb(L, lane, I_INFO2); if (ISR(I_INFO2) == 0 && ISR(I_NFREE) > 0) lb_subsm_head(L, lane); }
     LSYNC();
     if (lane == 0) *(volatile ldsi*)&ISC(I_HDONE) = c;

@@ -29,6 +29,7 @@
 #include <cfloat>
 #include <cmath>
 #include <mutex>
+#include <vector>
 #include "../../include/pcabo.h"      // PCABO_ERR_NAN
 
 #define LB_M 10
@@ -145,7 +146,7 @@ struct LbLds {
   __device__ ldsd* nlo() const { return base + OFF_NLO; }
   __device__ ldsd* nhi() const { return base + OFF_NHI; }
   __device__ ldsd* ev() const { return base + OFF_EV; }
-  __device__ ldsi* plan() const { return (ldsi*)(base + OFF_PLAN); }
+  __host__ __device__ ldsi* plan() const { return (ldsi*)(base + OFF_PLAN); }
   __device__ ldsd* ks() const { return base + OFF_KS; }
   __device__ ldsd* vb() const { return base + OFF_KS + LB_QS * NP; }
   __device__ ldsd* slots() const { return base + OFF_KS + 2 * LB_QS * NP; }       // partial sums of a pass: [slot][64][LB_GQ]
@@ -1327,7 +1328,7 @@ __device__ void lb_advance(const LbLds L, int maxiter, int lane) {
 // (unit, lo, hi).  The segment that starts a unit writes the unit's sums where the next phase reads them (dest -1), the others
 // go to numbered partial slots that the next phase adds in ascending order - a fixed order for a given (n, NP).
 // One thread, once per kernel (n and NP are the launch's).
-__device__ inline void lb_build_plan(const LbLds L, int n, int S) {
+__host__ __device__ inline void lb_build_plan(const LbLds L, int n, int S) {
   ldsi* plan = L.plan();
   for (int i = 0; i < LB_PLAN_INTS; ++i) plan[i] = 0;
   for (int pass = 0; pass < 2; ++pass) {
@@ -1911,6 +1912,21 @@ __global__ __launch_bounds__(256) void k_rt_build(const double* __restrict__ R, 
 
 void launch_rt_build(hipStream_t s, const double* R, int n, int NP, int ld, double* RT, ZB zb) {
   hipLaunchKernelGGL(k_rt_build, dim3(NP / 64, NP / 64, zb.B), dim3(256), 0, s, R, n, ld, RT, zb.zs);
+}
+
+// The passes' work plan as the kernel builds it, for the host-side test of its invariants (tests/test_lbfgsb_plan.py: every
+// column / row covered once, at most two segments per wave, partial slots in ascending order and within the LDS that
+// launch_lbfgsb_group asks for).  out: LB_PLAN_INTS ints; sizes[0..3] = ints per pass, ints per wave, slots the launch reserves,
+// dynamic LDS bytes of the launch.  Not part of the ABI in include/pcabo.h.
+extern "C" int pcabo_debug_lbfgsb_plan(int n, int NP, int* out, int* sizes) {
+  if (!out || !sizes || NP < 64 || NP > LB_MAXNP || (NP % 64) != 0 || n < 1 || n > NP || n <= NP - 64) return -1;
+  std::vector<double> buf((size_t)OFF_KS, 0.0);
+  LbLds L; L.base = (ldsd*)buf.data(); L.n = 0; L.NP = NP;
+  lb_build_plan(L, n, NP / 64);
+  const ldsi* p = L.plan();
+  for (int i = 0; i < LB_PLAN_INTS; ++i) out[i] = p[i];
+  sizes[0] = LB_PLAN_PASS; sizes[1] = LB_PLAN_WAVE; sizes[2] = lb_max_slots(NP); sizes[3] = (int)(lb_lds_doubles(NP) * sizeof(double));
+  return 0;
 }
 
 bool lbfgsb_device_possible(int NP, int kmax, int batch_limit) {

@@ -23,6 +23,7 @@
 #ifndef PCABO_H
 #define PCABO_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -246,6 +247,13 @@ int pcabo_batch_set_workers(pcabo_batch* batch, int workers);
  *   several batches of one process in flight the rest of the chip stays free for the short kernels of the others.  Results do
  *   not depend on it. */
 int pcabo_batch_set_option(pcabo_batch* batch, int option, int value);
+/* Shapes the device-resident optimiser (PCABO_OPT_DEVICE_LBFGSB = 1) covers: points n <= *max_n, reduced dimension k <= *max_k,
+ * batch_limit <= *max_group.  A call beyond them is NOT served by it: pcabo_batch_optimize_acqf takes the host-paced path for that
+ * call (pcabo_batch_optimize_acqf_begin returns 1), i.e. ANOTHER arithmetic mode.  A driver that promises one trajectory per seed
+ * therefore decides per RUN, before it starts, from (budget, dimension) - pcabo/batchrun.py refuses acq_kernel="device" for a
+ * run that could leave these limits, Algorithms/Experiment/ExperimentRunner.py resolves the mode per dimension of the experiment.
+ * Host code; no device needed. */
+int pcabo_device_lbfgsb_limits(int* max_n, int* max_k, int* max_group);
 int pcabo_batch_last_error(pcabo_batch* batch, char* buf, int buflen);
 pcabo_ctx* pcabo_batch_ctx(pcabo_batch* batch, int b);
 

@@ -59,6 +59,33 @@ def device_batch_plan(n_runs: int):
     return -(-n_runs // (nb * rounds)), nb
 
 
+def resolve_arithmetic_mode(batch_acq_kernel: str, batched: int, dim: int, runs_of_dim_in_experiment: int, budget: int) -> str:
+    """The arithmetic mode of every run of dimension `dim` - "latency" (per-query kernels), "group" (restart-group kernel, host-paced
+    L-BFGS-B) or "device" (device-resident L-BFGS-B).  The three sum in different orders (~1e-15 relative apart), and L-BFGS-B turns
+    that into another trajectory, so the mode is a property of the EXPERIMENT: it is taken from the experiment's own description -
+    the request, the dimension, the runs of that dimension over ALL ranks, the budget - and never from this rank's share, the
+    number of GPUs or the way the runs are grouped into batches.  One (function, instance, seed) therefore writes the same rows on
+    one GPU and on eight; the mode goes into the IOHprofiler experiment attributes (`arithmetic_mode`).
+
+      not batched            -> "latency"  (Algorithms.PCA_BO / Vanilla_BO, one run after the other: the reference's own loop)
+      "group" / "latency"    -> as asked
+      "device"               -> "device" where the device optimiser covers every iteration of the run (pcabo.batchrun.device_mode_covers:
+                                budget <= 512, d <= 40), "group" elsewhere - per dimension, decided before the first run starts
+      "auto"                 -> "device" for 20 <= d <= 40 when the experiment holds >= 30 runs of the dimension (measured, DESIGN.md
+                                section 7: 30 runs 1 602 it/s against 1 345 host-paced at d = 40, 2 061 / 1 797 at d = 20, more with more
+                                runs; at d = 10 the host paces the rounds faster than one wave steps them), "group" otherwise."""
+    from pcabo.batchrun import device_mode_covers
+    if batched <= 1:
+        return "latency"
+    if batch_acq_kernel in ("group", "latency"):
+        return batch_acq_kernel
+    if batch_acq_kernel == "device":
+        return "device" if device_mode_covers(dim, budget) else "group"
+    if batch_acq_kernel == "auto":
+        return "device" if runs_of_dim_in_experiment >= 30 and 20 <= dim <= 40 and device_mode_covers(dim, budget) else "group"
+    raise ValueError("batch_acq_kernel must be 'group', 'latency', 'device' or 'auto'")
+
+
 def split_evenly(cell, batched: int, side_by_side: int):
     """Divide the runs of one dimension over lock-step batches of AT MOST `batched` runs each, as evenly as possible and in
     order; the number of batches is rounded up to a multiple of `side_by_side` so that no batch advances with nothing
@@ -104,9 +131,11 @@ class ExperimentRunner:
         # one batch's host-paced L-BFGS-B rounds overlap the other's launches and bookkeeping.  Same runs, same numbers.
         self.side_by_side = max(1, int(side_by_side))
         # pcabo.batchrun.BatchedPCABO(acq_kernel=...): "group" (host-paced L-BFGS-B rounds, the default), "latency", "device"
-        # (device-resident L-BFGS-B: pays from ~30 runs in flight, e.g. batched=75, side_by_side=4) or "auto" (per dimension:
-        # "device" in up to four batches when this rank has >= 30 runs of it and 20 <= d <= 40, "group" otherwise)
+        # (device-resident L-BFGS-B: pays from ~30 runs in flight, e.g. batched=75, side_by_side=4) or "auto" (per dimension of the
+        # EXPERIMENT: resolve_arithmetic_mode above - the same answer on every rank of any world size)
         self.batch_acq_kernel = batch_acq_kernel
+        self.arithmetic_modes = {dim: resolve_arithmetic_mode(batch_acq_kernel, self.batched, dim, len(problem_ids) * num_runs,
+                                                              budget_factor * dim + 50) for dim in dimensions}
 
         self.triggers = [ALWAYS]
         self.logger_properties = [RAWYBEST]
@@ -176,18 +205,15 @@ class ExperimentRunner:
         groups = []                          # lists of (dim, runs of one batch, kernel): the batches of a list advance together
         for dim in sorted({r[1] for r in mine}, key=self.dimensions.index):
             cell = [r for r in mine if r[1] == dim]
-            kernel = self.batch_acq_kernel
-            if kernel == "auto":
-                # 30 runs or more of one dimension (20 <= d <= 40) on this GPU: the optimiser on the device, up to FOUR batches of >= 30
-                # runs interleaved on one host thread (measured, DESIGN.md 8b: 30 runs 1 602 it/s against 1 345 host-paced at d = 40,
-                # 2 061 / 1 797 at d = 20; 60 runs 2 854 / 2 033, 120 runs 4 148 / 2 625; bigger batches win, more than four at once do
-                # not); fewer runs, or small problems whose rounds the host paces faster than one wave steps them (d = 10): host-paced
-                kernel = "device" if len(cell) >= 30 and 20 <= dim <= 40 else "group"
-                if kernel == "device":
-                    per, nb = device_batch_plan(len(cell))
-                    parts = [cell[i:i + per] for i in range(0, len(cell), per)]
-                    groups += [[(dim, part, kernel) for part in parts[i:i + nb]] for i in range(0, len(parts), nb)]
-                    continue
+            kernel = self.arithmetic_modes[dim]              # (a property of the experiment, not of this rank's share)
+            if kernel == "device" and self.batch_acq_kernel == "auto":
+                # the optimiser on the device: up to FOUR batches of >= 30 runs interleaved on one host thread (bigger batches win,
+                # more than four at once do not: DESIGN.md section 7).  How this rank groups its runs changes no number: within a
+                # mode a run is bit-identical in any batch (tests/test_gpu_batch.py, tests/test_gpu_device_lbfgsb.py)
+                per, nb = device_batch_plan(len(cell))
+                parts = [cell[i:i + per] for i in range(0, len(cell), per)]
+                groups += [[(dim, part, kernel) for part in parts[i:i + nb]] for i in range(0, len(parts), nb)]
+                continue
             # the runs of a dimension are divided EVENLY over a multiple of `side_by_side` batches of about `batched` runs
             # (a lone last batch would advance with nothing beside it; larger batches amortise the rounds of the slowest
             # restart better: 90 runs with batched=30, side_by_side=2 go as 2 x 45 rather than 30 + 30 | 30)
@@ -223,12 +249,16 @@ class ExperimentRunner:
             # (pcabo.batchrun.run_interleaved); otherwise a host thread per batch
             (run_interleaved if kernel == "device" else run_side_by_side)([j[4] for j in jobs])
             elapsed = (time() - start_time) / sum(len(j[1]) for j in jobs)          # a run's share of its group of batches
-            # the reference's three phase timers (PCA_BO.py:65), as a run's share of its batch's host clock: the
-            # conditioning is enqueued together with the wPCA ("pca"), its wait falls into the optimiser's time as in
-            # the reference, where gpytorch factors K lazily inside optimize_acqf
-            shares = {id(j[4]): {"pca": (j[4].timing["host_prep"] + j[4].timing["pca"]) / len(j[1]), "SingleTaskGP": 0.0,
-                                 "optimize_acqf": (j[4].timing["wait_score"] + j[4].timing["init_pick"] +
-                                                   j[4].timing["lbfgsb"]) / len(j[1])} for j in jobs}
+            # the reference's three phase timers (PCA_BO.py:65) as FRACTIONS of the run's `time`: a batch's phase clocks are wall
+            # clock differences across its waits, and while it waits the host advances the other batches of the group (interleaved)
+            # or shares the cores with them (threads) - taken as seconds they would add up to several times `time`.  The
+            # conditioning is enqueued together with the wPCA ("pca"); its wait falls into the optimiser's time as in the
+            # reference, where gpytorch factors K lazily inside optimize_acqf
+            def _fractions(t):
+                total = sum(t.values()) or 1.0
+                return {"pca": elapsed * (t["host_prep"] + t["pca"]) / total, "SingleTaskGP": 0.0,
+                        "optimize_acqf": elapsed * (t["wait_score"] + t["init_pick"] + t["lbfgsb"]) / total}
+            shares = {id(j[4]): _fractions(j[4].timing) for j in jobs}
             if algorithm == "vanilla":       # Vanilla_BO.TIME_PROFILES: the enqueue of the conditioning is its "SingleTaskGP"
                 shares = {key: {"SingleTaskGP": v["pca"], "optimize_acqf": v["optimize_acqf"]} for key, v in shares.items()}
             for dim, chunk, probs, n_doe, runner in jobs:
@@ -265,15 +295,20 @@ class ExperimentRunner:
                 if algorithm not in ("vanilla", "pca"):
                     raise ValueError(f"Invalid algorithm name: '{algorithm}'")
                 logger = self._make_logger(algorithm)
+                # (the reference sets the first three, then REPLACES them by the PCA pair for "pca" - ExperimentRunner.py:105-117,
+                # kept; `arithmetic_mode` is this package's: which summation order produced the rows of each dimension)
+                provenance = {"arithmetic_mode": ",".join(f"d{dim}={self.arithmetic_modes[dim]}" for dim in self.dimensions)}
                 logger.set_experiment_attributes({
                     "budget_factor": f"{self.budget_factor}",
                     "doe_factor": f"{self.doe_factor}",
-                    "acquisition_function": f"{self.acquisition_function}"
+                    "acquisition_function": f"{self.acquisition_function}",
+                    **provenance
                 })
                 if algorithm == "pca":
                     logger.set_experiment_attributes({
                         "pca_components": f"{self.pca_components}",
-                        "var_threshold": f"{self.var_threshold}"
+                        "var_threshold": f"{self.var_threshold}",
+                        **provenance
                     })
                 optimizer_class = Vanilla_BO if algorithm == "vanilla" else PCA_BO
                 for time_profile in getattr(optimizer_class, "TIME_PROFILES", []):

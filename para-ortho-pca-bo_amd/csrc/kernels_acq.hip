@@ -1272,35 +1272,37 @@ __global__ __launch_bounds__(256) void k_acq_group(
 
 bool acq_group_possible(int NP, int k) { return NP <= 1280 && k <= PCABO_MAXD; }
 
-void launch_acq_group(hipStream_t st, const QueryArgs* tab, int entries, const double* Xq, int n, int k, int NP, int ld,
-                      const double* ZnT, const double* R, const double* alpha, const double* bounds4, const double* ystats,
-                      AcqParams p, double* partial, unsigned int* counters, double* val, double* grad, double* host_val,
-                      double* host_grad, HostMirror* hm, unsigned long long seq, AcqBatch ab) {
+// Returns 0, or -1 when nothing was launched (the caller must not wait for per-query flags then).
+int launch_acq_group(hipStream_t st, const QueryArgs* tab, int entries, const double* Xq, int n, int k, int NP, int ld,
+                     const double* ZnT, const double* R, const double* alpha, const double* bounds4, const double* ystats,
+                     AcqParams p, double* partial, unsigned int* counters, double* val, double* grad, double* host_val,
+                     double* host_grad, HostMirror* hm, unsigned long long seq, AcqBatch ab) {
   const size_t lds = ((size_t)GQ * NP + 4 * 64 * GT_LD + 64 * 8 + GQ * 64 + 2 * GQ + 4 + 2 * GQ + GQ * (((size_t)k + 1) & ~(size_t)1) + 8) * sizeof(double);
   const dim3 grid(NP / 64, entries), block(256);
   // Dynamic LDS beyond the 64 KB default needs the attribute - per DEVICE, and for every instantiation that can ask for
   // more: <2> does from (NP, k) = (512, 83) on (65 808 bytes at k = 89), <5> always.  Launched from the worker threads of
-  // a batch, hence the lock; a failure stays in the thread's last error and the launch below is skipped.
+  // a batch, hence the lock; on a failure nothing is launched and the caller is told (as launch_lbfgsb_group does).
   {
     static std::mutex attr_mu;
     static bool attr_done[64] = {false};
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
     std::lock_guard<std::mutex> lk(attr_mu);
     if (!attr_done[dev]) {
       if (hipFuncSetAttribute((const void*)k_acq_group<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
           hipFuncSetAttribute((const void*)k_acq_group<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
-        return;
+        return -1;
       attr_done[dev] = true;
     }
   }
-  if (lds > 96 * 1024) return;           // (cannot happen for NP <= 1280, k <= 128: 98 048 bytes at most)
+  if (lds > 96 * 1024) return -1;        // (cannot happen for NP <= 1280, k <= 128: 98 048 bytes at most)
 #define GROUP_ARGS *tab, Xq, n, k, NP, ld, ZnT, R, alpha, bounds4, ystats, p, partial, counters, val, grad, host_val, host_grad, \
                    hm, seq, ab
   if (NP <= 256) hipLaunchKernelGGL(k_acq_group<1>, grid, block, lds, st, GROUP_ARGS);
   else if (NP <= 512) hipLaunchKernelGGL(k_acq_group<2>, grid, block, lds, st, GROUP_ARGS);
   else hipLaunchKernelGGL(k_acq_group<5>, grid, block, lds, st, GROUP_ARGS);
 #undef GROUP_ARGS
+  return 0;
 }
 
 // =====================================================================================================================

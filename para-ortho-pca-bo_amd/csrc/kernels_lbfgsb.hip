@@ -26,6 +26,7 @@
 //    per batch (PCABO_OPT_DEVICE_LBFGSB), never mixed within a run.
 #include "pcabo_internal.h"
 #include "lbfgsb.h"
+#include "lb_plan.h"
 #include <cfloat>
 #include <cmath>
 #include <mutex>
@@ -33,11 +34,9 @@
 #include "../../include/pcabo.h"      // PCABO_ERR_NAN
 
 #define LB_M 10
-#define LB_THREADS 1024
 #define LB_GQ 5
 #define LB_QS 6             // stride of a point's per-query values in LDS (16-byte aligned pairs)
 #define LB_MAXK 40
-#define LB_MAXNP 512
 #define LB_MAXEVAL 20000    // hard cap on the evaluations of one group (the host's limits stop it long before)
 
 #define LSYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -86,10 +85,6 @@ enum { I_COL, I_HEAD, I_ITAIL, I_ITER, I_IUPDAT, I_UPDATD, I_WRK, I_NFREE, I_ILE
 #define LB_NVCAP (LB_GQ * LB_MAXK)
 // work plan of the two triangular passes (lb_build_plan): per pass and wave [count, 2 x (unit, lo, hi, dest)], then per unit
 // [first extra slot, extra slots]
-#define LB_WAVES (LB_THREADS / 64)
-#define LB_PLAN_WAVE 9
-#define LB_PLAN_PASS (LB_WAVES * LB_PLAN_WAVE + 2 * (LB_MAXNP / 64))
-#define LB_PLAN_INTS (2 * LB_PLAN_PASS)
 #define LB_LDW (LB_NVCAP | 1)
 #define LB_NVP ((LB_NVCAP + 3) & ~1)
 #define LB_EVEN(x) (((x) + 1) & ~1)
@@ -152,7 +147,6 @@ struct LbLds {
   __device__ ldsd* slots() const { return base + OFF_KS + 2 * LB_QS * NP; }       // partial sums of a pass: [slot][64][LB_GQ]
 };
 // the triangular passes' partial slots: at most (waves + two-slab pairs - slabs) segments do not start their slab (lb_build_plan)
-static inline int lb_max_slots(int NP) { const int S = NP / 64; return 16 + S / 2 - S; }
 static inline size_t lb_lds_doubles(int NP) { return (size_t)OFF_KS + (size_t)2 * LB_QS * NP + (size_t)lb_max_slots(NP) * 64 * LB_GQ; }
 
 #define SC(i) L.sc()[i]
@@ -1320,68 +1314,8 @@ __device__ void lb_advance(const LbLds L, int maxiter, int lane) {
 // =====================================================================================================================
 // Evaluation: value and gradient of the acquisition at the group's nq points (all LB_THREADS threads)
 // =====================================================================================================================
-// The triangular passes, balanced.  Unit u of pass 1 is the 64-row slab u of RT' (columns 0 .. min(n, 64 (u + 1)) - 1), unit u of
-// pass 2 the 64-column block u of R (rows 64 u .. n - 1): work 1 : 2 : ... : S.  A slab per wave (split in equal parts) leaves the
-// pass waiting for the longest wave - a chain of load round trips that the CU's load rate does not explain (16.4 us against
-// 12.3).  Here the units are folded into pairs (largest with smallest), the 16 waves are dealt out to the pairs in proportion
-// to their work, and the waves of a pair cut its columns (rows) into equal ranges: a wave gets one or two segments
-// (unit, lo, hi).  The segment that starts a unit writes the unit's sums where the next phase reads them (dest -1), the others
-// go to numbered partial slots that the next phase adds in ascending order - a fixed order for a given (n, NP).
-// One thread, once per kernel (n and NP are the launch's).
-__host__ __device__ inline void lb_build_plan(const LbLds L, int n, int S) {
-  ldsi* plan = L.plan();
-  for (int i = 0; i < LB_PLAN_INTS; ++i) plan[i] = 0;
-  for (int pass = 0; pass < 2; ++pass) {
-    ldsi* pw = plan + pass * LB_PLAN_PASS;
-    ldsi* pu = pw + LB_WAVES * LB_PLAN_WAVE;
-    int lo[8], hi[8], order[8];
-    for (int u = 0; u < S; ++u) {
-      if (pass == 0) { lo[u] = 0; hi[u] = n < 64 * (u + 1) ? n : 64 * (u + 1); }
-      else { lo[u] = 64 * u; hi[u] = n > 64 * u ? n : 64 * u; }
-    }
-    for (int t = 0; t < S; ++t) {                     // pass 1: S-1, 0, S-2, 1 ...; pass 2 (largest unit first): 0, S-1, 1, S-2 ...
-      const int a = t / 2, big = pass == 0 ? S - 1 - a : a, small = pass == 0 ? a : S - 1 - a;
-      order[t] = (t & 1) ? small : big;
-    }
-    const int P = (S + 1) / 2;
-    long long total = 0;
-    for (int u = 0; u < S; ++u) total += hi[u] - lo[u];
-    int waves_left = LB_WAVES, slot = 0, wave = 0;
-    long long work_left = total;
-    for (int p = 0; p < P; ++p) {
-      const int ua = order[2 * p], ub = 2 * p + 1 < S ? order[2 * p + 1] : -1;
-      const int wa = hi[ua] - lo[ua], wb = ub >= 0 ? hi[ub] - lo[ub] : 0, work = wa + wb;
-      int wp;
-      if (p == P - 1) wp = waves_left;
-      else {
-        wp = work_left > 0 ? (int)(((long long)work * waves_left + work_left / 2) / work_left) : 1;
-        const int keep = P - 1 - p;                   // a wave at least for every pair still to come
-        if (wp > waves_left - keep) wp = waves_left - keep;
-        if (wp < 1) wp = 1;
-      }
-      waves_left -= wp; work_left -= work;
-      int chunk = (work + wp - 1) / wp;
-      chunk = (chunk + 1) & ~1;                         // (pairs of columns / rows: both half-waves busy)
-      if (chunk < 2) chunk = 2;
-      for (int t = 0; t < wp; ++t, ++wave) {
-        const int r0 = t * chunk < work ? t * chunk : work, r1 = (t + 1) * chunk < work ? (t + 1) * chunk : work;
-        ldsi* e = pw + wave * LB_PLAN_WAVE;
-        int cnt = 0;
-        for (int g = 0; g < 2; ++g) {                   // the range's part in unit a ([0, wa) of the pair), then in unit b
-          const int u = g == 0 ? ua : ub, base = g == 0 ? 0 : wa, len = g == 0 ? wa : wb;
-          if (u < 0) continue;
-          const int a0 = r0 > base ? r0 - base : 0, a1 = (r1 - base) < len ? r1 - base : len;
-          if (a1 <= a0) continue;
-          int dest = -1;
-          if (a0 > 0) { dest = slot++; if (pu[2 * u + 1] == 0) pu[2 * u] = dest; pu[2 * u + 1] += 1; }
-          e[1 + 4 * cnt] = u; e[2 + 4 * cnt] = lo[u] + a0; e[3 + 4 * cnt] = lo[u] + a1; e[4 + 4 * cnt] = dest;
-          ++cnt;
-        }
-        e[0] = cnt;
-      }
-    }
-  }
-}
+// (the work plan of the two triangular passes: lb_plan.h)
+__host__ __device__ inline void lb_build_plan(const LbLds L, int n, int S) { lb_build_plan_t(L.plan(), n, S); }
 
 struct LbEval {
   gcd *ZnT, *R, *RT, *alpha, *nlo, *nhi;
@@ -1926,6 +1860,13 @@ extern "C" int pcabo_debug_lbfgsb_plan(int n, int NP, int* out, int* sizes) {
   const ldsi* p = L.plan();
   for (int i = 0; i < LB_PLAN_INTS; ++i) out[i] = p[i];
   sizes[0] = LB_PLAN_PASS; sizes[1] = LB_PLAN_WAVE; sizes[2] = lb_max_slots(NP); sizes[3] = (int)(lb_lds_doubles(NP) * sizeof(double));
+  return 0;
+}
+
+extern "C" int pcabo_device_lbfgsb_limits(int* max_n, int* max_k, int* max_group) {
+  if (max_n) *max_n = LB_MAXNP;
+  if (max_k) *max_k = LB_MAXK;
+  if (max_group) *max_group = LB_GQ;
   return 0;
 }
 

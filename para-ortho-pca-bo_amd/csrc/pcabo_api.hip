@@ -3,6 +3,7 @@
 #include "../../include/pcabo.h"
 #include "pcabo_internal.h"
 #include "lbfgsb.h"
+#include "host_side.h"
 
 #include <algorithm>
 #include <atomic>
@@ -862,9 +863,10 @@ static int eval_staged_groups(pcabo_ctx* ctx, const int* g0, const int* gn, int 
     int nq = 0;
     for (int g = 0; g < ng; ++g) nq += gn[g];
     ProfScope ps(ctx, 4, acq_bytes(ctx->n, ctx->k, nq, p.want_grad), acq_flops(ctx->n, ctx->k, nq, p.want_grad));
-    launch_acq_group(s, &tab, ng, ctx->hXq, ctx->n, ctx->k, ctx->NP, ctx->ld, ctx->dZnT, ctx->dR, ctx->dAlpha, ctx->dBounds4,
-                     ctx->dYstats, p, ctx->dPartial, ctx->dCounters + PCABO_GROUP_CNT_OFFSET, ctx->dVal, ctx->dGrad, ctx->hVal,
-                     ctx->hGrad, ctx->hm, seq, AcqBatch());
+    if (launch_acq_group(s, &tab, ng, ctx->hXq, ctx->n, ctx->k, ctx->NP, ctx->ld, ctx->dZnT, ctx->dR, ctx->dAlpha, ctx->dBounds4,
+                         ctx->dYstats, p, ctx->dPartial, ctx->dCounters + PCABO_GROUP_CNT_OFFSET, ctx->dVal, ctx->dGrad, ctx->hVal,
+                         ctx->hGrad, ctx->hm, seq, AcqBatch()) != 0)
+      return set_err(ctx, PCABO_ERR_HIP, "the restart-group acquisition kernel could not be launched%s", "");
   }
   HIPCHK(hipGetLastError());
   const auto t0 = std::chrono::steady_clock::now();
@@ -1329,101 +1331,8 @@ int pcabo_get_gram(pcabo_ctx* ctx, double* K) {
   return PCABO_OK;
 }
 
-static double cb_shim(const double*, double*, void*) { return 0.0; }
-
-int pcabo_lbfgsb_minimize(int nvar, double* x, const double* lower, const double* upper, pcabo_fg_callback fg,
-                          void* user, int m, double factr, double pgtol, int maxiter, int maxfun, int maxls,
-                          double* f_out, int* nit, int* nfev, int* task_out) {
-  (void)cb_shim;
-  if (nvar < 1 || !x || !fg || m < 1) return PCABO_ERR_ARG;
-  Lbfgsb opt;
-  opt.init(nvar, m, lower, upper, factr, pgtol, maxls);
-  if (lower && upper)
-    for (int i = 0; i < nvar; ++i) x[i] = x[i] < lower[i] ? lower[i] : (x[i] > upper[i] ? upper[i] : x[i]);
-  std::vector<double> g(nvar, 0.0), xc, gc;
-  double f = 0.0, fc = 0.0;
-  int iters = 0, evals = 0;
-  while (true) {
-    int task = opt.step(x, &f, g.data());
-    if (task == LBFGSB_FG) {
-      if (!xc.empty() && memcmp(x, xc.data(), nvar * sizeof(double)) == 0) { f = fc; g = gc; continue; }   // scipy's memoisation
-      f = fg(x, g.data(), user); ++evals;
-      xc.assign(x, x + nvar); gc = g; fc = f;
-      continue;
-    }
-    if (task == LBFGSB_NEW_X) {
-      ++iters;
-      if (iters >= maxiter) opt.stop(LBFGSB_STOP_ITER);
-      else if (evals > maxfun) opt.stop(LBFGSB_STOP_FUN);
-      continue;
-    }
-    break;
-  }
-  if (f_out) *f_out = f;
-  if (nit) *nit = iters;
-  if (nfev) *nfev = evals;
-  if (task_out) *task_out = opt.task();
-  return opt.warnflag();
-}
-
-int pcabo_lbfgsb_set_vector_kernels(int enabled) { return lbfgsb_set_vector_kernels(enabled); }
-
-int pcabo_sobol_scramble(int64_t* state, const int64_t* ltm, int k) {
-  if (!state || !ltm || k < 1) return PCABO_ERR_ARG;
-  const int MAXBIT = 30;
-  for (int d = 0; d < k; ++d) {
-    // matrix d over GF(2): unit diagonal, entries below it from ltm, nothing above (whatever ltm holds there - the caller
-    // need not clear the upper triangle).  col[c] = column c as a bit vector, row p at bit MAXBIT-1-p.
-    int64_t col[30];
-    for (int c = 0; c < MAXBIT; ++c) col[c] = (int64_t)1 << (MAXBIT - 1 - c);
-    for (int p = 1; p < MAXBIT; ++p) {
-      const int64_t* row = ltm + ((size_t)d * MAXBIT + p) * MAXBIT;
-      const int64_t pbit = (int64_t)1 << (MAXBIT - 1 - p);
-      for (int c = 0; c < p; ++c) col[c] |= (row[c] & 1) ? pbit : 0;
-    }
-    for (int j = 0; j < MAXBIT; ++j) {                  // state <- matrix * state, bit MAXBIT-1-c of the state = component c
-      unsigned long long v = (unsigned long long)state[(size_t)d * MAXBIT + j] & ((1ull << MAXBIT) - 1);
-      int64_t t2 = 0;
-      while (v) {
-        const int b = __builtin_ctzll(v);
-        t2 ^= col[MAXBIT - 1 - b];
-        v &= v - 1;
-      }
-      state[(size_t)d * MAXBIT + j] = t2;
-    }
-  }
-  return PCABO_OK;
-}
-
-// n points of a FRESH scrambled Sobol engine (state after pcabo_sobol_scramble, shift = the engine's shift vector), as
-// torch.quasirandom.SobolEngine.draw(n, dtype=float64) returns them for num_generated = 0 (first point = float32(shift) / 2^30, then
-// Gray-code steps: the state column of the lowest zero bit of the running index is XORed in), mapped into a box as botorch's
-// draw_sobol_samples does: out[i][j] = lo[j] + rng[j] * u[i][j] (multiply, then add: two roundings, as torch's two kernels).
-// lo = rng = NULL: u itself.
-int pcabo_sobol_draw(const int64_t* state, const int64_t* shift, int k, int n, const double* lo, const double* rng, double* out) {
-#pragma clang fp contract(off)
-  if (!state || !shift || !out || k < 1 || n < 1 || (lo == nullptr) != (rng == nullptr)) return PCABO_ERR_ARG;
-  const int MAXBIT = 30;
-  const double recip = 9.31322574615478515625e-10;      // 2^-30
-  std::vector<int64_t> q(shift, shift + k);
-  for (int i = 0; i < n; ++i) {
-    if (i > 0) {
-      unsigned v = (unsigned)(i - 1);
-      int l = 0;
-      while (v & 1u) { v >>= 1; ++l; }
-      if (l >= MAXBIT) return PCABO_ERR_ARG;
-      for (int j = 0; j < k; ++j) q[j] ^= state[(size_t)j * MAXBIT + l];
-    }
-    double* o = out + (size_t)i * k;
-    for (int j = 0; j < k; ++j) {
-      // (torch keeps the FIRST point as `quasi / 2**30` of an int64 tensor: a float32 tensor - that point has 24 bits)
-      const double u = i == 0 ? (double)((float)q[j]) * recip : (double)q[j] * recip;
-      if (lo) { const double t = rng[j] * u; o[j] = lo[j] + t; }
-      else o[j] = u;
-    }
-  }
-  return PCABO_OK;
-}
+// (pcabo_lbfgsb_minimize, pcabo_lbfgsb_set_vector_kernels, pcabo_sobol_scramble, pcabo_sobol_draw: host_entry.cpp - host code only,
+// built by g++ and, for the sanitizer targets of the Makefile, without the HIP runtime)
 
 int pcabo_set_profiling(pcabo_ctx* ctx, int enabled) {
   if (!ctx) return PCABO_ERR_ARG;
@@ -1487,110 +1396,7 @@ int pcabo_reset_profile(pcabo_ctx* ctx) {
 // =====================================================================================================================
 }  // extern "C"
 
-// One restart group of one run: scipy's L-BFGS-B state machine plus the memoisation of scipy's ScalarFunction (same
-// logic as in pcabo_optimize_acqf, which keeps its own copy for the resident-kernel path).
-struct RestartGroup {
-  Lbfgsb opt;
-  int q0 = 0, nq = 0, k = 0, maxiter = 200;
-  std::vector<double> x, g, lo, hi, xc, gc, vc;
-  double fval = 0.0, fc = 0.0;
-  bool have_cache = false, active = true;
-  int niter = 0, nfev = 0;
-  void init(const double* ics, const double* bounds, int q0_, int nq_, int k_, int maxiter_) {
-    q0 = q0_; nq = nq_; k = k_; maxiter = maxiter_;
-    const int nv = nq * k;
-    x.resize(nv); g.assign(nv, 0.0); lo.resize(nv); hi.resize(nv);
-    for (int j = 0; j < nq; ++j)
-      for (int c = 0; c < k; ++c) {
-        const double l = bounds[c], h = bounds[k + c], v = ics[(size_t)(q0 + j) * k + c];
-        lo[j * k + c] = l; hi[j * k + c] = h;
-        x[j * k + c] = v < l ? l : (v > h ? h : v);              // columnwise_clamp / np.clip
-      }
-    opt.init(nv, 10, lo.data(), hi.data(), 1e7, 1e-5, 20);
-  }
-  void advance() {                    // until the group needs f, g at x (or stops)
-    while (active) {
-      const int task = opt.step(x.data(), &fval, g.data());
-      if (task == LBFGSB_FG) {
-        if (have_cache && memcmp(x.data(), xc.data(), x.size() * sizeof(double)) == 0) { fval = fc; g = gc; continue; }
-        return;
-      }
-      if (task == LBFGSB_NEW_X) {
-        niter += 1;
-        if (niter >= maxiter) opt.stop(LBFGSB_STOP_ITER);
-        else if (nfev > 15000) opt.stop(LBFGSB_STOP_FUN);
-        continue;
-      }
-      active = false;
-    }
-  }
-  bool absorb(const double* hVal, const double* hGrad) {      // false: NaN in the gradient
-    double fs = 0.0;
-    bool nan = false;
-    for (int j = 0; j < nq; ++j) fs += hVal[q0 + j];
-    for (int t = 0; t < nq * k; ++t) {
-      const double gv = -hGrad[(size_t)q0 * k + t];
-      if (gv != gv) nan = true;
-      g[t] = gv;
-    }
-    if (nan) return false;
-    fval = -fs;
-    nfev += 1;
-    xc = x; gc = g; fc = fval; have_cache = true;
-    vc.assign(hVal + q0, hVal + q0 + nq);
-    return true;
-  }
-};
-
-// Worker pool of a batch: the calling thread is worker 0, n - 1 persistent threads are workers 1..n-1 (sleeping between
-// calls, woken per call).  With one worker nothing leaves the calling thread (PCABO_BATCH_THREADS=1: profiler runs).
-struct GangPool {
-  std::vector<std::thread> th;
-  std::mutex mu;
-  std::condition_variable cv, cv_done;
-  std::function<void(int)> fn;
-  unsigned epoch = 0;
-  int pending = 0;
-  bool quit = false;
-  void start(int n) {
-    const unsigned epoch0 = epoch;                         // (a restarted pool must not take the last call for a new one)
-    for (int i = 1; i < n; ++i)
-      th.emplace_back([this, i, epoch0] {
-        unsigned seen = epoch0;
-        for (;;) {
-          std::function<void(int)> f;
-          {
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return quit || epoch != seen; });
-            if (quit) return;
-            seen = epoch;
-            f = fn;
-          }
-          f(i);
-          { std::lock_guard<std::mutex> lk(mu); if (--pending == 0) cv_done.notify_all(); }
-        }
-      });
-  }
-  void run(std::function<void(int)> f) {                   // every worker runs f(worker index); returns when all are done
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      fn = f;
-      pending = (int)th.size();
-      ++epoch;
-    }
-    cv.notify_all();
-    f(0);
-    std::unique_lock<std::mutex> lk(mu);
-    cv_done.wait(lk, [&] { return pending == 0; });
-  }
-  void shutdown() {
-    { std::lock_guard<std::mutex> lk(mu); quit = true; }
-    cv.notify_all();
-    for (auto& t : th) if (t.joinable()) t.join();
-    th.clear();
-    quit = false;
-  }
-};
+// RestartGroup (one joint L-BFGS-B problem of a run) and GangPool (the batch's worker threads): host_side.h
 
 struct pcabo_batch {
   int device = 0, B = 0, max_n = 0, max_d = 0, max_q = 0;
@@ -1750,6 +1556,9 @@ int pcabo_batch_set_option(pcabo_batch* batch, int option, int value) {
   }
   if (option == PCABO_OPT_DEVICE_LBFGSB) {
     if (value < 0 || value > 2) return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_set_option: PCABO_OPT_DEVICE_LBFGSB takes 0, 1 or 2 (%s%d)", "", value);
+    // switched on after a conditioning: dGram holds K (or an older RT), not this GP's transposed root inverse - the next
+    // launch of the device optimiser rebuilds it (k_rt_build) instead of reading whatever is there
+    if (value != 0 && batch->dev_lbfgsb == 0) for (pcabo_ctx* c : batch->ctx) if (c->have_gp) c->rt_stale = true;
     batch->dev_lbfgsb = value;
     return PCABO_OK;
   }
@@ -2410,9 +2219,11 @@ int pcabo_batch_optimize_acqf(pcabo_batch* batch, const double* ics, int num_res
       if (nent == 0) break;
       const unsigned long long seq = batch->seq.fetch_add(1) + 1;
       if (use_group) {
-        launch_acq_group(st, &tab, nent, c0->hXq, batch->n, kmax, batch->NP, c0->ld, c0->dZnT, c0->dR, c0->dAlpha,
-                         c0->dBounds4, c0->dYstats, pg, c0->dPartial, c0->dCounters + PCABO_GROUP_CNT_OFFSET, c0->dVal,
-                         c0->dGrad, c0->hVal, c0->hGrad, c0->hm, seq, batch_ab(batch, 1, 1));
+        if (launch_acq_group(st, &tab, nent, c0->hXq, batch->n, kmax, batch->NP, c0->ld, c0->dZnT, c0->dR, c0->dAlpha,
+                             c0->dBounds4, c0->dYstats, pg, c0->dPartial, c0->dCounters + PCABO_GROUP_CNT_OFFSET, c0->dVal,
+                             c0->dGrad, c0->hVal, c0->hGrad, c0->hm, seq, batch_ab(batch, 1, 1)) != 0) {
+          hip_failed.store(1); return;                       // nothing was launched: no flags to wait for
+        }
       } else {
         launch_acq(st, &tab, c0->hXq, PCABO_INLAUNCH_MAXQ, batch->n, kmax, batch->NP, c0->ld, c0->dZnT, c0->dR,
                    c0->dAlpha, c0->dBounds4, c0->dYstats, pg, c0->dPartial, c0->dCounters, c0->dVal, c0->dGrad, c0->hVal,
@@ -2544,6 +2355,9 @@ int pcabo_batch_device_acq_eval(pcabo_batch* batch, const double* Xq, int q, con
     return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_device_acq_eval: bad argument (q <= 32)%s", "");
   if (!batch->have_gp || !batch->dev_lbfgsb)
     return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_device_acq_eval: needs a conditioned GP and PCABO_OPT_DEVICE_LBFGSB%s", "");
+  // the pinned table / point / value / gradient buffers below belong to an enqueued call until its _end has collected them
+  if (batch->opt_enqueued || batch->score_enqueued || batch->imap_enqueued)
+    return bset_err(batch, PCABO_ERR_ARG, "pcabo_batch_device_acq_eval: a _begin call of this batch has not been ended%s", "");
   BHIPCHK(hipSetDevice(batch->device));
   const int B = batch->B, MD = batch->max_d, kmax = batch_max_k(batch);
   if (!lbfgsb_device_possible(batch->NP, kmax, PCABO_GROUP_Q) || batch->max_q < 64)

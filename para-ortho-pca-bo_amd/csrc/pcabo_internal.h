@@ -198,10 +198,10 @@ void launch_acq(hipStream_t s, const QueryArgs* qa, const double* Xq, int q, int
 #define PCABO_GROUP_Q 5
 #define PCABO_GROUP_CNT_OFFSET 8192      // its tickets live in the upper half of the counter array (other slab count)
 bool acq_group_possible(int NP, int k);
-void launch_acq_group(hipStream_t st, const QueryArgs* tab, int entries, const double* Xq, int n, int k, int NP, int ld,
-                      const double* ZnT, const double* R, const double* alpha, const double* bounds4, const double* ystats,
-                      AcqParams p, double* partial, unsigned int* counters, double* val, double* grad, double* host_val,
-                      double* host_grad, HostMirror* hm, unsigned long long seq, AcqBatch ab);
+int launch_acq_group(hipStream_t st, const QueryArgs* tab, int entries, const double* Xq, int n, int k, int NP, int ld,
+                     const double* ZnT, const double* R, const double* alpha, const double* bounds4, const double* ystats,
+                     AcqParams p, double* partial, unsigned int* counters, double* val, double* grad, double* host_val,
+                     double* host_grad, HostMirror* hm, unsigned long long seq, AcqBatch ab);   // 0, or -1: nothing launched
 // value-only scoring of a large batch as a GEMM (KS, then V = R KS^T on MFMA, then the scalar chain); KS: q x ld scratch
 bool score_gemm_possible(int q);
 void launch_score(hipStream_t st, const double* Xq, int q, int n, int k, int NP, int ld, const double* ZnT, const double* R,

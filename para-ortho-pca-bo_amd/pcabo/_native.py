@@ -57,6 +57,7 @@ EXPORTS = [
     "pcabo_batch_optimize_acqf_begin", "pcabo_batch_optimize_acqf_end", "pcabo_batch_inverse_map_begin", "pcabo_batch_inverse_map_end",
     "pcabo_batch_set_input_strides", "pcabo_batch_gp_condition_begin",
     "pcabo_batch_set_profiling", "pcabo_batch_get_profile", "pcabo_batch_set_active", "pcabo_batch_set_workers", "pcabo_batch_set_option",
+    "pcabo_device_lbfgsb_limits",
     "pcabo_bbob_table_doubles", "pcabo_bbob_create", "pcabo_bbob_destroy", "pcabo_bbob_eval",
     "pcabo_comm_unique_id", "pcabo_comm_create", "pcabo_gather_best", "pcabo_comm_last_error", "pcabo_comm_destroy",
 ]
@@ -160,6 +161,13 @@ LIB.pcabo_lbfgsb_minimize.argtypes = [
 
 def device_count() -> int:
     return int(LIB.pcabo_device_count())
+
+
+def device_lbfgsb_limits():
+    """(max n, max k, max points per restart group) of the device-resident optimiser (pcabo_device_lbfgsb_limits; host code)."""
+    a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+    LIB.pcabo_device_lbfgsb_limits(C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
 
 
 def _ptr(a: Optional[np.ndarray]):

@@ -41,6 +41,13 @@ class _Share:
         return self.job.result()[self.key]
 
 
+def device_mode_covers(dimension: int, budget: int) -> bool:
+    """Can every iteration of a run of this shape go through the device-resident optimiser (acq_kernel="device")?  n never exceeds
+    the budget and k never exceeds the dimension; pcabo_device_lbfgsb_limits gives the kernel's bounds."""
+    max_n, max_k, _ = _native.device_lbfgsb_limits()
+    return int(budget) <= max_n and int(dimension) <= max_k
+
+
 class BatchedPCABO:
     """`problems[b]`: ioh-like objects (`.bounds.lb/.ub`, `.meta_data.n_variables`, callable) of ONE dimension;
     `seeds[b]`: the run's seed (ExperimentRunner.py:146).  After `run()`: `x_evals[b]`, `f_evals[b]`, `current_best[b]`,
@@ -119,6 +126,11 @@ class BatchedPCABO:
         # host's L-BFGS-B, launch by launch: what "device" is compared with bit for bit)
         if acq_kernel not in ("group", "latency", "device", "device-twin"):
             raise ValueError("acq_kernel must be 'group', 'latency', 'device' or 'device-twin'")
+        if acq_kernel in ("device", "device-twin") and not device_mode_covers(self.dimension, self.budget):
+            # the library would serve such a run's calls host-paced - another summation order - once it leaves the device
+            # optimiser's limits: one arithmetic mode per run, decided before it starts
+            raise ValueError("acq_kernel=%r: a run of dimension %d with budget %d can leave the device optimiser's limits "
+                             "(n <= %d, k <= %d); use 'group'" % ((acq_kernel, self.dimension, self.budget) + _native.device_lbfgsb_limits()[:2]))
         self._group_acq = acq_kernel != "latency"
         self._device_lbfgsb = {"device": 1, "device-twin": 2}.get(acq_kernel, 0)
         self._lbfgsb_cus = int(lbfgsb_cus)         # "device": the optimiser's launches confined to that many CUs (0: the whole chip)

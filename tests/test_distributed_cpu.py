@@ -102,3 +102,77 @@ def test_nccl_request_without_gpu_exits_instead_of_falling_back(monkeypatch):
     monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("LOCAL_RANK", "0"); monkeypatch.setenv("WORLD_SIZE", "2")
     with pytest.raises(SystemExit):
         D.init(backend="nccl")
+
+
+def _runner_worker8(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    import torch
+    torch.set_num_threads(1)
+    from pcabo import distributed as D
+    D.init(backend="gloo")
+    import importlib
+    er_mod = importlib.import_module("Algorithms.Experiment.ExperimentRunner")
+    er = er_mod.ExperimentRunner(algorithms=["pca"], dimensions=[20, 40], problem_ids=list(range(15, 25)), num_runs=30,
+                                 root_dir="/tmp", experiment_name="x", progress=False, batched=75, side_by_side=4,
+                                 batch_acq_kernel="auto")
+    mine = er._my_runs()
+    # what a rank would hand to the final gather: one best value per run, padded to the largest share (NaN)
+    share = max(len(s) for s in sharding.assign_runs(sharding.enumerate_runs(range(15, 25), [20, 40], 30), world))
+    local = [1000.0 * pid + 10.0 * dim + inst for pid, dim, inst in mine] + [float("nan")] * (share - len(mine))
+    gathered = D.gather_best(local)
+    seen = D.ranks_seen()
+    D.finalize()
+    q.put((rank, mine, gathered, dict(er.arithmetic_modes), seen))
+
+
+def test_sharded_experiment_runner_eight_ranks_gloo():
+    """BASELINE.json configs[3] on EIGHT ranks (gloo on the CPU): `_my_runs()` partitions the 600 runs, the gather returns
+    every run's value exactly once on every rank, and the arithmetic mode `auto` resolves to is the SAME on every rank and
+    the same as in a single process - it is taken from the experiment, not from the rank's share (37-38 runs per dimension
+    here, 300 in the experiment)."""
+    import math
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 8
+    procs = [ctx.Process(target=_runner_worker8, args=(r, world, 29617, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    all_runs = sharding.enumerate_runs(range(15, 25), [20, 40], 30)
+    mine = [r[1] for r in res]
+    assert sorted(x for m in mine for x in m) == sorted(all_runs)
+    assert all(r[4] == world for r in res)
+    for r in res:
+        assert r[2] == res[0][2] or all((a == b) or (math.isnan(a) and math.isnan(b)) for ra, rb in zip(r[2], res[0][2]) for a, b in zip(ra, rb))
+    flat = [v for row in res[0][2] for v in row if not math.isnan(v)]
+    assert sorted(flat) == sorted(1000.0 * pid + 10.0 * dim + inst for pid, dim, inst in all_runs)
+    assert all(r[3] == {20: "device", 40: "device"} for r in res)
+    loads = [sum(sharding.run_cost(x) for x in m) for m in mine]
+    assert max(loads) / min(loads) < 1.05
+
+
+def test_arithmetic_mode_is_a_property_of_the_experiment(monkeypatch):
+    """`auto` (and an explicit "device") resolve from the experiment's description only: any world size, any rank, any share."""
+    import importlib
+    er_mod = importlib.import_module("Algorithms.Experiment.ExperimentRunner")
+    R = er_mod.resolve_arithmetic_mode
+    assert R("auto", 0, 40, 600, 450) == "latency" and R("device", 1, 40, 600, 450) == "latency"      # not batched: the serial classes
+    assert R("auto", 30, 40, 30, 450) == "device" and R("auto", 30, 40, 29, 450) == "group"
+    assert R("auto", 30, 10, 300, 150) == "group" and R("auto", 30, 20, 300, 250) == "device"
+    assert R("auto", 30, 100, 300, 1050) == "group" and R("device", 30, 100, 300, 1050) == "group"     # beyond n <= 512, k <= 40
+    assert R("device", 30, 40, 3, 450) == "device" and R("device", 30, 40, 3, 600) == "group"
+    assert R("group", 30, 40, 300, 450) == "group" and R("latency", 30, 40, 300, 450) == "latency"
+    with pytest.raises(ValueError):
+        R("fastest", 30, 40, 300, 450)
+    seen = set()
+    for world in (1, 2, 8):
+        for rank in range(world):
+            monkeypatch.setenv("RANK", str(rank)); monkeypatch.setenv("LOCAL_RANK", str(rank)); monkeypatch.setenv("WORLD_SIZE", str(world))
+            er = er_mod.ExperimentRunner(algorithms=["pca"], dimensions=[10, 20, 40], problem_ids=[15, 16, 17], num_runs=30,
+                                         root_dir="/tmp", experiment_name="x", progress=False, batched=45, batch_acq_kernel="auto")
+            seen.add(tuple(sorted(er.arithmetic_modes.items())))
+    assert seen == {((10, "group"), (20, "device"), (40, "device"))}

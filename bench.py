@@ -168,34 +168,42 @@ def rocprof_summary():
 
 
 def batch_per_gpu(device: int, rank: int, size: int, B: int = 30):
-    """N > 1: what the product ships per GPU - ONE lock-step batch of B runs, taken from this rank's share of configs[3]'s d = 40
-    run list (f15..f24 x 30 instances, partitioned by pcabo.sharding.assign_runs); barrier before and after, the job's time is
-    the maximum over ranks, the aggregate the sum of the ranks' BO iterations over that time."""
-    from pcabo import batchrun
-    runs = sharding.enumerate_runs(list(range(15, 25)), [DIM], 30)
-    mine = sorted(sharding.assign_runs(runs, size)[rank])[:B]
-    r = batchrun.BatchedPCABO([BBOBProblem(f, i, d) for f, d, i in mine], [sharding.run_settings(x)["seed"] for x in mine],
-                              BUDGET, NDOE, device=device)
-    r.start()
-    torch.cuda.synchronize()
-    D.barrier()
-    t0 = time.perf_counter()
-    try:
-        batchrun.run_side_by_side([r], started=True)
+    """N > 1: what the product ships per GPU.  Every rank runs ITS SHARE OF configs[3] (30 runs x f15..f24 x d in {20, 40} = 600
+    runs, partitioned by the runner's own pcabo.sharding.assign_runs) through `ExperimentRunner(batched=75, side_by_side=4,
+    batch_acq_kernel="auto")` - the plan main.py runs: `auto` resolves to the device-resident optimiser for both dimensions from
+    the EXPERIMENT (300 runs per dimension), whatever the rank's share, so the rows are those of the 1-GPU experiment.  Whole
+    runs, DoE and IOHprofiler files included (a temporary folder); barrier before and after, the job's time is the maximum over
+    ranks, the aggregate the ranks' BO iterations over that time.  No data-path collective; the per-rank lines are gathered."""
+    import tempfile
+    from Algorithms import ExperimentRunner
+    with tempfile.TemporaryDirectory(prefix="pcabo_bench_") as tmp:
+        er = ExperimentRunner(algorithms=["pca"], dimensions=[20, 40], problem_ids=list(range(15, 25)), num_runs=30, root_dir=tmp,
+                              experiment_name="bench", progress=False, batched=75, side_by_side=4, batch_acq_kernel="auto")
+        mine = er._my_runs()
+        torch.cuda.synchronize()
+        D.barrier()
+        t0 = time.perf_counter()
+        er.run_experiment()
         torch.cuda.synchronize()
         dt_local = time.perf_counter() - t0
-    finally:
-        r.finish()
-    D.barrier()
-    iters = sum(len(f) - NDOE for f in r.f_evals)
+        D.barrier()
+    iters = float(sum(r["iterations"] for r in er.results))
     dt = D.max_over_ranks(dt_local)
     total = D.sum_over_ranks(iters)
-    per_rank = D.gather_best([iters / dt_local])
-    return {"runs_per_gpu": len(mine), "functions_on_rank0": sorted({f for f, _, _ in mine}), "seconds": dt,
-            "aggregate_bo_iterations_per_s": total / dt, "per_rank_bo_iterations_per_s": [p[0] for p in per_rank],
-            "bo_iterations": total, "stopped_early_on_rank0": sum(x is not None for x in r.failed),
-            "note": "one lock-step batch per GPU over pcabo.sharding.assign_runs of configs[3]'s d=40 list (first B runs of the "
-                    "rank's share); no data-path collective"}
+    cores = float(len(os.sched_getaffinity(0))) if hasattr(os, "sched_getaffinity") else float(os.cpu_count() or 0)
+    per_rank = D.gather_best([iters / dt_local, dt_local, float(len(mine)), cores, float(torch.get_num_threads()),
+                              float(len(er.failed_runs))])
+    return {"workload": "configs[3]: 30 runs x f15-f24 x d in {20,40} = 600 runs, this rank's share through ExperimentRunner("
+                        "batched=75, side_by_side=4, batch_acq_kernel='auto')",
+            "arithmetic_mode": {str(k): v for k, v in er.arithmetic_modes.items()},
+            "seconds": dt, "aggregate_bo_iterations_per_s": total / dt, "bo_iterations": total,
+            "per_rank": [{"bo_iterations_per_s": p[0], "seconds": p[1], "runs": int(p[2]), "cores_in_affinity_mask": int(p[3]),
+                          "torch_threads": int(p[4]), "failed_runs": int(p[5])} for p in per_rank],
+            "host_threads_per_rank": "one Python thread interleaves up to four device-mode batches; 8 pool threads draw the next "
+                                     "iteration's noise blocks and Sobol engines; no gang workers in device mode",
+            "backend": D.backend_name(), "rccl_ranks": D.ranks_seen(),
+            "note": "whole runs incl. DoE and IOHprofiler files; no data-path collective; the per-rank figures above were "
+                    "exchanged with one all-gather after the timed region"}
 
 
 def nearest_pmc(n_mean: float):

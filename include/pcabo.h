@@ -186,6 +186,12 @@ int pcabo_lbfgsb_minimize(int nvar, double* x, const double* lower, const double
  * same order, no fma); on by default where the CPU has AVX2.  0 selects the scalar loops (process-wide; the test that
  * compares the two uses it), 1 the default again.  Returns the previous setting. */
 int pcabo_lbfgsb_set_vector_kernels(int enabled);
+/* Summation order of the sums over the variables (d'd, g'd, r'r, W'd ...) in optimisers started by pcabo_lbfgsb_minimize from now
+ * on: 0 (default) the published order - scipy's iterates; 1 the 64-lane tree order in which the device-resident optimiser
+ * (PCABO_OPT_DEVICE_LBFGSB) steps: lane l adds terms l, l + 64, ..., then a balanced tree of adjacent pairs.  With 1 the host class
+ * is the device's twin bit for bit (tests/test_gpu_device_lbfgsb.py); against scipy it is one more rounding of the same sums
+ * (tests/test_lbfgsb_vs_scipy.py, tests/test_lbfgsb_divergence.py state what that does).  Returns the previous setting. */
+int pcabo_lbfgsb_set_sum_order(int order);
 
 /* Host-only helper for the initial-condition draw (botorch -> torch.quasirandom.SobolEngine, row K):
  * the matrix scramble of torch's `_sobol_engine_scramble_` on state[k*30] (in/out) with the k lower-

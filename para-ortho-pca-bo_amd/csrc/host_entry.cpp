@@ -46,6 +46,7 @@ int pcabo_lbfgsb_minimize(int nvar, double* x, const double* lower, const double
 }
 
 int pcabo_lbfgsb_set_vector_kernels(int enabled) { return lbfgsb_set_vector_kernels(enabled); }
+int pcabo_lbfgsb_set_sum_order(int order) { return lbfgsb_set_default_sum_order(order); }
 
 int pcabo_sobol_scramble(int64_t* state, const int64_t* ltm, int k) {
   if (!state || !ltm || k < 1) return PCABO_ERR_ARG;

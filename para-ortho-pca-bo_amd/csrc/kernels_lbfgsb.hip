@@ -9,11 +9,14 @@
 //
 //  * The optimiser state (S, Y of the last 10 pairs, the compact-representation matrices, the iterate, gradient, bounds,
 //    index sets) lives in LDS; the step is csrc/lbfgsb.cpp restated for ONE WAVE: loops over the variables run a variable
-//    per lane, the ordered sums of the published algorithm stay ordered (a chain per lane where several sums are
-//    independent, every lane the same chain otherwise), the small dense pieces (10 x 10 and 20 x 20 factorisations and
-//    triangular solves) keep a column or a right-hand side per lane and broadcast pivots with v_readlane.  Every number goes
-//    through the same operations in the same order as on the host (this file is compiled with -ffp-contract=off; IEEE
-//    divide and square root), so that fed the same f / g values the device takes the host's iterates bit for bit
+//    per lane; the sums over the variables (d'd, g'd, r'r, the 2m accumulations W'd, f1 of the Cauchy search) are formed in
+//    the 64-LANE TREE ORDER - lane l adds the terms l, l + 64, ..., the lane sums meet in a balanced tree of adjacent pairs
+//    (DPP row operations; several sums at once through an LDS tile) - which csrc/lbfgsb.cpp implements behind
+//    Lbfgsb::set_sum_order(1): the host class in that order is this kernel's twin.  The short ordered sums over the <= 2m
+//    history columns and the small dense pieces (10 x 10 and 20 x 20 factorisations and triangular solves) keep the
+//    published order: a column or a right-hand side per lane, pivots broadcast with v_readlane.  Every number goes
+//    through the same operations in the same order as in the twin (this file is compiled with -ffp-contract=off; IEEE
+//    divide and square root), so that fed the same f / g values the device takes the twin's iterates bit for bit
 //    (tests/test_gpu_device_lbfgsb.py compares the two through the evaluation-only mode of the same kernel).  Wave 1 helps:
 //    it runs the routines whose results wave 0 does not need at once (second half of matupd + formt beside the head of the
 //    Cauchy search, cmprlb + the head of subsm beside formk) - same routines, same data, handed over through two LDS words.
@@ -65,10 +68,14 @@ extern "C" int pcabo_debug_lb_ticks(unsigned long long* ticks32, unsigned long l
 typedef __attribute__((address_space(3))) double ldsd;
 typedef __attribute__((address_space(3))) int ldsi;
 typedef const __attribute__((address_space(1))) double gcd;      // global memory, read only: global_load even behind a call
+typedef double lb_v2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) lb_v2 ldsv2;     // two neighbouring doubles of an LDS array: ds_read_b128
 #else
 typedef double ldsd;
 typedef int ldsi;
 typedef const double gcd;
+typedef double lb_v2 __attribute__((ext_vector_type(2)));
+typedef const lb_v2 ldsv2;
 #endif
 
 // ---- persistent scalars of a group (LDS) ----------------------------------------------------------------------------
@@ -83,6 +90,8 @@ enum { I_COL, I_HEAD, I_ITAIL, I_ITER, I_IUPDAT, I_UPDATD, I_WRK, I_NFREE, I_ILE
 // largest group, LB_GQ * LB_MAXK variables), the evaluation's three NP-sized arrays last.  The struct is three words and
 // travels by value.
 #define LB_NVCAP (LB_GQ * LB_MAXK)
+#define LB_TILE_LD 66                         // leading dimension of a transposition tile: 16-byte aligned rows, 4 banks apart
+#define LB_TILE (4 * LB_M * LB_TILE_LD)       // 40 sums x 64 lane terms
 // work plan of the two triangular passes (lb_build_plan): per pass and wave [count, 2 x (unit, lo, hi, dest)], then per unit
 // [first extra slot, extra slots]
 #define LB_LDW (LB_NVCAP | 1)
@@ -145,6 +154,8 @@ struct LbLds {
   __device__ ldsd* ks() const { return base + OFF_KS; }
   __device__ ldsd* vb() const { return base + OFF_KS + LB_QS * NP; }
   __device__ ldsd* slots() const { return base + OFF_KS + 2 * LB_QS * NP; }       // partial sums of a pass: [slot][64][LB_GQ]
+  // the step's transposition tiles (lb_accum): the evaluation's arrays are dead while the optimiser steps; one tile per stepping wave
+  __device__ ldsd* tile(int w) const { return base + OFF_KS + w * LB_TILE; }
 };
 // the triangular passes' partial slots: at most (waves + two-slab pairs - slabs) segments do not start their slab (lb_build_plan)
 static inline size_t lb_lds_doubles(int NP) { return (size_t)OFF_KS + (size_t)2 * LB_QS * NP + (size_t)lb_max_slots(NP) * 64 * LB_GQ; }
@@ -180,41 +191,21 @@ __device__ inline void st0(ldsd* p, double v, int lane) { if (lane == 0) *p = v;
 __device__ inline void sti0(ldsi* p, int v, int lane) { if (lane == 0) *p = v; }
 __device__ inline unsigned long long lanes_below(int lane) { return lane == 0 ? 0ull : (~0ull >> (64 - lane)); }
 
-// ordered sum of an LDS array, every lane the same chain: s = (((s0 op a[0]) op a[1]) ...); 16 loads per LDS round trip
-__device__ inline double chain_add(double s, const ldsd* a, int n) {
-  int i = 0;
-  for (; i + 16 <= n; i += 16) {
-    double v[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) v[u] = a[i + u];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) s += v[u];
-  }
-  for (; i < n; ++i) s += a[i];
-  return s;
+// ---- sums over the variables in the 64-lane tree order (lbfgsb.cpp: tree_sum / tree_dot / tree_accum) -------------------------
+// lane l adds its terms l, l + 64, l + 128 ... in that order (a lane without a term holds 0.0); wave_sum (pcabo_internal.h) joins
+// the 64 lane sums in the balanced tree of adjacent pairs: quad_perm 1 + 1, 2 + 2, row_half_mirror 4 + 4, row_mirror 8 + 8,
+// row_bcast15 16 + 16, row_bcast31 32 + 32 (a + b == b + a bit for bit, so which lane holds which operand does not matter).
+__device__ inline double wave_tsum(const ldsd* p, int n, int lane) {
+  double s = lane < n ? p[lane] : 0.0;
+  for (int i = lane + 64; i < n; i += 64) s += p[i];
+  return wave_sum(s);
 }
-__device__ inline double chain_sub(double s, const ldsd* a, int n) {
-  int i = 0;
-  for (; i + 16 <= n; i += 16) {
-    double v[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) v[u] = a[i + u];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) s -= v[u];
-  }
-  for (; i < n; ++i) s -= a[i];
-  return s;
+__device__ inline double wave_ddot(const ldsd* a, const ldsd* b, int n, int lane) {
+  double s = lane < n ? a[lane] * b[lane] : 0.0;
+  for (int i = lane + 64; i < n; i += 64) s += a[i] * b[i];
+  return wave_sum(s);
 }
-// ddot of two LDS vectors in the host's order (products rounded, then added from 0.0): lanes form the products, every lane the chain
-__device__ inline double wave_ddot_in(ldsd* buf, const ldsd* a, const ldsd* b, int n, int lane) {
-  for (int i = lane; i < n; i += 64) buf[i] = a[i] * b[i];
-  LSYNC();
-  const double s = chain_add(0.0, buf, n);
-  LSYNC();
-  return s;
-}
-__device__ inline double wave_ddot(const LbLds L, const ldsd* a, const ldsd* b, int n, int lane) { return wave_ddot_in(L.prod(), a, b, n, lane); }
-// ddot of two short LDS vectors (n <= 2 LB_M) in the host's order: lane j forms product j, every lane adds them in order
+// ddot of two short LDS vectors (n <= 2 LB_M) in the published order: lane j forms product j, every lane adds them in order
 __device__ inline double small_ddot(const ldsd* a, const ldsd* b, int n, int lane) {
   const int j = lane < n ? lane : 0;
   const double pr = a[j] * b[j];
@@ -224,26 +215,55 @@ __device__ inline double small_ddot(const ldsd* a, const ldsd* b, int n, int lan
   return s;
 }
 
-// "reduce over variables" (lbfgsb.cpp: accum): lanes 0 .. 2 LB_M - 1 (physical columns of WY | WS) each run
-// acc += coefA[t] * W(t, column) over ALL variables t = 0 .. n-1 in increasing order - a variable outside the host's index list
-// carries coefficient 0.0, which leaves every non-zero partial sum as it is (the host skips it); lanes 32 .. 32 + 2 LB_M - 1
-// run coefB over t = n-1 .. 0 (the host's list of active variables is in decreasing order).  Results in L.acc()[lane].
-__device__ inline void lb_accum(const LbLds L, const ldsd* coefA, const ldsd* coefB, int lane, ldsd* out) {
-  const int n = L.n, half = lane >> 5, c = (lane & 31) % (2 * LB_M);
-  const ldsd* col = c < LB_M ? L.wy() + c * LB_LDW : L.ws() + (c - LB_M) * LB_LDW;
-  const bool down = half && coefB;
-  const ldsd* cf = down ? coefB : coefA;
-  double a = 0.0;
-  int s = 0;
-  for (; s + 8 <= n; s += 8) {
-    double w[8], cc[8];
+// balanced adjacent-pair tree over 16 neighbouring doubles of an LDS row (8 ds_read_b128)
+__device__ inline double tree16(const ldsd* row) {
+  lb_v2 v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { const int t = down ? n - 1 - (s + u) : s + u; w[u] = col[t]; cc[u] = cf[t]; }
+  for (int u = 0; u < 8; ++u) v[u] = *(ldsv2*)(row + 2 * u);
+  double b[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) a += cc[u] * w[u];
+  for (int u = 0; u < 8; ++u) b[u] = v[u].x + v[u].y;
+  const double c0 = b[0] + b[1], c1 = b[2] + b[3], c2 = b[4] + b[5], c3 = b[6] + b[7];
+  return (c0 + c1) + (c2 + c3);
+}
+// "reduce over variables" (lbfgsb.cpp: tree_accum): out[c] = tree sum over ALL variables t of coefA[t] * W(t, c), c over the
+// 2 LB_M physical columns of WY | WS - a variable outside the published algorithm's index list carries the coefficient 0.0 -
+// and, with TWO, out[32 + c] the same with coefB.  Lane l forms the terms of variables l, l + 64, ... in registers; the 64 lane
+// sums of an output meet through an LDS tile (a row of LB_TILE_LD doubles per output, conflict-free both ways), where lane o
+// reduces output o in the tree's order, 16 values at a time.
+template <bool TWO>
+__device__ inline void lb_accum(const LbLds L, const ldsd* coefA, const ldsd* coefB, int lane, ldsd* out, ldsd* tile) {
+  const int n = L.n;
+  constexpr int NO = TWO ? 4 * LB_M : 2 * LB_M;
+  double p[NO];
+  {
+    const bool in = lane < n;
+    const int v = in ? lane : 0;
+    const double ca = coefA[v], cb = TWO ? coefB[v] : 0.0;
+#pragma unroll
+    for (int c = 0; c < LB_M; ++c) {
+      const double wy = L.wy()[c * LB_LDW + v], ws = L.ws()[c * LB_LDW + v];
+      p[c] = in ? ca * wy : 0.0; p[LB_M + c] = in ? ca * ws : 0.0;
+      if (TWO) { p[2 * LB_M + c] = in ? cb * wy : 0.0; p[3 * LB_M + c] = in ? cb * ws : 0.0; }
+    }
   }
-  for (; s < n; ++s) { const int t = down ? n - 1 - s : s; a += cf[t] * col[t]; }
-  out[lane] = a;
+  for (int v = lane + 64; v < n; v += 64) {
+    const double ca = coefA[v], cb = TWO ? coefB[v] : 0.0;
+#pragma unroll
+    for (int c = 0; c < LB_M; ++c) {
+      const double wy = L.wy()[c * LB_LDW + v], ws = L.ws()[c * LB_LDW + v];
+      p[c] += ca * wy; p[LB_M + c] += ca * ws;
+      if (TWO) { p[2 * LB_M + c] += cb * wy; p[3 * LB_M + c] += cb * ws; }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < NO; ++o) tile[o * LB_TILE_LD + lane] = p[o];
+  LSYNC();
+  if (lane < NO) {
+    const ldsd* row = tile + lane * LB_TILE_LD;
+    const double q0 = tree16(row), q1 = tree16(row + 16), q2 = tree16(row + 32), q3 = tree16(row + 48);
+    out[(TWO && lane >= 2 * LB_M) ? 32 + lane - 2 * LB_M : lane] = (q0 + q1) + (q2 + q3);
+  }
   LSYNC();
 }
 
@@ -471,9 +491,9 @@ __device__ __noinline__ void lb_cauchy(const LbLds L, int lane) {
     nbreak += __popcll(mb);
   }
   LSYNC();
-  double f1 = chain_sub(0.0, L.prod(), n);         // f1 -= neggi^2 over the moving variables, in order (others subtract 0.0)
+  double f1 = -wave_tsum(L.prod(), n, lane);       // f1 = -(sum of neggi^2 over the moving variables; the others add 0.0), tree order
   if (col > 0) {
-    lb_accum(L, d, nullptr, lane, L.acc());                   // d[i] = -g[i] for the moving variables, 0.0 for the others
+    lb_accum<false>(L, d, nullptr, lane, L.acc(), L.tile(0));   // d[i] = -g[i] for the moving variables, 0.0 for the others
     if (lane < col) {
       int pointr = head + lane; if (pointr >= LB_M) pointr -= LB_M;
       p[lane] = L.acc()[pointr];
@@ -654,7 +674,7 @@ __device__ __noinline__ void lb_formk(const LbLds L, int lane) {
     }
     LSYNC();
     LBT_NEXT(18);
-    lb_accum(L, L.coef(), L.prod(), lane, L.acc());
+    lb_accum<true>(L, L.coef(), L.prod(), lane, L.acc(), L.tile(0));
     LBT_NEXT(19);
     if (lane < col) {
       int jp = head + lane; if (jp >= m) jp -= m;
@@ -763,11 +783,24 @@ __device__ __noinline__ void lb_cmprlb(const LbLds L, int lane, int info_word) {
   LSYNC();
   const int info = lb_bmv(L, L.wa() + 2 * LB_M, L.wa(), lane);
   if (info != 0) { sti0(&ISC(info_word), -8, lane); LSYNC(); return; }
-  int pointr = ISR(I_HEAD);
-  for (int j = 0; j < col; ++j) {
-    const double a1 = L.wa()[j], a2 = theta * L.wa()[col + j];
-    for (int k = lane; k < n; k += 64) L.full()[k] += WY_(k, pointr) * a1 + WS_(k, pointr) * a2;
-    pointr = nxt(pointr);
+  {
+    // a chain per variable over the history columns (the published order), the variable's value in a register meanwhile
+    constexpr int NU = (LB_NVCAP + 63) / 64;
+    double f[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) { const int k = lane + 64 * u; f[u] = k < n ? L.full()[k] : 0.0; }
+    int pointr = ISR(I_HEAD);
+#pragma unroll
+    for (int j = 0; j < LB_M; ++j) {
+      if (j < col) {
+        const double a1 = L.wa()[j], a2 = theta * L.wa()[col + j];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) { const int k = lane + 64 * u; if (k < n) f[u] += WY_(k, pointr) * a1 + WS_(k, pointr) * a2; }
+        pointr = nxt(pointr);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) { const int k = lane + 64 * u; if (k < n) L.full()[k] = f[u]; }
   }
   LSYNC();
   for (int i = lane; i < nfree; i += 64) L.r()[i] = L.full()[L.index()[i]];
@@ -784,7 +817,7 @@ __device__ inline void lb_subsm_head(const LbLds L, int lane) {
   LSYNC();
   for (int i = lane; i < nsub; i += 64) L.full()[ind[i]] = d[i];
   LSYNC();
-  lb_accum(L, L.full(), nullptr, lane, L.acc2());
+  lb_accum<false>(L, L.full(), nullptr, lane, L.acc2(), L.tile(1));
 }
 
 __device__ __noinline__ void lb_subsm(const LbLds L, int lane) {
@@ -809,11 +842,23 @@ __device__ __noinline__ void lb_subsm(const LbLds L, int lane) {
   LBT_NEXT(29);
   if (lane < col2) wv[lane] = b;
   LSYNC();
-  int pointr = ISR(I_HEAD);
-  for (int jy = 0; jy < col; ++jy) {
-    const double a1 = wv[jy], a2 = wv[col + jy];
-    for (int k = lane; k < n; k += 64) L.full()[k] = L.full()[k] + WY_(k, pointr) * a1 / theta + WS_(k, pointr) * a2;
-    pointr = nxt(pointr);
+  {
+    constexpr int NU = (LB_NVCAP + 63) / 64;
+    double f[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) { const int k = lane + 64 * u; f[u] = k < n ? L.full()[k] : 0.0; }
+    int pointr = ISR(I_HEAD);
+#pragma unroll
+    for (int jy = 0; jy < LB_M; ++jy) {
+      if (jy < col) {
+        const double a1 = wv[jy], a2 = wv[col + jy];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) { const int k = lane + 64 * u; if (k < n) f[u] = f[u] + WY_(k, pointr) * a1 / theta + WS_(k, pointr) * a2; }
+        pointr = nxt(pointr);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) { const int k = lane + 64 * u; if (k < n) L.full()[k] = f[u]; }
   }
   LSYNC();
   LBT_NEXT(30);
@@ -837,7 +882,7 @@ __device__ __noinline__ void lb_subsm(const LbLds L, int lane) {
   if (iword == 0) return;
   for (int i = lane; i < n; i += 64) L.prod()[i] = (x[i] - L.x()[i]) * L.g()[i];
   LSYNC();
-  const double dd_p = chain_add(0.0, L.prod(), n);
+  const double dd_p = wave_tsum(L.prod(), n, lane);
   if (dd_p > 0.0) {
     for (int i = lane; i < n; i += 64) x[i] = L.xp()[i];
     LSYNC();
@@ -1057,7 +1102,7 @@ __device__ __noinline__ void lb_lnsrlb(const LbLds L, int lane) {
     ls_load(L, ls);
     stp = SR(S_STP); stpmx = SR(S_STPMX);
   }
-  const double gd = wave_ddot(L, L.g(), L.d(), n, lane);
+  const double gd = wave_ddot(L.g(), L.d(), n, lane);
   if (first_call) lb_help_wait(L, lane);              // (the helper's chain ran beside this one)
   int ifun = ISR(I_IFUN);
   LSYNC();
@@ -1115,7 +1160,7 @@ __device__ __noinline__ void lb_matupd_b(const LbLds L, int lane) {
     for (int u = 0; u < 2; ++u) { if (dst[u] > 0) L.ss()[dst[u] - 1] = src[u]; else if (dst[u] < 0) L.sy()[-dst[u] - 1] = src[u]; }
   }
   LSYNC();
-  lb_accum(L, &WS_(0, itail), nullptr, lane, L.acc2());
+  lb_accum<false>(L, &WS_(0, itail), nullptr, lane, L.acc2(), L.tile(1));
   if (lane < col - 1) {
     int pointr = head + lane; if (pointr >= m) pointr -= m;
     SY_(col - 1, lane) = L.acc2()[pointr];
@@ -1179,7 +1224,7 @@ __device__ int lb_step(const LbLds L, int lane) {
     }
     for (int i = lane; i < n; i += 64) L.r()[i] = L.g()[i] - L.r()[i];
     LSYNC();
-    const double rr = wave_ddot(L, L.r(), L.r(), n, lane);
+    const double rr = wave_ddot(L.r(), L.r(), n, lane);
     const double stp = SR(S_STP), gd = SR(S_GD), gdold = SR(S_GDOLD);
     double dr, ddum2;
     if (stp == 1.0) { dr = gd - gdold; ddum2 = -gdold; }
@@ -1268,7 +1313,7 @@ __device__ void lb_helper(const LbLds L, int lane, int& last) {
     if (op == LB_OP_END) return;
     if (op == LB_OP_FORMT) { lb_matupd_b(L, lane); lb_formt(L, lane); }
     else if (op == LB_OP_DTD) {
-      const double dtd = wave_ddot_in(L.coef(), L.d(), L.d(), L.n, lane);
+      const double dtd = wave_ddot(L.d(), L.d(), L.n, lane);
       if (lane == 0) { SC(S_DTD) = dtd; SC(S_DNORM) = sqrt(dtd); }
     }
     else if (op == LB_OP_CMPRLB) { lb_cmprlb(L, lane, I_INFO2); if (ISR(I_INFO2) == 0 && ISR(I_NFREE) > 0) lb_subsm_head(L, lane); }
@@ -1881,6 +1926,7 @@ int launch_lbfgsb_group(hipStream_t st, const unsigned* table, int entries, int 
                         int maximize, int acq, int kernel, double* out_x, double* out_v, size_t zs) {
   const size_t lds = lb_lds_doubles(NP) * sizeof(double);
   if (lds > 150 * 1024) return -1;
+  if (lb_lds_doubles(NP) < (size_t)OFF_KS + 2 * LB_TILE) return -1;      // the step's two transposition tiles lie in the evaluation's arrays
   {
     static std::mutex attr_mu;
     static bool attr_done[64] = {false};

@@ -128,6 +128,50 @@ inline double ddot(int n, const double* x, const double* y) {
   return s;
 }
 
+// ---- the second summation order ("tree", Lbfgsb::set_sum_order(1)) ---------------------------------------------------
+// The sums over the VARIABLES (the inner products d'd, g'd, r'r, the 2m accumulations W'd of cauchy / formk / subsm / matupd,
+// f1 of the Cauchy search, the descent test of subsm) in the order a 64-lane wavefront forms them without a serial chain:
+// lane l adds the terms l, l + 64, l + 128, ... in that order, then the 64 lane sums meet in a balanced tree of adjacent
+// pairs (1 + 1, 2 + 2, 4 + 4 ... 32 + 32).  csrc/kernels_lbfgsb.hip steps in this order on the device (DPP row operations form
+// exactly this tree); with the switch set the host class is its twin, bit for bit.  The short sums over the <= 2m history
+// columns (bmv, dtrsl, dpofa, the small ddots) keep the published order in both modes.  A variable that the published
+// algorithm skips carries the coefficient 0.0 here (full-length vectors): x + 0.0 w leaves every partial sum as it is.
+inline double tree64(double* t) {
+  for (int w = 1; w < 64; w <<= 1)
+    for (int i = 0; i < 64; i += 2 * w) t[i] += t[i + w];
+  return t[0];
+}
+inline double tree_sum(int n, const double* p) {
+  double t[64];
+  const int n0 = n < 64 ? n : 64;
+  for (int i = 0; i < n0; ++i) t[i] = p[i];
+  for (int i = n0; i < 64; ++i) t[i] = 0.0;
+  for (int i = 64; i < n; ++i) t[i & 63] += p[i];
+  return tree64(t);
+}
+inline double tree_dot(int n, const double* x, const double* y) {
+  double t[64];
+  const int n0 = n < 64 ? n : 64;
+  for (int i = 0; i < n0; ++i) t[i] = x[i] * y[i];
+  for (int i = n0; i < 64; ++i) t[i] = 0.0;
+  for (int i = 64; i < n; ++i) t[i & 63] += x[i] * y[i];
+  return tree64(t);
+}
+// acc[j] = tree sum over ALL variables i of coef[i] * W(i, j), j over the 2 mp physical columns of the mirror
+void tree_accum(const double* wr, int rs, int mp, const double* coef, int n, double* acc) {
+  const int w = 2 * mp;
+  static thread_local double t[2 * LBFGSB_MAXM + 8][64];
+  for (int j = 0; j < w; ++j) for (int l = 0; l < 64; ++l) t[j][l] = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const double* row = wr + (size_t)i * rs;
+    const double c = coef[i];
+    const int l = i & 63;
+    if (i < 64) for (int j = 0; j < w; ++j) t[j][l] = c * row[j];
+    else for (int j = 0; j < w; ++j) t[j][l] += c * row[j];
+  }
+  for (int j = 0; j < w; ++j) acc[j] = tree64(t[j]);
+}
+
 // LINPACK dpofa: upper Cholesky factor of the leading nn x nn block (leading dimension lda).
 int dpofa(double* a, int lda, int nn) {
   for (int j = 0; j < nn; ++j) {
@@ -169,6 +213,9 @@ int dtrsl(const double* t, int ldt, int nn, double* b, int job) {
 
 }  // namespace
 
+namespace { std::atomic<int> g_default_sum_order{0}; }
+int lbfgsb_set_default_sum_order(int order) { return g_default_sum_order.exchange(order ? 1 : 0); }
+
 int lbfgsb_set_vector_kernels(int enabled) {
   const bool was = &vec_kernels() != &g_scalar_kernels;
   g_kernels.store(enabled ? default_kernels() : &g_scalar_kernels, std::memory_order_release);
@@ -178,6 +225,7 @@ int lbfgsb_set_vector_kernels(int enabled) {
 void Lbfgsb::init(int n, int m, const double* lower, const double* upper, double factr, double pgtol, int maxls) {
   if (m > LBFGSB_MAXM) m = LBFGSB_MAXM;
   n_ = n; m_ = m; factr_ = factr; pgtol_ = pgtol; maxls_ = maxls;
+  sum_order_ = g_default_sum_order.load();
   l_.assign(n, 0.0); u_.assign(n, 0.0); nbd_.assign(n, 0);
   for (int i = 0; i < n; ++i) {
     double lo = lower ? lower[i] : -INFINITY, hi = upper ? upper[i] : INFINITY;
@@ -393,9 +441,15 @@ void Lbfgsb::cauchy(const double* x, const double* g) {
       }
     }
   }
+  if (sum_order_ == 1) {
+    // f1 = -(sum of neggi^2 over the moving variables), d itself is the full-length coefficient vector (0.0 elsewhere)
+    for (int i = 0; i < n; ++i) sc_full_[i] = d[i] * d[i];
+    f1 = -tree_sum(n, sc_full_.data());
+  }
   if (col > 0) {
     double acc[2 * LBFGSB_MAXM] = {0.0};
-    vec_kernels().accum(wr_.data(), rs_, mp_, sc_rows_.data(), sc_coef_.data(), nmove, acc);
+    if (sum_order_ == 1) tree_accum(wr_.data(), rs_, mp_, d, n, acc);
+    else vec_kernels().accum(wr_.data(), rs_, mp_, sc_rows_.data(), sc_coef_.data(), nmove, acc);
     int pointr = head_;
     for (int j = 0; j < col; ++j) { p[j] = acc[pointr]; p[col + j] = acc[mp_ + pointr]; pointr = nxt(pointr, m); }
 #ifdef LBFGSB_CHECK
@@ -540,8 +594,16 @@ void Lbfgsb::formk() {
       double* coef = sc_coef_.data();
       for (int k = 0; k < nsub; ++k) coef[k] = WY(ind[k], ipntr);
       for (int k = nsub; k < n; ++k) coef[k] = WS(ind[k], ipntr);
+      if (sum_order_ == 1) {
+        // full-length coefficient vectors: WY(k, ipntr) on the free variables / WS(k, ipntr) on the active ones, 0.0 elsewhere
+        double* cb = sc_full_.data();
+        for (int k = 0; k < n; ++k) { const bool fr = iwhere_[k] <= 0; coef[k] = fr ? WY(k, ipntr) : 0.0; cb[k] = fr ? 0.0 : WS(k, ipntr); }
+        tree_accum(wr_.data(), rs_, mp_, coef, n, accf);
+        tree_accum(wr_.data(), rs_, mp_, cb, n, acca);
+      } else {
       vec_kernels().accum(wr_.data(), rs_, mp_, ind, coef, nsub, accf);
       vec_kernels().accum(wr_.data(), rs_, mp_, ind + nsub, coef + nsub, n - nsub, acca);
+      }
       int jp = head;
       const int jyc = col - 1;
       for (int jy = 0; jy < col; ++jy) {
@@ -650,6 +712,12 @@ void Lbfgsb::subsm(const double* xx, const double* gg) {
   {
     // wv = W' Z d over the free variables (their order), all 2 col inner products in one pass over the mirror
     double acc[2 * LBFGSB_MAXM] = {0.0};
+    if (sum_order_ == 1) {
+      double* full = sc_coef_.data();                // d scattered to the variables' own places, 0.0 elsewhere
+      for (int k = 0; k < n; ++k) full[k] = 0.0;
+      for (int i = 0; i < nsub; ++i) full[ind[i]] = d[i];
+      tree_accum(wr_.data(), rs_, mp_, full, n, acc);
+    } else
     vec_kernels().accum(wr_.data(), rs_, mp_, ind, d, nsub, acc);
     for (int i = 0; i < col; ++i) { wv[i] = acc[pointr]; wv[col + i] = theta_ * acc[mp_ + pointr]; pointr = nxt(pointr, m); }
 #ifdef LBFGSB_CHECK
@@ -713,6 +781,10 @@ void Lbfgsb::subsm(const double* xx, const double* gg) {
   }
   if (iword_ == 0) return;
   double dd_p = 0.0;
+  if (sum_order_ == 1) {
+    for (int i = 0; i < n; ++i) sc_coef_[i] = (x[i] - xx[i]) * gg[i];
+    dd_p = tree_sum(n, sc_coef_.data());
+  } else
   for (int i = 0; i < n; ++i) dd_p += (x[i] - xx[i]) * gg[i];
   if (dd_p > 0.0) {
     std::memcpy(x, xp_.data(), sizeof(double) * n);
@@ -868,7 +940,7 @@ void Lbfgsb::lnsrlb(double* x, double f, const double* g) {
   const int n = n_;
   const double big = 1e10, ftol = 1e-3, gtol = 0.9, xtol = 0.1;
   if (phase_ != 2) {
-    dtd_ = ddot(n, d_.data(), d_.data());
+    dtd_ = sum_order_ == 1 ? tree_dot(n, d_.data(), d_.data()) : ddot(n, d_.data(), d_.data());
     dnorm_ = std::sqrt(dtd_);
     stpmx_ = big;
     if (cnstnd_) {
@@ -899,7 +971,7 @@ void Lbfgsb::lnsrlb(double* x, double f, const double* g) {
     iback_ = 0;
     ls_ = Dcsrch();
   }
-  gd_ = ddot(n, g, d_.data());
+  gd_ = sum_order_ == 1 ? tree_dot(n, g, d_.data()) : ddot(n, g, d_.data());
   if (ifun_ == 0) {
     gdold_ = gd_;
     if (gd_ >= 0.0) { info_ = -4; return; }     // ascent direction: line search impossible
@@ -945,7 +1017,8 @@ void Lbfgsb::matupd(double rr, double dr) {
   {
     // SY(col-1, j) = d . WY(:, j), SS(j, col-1) = WS(:, j) . d for the older columns j: one pass over the mirror
     double acc[2 * LBFGSB_MAXM] = {0.0};
-    vec_kernels().accum(wr_.data(), rs_, mp_, nullptr, d_.data(), n, acc);
+    if (sum_order_ == 1) tree_accum(wr_.data(), rs_, mp_, d_.data(), n, acc);
+    else vec_kernels().accum(wr_.data(), rs_, mp_, nullptr, d_.data(), n, acc);
     int pointr = head_;
     for (int j = 0; j < col - 1; ++j) { SY(col - 1, j) = acc[pointr]; SS(j, col - 1) = acc[mp_ + pointr]; pointr = nxt(pointr, m); }
 #ifdef LBFGSB_CHECK
@@ -1013,7 +1086,7 @@ int Lbfgsb::step(double* x, double* fp, double* g) {
       return task_;
     }
     for (int i = 0; i < n; ++i) r_[i] = g[i] - r_[i];
-    const double rr = ddot(n, r_.data(), r_.data());
+    const double rr = sum_order_ == 1 ? tree_dot(n, r_.data(), r_.data()) : ddot(n, r_.data(), r_.data());
     double dr, ddum2;
     if (stp_ == 1.0) { dr = gd_ - gdold_; ddum2 = -gdold_; }
     else {

@@ -26,6 +26,9 @@ enum {
 
 // 0: scalar O(m n) loops, 1: the default (AVX2 where available); same iterates either way.  Returns the previous setting.
 int lbfgsb_set_vector_kernels(int enabled);
+// Summation order of the sums over the variables for optimisers initialised from now on: 0 the published order (scipy's iterates),
+// 1 the 64-lane tree order the device-resident optimiser steps in (see lbfgsb.cpp).  Returns the previous default.
+int lbfgsb_set_default_sum_order(int order);
 
 class Lbfgsb {
  public:
@@ -41,10 +44,13 @@ class Lbfgsb {
     return 2;
   }
   int iterations() const { return iter_; }
+  void set_sum_order(int order) { sum_order_ = order ? 1 : 0; }      // (after init, before the first step)
+  int sum_order() const { return sum_order_; }
 
  private:
   // problem
   int n_ = 0, m_ = 0, maxls_ = 20;
+  int sum_order_ = 0;        // 0: the published order, 1: the 64-lane tree order (the device optimiser's twin)
   double factr_ = 1e7, pgtol_ = 1e-5;
   std::vector<double> l_, u_;
   std::vector<int> nbd_;

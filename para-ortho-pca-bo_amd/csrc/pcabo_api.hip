@@ -2058,6 +2058,7 @@ static int batch_optimize_device(pcabo_batch* batch, const double* ics, int num_
     for (int gi = 0; gi < ngroups; ++gi) {
       const int q0 = gi * batch_limit, nq = std::min(batch_limit, num_restarts - q0);
       groups[b][gi].init(ics + (size_t)b * num_restarts * MD, bounds + (size_t)b * 2 * MD, q0, nq, batch->ctx[b]->k, maxiter);
+      groups[b][gi].opt.set_sum_order(1);              // the device steps in the 64-lane tree order (lbfgsb.cpp): so does its twin
     }
   }
   struct Pending { int b, gi; };

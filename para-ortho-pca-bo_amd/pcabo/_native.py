@@ -48,7 +48,7 @@ EXPORTS = [
     "pcabo_gp_condition_end", "pcabo_gp_condition_end_eval", "pcabo_wpca_gp_condition_begin", "pcabo_wpca_results",
     "pcabo_acq_bounds",
     "pcabo_acq_eval", "pcabo_logei", "pcabo_optimize_acqf", "pcabo_inverse_map", "pcabo_get_gp_state",
-    "pcabo_get_gram", "pcabo_lbfgsb_minimize", "pcabo_lbfgsb_set_vector_kernels", "pcabo_sobol_scramble", "pcabo_sobol_draw", "pcabo_set_profiling",
+    "pcabo_get_gram", "pcabo_lbfgsb_minimize", "pcabo_lbfgsb_set_vector_kernels", "pcabo_lbfgsb_set_sum_order", "pcabo_sobol_scramble", "pcabo_sobol_draw", "pcabo_set_profiling",
     "pcabo_get_profile", "pcabo_get_profile_calibration", "pcabo_reset_profile",
     "pcabo_batch_create", "pcabo_batch_destroy", "pcabo_batch_last_error", "pcabo_batch_ctx",
     "pcabo_batch_wpca_gp_condition_begin", "pcabo_batch_wpca_results", "pcabo_batch_acq_bounds",
@@ -755,6 +755,11 @@ class Comm:
 def lbfgsb_set_vector_kernels(enabled: bool) -> bool:
     """Host L-BFGS-B: AVX2 (default) or scalar O(m n) loops - same iterates; returns the previous setting (tests)."""
     return bool(LIB.pcabo_lbfgsb_set_vector_kernels(int(bool(enabled))))
+
+
+def lbfgsb_set_sum_order(order: int) -> int:
+    """0: the published summation order (scipy's iterates), 1: the device optimiser's 64-lane tree order.  Returns the previous one."""
+    return int(LIB.pcabo_lbfgsb_set_sum_order(int(order)))
 
 
 def lbfgsb_minimize(fun, x0, bounds, m=10, factr=1e7, pgtol=1e-5, maxiter=15000, maxfun=15000, maxls=20):

@@ -233,3 +233,78 @@ def test_device_stepping_with_probability_of_improvement(native):
         assert np.array_equal(np.vstack(dev.x_evals[b]), np.vstack(twin.x_evals[b])), b
         assert np.array_equal(np.array(dev.f_evals[b]), np.array(twin.f_evals[b])), b
         assert len(dev.f_evals[b]) == budget
+
+
+def test_auto_mode_is_one_trajectory_per_seed_on_any_number_of_ranks(native, tmp_path, monkeypatch):
+    """ExperimentRunner(batch_acq_kernel="auto") end to end on a d = 20 cell with 30 runs (ADVICE):
+    `auto` resolves to the device-resident optimiser from the EXPERIMENT's description, so
+      * the files equal those of an explicit "device" experiment byte for byte,
+      * the same experiment cut into the shares of two ranks (each share 15 runs - below the 30 that `auto` looks for, had it
+        looked at the share) writes the same rows per run, and
+      * the mode is written into the experiment attributes of every file."""
+    import os
+    from Algorithms import ExperimentRunner
+    from pcabo import iohlog
+    common = dict(algorithms=["pca"], dimensions=[20], problem_ids=[15], num_runs=30, budget_factor=4, doe_factor=3.0,
+                  experiment_name="experiment", progress=False, batched=30, side_by_side=2)
+    rel = os.path.join("data_f15_RastriginRotated", "IOHprofiler_f15_DIM20.dat")
+
+    def blocks(folder):
+        return iohlog.read_dat(os.path.join(folder, rel))
+
+    for var in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(var, raising=False)
+    er = ExperimentRunner(root_dir=str(tmp_path / "auto"), batch_acq_kernel="auto", **common)
+    assert er.arithmetic_modes == {20: "device"}
+    er.run_experiment()
+    assert len(er.results) == 30 and not er.failed_runs
+    er_dev = ExperimentRunner(root_dir=str(tmp_path / "device"), batch_acq_kernel="device", **common)
+    er_dev.run_experiment()
+    a = open(os.path.join(str(tmp_path / "auto"), "pca-experiment", rel)).read()
+    assert a == open(os.path.join(str(tmp_path / "device"), "pca-experiment", rel)).read()
+    js = open(os.path.join(str(tmp_path / "auto"), "pca-experiment", "IOHprofiler_f15_RastriginRotated.json")).read()
+    assert '"arithmetic_mode": "d20=device"' in js
+    # the phase timers are shares of the run's time (ADVICE: they used to sum to a multiple of it in interleaved mode)
+    for r in er.results:
+        assert r["pca"] + r["optimize_acqf"] + r["SingleTaskGP"] <= r["time"] * (1 + 1e-9)
+    whole = {tuple(b[0, 3:]): b for b in blocks(os.path.join(str(tmp_path / "auto"), "pca-experiment"))}     # keyed by the first DoE point
+    assert len(whole) == 30
+    seen = 0
+    for rank in range(2):
+        monkeypatch.setenv("RANK", str(rank)); monkeypatch.setenv("LOCAL_RANK", "0"); monkeypatch.setenv("WORLD_SIZE", "2")
+        part = ExperimentRunner(root_dir=str(tmp_path / "ranks"), batch_acq_kernel="auto", **common)
+        assert part.arithmetic_modes == {20: "device"} and len(part._my_runs()) == 15
+        part.run_experiment()
+        for b in blocks(os.path.join(str(tmp_path / "ranks"), f"pca-experiment-rank{rank}")):
+            assert np.array_equal(b, whole[tuple(b[0, 3:])])
+            seen += 1
+    assert seen == 30
+
+
+def test_device_option_switched_on_after_a_conditioning(native):
+    """PCABO_OPT_DEVICE_LBFGSB switched on AFTER a conditioning - the transposed root inverse does not exist
+    yet (the Gram buffer holds K); the next evaluation must build it instead of reading whatever is there.  Same bits as a batch
+    that had the option from the start; and the evaluation refuses to run between the halves of another call."""
+    from pcabo import _native as N
+    rng = np.random.default_rng(11)
+    B, n, d, q = 2, 150, 12, 64
+    X = rng.uniform(-5, 5, (B, n, d))
+    y = (X ** 2).sum(axis=2) + rng.normal(size=(B, n))
+    ranks = np.argsort(np.argsort(y, axis=1), axis=1) + 1
+    noise = rng.normal(0, 1e-8, (B, n, d))
+    out = []
+    for late in (False, True):
+        bt = N.Batch(B, max_n=n, max_d=d, max_q=q, device_lbfgsb=0 if late else 1)
+        bt.wpca_gp_condition_begin(X, ranks, noise, y)
+        res = bt.wpca_results()
+        boxes = bt.acq_bounds()
+        raw = [boxes[b][0] + (boxes[b][1] - boxes[b][0]) * np.random.default_rng(5 + b).uniform(size=(q, res[b]["k"])) for b in range(B)]
+        best = [float(y[b].min()) for b in range(B)]
+        bt.gp_wait_eval(raw, best)
+        if late:
+            bt._chk(N.LIB.pcabo_batch_set_option(bt._h, N.OPT_DEVICE_LBFGSB, 1))
+            bt.device_lbfgsb = 1
+        out.append(bt.device_acq_eval([r[:10] for r in raw], best))
+    for b in range(B):
+        assert np.array_equal(out[0][0][b], out[1][0][b]) and np.array_equal(out[0][1][b], out[1][1][b])
+        assert np.isfinite(out[0][0][b]).all()

@@ -43,8 +43,9 @@ double fg_objective(const double* x, double* g, void* user) {
 
 void test_minimize() {
   for (int nvar : {1, 2, 7, 33, 64, 65, 200}) {
-    for (int vec = 0; vec < 2; ++vec) {
-      pcabo_lbfgsb_set_vector_kernels(vec);
+    for (int variant = 0; variant < 3; ++variant) {       // scalar loops, vector kernels, the device optimiser's tree order
+      pcabo_lbfgsb_set_vector_kernels(variant == 1);
+      pcabo_lbfgsb_set_sum_order(variant == 2);
       Lcg r(17 + nvar);
       Objective o; o.c.resize(nvar);
       std::vector<double> x(nvar), lo(nvar), hi(nvar);
@@ -57,6 +58,7 @@ void test_minimize() {
     }
   }
   pcabo_lbfgsb_set_vector_kernels(1);
+  pcabo_lbfgsb_set_sum_order(0);
   // unbounded and half-bounded sides, a history longer than the default
   {
     const int nvar = 12;
@@ -135,7 +137,10 @@ void test_gang_pool(int workers, int runs) {
     for (auto& v : ics) v = 4.0 * r.uni() - 2.0;
     for (int c = 0; c < k; ++c) { bounds[c] = -1.25; bounds[k + c] = 1.5; }
     groups[b].resize(ngroups);
-    for (int gi = 0; gi < ngroups; ++gi) groups[b][gi].init(ics.data(), bounds.data(), gi * nq, nq, k, 200);
+    for (int gi = 0; gi < ngroups; ++gi) {
+      groups[b][gi].init(ics.data(), bounds.data(), gi * nq, nq, k, 200);
+      groups[b][gi].opt.set_sum_order(b & 1);          // every second run steps in the device optimiser's order (the twin's setting)
+    }
     hXq[b].assign((size_t)restarts * k, 0.0); hVal[b].assign(restarts, 0.0); hGrad[b].assign((size_t)restarts * k, 0.0);
   }
   GangPool pool;

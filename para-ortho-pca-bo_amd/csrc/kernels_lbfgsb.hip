@@ -47,12 +47,12 @@
 // In-kernel clocks of the timing build (make timing; tools/gpu_device_lbfgsb_phases.py): ticks (100 MHz) and calls per phase,
 // accumulated by work-group 0 (its thread 0 / lane 0 of wave 0)
 #ifdef PCABO_ACQ_TIMING
-__device__ unsigned long long g_lb_ticks[32], g_lb_calls[32];
-extern "C" int pcabo_debug_lb_ticks(unsigned long long* ticks32, unsigned long long* calls32, int reset) {
-  if (hipMemcpyFromSymbol(ticks32, HIP_SYMBOL(g_lb_ticks), sizeof(g_lb_ticks)) != hipSuccess) return -3;
-  if (hipMemcpyFromSymbol(calls32, HIP_SYMBOL(g_lb_calls), sizeof(g_lb_calls)) != hipSuccess) return -3;
+__device__ unsigned long long g_lb_ticks[64], g_lb_calls[64];
+extern "C" int pcabo_debug_lb_ticks(unsigned long long* ticks64, unsigned long long* calls64, int reset) {
+  if (hipMemcpyFromSymbol(ticks64, HIP_SYMBOL(g_lb_ticks), sizeof(g_lb_ticks)) != hipSuccess) return -3;
+  if (hipMemcpyFromSymbol(calls64, HIP_SYMBOL(g_lb_calls), sizeof(g_lb_calls)) != hipSuccess) return -3;
   if (reset) {
-    unsigned long long z[32] = {0};
+    unsigned long long z[64] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_lb_ticks), z, sizeof(z)) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(g_lb_calls), z, sizeof(z)) != hipSuccess) return -3;
   }
   return 0;
@@ -267,33 +267,32 @@ __device__ inline void lb_accum(const LbLds L, const ldsd* coefA, const ldsd* co
   LSYNC();
 }
 
-// LINPACK dpofa on an LDS matrix (upper factor, column-major, leading dimension lda), a column per lane: at step k every lane
-// j > k forms  t = (a[k][j] - sum_{i<k} a[i][k] a[i][j]) / a[k][k]  (the host's order), the pivot column is broadcast.
-// Returns 0 or 1 + the index of the failing pivot.
+// LINPACK dpofa on an LDS matrix (upper factor, column-major, leading dimension lda), a column per lane, RIGHT-LOOKING: at step k
+// every lane j > k forms  t = (a[k][j] - dot_k) / a[k][k]  where dot_k = sum_{i<k} a[i][k] a[i][j] has been accumulated as the
+// rows i became final (ascending i, products rounded, then added from 0.0: the host's ddot, term for term) - so a step's chain
+// is pivot -> square root -> divide, and the products for the later pivots issue beside the next step's square root.  Straight-line:
+// steps beyond nn run on a unit pivot and zeros, a failed pivot goes on in NaNs (the caller resets the memory and reads nothing
+// of the matrix).  Returns 0 or 1 + the index of the failing pivot.
 __device__ inline int lb_dpofa(ldsd* A, int lda, int nn, int lane) {
   const int j = lane < LB_M ? lane : LB_M - 1;
-  double a[LB_M];
+  double a[LB_M], dot[LB_M];
 #pragma unroll
-  for (int i = 0; i < LB_M; ++i) a[i] = (i <= j && j < nn) ? A[j * lda + i] : 0.0;
+  for (int i = 0; i < LB_M; ++i) { a[i] = (i <= j && j < nn) ? A[j * lda + i] : 0.0; dot[i] = 0.0; }
   double s = 0.0;
   int info = 0;
 #pragma unroll
   for (int k = 0; k < LB_M; ++k) {
-    if (k < nn && info == 0) {
-      const double dk = bcast(a[k] - s, k);
-      if (dk <= 0.0) { info = k + 1; }
-      else {
-        const double akk = sqrt(dk);
-        double dot = 0.0;
+    const double dk0 = bcast(a[k] - s, k);
+    const bool live = k < nn;
+    if (live && info == 0 && dk0 <= 0.0) info = k + 1;
+    const double akk = sqrt(live ? dk0 : 1.0);
+    const double t = (a[k] - dot[k]) / akk;
+    if (lane == k) a[k] = akk;
+    else if (lane > k) { a[k] = t; s += t * t; }
 #pragma unroll
-        for (int i = 0; i < k; ++i) dot += bcast(a[i], k) * a[i];
-        const double t = (a[k] - dot) / akk;
-        if (lane == k) a[k] = akk;
-        else if (lane > k) { a[k] = t; s += t * t; }
-      }
-    }
+    for (int m = k + 1; m < LB_M; ++m) dot[m] += bcast(a[k], m) * a[k];
   }
-  if (lane < nn) {
+  if (info == 0 && lane < nn) {
 #pragma unroll
     for (int i = 0; i < LB_M; ++i) if (i <= lane) A[lane * lda + i] = a[i];
   }
@@ -307,17 +306,18 @@ __device__ inline int lb_trsl_zero_diag(double tdiag, int nn, int lane) {
 }
 
 // LINPACK dtrsl with an upper-triangular T of order nn <= NN held in registers - lane l: tc[j] = T(j, l) (its column),
-// tr[j] = T(l, j) (its row), td = T(l, l) - and ONE right-hand side spread over the lanes (lane l holds b[l]).
-// job 11: T' x = b, job 1: T x = b; the host's operation order.  Returns the solution in the same lanes.
+// tr[j] = T(l, j) (its row), rd = 1 / T(l, l) (the reciprocal of its pivot: lbfgsb.cpp dtrsl_recip - the pivots' reciprocals are
+// formed side by side and multiplied in, the solve's chain holds no division) - and ONE right-hand side spread over the lanes
+// (lane l holds b[l]).  job 11: T' x = b, job 1: T x = b; the twin's operation order.  Returns the solution in the same lanes.
 template <int NN>
-__device__ inline double lb_dtrsl_regs(const double (&tc)[NN], const double (&tr)[NN], double td, int nn, double b, int job, int lane) {
+__device__ inline double lb_dtrsl_regs(const double (&tc)[NN], const double (&tr)[NN], double rd, int nn, double b, int job, int lane) {
   if (job == 11) {
     double s = 0.0;
 #pragma unroll
     for (int j = 0; j < NN; ++j) {
       if (j < nn) {
-        const double tjj = bcast(td, j);
-        const double cand = (j == 0) ? b / tjj : (b - s) / tjj;       // (b[0] / t[0]: no subtraction on the host)
+        const double rjj = bcast(rd, j);
+        const double cand = (j == 0) ? b * rjj : (b - s) * rjj;       // (b[0] r[0]: no subtraction on the host)
         const double xj = bcast(cand, j);
         if (lane == j) b = xj;
         if (lane > j && lane < nn) s += tc[j] * xj;
@@ -325,9 +325,9 @@ __device__ inline double lb_dtrsl_regs(const double (&tc)[NN], const double (&tr
     }
     return b;
   }
-  // job 1: b[nn-1] /= T(nn-1, nn-1); for j = nn-2 .. 0: b[0..j] += -b[j+1] T(0..j, j+1); b[j] /= T(j, j)
+  // job 1: b[nn-1] *= r[nn-1]; for j = nn-2 .. 0: b[0..j] += -b[j+1] T(0..j, j+1); b[j] *= r[j]
   {
-    const double last = bcast(b, nn - 1) / bcast(td, nn - 1);
+    const double last = bcast(b, nn - 1) * bcast(rd, nn - 1);
     if (lane == nn - 1) b = last;
   }
 #pragma unroll
@@ -335,7 +335,7 @@ __device__ inline double lb_dtrsl_regs(const double (&tc)[NN], const double (&tr
     if (j <= nn - 2) {
       const double temp = -bcast(b, j + 1);
       if (lane <= j) b += temp * tr[j + 1];
-      const double q = bcast(b, j) / bcast(td, j);
+      const double q = bcast(b, j) * bcast(rd, j);
       if (lane == j) b = q;
     }
   }
@@ -354,29 +354,30 @@ __device__ __noinline__ int lb_bmv(const LbLds L, const ldsd* v, ldsd* p, int la
   for (int k = 0; k < LB_M; ++k) { syr[k] = SY_(i, k); syc[k] = SY_(k, i); tc[k] = WT_(k, i); tr[k] = WT_(i, k); }
   const double sydiag = SY_(i, i), tdiag = WT_(i, i);
   const double vin1 = v[ic], vin2 = v[col + ic];
-  // p2[i] = v[col + i] + sum_{k < i} SY(i, k) v[k] / SY(k, k)
+  // the lane's reciprocals (lbfgsb.cpp bmv, tree / wave order): rs = 1 / SY(i, i), rq = 1 / sqrt(SY(i, i)), rt = 1 / T(i, i)
+  const double rs = 1.0 / sydiag, rq = 1.0 / sqrt(sydiag), rt = 1.0 / tdiag;
+  // p2[i] = v[col + i] + sum_{k < i} SY(i, k) v[k] rs[k]
   double sum = 0.0;
 #pragma unroll
   for (int k = 0; k < LB_M - 1; ++k) {
     if (k + 1 < col) {
-      const double vk = bcast(vin1, k), skk = bcast(sydiag, k);
-      if (i > k && i < col) sum += syr[k] * vk / skk;
+      const double vk = bcast(vin1, k), rk = bcast(rs, k);
+      if (i > k && i < col) sum += syr[k] * vk * rk;
     }
   }
   double p2 = (i == 0) ? vin2 : vin2 + sum;
   const int info = lb_trsl_zero_diag(tdiag, col, lane);
   if (info != 0) return info;
-  p2 = lb_dtrsl_regs<LB_M>(tc, tr, tdiag, col, p2, 11, lane);
-  const double sq = sqrt(sydiag);
-  double p1 = vin1 / sq;
-  p2 = lb_dtrsl_regs<LB_M>(tc, tr, tdiag, col, p2, 1, lane);
-  p1 = -p1 / sq;
+  p2 = lb_dtrsl_regs<LB_M>(tc, tr, rt, col, p2, 11, lane);
+  double p1 = vin1 * rq;
+  p2 = lb_dtrsl_regs<LB_M>(tc, tr, rt, col, p2, 1, lane);
+  p1 = -p1 * rq;
   double s2 = 0.0;
 #pragma unroll
   for (int k = 1; k < LB_M; ++k) {
     if (k < col) {
       const double pk = bcast(p2, k);
-      if (i < k) s2 += syc[k] * pk / sydiag;
+      if (i < k) s2 += syc[k] * pk * rs;
     }
   }
   p1 += s2;
@@ -397,15 +398,42 @@ __device__ __noinline__ double lb_subsm_solves(const LbLds L, double b, int* inf
   const double td = WN_(l, l);
   *info = lb_trsl_zero_diag(td, col2, lane);
   if (*info != 0) return b;
-  b = lb_dtrsl_regs<2 * LB_M>(tc, tr, td, col2, b, 11, lane);
+  const double rd = 1.0 / td;
+  b = lb_dtrsl_regs<2 * LB_M>(tc, tr, rd, col2, b, 11, lane);
   if (lane < col) b = -b;
-  b = lb_dtrsl_regs<2 * LB_M>(tc, tr, td, col2, b, 1, lane);
+  b = lb_dtrsl_regs<2 * LB_M>(tc, tr, rd, col2, b, 1, lane);
   return b;
 }
 
-__device__ inline double wave_max(double v) {
-  for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
-  return v;
+// DPP reductions whose excluded lanes read `old` (the operation's neutral element: the lane's own value)
+template <int CTRL, int ROW_MASK>
+__device__ inline double dpp_get_or(double v, double old) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROW_MASK>
+__device__ inline int dpp_geti_or(int v, int old) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, false); }
+#define LB_DPP_REDUCE(T, GET, v, OP)                                                                       \
+  do {                                                                                                      \
+    T o_;                                                                                                   \
+    o_ = GET<0xB1, 0xf>(v, v); v = OP(o_, v); o_ = GET<0x4E, 0xf>(v, v); v = OP(o_, v);                     \
+    o_ = GET<0x141, 0xf>(v, v); v = OP(o_, v); o_ = GET<0x140, 0xf>(v, v); v = OP(o_, v);                   \
+    o_ = GET<0x142, 0xa>(v, v); v = OP(o_, v); o_ = GET<0x143, 0xc>(v, v); v = OP(o_, v);                   \
+  } while (0)
+#define LB_MAXOP(o, v) ((o) > (v) ? (o) : (v))
+#define LB_MINOP(o, v) ((o) < (v) ? (o) : (v))
+__device__ inline double wave_max(double v) {          // uniform (the comparisons of the shuffle form it replaces; no LDS traffic)
+  LB_DPP_REDUCE(double, dpp_get_or, v, LB_MAXOP);
+  return bcast(v, 63);
+}
+__device__ inline double wave_min(double v) {
+  LB_DPP_REDUCE(double, dpp_get_or, v, LB_MINOP);
+  return bcast(v, 63);
+}
+__device__ inline int wave_min_i(int v) {
+  LB_DPP_REDUCE(int, dpp_geti_or, v, LB_MINOP);
+  return __builtin_amdgcn_readlane(v, 63);
 }
 
 __device__ inline void lb_projgr(const LbLds L, int lane) {
@@ -465,6 +493,7 @@ __device__ __noinline__ void lb_cauchy(const LbLds L, int lane) {
   ldsd* t = L.t(); ldsd* d = L.d(); ldsd* xcp = L.z();
   ldsi* iorder = L.indx2();
   if (SR(S_SBGNRM) <= 0.0) { for (int i = lane; i < n; i += 64) xcp[i] = L.x()[i]; LSYNC(); return; }
+  LBT_BEGIN();
   int nbreak = 0;
   for (int base = 0; base < n; base += 64) {
     const int i = base + lane;
@@ -491,6 +520,7 @@ __device__ __noinline__ void lb_cauchy(const LbLds L, int lane) {
     nbreak += __popcll(mb);
   }
   LSYNC();
+  LBT_NEXT(32);
   double f1 = -wave_tsum(L.prod(), n, lane);       // f1 = -(sum of neggi^2 over the moving variables; the others add 0.0), tree order
   if (col > 0) {
     lb_accum<false>(L, d, nullptr, lane, L.acc(), L.tile(0));   // d[i] = -g[i] for the moving variables, 0.0 for the others
@@ -503,11 +533,13 @@ __device__ __noinline__ void lb_cauchy(const LbLds L, int lane) {
   for (int i = lane; i < n; i += 64) xcp[i] = L.x()[i];
   if (lane < col2) c[lane] = 0.0;
   LSYNC();
+  LBT_NEXT(33);
   if (nbreak == 0) return;                        // (with both bounds everywhere nfree stays n)
   double f2 = -theta * f1;
   const double f2_org = f2;
   if (col > 0) {
     lb_await_formt(L, lane);                        // T comes from the helper wave (lb_step)
+    LBT_NEXT(34);
     if (ISR(I_INFO) != 0) return;                   // formt failed: the caller resets the memory and starts the iteration again
     const int info = lb_bmv(L, p, v, lane);
     if (info != 0) { sti0(&ISC(I_INFO), info, lane); LSYNC(); return; }
@@ -516,24 +548,25 @@ __device__ __noinline__ void lb_cauchy(const LbLds L, int lane) {
   double dtm = -f1 / f2;
   double tsum = 0.0;
   bool skip_to_999 = false;
+  LBT_NEXT(35);
   {
     int nleft = nbreak;
     double tj = 0.0;
     int ties = 0;
+    int nleft_dbg = nbreak; (void)nleft_dbg;
     while (true) {
       const double tj0 = tj;
       // smallest remaining breakpoint.  The host pops a heap; the order of DISTINCT values does not depend on the heap's shape -
       // two bit-equal breakpoints do (counted in I_TIES; the position of the first one in the array decides here)
       double bv = INFINITY; int bp = 0x7fffffff;
-      for (int e = lane; e < nleft; e += 64) { const double tv = t[e]; if (tv < bv) { bv = tv; bp = e; } }
-      for (int off = 32; off > 0; off >>= 1) {
-        const double ov = __shfl_xor(bv, off, 64); const int op = __shfl_xor(bp, off, 64);
-        if (ov < bv || (ov == bv && op < bp)) { bv = ov; bp = op; }
-      }
+      int mine = 0;                                // the lane's elements that equal its minimum
+      for (int e = lane; e < nleft; e += 64) { const double tv = t[e]; if (tv < bv) { bv = tv; bp = e; mine = 1; } else if (tv == bv) ++mine; }
+      const double gmin = wave_min(bv);
+      const bool at = bv == gmin;
+      bp = wave_min_i(at ? bp : 0x7fffffff);
       if (bp == 0x7fffffff) bp = 0;               // (all NaN cannot happen; keep the index in range)
-      { int cnt = 0; for (int e = lane; e < nleft; e += 64) cnt += (t[e] == bv) ? 1 : 0;
-        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
-        if (cnt > 1) ++ties; }
+      { const unsigned long long ma = __ballot(at && nleft > 0);
+        if (__popcll(ma) > 1 || __ballot(at && mine > 1)) ++ties; }
       tj = t[bp];
       const int ibp = iorder[bp];
       LSYNC();
@@ -542,7 +575,7 @@ __device__ __noinline__ void lb_cauchy(const LbLds L, int lane) {
       const double dt = tj - tj0;
       if (dtm < dt) break;
       tsum += dt;
-      --nleft;
+      --nleft; nleft_dbg = nleft;
 
       const double dibp = d[ibp];
       double zibp;
@@ -581,7 +614,11 @@ __device__ __noinline__ void lb_cauchy(const LbLds L, int lane) {
       break;
     }
     if (ties && lane == 0) ISC(I_TIES) += ties;
+#ifdef PCABO_ACQ_TIMING
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_lb_calls[40] += nbreak - nleft_dbg;       // breakpoints crossed
+#endif
   }
+  LBT_NEXT(36);
   if (!skip_to_999) {
     if (dtm <= 0.0) dtm = 0.0;
     tsum += dtm;
@@ -740,16 +777,18 @@ __device__ __noinline__ void lb_formk(const LbLds L, int lane) {
     double b[LB_M];
 #pragma unroll
     for (int i = 0; i < LB_M; ++i) b[i] = i < col ? WN_(i, js) : 0.0;
+    const double rl = 1.0 / WN_(lane < col ? lane : 0, lane < col ? lane : 0);      // the pivots' reciprocals, one per lane (dtrsl_recip)
 #pragma unroll
     for (int j = 0; j < LB_M; ++j) {
       if (j < col) {
-        if (j == 0) b[0] = b[0] / WN_(0, 0);
+        const double rj = bcast(rl, j);
+        if (j == 0) b[0] = b[0] * rj;
         else {
           double s = 0.0;
 #pragma unroll
           for (int i = 0; i < j; ++i) s += WN_(i, j) * b[i];
           b[j] = b[j] - s;
-          b[j] = b[j] / WN_(j, j);
+          b[j] = b[j] * rj;
         }
       }
     }
@@ -842,6 +881,7 @@ __device__ __noinline__ void lb_subsm(const LbLds L, int lane) {
   LBT_NEXT(29);
   if (lane < col2) wv[lane] = b;
   LSYNC();
+  const double inv_theta = 1.0 / theta;
   {
     constexpr int NU = (LB_NVCAP + 63) / 64;
     double f[NU];
@@ -853,7 +893,7 @@ __device__ __noinline__ void lb_subsm(const LbLds L, int lane) {
       if (jy < col) {
         const double a1 = wv[jy], a2 = wv[col + jy];
 #pragma unroll
-        for (int u = 0; u < NU; ++u) { const int k = lane + 64 * u; if (k < n) f[u] = f[u] + WY_(k, pointr) * a1 / theta + WS_(k, pointr) * a2; }
+        for (int u = 0; u < NU; ++u) { const int k = lane + 64 * u; if (k < n) f[u] = f[u] + WY_(k, pointr) * a1 * inv_theta + WS_(k, pointr) * a2; }
         pointr = nxt(pointr);
       }
     }
@@ -862,7 +902,6 @@ __device__ __noinline__ void lb_subsm(const LbLds L, int lane) {
   }
   LSYNC();
   LBT_NEXT(30);
-  const double inv_theta = 1.0 / theta;
   for (int i = lane; i < nsub; i += 64) d[i] = L.full()[ind[i]] * inv_theta;
   for (int i = lane; i < n; i += 64) L.xp()[i] = x[i];
   LSYNC();
@@ -1061,6 +1100,7 @@ __device__ __noinline__ void lb_lnsrlb(const LbLds L, int lane) {
   LsState ls;
   double stp, stpmx;
   const bool first_call = ISR(I_PHASE) != 2;
+  LBT_BEGIN();
   if (first_call) {
     // d'd is not needed before the next matupd: the helper wave forms it (its own product buffer) while this wave goes on
     lb_help_post(L, LB_OP_DTD, lane);
@@ -1102,7 +1142,9 @@ __device__ __noinline__ void lb_lnsrlb(const LbLds L, int lane) {
     ls_load(L, ls);
     stp = SR(S_STP); stpmx = SR(S_STPMX);
   }
+  LBT_NEXT(37);
   const double gd = wave_ddot(L.g(), L.d(), n, lane);
+  LBT_NEXT(38);
   if (first_call) lb_help_wait(L, lane);              // (the helper's chain ran beside this one)
   int ifun = ISR(I_IFUN);
   LSYNC();
@@ -1122,6 +1164,7 @@ __device__ __noinline__ void lb_lnsrlb(const LbLds L, int lane) {
     if (lane == 0) ISC(I_TASK) = LBFGSB_NEW_X;
   }
   LSYNC();
+  LBT_NEXT(39);
 }
 
 // lbfgsb.cpp: matupd, in two parts.  Part A (wave 0): the new columns of WS / WY, theta and the ring's pointers - what the Cauchy
@@ -1177,6 +1220,9 @@ __device__ __noinline__ void lb_matupd_b(const LbLds L, int lane) {
 __device__ __noinline__ void lb_formt(const LbLds L, int lane) {
   const int col = ISR(I_COL);
   const double theta = SR(S_THETA);
+  ldsd* rs = L.acc2() + 40;                            // 1 / SY(k, k), formed side by side (lbfgsb.cpp formt, tree / wave order)
+  if (lane < col) rs[lane] = 1.0 / SY_(lane, lane);
+  LSYNC();
   for (int e = lane; e < col * (col + 1) / 2; e += 64) {
     int j = 0, ee = e;
     while (ee > j) { ee -= j + 1; ++j; }
@@ -1184,7 +1230,7 @@ __device__ __noinline__ void lb_formt(const LbLds L, int lane) {
     if (i == 0) WT_(0, j) = theta * SS_(0, j);
     else {
       double ddum = 0.0;
-      for (int k = 0; k < i; ++k) ddum += SY_(i, k) * SY_(j, k) / SY_(k, k);
+      for (int k = 0; k < i; ++k) ddum += SY_(i, k) * SY_(j, k) * rs[k];
       WT_(i, j) = ddum + theta * SS_(i, j);
     }
   }

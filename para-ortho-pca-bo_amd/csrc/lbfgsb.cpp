@@ -211,6 +211,33 @@ int dtrsl(const double* t, int ldt, int nn, double* b, int job) {
   return 0;
 }
 
+// dtrsl with the pivots' reciprocals formed first (r_j = 1 / t_jj, one division each) and multiplied in: the form of the tree /
+// wave order (set_sum_order(1)) - on a wavefront the pivots' reciprocals are formed side by side, and the solve's chain of nn
+// dependent divisions becomes a chain of multiplications.  One more rounding per pivot than the published division.
+int dtrsl_recip(const double* t, int ldt, int nn, double* b, int job) {
+  double r[2 * LBFGSB_MAXM];
+  for (int i = 0; i < nn; ++i) {
+    if (t[(size_t)i * ldt + i] == 0.0) return i + 1;
+    r[i] = 1.0 / t[(size_t)i * ldt + i];
+  }
+  if (job == 1) {
+    b[nn - 1] = b[nn - 1] * r[nn - 1];
+    for (int j = nn - 2; j >= 0; --j) {
+      double temp = -b[j + 1];
+      const double* col = t + (size_t)(j + 1) * ldt;
+      for (int i = 0; i <= j; ++i) b[i] += temp * col[i];
+      b[j] = b[j] * r[j];
+    }
+  } else {
+    b[0] = b[0] * r[0];
+    for (int j = 1; j < nn; ++j) {
+      b[j] = b[j] - ddot(j, t + (size_t)j * ldt, b);
+      b[j] = b[j] * r[j];
+    }
+  }
+  return 0;
+}
+
 }  // namespace
 
 namespace { std::atomic<int> g_default_sum_order{0}; }
@@ -334,6 +361,29 @@ void Lbfgsb::hpsolb(int n, double* t, int* iorder, int iheap) {
 void Lbfgsb::bmv(const double* v, double* p) {
   const int col = col_;
   if (col == 0) return;
+  if (sum_order_ == 1) {
+    // the same products with the reciprocals rs_k = 1 / SY(k, k), rq_i = 1 / sqrt(SY(i, i)) and the pivots' reciprocals multiplied in
+    double rs[LBFGSB_MAXM], rq[LBFGSB_MAXM];
+    for (int i = 0; i < col; ++i) { rs[i] = 1.0 / SY(i, i); rq[i] = 1.0 / std::sqrt(SY(i, i)); }
+    p[col] = v[col];
+    for (int i = 1; i < col; ++i) {
+      double sum = 0.0;
+      for (int k = 0; k < i; ++k) sum += SY(i, k) * v[k] * rs[k];
+      p[col + i] = v[col + i] + sum;
+    }
+    info_ = dtrsl_recip(wt_.data(), m_, col, p + col, 11);
+    if (info_ != 0) return;
+    for (int i = 0; i < col; ++i) p[i] = v[i] * rq[i];
+    info_ = dtrsl_recip(wt_.data(), m_, col, p + col, 1);
+    if (info_ != 0) return;
+    for (int i = 0; i < col; ++i) p[i] = -p[i] * rq[i];
+    for (int i = 0; i < col; ++i) {
+      double sum = 0.0;
+      for (int k = i + 1; k < col; ++k) sum += SY(k, i) * p[col + k] * rs[i];
+      p[i] += sum;
+    }
+    return;
+  }
   p[col] = v[col];
   for (int i = 1; i < col; ++i) {
     double sum = 0.0;
@@ -670,7 +720,7 @@ void Lbfgsb::formk() {
   int info = dpofa(wn_.data(), m2, col);
   if (info != 0) { info_ = -1; return; }
   const int col2 = 2 * col;
-  for (int js = col; js < col2; ++js) dtrsl(wn_.data(), m2, col, &WN(0, js), 11);
+  for (int js = col; js < col2; ++js) (sum_order_ == 1 ? dtrsl_recip : dtrsl)(wn_.data(), m2, col, &WN(0, js), 11);
   for (int is = col; is < col2; ++is)
     for (int js = is; js < col2; ++js) WN(is, js) += ddot(col, &WN(0, is), &WN(0, js));
   info = dpofa(&WN(col, col), m2, col);
@@ -727,10 +777,10 @@ void Lbfgsb::subsm(const double* xx, const double* gg) {
 #endif
   }
   const int m2 = 2 * m, col2 = 2 * col;
-  info_ = dtrsl(wn_.data(), m2, col2, wv, 11);
+  info_ = (sum_order_ == 1 ? dtrsl_recip : dtrsl)(wn_.data(), m2, col2, wv, 11);
   if (info_ != 0) return;
   for (int i = 0; i < col; ++i) wv[i] = -wv[i];
-  info_ = dtrsl(wn_.data(), m2, col2, wv, 1);
+  info_ = (sum_order_ == 1 ? dtrsl_recip : dtrsl)(wn_.data(), m2, col2, wv, 1);
   if (info_ != 0) return;
   pointr = head_;
   {
@@ -740,6 +790,11 @@ void Lbfgsb::subsm(const double* xx, const double* gg) {
     double* full = all_free ? d : sc_full_.data();
     if (!all_free) { for (int k = 0; k < n; ++k) full[k] = 0.0; for (int i = 0; i < nsub; ++i) full[ind[i]] = d[i]; }
     for (int jy = 0; jy < col; ++jy) {
+      if (sum_order_ == 1) {                         // (out + wy a1 (1 / theta)) + ws a2: the reciprocal of theta formed once
+        const double it = 1.0 / theta_, a1 = wv[jy], a2 = wv[col + jy];
+        const double* wy = &WY(0, pointr); const double* ws = &WS(0, pointr);
+        for (int k = 0; k < n; ++k) full[k] = full[k] + wy[k] * a1 * it + ws[k] * a2;
+      } else
       vec_kernels().chain_d(full, &WY(0, pointr), &WS(0, pointr), wv[jy], wv[col + jy], theta_, n);
       pointr = nxt(pointr, m);
     }
@@ -1038,6 +1093,8 @@ void Lbfgsb::formt() {
     for (int j = i; j < col; ++j) {
       const int k1 = (i < j ? i : j);
       double ddum = 0.0;
+      if (sum_order_ == 1) for (int k = 0; k < k1; ++k) ddum += SY(i, k) * SY(j, k) * (1.0 / SY(k, k));
+      else
       for (int k = 0; k < k1; ++k) ddum += SY(i, k) * SY(j, k) / SY(k, k);
       WT(i, j) = ddum + theta_ * SS(i, j);
     }

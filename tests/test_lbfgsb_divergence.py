@@ -59,23 +59,31 @@ def _side_by_side(native, acq, bounds, ics):
             "f": (float(ref.fun), float(mine["fun"]))}
 
 
-def test_first_divergence_of_lbfgsb_cpp_and_scipy_is_rounding(native, capsys):
+@pytest.mark.parametrize("order", [0, 1])
+def test_first_divergence_of_lbfgsb_cpp_and_scipy_is_rounding(native, capsys, order):
+    """order 0: the published summation order (what the host-paced paths run); order 1: the 64-lane tree order with reciprocal
+    pivots in which the device-resident optimiser steps (pcabo_lbfgsb_set_sum_order) - the same gates for both: against scipy
+    each is a re-rounding of the same sums, nothing more."""
     torch.set_num_threads(1)
     data = np.load(GOLDEN)
     rows = []
-    for n in (int(v) for v in data["ns"]):
-        rec = _oracle_state(data, n)
-        for g in range(2):
-            r = _side_by_side(native, rec.acq, rec.acq_bounds, rec.trace.ics[5 * g:5 * g + 5])
-            r["n"], r["k"], r["group"] = n, rec.k, g
-            rows.append(r)
+    was = native.lbfgsb_set_sum_order(order)
+    try:
+        for n in (int(v) for v in data["ns"]):
+            rec = _oracle_state(data, n)
+            for g in range(2):
+                r = _side_by_side(native, rec.acq, rec.acq_bounds, rec.trace.ics[5 * g:5 * g + 5])
+                r["n"], r["k"], r["group"] = n, rec.k, g
+                rows.append(r)
+    finally:
+        native.lbfgsb_set_sum_order(was)
     for r in rows:
         d, f = r["rel"], r["first"]
         if f is not None:
             small = [i for i in range(f, len(d) - 1) if d[i] < 1e-8]
             r["max_step_factor"] = max(d[i + 1] / max(d[i], 1e-16) for i in small)
     with capsys.disabled():
-        print()
+        print("\n  summation order %d (%s)" % (order, "published" if order == 0 else "64-lane tree, reciprocal pivots: the device optimiser's"))
         for r in rows:
             d = r["rel"]
             f = r["first"]

@@ -119,3 +119,27 @@ def test_vector_kernels_take_the_scalar_iterates(native):
     vector = run_all()
     assert scalar == vector
     assert all(r[0] > 3 for r in vector)            # real optimisation runs, not immediate exits
+
+
+def test_tree_order_of_the_device_optimiser_keeps_scipys_counts(native):
+    """The summation order in which the device-resident optimiser steps (64-lane tree over the variables, reciprocal pivots in the
+    small triangular solves; Lbfgsb::set_sum_order(1), the device's bit-for-bit twin - tests/test_gpu_device_lbfgsb.py) on the same
+    35 bounded problems and the joint 5-restart acquisition problem: iteration and evaluation counts are scipy's on every one of
+    them, end points within the same tolerance (the gate for a second arithmetic order)."""
+    was = native.lbfgsb_set_sum_order(1)
+    try:
+        test_bounded_rosenbrock_same_path_as_scipy(native)
+        test_unbounded_and_half_bounded_variables(native)
+        test_joint_five_restart_acquisition_problem_same_path_as_scipy(native)
+        test_abnormal_line_search_and_memoised_repeats_like_scipy(native)
+        # and it IS another order: on a long sum-dominated problem the two orders part in the last bits
+        rng = np.random.default_rng(3)
+        n = 150
+        x0, lo, hi = rng.uniform(-2, 2, n), np.full(n, -3.0), np.full(n, 3.0)
+        tree = native.lbfgsb_minimize(rosen, x0, list(zip(lo, hi)), maxiter=60)
+        native.lbfgsb_set_sum_order(0)
+        seq = native.lbfgsb_minimize(rosen, x0, list(zip(lo, hi)), maxiter=60)
+        assert not np.array_equal(tree["x"], seq["x"])
+        assert np.abs(tree["x"] - seq["x"]).max() < 1e-3          # (60 unconverged iterations amplify the last bit: tests/test_lbfgsb_divergence.py)
+    finally:
+        native.lbfgsb_set_sum_order(was)

@@ -30,11 +30,12 @@ names = {0: "cauchy", 1: "freev", 2: "formk", 3: "cmprlb", 4: "subsm", 5: "lnsrl
          14: "eval: contraction", 16: "step (advance, all of it)", 17: "evaluation (all of it)",
          18: "formk: shift + fill", 19: "formk: accum", 20: "formk: new column", 21: "formk: corrections", 22: "formk: assemble WN",
          23: "formk: dpofa 1", 24: "formk: solves", 25: "formk: products", 26: "formk: dpofa 2",
+         32: "cauchy: classify", 33: "cauchy: f1 + accum + copy", 34: "cauchy: wait for formt", 35: "cauchy: bmv + ddot", 36: "cauchy: breakpoint loop", 37: "lnsrlb: head (stpmx scan, copies / state load)", 38: "lnsrlb: g'd", 39: "lnsrlb: dcsrch + trial point", 40: "cauchy: breakpoints crossed (count)",
          27: "subsm: scatter", 28: "subsm: accum", 29: "subsm: solves", 30: "subsm: update full", 31: "subsm: project"}
 have = hasattr(N.LIB, "pcabo_debug_lb_ticks")
 for rep in range(3):
     if have:
-        t, c = (C.c_ulonglong * 32)(), (C.c_ulonglong * 32)()
+        t, c = (C.c_ulonglong * 64)(), (C.c_ulonglong * 64)()
         N.LIB.pcabo_debug_lb_ticks(t, c, 1)
     t0 = time.perf_counter()
     o, st = bt.optimize_acqf(ics, boxes, best)

@@ -175,6 +175,13 @@ static inline size_t lb_lds_doubles(int NP) { return (size_t)OFF_KS + (size_t)2 
 #define WN1_(i, j) L.wn1()[(j) * 2 * LB_M + (i)]
 
 __device__ inline int nxt(int p) { return p + 1 == LB_M ? 0 : p + 1; }
+// e = a (a + 1) / 2 + r with r <= a, for e < 64: the pair (r <= a) of a packed triangle without a search loop.  8 e + 1 is the
+// square of 2 a + 1 at the start of a row and at least 4 / (2 a + 3) below the next odd square at its end: the margins cover
+// any rounding of the single-precision square root.
+__device__ inline void tri_decode(int e, int& a, int& r) {
+  a = (int)((sqrtf(8.0f * (float)e + 1.0f) - 0.999f) * 0.5f);
+  r = e - a * (a + 1) / 2;
+}
 __device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ inline double uni(double v) {
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
@@ -495,6 +502,7 @@ __device__ __noinline__ void lb_cauchy(const LbLds L, int lane) {
   if (SR(S_SBGNRM) <= 0.0) { for (int i = lane; i < n; i += 64) xcp[i] = L.x()[i]; LSYNC(); return; }
   LBT_BEGIN();
   int nbreak = 0;
+  double bk_lane = INFINITY;                       // the lane's smallest breakpoint (the search below starts from the wave's)
   for (int base = 0; base < n; base += 64) {
     const int i = base + lane;
     double neggi = 0.0, tl = 0.0, tu = 0.0;
@@ -516,7 +524,11 @@ __device__ __noinline__ void lb_cauchy(const LbLds L, int lane) {
     const bool brk = moving && neggi != 0.0;
     const unsigned long long mb = __ballot(brk);
     const int pb = nbreak + __popcll(mb & lanes_below(lane));
-    if (brk) { const double ahead = neggi < 0.0 ? tl : tu; iorder[pb] = i; t[pb] = ahead / fabs(neggi); }
+    if (brk) {
+      const double ahead = neggi < 0.0 ? tl : tu, tb = ahead / fabs(neggi);
+      iorder[pb] = i; t[pb] = tb;
+      bk_lane = tb < bk_lane ? tb : bk_lane;
+    }
     nbreak += __popcll(mb);
   }
   LSYNC();
@@ -549,7 +561,9 @@ __device__ __noinline__ void lb_cauchy(const LbLds L, int lane) {
   double tsum = 0.0;
   bool skip_to_999 = false;
   LBT_NEXT(35);
-  {
+  // the minimiser lies in front of the first breakpoint (the usual case late in a run): the search's first test, taken on the
+  // minimum the classification loop has kept in registers - nothing of the breakpoint set is read or reordered
+  if (!(dtm < wave_min(bk_lane))) {
     int nleft = nbreak;
     double tj = 0.0;
     int ties = 0;
@@ -684,9 +698,10 @@ __device__ __noinline__ void lb_formk(const LbLds L, int lane) {
         const int e = lane + 64 * u;
         int di = 0, dj = 0, si = 0, sj = 0;
         if (e < 2 * tri) {
-          int ee = e < tri ? e : e - tri, jy = 0, rowlen = m - 1;
-          while (ee >= rowlen) { ee -= rowlen; ++jy; --rowlen; }
-          const int tt = ee;
+          // rows of m - 1, m - 2, ... 1 elements: the packed triangle read backwards
+          int ap, rp;
+          tri_decode(tri - 1 - (e < tri ? e : e - tri), ap, rp);
+          const int jy = m - 2 - ap, tt = ap - rp;
           if (e < tri) { di = jy + tt; dj = jy; si = jy + 1 + tt; sj = jy + 1; }
           else { const int js = m + jy; di = js + tt; dj = js; si = js + 1 + tt; sj = js + 1; }
         } else if (e < tot) {
@@ -731,9 +746,9 @@ __device__ __noinline__ void lb_formk(const LbLds L, int lane) {
   {
     const int npair = upcl * (upcl + 1) / 2;
     for (int e = lane; e < npair; e += 64) {
-      int iy = 0, ee = e;
-      while (ee > iy) { ee -= iy + 1; ++iy; }
-      const int jy = ee, is = m + iy, js = m + jy;
+      int iy, jy;
+      tri_decode(e, iy, jy);
+      const int is = m + iy, js = m + jy;
       int ipntr = head + iy; if (ipntr >= m) ipntr -= m;
       int jpntr = head + jy; if (jpntr >= m) jpntr -= m;
       double temp1 = 0.0, temp2 = 0.0, temp3 = 0.0, temp4 = 0.0;
@@ -742,8 +757,9 @@ __device__ __noinline__ void lb_formk(const LbLds L, int lane) {
       WN1_(iy, jy) = WN1_(iy, jy) + temp1 - temp3;
       WN1_(is, js) = WN1_(is, js) - temp2 + temp4;
     }
-    for (int e = lane; e < upcl * upcl; e += 64) {
-      const int isr = e / upcl, jy = e % upcl, is = m + isr;
+    for (int e = lane; e < LB_M * LB_M; e += 64) {          // (a fixed 10 x 10 grid, masked: no division by a runtime number)
+      const int isr = e / LB_M, jy = e % LB_M, is = m + isr;
+      if (isr >= upcl || jy >= upcl) continue;
       int ipntr = head + isr; if (ipntr >= m) ipntr -= m;
       int jpntr = head + jy; if (jpntr >= m) jpntr -= m;
       double temp1 = 0.0, temp3 = 0.0;
@@ -756,8 +772,9 @@ __device__ __noinline__ void lb_formk(const LbLds L, int lane) {
   }
   LBT_NEXT(21);
   // upper triangle of WN
-  for (int e = lane; e < col * col; e += 64) {
-    const int iy = e / col, jy = e % col, is = col + iy, is1 = m + iy, js = col + jy, js1 = m + jy;
+  for (int e = lane; e < LB_M * LB_M; e += 64) {
+    const int iy = e / LB_M, jy = e % LB_M, is = col + iy, is1 = m + iy, js = col + jy, js1 = m + jy;
+    if (iy >= col || jy >= col) continue;
     if (jy <= iy) {
       double w = WN1_(iy, jy) / theta;
       if (jy == iy) w += SY_(iy, iy);
@@ -801,8 +818,8 @@ __device__ __noinline__ void lb_formk(const LbLds L, int lane) {
   }
   LBT_NEXT(24);
   for (int e = lane; e < col * (col + 1) / 2; e += 64) {
-    int a = 0, ee = e;
-    while (ee > a) { ee -= a + 1; ++a; }           // pair (ee <= a)
+    int a, ee;
+    tri_decode(e, a, ee);                          // pair (ee <= a)
     const int is = col + ee, js = col + a;
     double s = 0.0;
     for (int i = 0; i < col; ++i) s += WN_(i, is) * WN_(i, js);
@@ -1191,10 +1208,13 @@ __device__ __noinline__ void lb_matupd_b(const LbLds L, int lane) {
       const int e = lane + 64 * u;
       src[u] = 0.0; dst[u] = 0;
       if (e < tri) {                                   // SS(t, j) = SS(t + 1, j + 1), t <= j < col - 1
-        int ee = e, j = 0; while (ee > j) { ee -= j + 1; ++j; }
+        int ee, j;
+        tri_decode(e, j, ee);
         src[u] = SS_(ee + 1, j + 1); dst[u] = j * m + ee + 1;
-      } else if (e < 2 * tri) {                        // SY(j + t, j) = SY(j + 1 + t, j + 1), t < col - 1 - j
-        int ee = e - tri, j = 0, rowlen = col - 1; while (ee >= rowlen) { ee -= rowlen; ++j; --rowlen; }
+      } else if (e < 2 * tri) {                        // SY(j + t, j) = SY(j + 1 + t, j + 1), t < col - 1 - j: rows of col - 1 ... 1 elements
+        int ap, rp;
+        tri_decode(2 * tri - 1 - e, ap, rp);
+        const int j = col - 2 - ap, ee = ap - rp;
         src[u] = SY_(j + 1 + ee, j + 1); dst[u] = -(j * m + j + ee) - 1;
       }
     }
@@ -1224,9 +1244,8 @@ __device__ __noinline__ void lb_formt(const LbLds L, int lane) {
   if (lane < col) rs[lane] = 1.0 / SY_(lane, lane);
   LSYNC();
   for (int e = lane; e < col * (col + 1) / 2; e += 64) {
-    int j = 0, ee = e;
-    while (ee > j) { ee -= j + 1; ++j; }
-    const int i = ee;                                  // i <= j
+    int j, i;
+    tri_decode(e, j, i);                               // i <= j
     if (i == 0) WT_(0, j) = theta * SS_(0, j);
     else {
       double ddum = 0.0;

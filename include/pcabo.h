@@ -203,6 +203,15 @@ int pcabo_sobol_scramble(int64_t* state, const int64_t* ltm, int k);
  * botorch's map into the box, out[i*k + j] = lo[j] + rng[j] * u[i][j] (lo = rng = NULL: u itself).  state[k*30] after
  * pcabo_sobol_scramble, shift[k] = sum_b bit_b 2^b of the k x 30 shift bits (torch's `shift`). */
 int pcabo_sobol_draw(const int64_t* state, const int64_t* shift, int k, int n, const double* lo, const double* rng, double* out);
+/* torch's CPU generator restated for the host's pacing thread (csrc/host_entry.cpp): `blob` = the generator's state exactly as
+ * torch.Generator.get_state() exports it (5056 bytes), read and ADVANCED in place - set_state(blob) afterwards leaves torch's
+ * generator where torch's own call would have left it.
+ * pcabo_torch_randint2: torch.randint(2, (count,), generator=g) - the Sobol scramble bits of botorch's draw_sobol_samples.
+ * pcabo_torch_multinomial_rows: torch.multinomial(weights[r], n_pick, replacement=False, generator=g_r) for `rows` rows, one
+ *   generator each (blobs[r] == NULL: row skipped) - the Boltzmann pick of botorch's initialize_q_batch; out[rows][n_pick].
+ * pcabo/hostrng.py verifies both against torch at import and keeps torch's own calls if they ever differ. */
+int pcabo_torch_randint2(void* blob, int64_t count, int64_t* out);
+int pcabo_torch_multinomial_rows(void* const* blobs, const double* weights, int rows, int n, int n_pick, int64_t* out);
 
 /* Device-time accounting: accumulated HIP-event time (ms, events recorded on the context's own
  * stream), launch count and ALGORITHMIC bytes / flops of the kernel groups since the last reset.

@@ -5,6 +5,7 @@
 #include "../../include/pcabo.h"
 #include "lbfgsb.h"
 
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -104,5 +105,83 @@ int pcabo_sobol_draw(const int64_t* state, const int64_t* shift, int k, int n, c
   return PCABO_OK;
 }
 
+
+// ---- torch's CPU generator, restated (the host's pacing thread draws the reference's random numbers without torch calls) ----
+// The reference's restart heuristic draws from torch's global CPU generator: the Sobol scramble bits (torch.randint(2, ...)) and
+// botorch's initialize_q_batch -> torch.multinomial(weights, n, replacement=False) (behind PCA_BO.py:607-614).  With hundreds of
+// runs per host thread those two calls were 40 % of the thread's time.  torch's generator is a 32-bit Mersenne Twister
+// (at::mt19937: the published MT19937 with `left` / `next` bookkeeping); `blob` is its state exactly as
+// torch.Generator.get_state() exports it (CPUGeneratorImplStateLegacy: uint64 seed, int left, int seeded, uint64 next, uint64
+// state[624], ...), read and ADVANCED in place, so set_state(blob) puts torch's own generator where torch's own calls would
+// have left it.  pcabo/hostrng.py checks both functions against torch when it is imported and falls back to torch on a mismatch.
+namespace {
+struct TorchMt {
+  uint64_t seed; int32_t left; int32_t seeded; uint64_t next; uint64_t state[624];
+};
+inline uint32_t mt_twist(uint64_t u, uint64_t v) {
+  return (uint32_t)((((uint32_t)u & 0x80000000u) | ((uint32_t)v & 0x7fffffffu)) >> 1) ^ (((uint32_t)v & 1u) ? 0x9908b0dfu : 0u);
+}
+inline void mt_next_state(TorchMt* s) {
+  const int N = 624, M = 397;
+  uint64_t* p = s->state;
+  for (int j = N - M + 1; --j; ++p) *p = (uint32_t)p[M] ^ mt_twist(p[0], p[1]);
+  for (int j = M; --j; ++p) *p = (uint32_t)p[M - N] ^ mt_twist(p[0], p[1]);
+  *p = (uint32_t)p[M - N] ^ mt_twist(p[0], s->state[0]);
+  s->left = N;
+  s->next = 0;
+}
+inline uint32_t mt_draw(TorchMt* s) {
+  if (--s->left == 0) mt_next_state(s);
+  uint32_t y = (uint32_t)s->state[s->next++];
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  return y;
+}
+}  // namespace
+
+// torch.randint(2, (count,), generator=g): one 32-bit draw per element, value = draw % 2 (int64 out).
+int pcabo_torch_randint2(void* blob, int64_t count, int64_t* out) {
+  if (!blob || !out || count < 0) return PCABO_ERR_ARG;
+  TorchMt* s = static_cast<TorchMt*>(blob);
+  if (!s->seeded || s->left < 1 || s->left > 624 || s->next > 624) return PCABO_ERR_ARG;
+  for (int64_t i = 0; i < count; ++i) out[i] = (int64_t)(mt_draw(s) & 1u);
+  return PCABO_OK;
+}
+
+// torch.multinomial(weights[r], n_pick, replacement=False, generator=g_r) for `rows` rows with a generator each (blobs[r]; NULL =
+// skip the row): q_i = -log1p(-u_i) with u_i = ((hi << 32 | lo) & (2^53 - 1)) 2^-53 from two draws per element (an Exp(1) variate:
+// torch's exponential_), picks = the n_pick largest weights[i] / q_i, largest first (torch's topk).  out[rows][n_pick].
+int pcabo_torch_multinomial_rows(void* const* blobs, const double* weights, int rows, int n, int n_pick, int64_t* out) {
+  if (!blobs || !weights || !out || rows < 1 || n < 1 || n_pick < 1 || n_pick > n) return PCABO_ERR_ARG;
+  std::vector<double> ratio((size_t)n);
+  std::vector<int> best((size_t)n_pick);
+  for (int r = 0; r < rows; ++r) {
+    TorchMt* s = static_cast<TorchMt*>(blobs[r]);
+    if (!s) continue;
+    if (!s->seeded || s->left < 1 || s->left > 624 || s->next > 624) return PCABO_ERR_ARG;
+    const double* w = weights + (size_t)r * n;
+    for (int i = 0; i < n; ++i) {
+      const uint64_t hi = mt_draw(s), lo = mt_draw(s);
+      const uint64_t r64 = (hi << 32) | lo;
+      const double u = (double)(r64 & ((1ull << 53) - 1)) * 1.1102230246251565e-16;      // 2^-53
+      const double q = -std::log1p(-u);
+      ratio[i] = w[i] / q;
+    }
+    // the n_pick largest, in decreasing order (n_pick is 10 of 512: selection by insertion)
+    int have = 0;
+    for (int i = 0; i < n; ++i) {
+      const double v = ratio[i];
+      if (have == n_pick && !(v > ratio[best[have - 1]])) continue;
+      int pos = have < n_pick ? have : n_pick - 1;
+      while (pos > 0 && v > ratio[best[pos - 1]]) { if (pos < n_pick) best[pos] = best[pos - 1]; --pos; }
+      best[pos] = i;
+      if (have < n_pick) ++have;
+    }
+    for (int j = 0; j < n_pick; ++j) out[(size_t)r * n_pick + j] = best[j];
+  }
+  return PCABO_OK;
+}
 
 }  // extern "C"

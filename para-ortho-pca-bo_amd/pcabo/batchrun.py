@@ -22,6 +22,7 @@ import numpy as np
 import torch
 
 from . import _native
+from .hostrng import HostMT
 from . import initializers as _init
 from .lhs import lhs_center
 
@@ -149,7 +150,9 @@ class BatchedPCABO:
             gcguard.enter()
             self._gc_entered = True
         self._rs = [np.random.RandomState(s) for s in self.seeds]
-        self._tg = [torch.Generator().manual_seed(s) for s in self.seeds]
+        # a run's torch CPU generator as the state blob torch exports, advanced by libpcabo's host helpers (pcabo/hostrng.py: same
+        # numbers and consumption as torch's randint / multinomial, checked at import; a real torch.Generator otherwise)
+        self._tg = [HostMT(s) for s in self.seeds]
         self._X = np.empty((B, self.budget, d))
         self._F = np.empty((B, self.budget))
         for b in range(B):

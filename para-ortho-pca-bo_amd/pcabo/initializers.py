@@ -19,6 +19,7 @@ INIT_ETA = 1.0   # botorch initialize_q_batch(eta=1.0)
 
 _MAXBIT = 30
 _POW_LOW = torch.pow(2, torch.arange(0, _MAXBIT))
+_POW_LOW_NP = _POW_LOW.numpy().astype(np.int64)
 
 
 _UNSCRAMBLED = {}      # k -> (k, 30) int64 direction numbers of torch's unscrambled engine (its table; copied per use)
@@ -50,11 +51,16 @@ def scrambled_sobol_engine(k: int, generator=None) -> ScrambledSobol:
     base = _UNSCRAMBLED.get(k)
     if base is None:
         base = _UNSCRAMBLED[k] = torch.quasirandom.SobolEngine(k, scramble=False).sobolstate.numpy().copy()
-    shift_ints = torch.randint(2, (k, _MAXBIT), generator=generator)
-    shift = torch.mv(shift_ints, _POW_LOW).numpy()
-    ltm = torch.randint(2, (k, _MAXBIT, _MAXBIT), generator=generator)     # (torch's .tril(): the helper reads below the diagonal only)
+    from .hostrng import HostMT
+    if isinstance(generator, HostMT):       # the run's generator as a state blob: the same draws without torch calls (pcabo/hostrng.py)
+        shift = generator.randint2((k, _MAXBIT)) @ _POW_LOW_NP
+        ltm = generator.randint2((k, _MAXBIT, _MAXBIT))
+    else:
+        shift_ints = torch.randint(2, (k, _MAXBIT), generator=generator)
+        shift = torch.mv(shift_ints, _POW_LOW).numpy()
+        ltm = torch.randint(2, (k, _MAXBIT, _MAXBIT), generator=generator).numpy()     # (torch's .tril(): the helper reads below the diagonal only)
     state = base.copy()
-    _native.sobol_scramble(state, ltm.numpy())
+    _native.sobol_scramble(state, ltm)
     return ScrambledSobol(k, state, shift)
 
 
@@ -68,6 +74,24 @@ def draw_sobol(bounds: np.ndarray, n: int, engine=None, out=None) -> np.ndarray:
     return _native.sobol_draw(engine.state, engine.shift, n, bounds[0], bounds[1] - bounds[0], out=out)
 
 
+def _with_torch_generator(fn):
+    """`generator` may be a pcabo.hostrng.HostMT: the call runs on a real torch generator in its state, which is taken back after."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, generator=None, **kw):
+        from .hostrng import HostMT
+        if isinstance(generator, HostMT):
+            g = generator.torch_generator()
+            try:
+                return fn(*args, generator=g, **kw)
+            finally:
+                generator.absorb(g)
+        return fn(*args, generator=generator, **kw)
+    return wrapped
+
+
+@_with_torch_generator
 @torch.inference_mode()
 def initialize_q_batch(acq_vals: np.ndarray, n: int, eta: float = INIT_ETA, generator=None) -> np.ndarray:
     """Boltzmann sampling of n restart indices (without replacement) + forced arg-max."""
@@ -115,30 +139,43 @@ def initialize_q_batch_rows(acq_vals: np.ndarray, n: int, generators, eta: float
     safe = torch.where(std == 0.0, torch.ones_like(std), std)
     weights = torch.exp(eta * ((v - mean[:, None]) / safe[:, None]))
     check = eta * (n_samples - 1) / math.sqrt(n_samples) >= 700.0
-    out = []
+    from .hostrng import HostMT, multinomial_rows
+    std_np = std.numpy()
+    out = [None] * B
+    draw = []
     for b in range(B):
         if b in skip:
-            out.append(np.arange(n))
-            continue
-        if float(std[b]) == 0.0:
+            out[b] = np.arange(n)
+        elif std_np[b] == 0.0:
             warnings.warn("All acquisition values for raw samples points are the same. "
                           "Choosing initial conditions at random.", RuntimeWarning)
-            out.append(torch.randperm(n=n_samples, generator=generators[b])[:n].numpy())
-            continue
-        w = weights[b]
-        if check:
-            eta_z = eta * ((v[b] - mean[b]) / std[b])
+            g = generators[b]
+            tg = g.torch_generator() if isinstance(g, HostMT) else g
+            out[b] = torch.randperm(n=n_samples, generator=tg)[:n].numpy()
+            if isinstance(g, HostMT):
+                g.absorb(tg)
+        else:
+            draw.append(b)
+    if check:
+        for b in draw:
+            w, eta_z = weights[b], eta * ((v[b] - mean[b]) / std[b])
             while bool(torch.isinf(w).any()):
                 eta_z = eta_z * 0.5
                 w = torch.exp(eta_z)
-        idcs = torch.multinomial(w, n, generator=generators[b]).numpy()
-        mi = int(max_idx[b])
-        if mi not in idcs:
-            idcs[-1] = mi
-        out.append(idcs)
+            weights[b] = w
+    # the multinomial draws of all rows: one call into libpcabo for the runs whose generator is a state blob (pcabo/hostrng.py:
+    # torch's exponential variates and top-k restated, checked against torch at import), torch's own call for the others
+    picks = multinomial_rows(weights.numpy(), n, generators, draw)
+    mi = max_idx.numpy()
+    for b in draw:
+        idcs = picks[b]
+        if mi[b] not in idcs:
+            idcs[-1] = mi[b]
+        out[b] = idcs
     return out
 
 
+@_with_torch_generator
 def initialize_q_batch_nonneg(acq_vals: np.ndarray, n: int, eta: float = 1.0, alpha: float = 1e-4,
                               generator=None) -> np.ndarray:
     """Variant botorch uses for non-negative acquisitions (probability of improvement)."""

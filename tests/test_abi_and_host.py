@@ -213,3 +213,49 @@ def test_hardware_queue_advice_reads_the_environment_and_never_writes_it(native,
     assert native.hw_queues_advice(10) is None
     src = open(os.path.join(ROOT, "para-ortho-pca-bo_amd", "pcabo", "_native.py")).read()
     assert "os.environ.setdefault" not in src and "os.environ[" not in src
+
+
+def test_host_generator_blob_equals_torchs_generator_on_ten_thousand_picks(native):
+    """pcabo/hostrng.py: torch's CPU generator held as its own state blob and advanced by libpcabo's
+    host helpers - the Sobol scramble bits (`torch.randint(2, ...)`) and the Boltzmann pick (`torch.multinomial(w, 10)`) of botorch's
+    initialize_q_batch.  10 000 random weight vectors on generators at random positions of their streams: the picks AND the
+    generator's state after every call are torch's, bit for bit; the rows-at-once form equals row-by-row calls."""
+    import torch
+    from pcabo import hostrng as H
+    from pcabo import initializers as I
+    assert H.native_ok()
+    rng = np.random.default_rng(2024)
+    gens = [(H.HostMT(int(s)), torch.Generator().manual_seed(int(s))) for s in rng.integers(0, 2 ** 31, size=50)]
+    for trial in range(10000):
+        h, g = gens[trial % len(gens)]
+        if trial % 7 == 0:                     # move along the stream by the scramble draws of one engine (k x 30 + k x 30 x 30 bits)
+            k = int(rng.integers(1, 6))
+            a = np.concatenate([h.randint2((k, 30)).ravel(), h.randint2((k, 30, 30)).ravel()])
+            b = torch.cat([torch.randint(2, (k, 30), generator=g).ravel(), torch.randint(2, (k, 30, 30), generator=g).ravel()]).numpy()
+            assert np.array_equal(a, b)
+        n = int(rng.choice([16, 64, 512]))
+        w = np.exp(rng.normal(size=n) * rng.uniform(0.05, 4.0))
+        if trial % 11 == 0:
+            w[rng.integers(0, n, size=n // 4)] = 0.0                      # zero weights are never picked before positive ones
+        got = H.multinomial_rows(w[None], 10, [h], [0])[0]
+        want = torch.multinomial(torch.from_numpy(w), 10, generator=g).numpy()
+        assert np.array_equal(got, want), trial
+        assert np.array_equal(h.blob, g.get_state().numpy()), trial
+    # the engine built from a blob equals the one built from torch's generator, and so do the picks of initialize_q_batch_rows
+    hs, gs = [H.HostMT(77 + b) for b in range(6)], [torch.Generator().manual_seed(77 + b) for b in range(6)]
+    for k in (3, 36):
+        for b in range(6):
+            e1, e2 = I.scrambled_sobol_engine(k, hs[b]), I.scrambled_sobol_engine(k, gs[b])
+            assert np.array_equal(e1.state, e2.state) and np.array_equal(e1.shift, e2.shift)
+    vals = rng.normal(size=(6, 512))
+    vals[4] = 1.25                                                        # all values tie: the random-permutation path
+    with pytest.warns(RuntimeWarning):
+        p1 = I.initialize_q_batch_rows(vals, 10, hs, skip={2})
+    with pytest.warns(RuntimeWarning):
+        p2 = I.initialize_q_batch_rows(vals, 10, gs, skip={2})
+    for a, b in zip(p1, p2):
+        assert np.array_equal(a, b)
+    for b in range(6):
+        assert np.array_equal(hs[b].get_state().numpy(), gs[b].get_state().numpy())
+        one = I.initialize_q_batch(vals[b] if b != 4 else rng.normal(size=512), 10, generator=hs[b])
+        assert len(one) == 10

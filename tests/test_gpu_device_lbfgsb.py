@@ -80,14 +80,28 @@ def test_device_evaluation_against_oracle(native, dim, budget, n_doe, states):
         v, g = bt.device_acq_eval([Xs], [rec.best_f])
         worst["val"] = max(worst["val"], float((np.abs(v[0] - ov) / np.maximum(1.0, np.abs(ov))).max()))
         worst["grad"] = max(worst["grad"], _rel(g[0], og))
+        # the per-query kernels (k_acq_fast: DPP tree sums) on the SAME factor R at the same points: what part of the distance to
+        # the oracle is the evaluation's summation order, what part the factorisation both share
+        bt.ctx[0].k, bt.ctx[0].n = k, n                     # (the batch's borrowed context: its shape is the batch's)
+        vq, gq = bt.ctx[0].acq_eval(Xs, rec.best_f)
+        worst["val_per_query"] = max(worst.get("val_per_query", 0.0), float((np.abs(vq - ov) / np.maximum(1.0, np.abs(ov))).max()))
+        worst["grad_per_query"] = max(worst.get("grad_per_query", 0.0), _rel(gq, og))
+        worst["val_between"] = max(worst.get("val_between", 0.0), float((np.abs(vq - v[0]) / np.maximum(1.0, np.abs(vq))).max()))
+        worst["grad_between"] = max(worst.get("grad_between", 0.0), _rel(g[0], gq))
         v7, g7 = bt.device_acq_eval([Xs[:7]], [rec.best_f])           # a point's numbers do not depend on its group
         assert np.array_equal(v7[0], v[0][:7]) and np.array_equal(g7[0], g[0][:7])
         vo = rec.acq(torch.from_numpy(np.ascontiguousarray(tr["cands"]))).detach().numpy()
         worst["run_vals"] = max(worst["run_vals"], float((np.abs(vo - tr["vals"]) / np.maximum(1.0, np.abs(tr["vals"]))).max()))
         del bt
-    print("[device evaluation vs oracle, d=%d] value %.2e gradient %.2e, the run's own end-point values %.2e" % (
-        dim, worst["val"], worst["grad"], worst["run_vals"]))
-    assert worst["val"] < 1e-8 and worst["grad"] < 1e-6 and worst["run_vals"] < 1e-8, worst
+    print("[device evaluation vs oracle, d=%d] value %.2e gradient %.2e, the run's own end-point values %.2e; the per-query kernels at the "
+          "same points: value %.2e gradient %.2e; the two kernels against each other: value %.2e gradient %.2e" % (
+        dim, worst["val"], worst["grad"], worst["run_vals"], worst["val_per_query"], worst["grad_per_query"], worst["val_between"],
+        worst["grad_between"]))
+    # measured (round 4, profiles/r04/device_eval_accuracy.txt): the two kernels agree with EACH OTHER to ~1e-13 on the same factor -
+    # their distance to the oracle at these points (restart end points: the posterior variance is tiny there, 1 - |v|^2 cancels) is
+    # the distance between the device's factorisation and torch's, shared by every kernel.  Thresholds: measured x 10.
+    assert worst["val"] < 5e-9 and worst["grad"] < 3e-10 and worst["run_vals"] < 5e-9, worst
+    assert worst["val_between"] < 1e-10 and worst["grad_between"] < 1e-10, worst
 
 
 def test_device_mode_batch_replayed_by_oracle(native):

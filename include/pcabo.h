@@ -212,6 +212,10 @@ int pcabo_sobol_draw(const int64_t* state, const int64_t* shift, int k, int n, c
  * pcabo/hostrng.py verifies both against torch at import and keeps torch's own calls if they ever differ. */
 int pcabo_torch_randint2(void* blob, int64_t count, int64_t* out);
 int pcabo_torch_multinomial_rows(void* const* blobs, const double* weights, int rows, int n, int n_pick, int64_t* out);
+/* botorch's initialize_q_batch (Boltzmann pick of the restarts' initial conditions) for `rows` runs in one call: vals[rows][n] raw-sample
+ * scores, eta the temperature; out[rows][n_pick]; flags[rows]: 0 picked, 1 all values equal (nothing drawn: the caller takes the
+ * random-permutation path), 2 skipped (blobs[r] == NULL). */
+int pcabo_boltzmann_pick_rows(void* const* blobs, const double* vals, int rows, int n, int n_pick, double eta, int64_t* out, int* flags);
 
 /* Device-time accounting: accumulated HIP-event time (ms, events recorded on the context's own
  * stream), launch count and ALGORITHMIC bytes / flops of the kernel groups since the last reset.

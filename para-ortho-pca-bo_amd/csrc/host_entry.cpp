@@ -150,6 +150,71 @@ int pcabo_torch_randint2(void* blob, int64_t count, int64_t* out) {
   return PCABO_OK;
 }
 
+namespace {
+// the n_pick largest of w_i / q_i, largest first (torch's topk on the ratios), q_i an Exp(1) variate drawn as torch's exponential_ does
+void multinomial_row(TorchMt* s, const double* w, int n, int n_pick, double* ratio, int* best, int64_t* out) {
+  for (int i = 0; i < n; ++i) {
+    const uint64_t hi = mt_draw(s), lo = mt_draw(s);
+    const uint64_t r64 = (hi << 32) | lo;
+    const double u = (double)(r64 & ((1ull << 53) - 1)) * 1.1102230246251565e-16;      // 2^-53
+    const double q = -std::log1p(-u);
+    ratio[i] = w[i] / q;
+  }
+  int have = 0;                        // (n_pick is 10 of 512: selection by insertion)
+  for (int i = 0; i < n; ++i) {
+    const double v = ratio[i];
+    if (have == n_pick && !(v > ratio[best[have - 1]])) continue;
+    int pos = have < n_pick ? have : n_pick - 1;
+    while (pos > 0 && v > ratio[best[pos - 1]]) { if (pos < n_pick) best[pos] = best[pos - 1]; --pos; }
+    best[pos] = i;
+    if (have < n_pick) ++have;
+  }
+  for (int j = 0; j < n_pick; ++j) out[j] = best[j];
+}
+}  // namespace
+
+// botorch's initialize_q_batch for `rows` runs at once (behind PCA_BO.py:607-614): per row z = (v - mean) / std (unbiased), weights
+// exp(eta z) (halved exponents while one overflows), torch.multinomial(weights, n_pick) on the row's generator, the arg-max forced
+// into the last place if it was not drawn.  flags[r]: 0 picked; 1 all values equal (std == 0: the caller takes botorch's random
+// permutation path on torch's generator - nothing was drawn here); 2 row skipped (blobs[r] == NULL).  The statistics are formed
+// in this file's order (Welford), not torch's: the weights can differ from a torch-formed row in the last bit, the picks - an
+// ordering of weights over independent exponential variates - do not (tests/test_abi_and_host.py compares 10 000 rows).
+int pcabo_boltzmann_pick_rows(void* const* blobs, const double* vals, int rows, int n, int n_pick, double eta, int64_t* out, int* flags) {
+  if (!blobs || !vals || !out || !flags || rows < 1 || n < 2 || n_pick < 1 || n_pick > n) return PCABO_ERR_ARG;
+  std::vector<double> w((size_t)n), ratio((size_t)n);
+  std::vector<int> best((size_t)n_pick);
+  for (int r = 0; r < rows; ++r) {
+    TorchMt* s = static_cast<TorchMt*>(blobs[r]);
+    if (!s) { flags[r] = 2; continue; }
+    if (!s->seeded || s->left < 1 || s->left > 624 || s->next > 624) return PCABO_ERR_ARG;
+    const double* v = vals + (size_t)r * n;
+    double mean = 0.0, m2 = 0.0;
+    int arg = 0;
+    for (int i = 0; i < n; ++i) {
+      const double d = v[i] - mean;
+      mean += d / (double)(i + 1);
+      m2 += d * (v[i] - mean);
+      if (v[i] > v[arg]) arg = i;
+    }
+    const double sd = std::sqrt(m2 / (double)(n - 1));
+    if (!(sd > 0.0)) { flags[r] = 1; continue; }
+    double scale = eta;
+    for (;;) {
+      bool inf = false;
+      for (int i = 0; i < n; ++i) { w[i] = std::exp(scale * ((v[i] - mean) / sd)); inf = inf || std::isinf(w[i]); }
+      if (!inf) break;
+      scale *= 0.5;
+    }
+    int64_t* o = out + (size_t)r * n_pick;
+    multinomial_row(s, w.data(), n, n_pick, ratio.data(), best.data(), o);
+    bool has = false;
+    for (int j = 0; j < n_pick; ++j) has = has || o[j] == arg;
+    if (!has) o[n_pick - 1] = arg;
+    flags[r] = 0;
+  }
+  return PCABO_OK;
+}
+
 // torch.multinomial(weights[r], n_pick, replacement=False, generator=g_r) for `rows` rows with a generator each (blobs[r]; NULL =
 // skip the row): q_i = -log1p(-u_i) with u_i = ((hi << 32 | lo) & (2^53 - 1)) 2^-53 from two draws per element (an Exp(1) variate:
 // torch's exponential_), picks = the n_pick largest weights[i] / q_i, largest first (torch's topk).  out[rows][n_pick].
@@ -161,25 +226,7 @@ int pcabo_torch_multinomial_rows(void* const* blobs, const double* weights, int 
     TorchMt* s = static_cast<TorchMt*>(blobs[r]);
     if (!s) continue;
     if (!s->seeded || s->left < 1 || s->left > 624 || s->next > 624) return PCABO_ERR_ARG;
-    const double* w = weights + (size_t)r * n;
-    for (int i = 0; i < n; ++i) {
-      const uint64_t hi = mt_draw(s), lo = mt_draw(s);
-      const uint64_t r64 = (hi << 32) | lo;
-      const double u = (double)(r64 & ((1ull << 53) - 1)) * 1.1102230246251565e-16;      // 2^-53
-      const double q = -std::log1p(-u);
-      ratio[i] = w[i] / q;
-    }
-    // the n_pick largest, in decreasing order (n_pick is 10 of 512: selection by insertion)
-    int have = 0;
-    for (int i = 0; i < n; ++i) {
-      const double v = ratio[i];
-      if (have == n_pick && !(v > ratio[best[have - 1]])) continue;
-      int pos = have < n_pick ? have : n_pick - 1;
-      while (pos > 0 && v > ratio[best[pos - 1]]) { if (pos < n_pick) best[pos] = best[pos - 1]; --pos; }
-      best[pos] = i;
-      if (have < n_pick) ++have;
-    }
-    for (int j = 0; j < n_pick; ++j) out[(size_t)r * n_pick + j] = best[j];
+    multinomial_row(s, weights + (size_t)r * n, n, n_pick, ratio.data(), best.data(), out + (size_t)r * n_pick);
   }
   return PCABO_OK;
 }

@@ -48,7 +48,7 @@ EXPORTS = [
     "pcabo_gp_condition_end", "pcabo_gp_condition_end_eval", "pcabo_wpca_gp_condition_begin", "pcabo_wpca_results",
     "pcabo_acq_bounds",
     "pcabo_acq_eval", "pcabo_logei", "pcabo_optimize_acqf", "pcabo_inverse_map", "pcabo_get_gp_state",
-    "pcabo_get_gram", "pcabo_lbfgsb_minimize", "pcabo_lbfgsb_set_vector_kernels", "pcabo_lbfgsb_set_sum_order", "pcabo_sobol_scramble", "pcabo_sobol_draw", "pcabo_torch_randint2", "pcabo_torch_multinomial_rows", "pcabo_set_profiling",
+    "pcabo_get_gram", "pcabo_lbfgsb_minimize", "pcabo_lbfgsb_set_vector_kernels", "pcabo_lbfgsb_set_sum_order", "pcabo_sobol_scramble", "pcabo_sobol_draw", "pcabo_torch_randint2", "pcabo_torch_multinomial_rows", "pcabo_boltzmann_pick_rows", "pcabo_set_profiling",
     "pcabo_get_profile", "pcabo_get_profile_calibration", "pcabo_reset_profile",
     "pcabo_batch_create", "pcabo_batch_destroy", "pcabo_batch_last_error", "pcabo_batch_ctx",
     "pcabo_batch_wpca_gp_condition_begin", "pcabo_batch_wpca_results", "pcabo_batch_acq_bounds",

@@ -27,6 +27,7 @@ BLOB_BYTES = 5056
 _LIB = _native.LIB
 _LIB.pcabo_torch_randint2.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
 _LIB.pcabo_torch_multinomial_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+_LIB.pcabo_boltzmann_pick_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
 
 _native_ok: Optional[bool] = None
 
@@ -130,3 +131,21 @@ def multinomial_rows(weights: np.ndarray, n_pick: int, generators: Sequence, row
             g = g._gen if isinstance(g, HostMT) else g
             out[b] = torch.multinomial(torch.from_numpy(np.ascontiguousarray(weights[b])), n_pick, generator=g).numpy()
     return out
+
+
+def boltzmann_pick_rows(vals: np.ndarray, n_pick: int, eta: float, generators: Sequence, skip=()):
+    """botorch's initialize_q_batch for every row of `vals` in ONE native call (pcabo_boltzmann_pick_rows) when every generator is
+    a state blob; returns (indices [B x n_pick], flags [B]: 0 picked, 1 all values equal - nothing drawn, 2 skipped) or None when a
+    generator is a real torch generator (the caller keeps its torch path)."""
+    if not native_ok() or any(not isinstance(g, HostMT) or g._gen is not None for g in generators):
+        return None
+    vals = np.ascontiguousarray(vals, dtype=np.float64)
+    rows, n = vals.shape
+    skip = set(skip)
+    ptrs = (C.c_void_p * rows)(*[(None if b in skip else generators[b].blob.ctypes.data) for b in range(rows)])
+    out = np.zeros((rows, n_pick), dtype=np.int64)
+    flags = np.zeros(rows, dtype=np.int32)
+    rc = _LIB.pcabo_boltzmann_pick_rows(ptrs, vals.ctypes.data, rows, n, int(n_pick), float(eta), out.ctypes.data, flags.ctypes.data)
+    if rc != 0:
+        raise _native.PcaboError(rc, "pcabo_boltzmann_pick_rows: bad arguments")
+    return out, flags

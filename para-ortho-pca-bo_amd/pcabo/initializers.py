@@ -133,6 +133,25 @@ def initialize_q_batch_rows(acq_vals: np.ndarray, n: int, generators, eta: float
         raise RuntimeError(f"n ({n}) cannot be larger than the number of provided samples ({n_samples})")
     if n == n_samples:
         return [np.arange(n) for _ in range(B)]
+    from .hostrng import boltzmann_pick_rows
+    native = boltzmann_pick_rows(acq_vals, n, eta, generators, skip) if n_samples >= 2 else None
+    if native is not None:
+        # every run's generator is a state blob: statistics, weights, multinomial draw and the forced arg-max of all rows in one
+        # call into libpcabo (csrc/host_entry.cpp; the same picks as the torch path below - tests/test_abi_and_host.py)
+        idx, flags = native
+        out = []
+        for b in range(B):
+            if flags[b] == 2:
+                out.append(np.arange(n))
+            elif flags[b] == 1:
+                warnings.warn("All acquisition values for raw samples points are the same. "
+                              "Choosing initial conditions at random.", RuntimeWarning)
+                tg = generators[b].torch_generator()
+                out.append(torch.randperm(n=n_samples, generator=tg)[:n].numpy())
+                generators[b].absorb(tg)
+            else:
+                out.append(idx[b])
+        return out
     std = torch.stack([v[b].std(dim=0) for b in range(B)])
     mean = v.mean(dim=1)
     max_idx = torch.max(v, dim=1)[1]

@@ -259,3 +259,32 @@ def test_host_generator_blob_equals_torchs_generator_on_ten_thousand_picks(nativ
         assert np.array_equal(hs[b].get_state().numpy(), gs[b].get_state().numpy())
         one = I.initialize_q_batch(vals[b] if b != 4 else rng.normal(size=512), 10, generator=hs[b])
         assert len(one) == 10
+
+
+def test_native_boltzmann_pick_equals_the_torch_path_on_ten_thousand_rows(native):
+    """initialize_q_batch for all runs of a batch in one native call (pcabo_boltzmann_pick_rows: Welford statistics, exp, torch's
+    multinomial restated, forced arg-max) against the torch path of pcabo.initializers on 10 000 rows of raw-sample scores: same
+    picks, same generator states - including rows whose values all tie (random-permutation path) and rows with ties at the top."""
+    import warnings
+    import torch
+    from pcabo import hostrng as H
+    from pcabo import initializers as I
+    rng = np.random.default_rng(7)
+    B = 50
+    hs = [H.HostMT(1000 + b) for b in range(B)]
+    gs = [torch.Generator().manual_seed(1000 + b) for b in range(B)]
+    for rep in range(200):
+        vals = rng.normal(size=(B, 512)) * rng.uniform(0.01, 30.0, size=(B, 1)) + rng.normal(size=(B, 1)) * 100.0
+        if rep % 10 == 0:
+            vals[3] = -7.5                                   # all equal
+            vals[5, rng.integers(0, 512, size=200)] = vals[5].max() + 1.0      # many ties at the maximum
+            vals[6] = np.round(vals[6])                      # heavy ties everywhere
+        skip = {11} if rep % 3 == 0 else set()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            a = I.initialize_q_batch_rows(vals, 10, hs, skip=skip)
+            b = I.initialize_q_batch_rows(vals, 10, gs, skip=skip)
+        for r in range(B):
+            assert np.array_equal(a[r], b[r]), (rep, r)
+    for r in range(B):
+        assert np.array_equal(hs[r].get_state().numpy(), gs[r].get_state().numpy()), r

@@ -1,9 +1,9 @@
 """Initial design + evaluation bookkeeping shared by the Bayesian optimisers.
 
 Host-side mirror of /root/reference/Algorithms/BayesianOptimization/AbstractBayesianOptimizer.py
-(:8-103 `LHS_sampler`, :106-270 `AbstractBayesianOptimizer`).  The Latin-hypercube draw is the
-`criterion="center"` design of pyDOE restated in `pcabo.lhs` (pyDOE is not installed here); the other
-pyDOE criteria are not restated and raise.
+(:8-103 `LHS_sampler`, :106-270 `AbstractBayesianOptimizer`).  The Latin-hypercube draw is pyDOE's
+`lhs` restated in `pcabo.lhs` (pyDOE is not installed here): "center" pinned by the reference's committed runs, the other
+three criteria restated from the published algorithm (parity unpinned).
 """
 from __future__ import annotations
 
@@ -13,7 +13,7 @@ from typing import List, Optional
 import numpy as np
 
 from ..AbstractAlgorithm import AbstractAlgorithm
-from pcabo.lhs import lhs_center
+from pcabo.lhs import lhs
 
 _CRITERIA = ("center", "maximin", "centermaximin", "correlation")
 _SHORT = {"c": "center", "m": "maximin", "cm": "centermaximin", "corr": "correlation"}
@@ -26,10 +26,7 @@ class LHS_sampler:
         self.sample_zero = sample_zero
 
     def __call__(self, dim: int, n_samples: int) -> np.ndarray:
-        if self.criterion != "center":
-            raise NotImplementedError(f"LHS criterion '{self.criterion}' is not restated; the reference's runner and "
-                                      "defaults use 'center' (ExperimentRunner.py:75)")
-        points = lhs_center(dim, n_samples)
+        points = lhs(dim, n_samples, criterion=self.criterion, iterations=self.iterations)
         if self.sample_zero:
             points[0, :] = 0.0
         return points.reshape((n_samples, dim))

@@ -288,3 +288,31 @@ def test_native_boltzmann_pick_equals_the_torch_path_on_ten_thousand_rows(native
             assert np.array_equal(a[r], b[r]), (rep, r)
     for r in range(B):
         assert np.array_equal(hs[r].get_state().numpy(), gs[r].get_state().numpy()), r
+
+
+def test_every_lhs_criterion_of_the_reference_surface():
+    """pyDOE's four criteria as the reference's LHS_sampler accepts them (AbstractBayesianOptimizer.py:8-103): "center" is pinned by
+    the reference's runs (tests/test_reference_kats.py); the other three are restated from the published algorithm - asserted here:
+    a Latin hypercube (one point per bin in every column), the candidates' RNG consumption, the criterion no worse than a single draw."""
+    from Algorithms.BayesianOptimization.AbstractBayesianOptimizer import LHS_sampler
+    from pcabo import lhs as L
+    m, d = 12, 4
+    for crit in ("center", "maximin", "centermaximin", "correlation", "c", "m", "cm", "corr"):
+        np.random.seed(5)
+        pts = LHS_sampler(crit, iterations=7)(d, m)
+        assert pts.shape == (m, d) and (pts >= 0).all() and (pts < 1).all()
+        for j in range(d):
+            assert sorted(np.floor(pts[:, j] * m).astype(int)) == list(range(m)), crit          # one point per bin
+        after = np.random.rand()
+        np.random.seed(5)
+        for _ in range(1 if crit in ("center", "c") else 7):                                   # per candidate: rand(m, d) + d permutations
+            np.random.rand(m, d)
+            for _j in range(d):
+                np.random.permutation(m)
+        assert np.random.rand() == after, crit
+    rs = np.random.RandomState(9)
+    one = L._pdist_min(L._lhs_classic(d, m, np.random.RandomState(9)))
+    assert L._pdist_min(L.lhs(d, m, "maximin", 25, rs)) >= one
+    with pytest.raises(ValueError):
+        LHS_sampler("optimal")
+    assert np.array_equal(LHS_sampler("center", sample_zero=True)(3, 5)[0], np.zeros(3))

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Instruction-cache behaviour and wave-cycle buckets of k_lbfgsb_group (one optimize call of 30 runs at n = 449, three dispatches):
-# three --pmc passes (kernel trace only; the third counts the vector memory instructions).  Writes gpurun_out/r03dev/icache.json.
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r03dev
+# three --pmc passes (kernel trace only; the third counts the vector memory instructions).  $1 = round tag (default r04); writes gpurun_out/<tag>dev/icache.json.
+TAG=${1:-r04}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/${TAG}dev
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE --kernel-trace -d $OUT/pmc_ic -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/tools/gpu_device_lbfgsb_phases.py 449 40 30 > $OUT/pmc_ic.log 2> $OUT/pmc_ic.err

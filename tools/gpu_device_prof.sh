@@ -1,9 +1,10 @@
 #!/bin/bash
-# Round 3, device-resident L-BFGS-B (k_lbfgsb_group): (1) rocprofv3 --kernel-trace --stats over one 30-run batch of the headline
+# Device-resident L-BFGS-B (first used in round 3; $1 = round tag, default r04) (k_lbfgsb_group): (1) rocprofv3 --kernel-trace --stats over one 30-run batch of the headline
 # cell in device mode; (2) FETCH_SIZE / WRITE_SIZE (separate --pmc passes, kernel trace only) over a shorter batch (8 runs), summed
 # per kernel: fabric bytes of k_lbfgsb_group per launch and per L-BFGS-B evaluation against the algorithmic bytes.
-# Run on the GPU box from the repo root; writes gpurun_out/r03dev/.
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r03dev
+# Run on the GPU box from the repo root; writes gpurun_out/<tag>dev/.
+TAG=${1:-r04}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/${TAG}dev
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 420 rocprofv3 --kernel-trace --stats -d $OUT/trace -o batch30dev --output-format csv -- python3 $GRAFT_REPO_ROOT/tools/gpu_batch_clock.py 30 40 15 1 0 device > $OUT/batch30_device_under_rocprof.json 2> $OUT/batch30_device_under_rocprof.err

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Profiling recipe (run on the GPU box from the repo root; $1 = round tag, default r03): kernel statistics of the benchmark
+# Profiling recipe (run on the GPU box from the repo root; $1 = round tag, default r04): kernel statistics of the benchmark
 # and of a 30-run batch with its DEFAULT worker threads, then three counter passes over fixed shapes (counters in their own
 # runs, no tracing domains besides the kernel trace).  Copy what is to be judged from gpurun_out/<tag>/ into profiles/<tag>/.
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

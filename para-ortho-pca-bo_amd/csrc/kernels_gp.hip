@@ -8,6 +8,7 @@
 // The padding block is the identity, so every kernel works on whole 64 x 64 tiles and the
 // padded rows/columns never influence the leading n x n part.
 #include "pcabo_internal.h"
+#include <mutex>
 #include <cstdlib>
 
 #define BS PCABO_BS
@@ -24,8 +25,9 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ AT, con
                                               int KP, int ld, double noise, int kernel, double* __restrict__ K,
                                               const int* __restrict__ k_dev, double* __restrict__ K2,
                                               int* __restrict__ info_reset, size_t zs) {
-  ZRUN(AT); ZRUN(nrm); ZRUN(K); ZRUN(k_dev); ZRUN(K2); ZRUN(info_reset);
-  const int ti = blockIdx.x, tj = blockIdx.y;
+  const XcdTile xt_ = xcd_tile();                    // (the tiles of a run read the same rows of AT: one XCD)
+  ZRUNX(AT); ZRUNX(nrm); ZRUNX(K); ZRUNX(k_dev); ZRUNX(K2); ZRUNX(info_reset);
+  const int ti = (int)xt_.x, tj = (int)xt_.y;
   // K2: the copy the factorisation works on in place; info_reset: its failure flag (saves a copy and a fill launch).
   // K itself is written only when somebody asks for it (pcabo_get_gram): a second full-size store doubled the kernel's
   // HBM traffic for a matrix that a retry can just as well build again.
@@ -100,16 +102,17 @@ __device__ inline void load_tile(const double* __restrict__ src, int ld, double*
 // the current one run.  The extra last work-group puts the previous panel's diagonal factor in place (see above).
 __global__ __launch_bounds__(256) void k_chol_lookback(double* __restrict__ A, int J, int nblk, int ld,
                                                        const double* __restrict__ diag_scratch, size_t zs) {
-  ZRUN(A); ZRUN(diag_scratch);
+  const XcdTile xt_ = xcd_tile();                    // (all tiles of a run on one XCD: they share the block row L[J][.])
+  ZRUNX(A); ZRUNX(diag_scratch);
   __shared__ __attribute__((aligned(16))) double s_a[BS * TLD];
   __shared__ __attribute__((aligned(16))) double s_b[BS * TLD];
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-  if (blockIdx.x == gridDim.x - 1) {                 // panel J-1's diagonal factor: scratch -> its place
+  if (xt_.x == gridDim.x - 1) {                      // panel J-1's diagonal factor: scratch -> its place
     double* Add = A + (size_t)((J - 1) * BS) * ld + (J - 1) * BS;
     for (int idx = tid; idx < BS * BS; idx += 256) Add[(size_t)(idx >> 6) * ld + (idx & 63)] = diag_scratch[idx];
     return;
   }
-  const int I = J + blockIdx.x;
+  const int I = J + (int)xt_.x;
   const bool diag = I == J;
   double* dst = A + (size_t)(I * BS) * ld + J * BS;
   const double* Arow = A + (size_t)(I * BS) * ld;    // L[I][p] tiles
@@ -168,6 +171,99 @@ __global__ __launch_bounds__(256) void k_chol_lookback(double* __restrict__ A, i
     for (int r = 0; r < 4; ++r) dst[(size_t)(16 * w + (l >> 4) + 4 * r) * ld + 16 * q + (l & 15)] = cold[q][r];
 }
 
+// Look-back over SEVERAL block columns at once (round 4; the form launch_cholesky uses when a batch oversubscribes the chip).
+// With many runs side by side the look-back is bound by the bytes it pulls through the fabric (3.2-3.8 TB/s in 512-byte row
+// segments, profiles/r03/pmc_summary.txt), and the bytes that cannot be shared are the tiles L[I][p] of the row being updated:
+// every block column J > p reads them again.  A work-group therefore updates its block row I in NC neighbouring block columns
+// Jc .. Jc + ncols - 1 per step: the tile L[I][p] goes into the LDS once, the tiles L[Jc + c][p] (shared by the whole launch,
+// L2 hits on the run's XCD) follow one after the other, each with 64 MFMAs per wave - the unshared traffic per flop falls by
+// ncols.  Steps p0 <= p < p1: the schedule (launch_cholesky) runs it once per group of NC columns over all earlier panels and
+// once after each panel inside the group for the columns still to come (p1 = p0 + 1).  Per element nothing changes - the
+// products of panel p accumulate from zero over ascending k and are subtracted from the tile in ascending p, the value merely
+// passes through memory between two launches - so the factors are those of k_chol_lookback / k_chol_step bit for bit
+// (tests/golden/gp_factor_hashes.json).  copy_panel >= 0: the extra last work-group puts that panel's diagonal factor in place.
+template <int NC>
+__global__ __launch_bounds__(256 * NC) void k_chol_lookn(double* __restrict__ A, int Jc, int ncols, int p0, int p1, int ld,
+                                                         const double* __restrict__ diag_scratch, int copy_panel, size_t zs) {
+  const XcdTile xt_ = xcd_tile();
+  ZRUNX(A); ZRUNX(diag_scratch);
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];      // the row tile, then one tile per column group
+  double* s_a = s_dyn;
+  const int tid = threadIdx.x, c = __builtin_amdgcn_readfirstlane(tid >> 8), lt = tid & 255, w = lt >> 6, l = lt & 63;
+  double* s_b = s_dyn + (size_t)(1 + c) * BS * TLD;
+  if (xt_.x == gridDim.x - 1) {
+    if (copy_panel >= 0) {
+      double* Add = A + (size_t)(copy_panel * BS) * ld + copy_panel * BS;
+      for (int idx = tid; idx < BS * BS; idx += 256 * NC) Add[(size_t)(idx >> 6) * ld + (idx & 63)] = diag_scratch[idx];
+    }
+    return;
+  }
+  // four waves per block column of the group (wave group c: column Jc + c), every wave group its own tile L[Jc + c][p]; the
+  // row tile L[I][p] is loaded once by all of them together
+  const int I = Jc + (int)xt_.x;
+  const bool live = c < ncols && Jc + c <= I;          // (a column right of the diagonal: nothing to update in this block row)
+  const double* Arow = A + (size_t)(I * BS) * ld;
+  const double* Brow = A + (size_t)((Jc + c) * BS) * ld;
+  double* dst = A + (size_t)(I * BS) * ld + (size_t)(Jc + c) * BS;
+  double cold[4][4];
+  if (live) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cold[q][r] = dst[(size_t)(16 * w + (l >> 4) + 4 * r) * ld + 16 * q + (l & 15)];
+  }
+  constexpr int NA = 16 / NC;                          // elements of the row tile per thread
+  double pa[NA], pb[16];
+  auto fetch = [&](int p) {
+#pragma unroll
+    for (int u = 0; u < NA; ++u) { const int idx = tid + 256 * NC * u; pa[u] = Arow[(size_t)(idx >> 6) * ld + p * BS + (idx & 63)]; }
+    if (live) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { const int idx = lt + 256 * u; pb[u] = Brow[(size_t)(idx >> 6) * ld + p * BS + (idx & 63)]; }
+    }
+  };
+  auto put = [&]() {
+#pragma unroll
+    for (int u = 0; u < NA; ++u) { const int idx = tid + 256 * NC * u; s_a[(idx >> 6) * TLD + (idx & 63)] = pa[u]; }
+    if (live) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { const int idx = lt + 256 * u; s_b[(idx >> 6) * TLD + (idx & 63)] = pb[u]; }
+    }
+  };
+  fetch(p0);
+  for (int p = p0; p < p1; ++p) {
+    __syncthreads();                                  // the previous step's MFMAs have read the LDS tiles
+    put();
+    if (p + 1 < p1) fetch(p + 1);
+    __syncthreads();
+    if (live) {
+      double4_t acc[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = (double4_t){0.0, 0.0, 0.0, 0.0};
+      for (int kk = 0; kk < BS; kk += 4) {
+        const double a = s_a[(16 * w + (l & 15)) * TLD + kk + (l >> 4)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double bb = s_b[(16 * q + (l & 15)) * TLD + kk + (l >> 4)];
+          acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[q], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cold[q][r] -= acc[q][r];
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[(size_t)(16 * w + (l >> 4) + 4 * r) * ld + 16 * q + (l & 15)] = cold[q][r];
+  }
+}
+#define CHOL_LOOKN_NC 2
+#define CHOL_LOOKN_LDS ((size_t)(1 + CHOL_LOOKN_NC) * BS * TLD * sizeof(double))
+
 // ---------------------------------------------------------------------------------------------
 // Root inverse R = L^-1 (what gpytorch caches as `covar_cache`, stored here un-transposed).
 // Step 1 (k_trinv_diag_w, kernels_gpw.hip): invert every 64x64 diagonal block, a column of the inverse per lane.
@@ -182,11 +278,12 @@ __global__ __launch_bounds__(256) void k_chol_lookback(double* __restrict__ A, i
 // and each used to pay a full global-load latency (2 us per step, 62 us per call on average).
 __global__ __launch_bounds__(256) void k_trinv_cols(const double* __restrict__ L, int nblk, int ld,
                                                     double* R, size_t zs) {
-  ZRUN(L); ZRUN(R);
+  const XcdTile xt_ = xcd_tile();                    // (the column chunks of a run walk the same L tiles: one XCD, one L2 copy)
+  ZRUNX(L); ZRUNX(R);
   __shared__ __attribute__((aligned(16))) double s_t[BS * TLD];   // 64x64 operand tile
   __shared__ __attribute__((aligned(16))) double s_xk[BS * 16];   // 64x16 block of X (or S)
   const int tid = threadIdx.x;
-  const int c0 = blockIdx.x * 16;
+  const int c0 = (int)xt_.x * 16;
   const int J = c0 / BS;
   const int w = tid >> 6, l = tid & 63;
   double pt[16], px[4];                                            // prefetched tile / X block (this thread's share)
@@ -302,11 +399,51 @@ void launch_cholesky(hipStream_t s, double* L, int NP, int ld, int* info, double
   //    (measured round 3, us: n=450: 223 -> 161 (1 run), 248 -> 221 (30 runs); n=1050: 709 -> 514 (1 run));
   //  * look-back launch + panel launch per panel (round 2) where the chip is oversubscribed anyway and the lighter
   //    look-back groups (2-3 per CU) keep the matrix cores busier: 30 runs at n = 1050: 983 us against 1132 fused.
+  //  * round 4, the oversubscribed case in groups of NC = 4 block columns (k_chol_lookn): one look-back over all earlier panels
+  //    for the four columns together (the row tiles L[I][p] read once instead of four times), then per panel of the group the
+  //    panel launch and one single-step update of the group's remaining columns - the same number of launches, the same bits.
   if (zb.B * nblk <= 256) { launch_chol_steps(s, L, NP, ld, info, diag_scratch, zb); return; }
-  for (int p = 0; p < nblk; ++p) {                   // bring block column p up to date, then factor it
-    if (p > 0)
-      hipLaunchKernelGGL(k_chol_lookback, dim3(nblk - p + 1, 1, zb.B), dim3(256), 0, s, L, p, nblk, ld, diag_scratch, zb.zs);
-    launch_chol_panel(s, L, p, nblk - p, ld, info, diag_scratch, zb);
+  if (zb.B * nblk > 1024) {
+    // several waves of work-groups per launch: two independent 4-wave groups per CU overlap one's loads with the other's MFMAs
+    // better than one 8-wave group in lock-step (measured round 4, us: 120 runs at n = 1050: 2 468 against 2 602 grouped; the
+    // grouped form wins below: 30 runs at n = 1050 947 -> 913, 120 runs at n = 450 444 -> 431)
+    for (int p = 0; p < nblk; ++p) {                   // bring block column p up to date, then factor it
+      if (p > 0)
+        hipLaunchKernelGGL(k_chol_lookback, dim3(nblk - p + 1, 1, zb.B), dim3(256), 0, s, L, p, nblk, ld, diag_scratch, zb.zs);
+      launch_chol_panel(s, L, p, nblk - p, ld, info, diag_scratch, zb);
+    }
+    return;
+  }
+  constexpr int NC = CHOL_LOOKN_NC;
+  {
+    static std::mutex attr_mu;
+    static bool attr_done[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+    std::lock_guard<std::mutex> lk(attr_mu);
+    if (!attr_done[dev]) {
+      if (hipFuncSetAttribute((const void*)k_chol_lookn<NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHOL_LOOKN_LDS) != hipSuccess) return;
+      attr_done[dev] = true;
+    }
+  }
+  int last_panel = -1;                               // the panel whose diagonal factor still sits in the scratch tile
+  for (int Jc = 0; Jc < nblk; Jc += NC) {
+    const int ncols = nblk - Jc < NC ? nblk - Jc : NC;
+    if (Jc > 0) {
+      hipLaunchKernelGGL(k_chol_lookn<NC>, dim3(nblk - Jc + 1, 1, zb.B), dim3(256 * NC), CHOL_LOOKN_LDS, s, L, Jc, ncols, 0, Jc, ld,
+                         diag_scratch, last_panel, zb.zs);
+      last_panel = -1;
+    }
+    for (int c = 0; c < ncols; ++c) {
+      const int p = Jc + c;
+      launch_chol_panel(s, L, p, nblk - p, ld, info, diag_scratch, zb);
+      last_panel = nblk - p > 1 ? p : -1;            // (the last panel has one group and stores its factor directly)
+      if (c + 1 < ncols) {                           // columns p + 1 .. of the group: the contribution of panel p
+        hipLaunchKernelGGL(k_chol_lookn<NC>, dim3(nblk - (p + 1) + 1, 1, zb.B), dim3(256 * NC), CHOL_LOOKN_LDS, s, L, p + 1,
+                           ncols - c - 1, p, p + 1, ld, diag_scratch, last_panel, zb.zs);
+        last_panel = -1;
+      }
+    }
   }
 }
 void launch_trinv(hipStream_t s, const double* L, int NP, int ld, double* R, ZB zb) {

@@ -159,12 +159,13 @@ __device__ inline void panel_m_solve_step(double4_t (&acc)[4][4], const double* 
 
 __global__ __launch_bounds__(128) void k_chol_panel_m(double* __restrict__ A, int p, int ld, int* __restrict__ info,
                                                       double* __restrict__ diag_scratch, size_t zs) {
-  ZRUN(A); ZRUN(info); ZRUN(diag_scratch);
+  const XcdTile xt_ = xcd_tile();                    // (every group of a run reads the run's diagonal block: one XCD)
+  ZRUNX(A); ZRUNX(info); ZRUNX(diag_scratch);
   __shared__ double s_d[BS * WLD];
   __shared__ double s_a[BS * WLD];
   __shared__ double s_rs[BS];
   __shared__ double s_col[2 * BS];
-  const int r = threadIdx.x & 63, role = threadIdx.x >> 6, b = blockIdx.x;
+  const int r = threadIdx.x & 63, role = threadIdx.x >> 6, b = (int)xt_.x;
   PSTAMP(0);
   double* Add = A + (size_t)(p * BS) * ld + p * BS;
   double* Abd = A + (size_t)((p + b) * BS) * ld + p * BS;

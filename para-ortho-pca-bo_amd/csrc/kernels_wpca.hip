@@ -217,6 +217,9 @@ extern "C" int pcabo_debug_jacobi_stamps(unsigned long long* out4) {
 struct PcaSelect {        // arguments of the selection step that ends the kernel (rows C, PCA_BO.py:389-399)
   int n; double var_threshold; int n_components; double* comps; double* evr; int* k_dev; HostMirror* hm;
 };
+// NT: rows of a column pair that a lane keeps in registers between the dot products and the rotation (16 lanes per pair: NT = 4 covers
+// d <= 64, NT = 8 the whole range d <= 128 - configs[4]'s d = 100 used to take the second loop, two LDS reads per element and round)
+template <int NT>
 __global__ __launch_bounds__(JAC_THREADS) void k_jacobi(const double* __restrict__ C, int d, int DP,
                                                         const double* __restrict__ V0, double* __restrict__ Gout,
                                                         double* __restrict__ lam, int* __restrict__ sweeps_out,
@@ -245,10 +248,19 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi(const double* __restrict
     __syncthreads();
   }
   if (V0) {                                  // usable only if every column has unit norm (none collapsed to zero)
-    for (int col = tid; col < d; col += (int)blockDim.x) {
-      double a = 0.0;
-      for (int r = 0; r < d; ++r) { double v = staged ? s_v[col * LD + r] : V0[(size_t)col * d + r]; a += v * v; }
-      if (!(fabs(a - 1.0) < 1e-8)) s_rot = 1;
+    if (staged) {
+      for (int col = tid; col < d; col += (int)blockDim.x) {
+        double a = 0.0;
+        for (int r = 0; r < d; ++r) { double v = s_v[col * LD + r]; a += v * v; }
+        if (!(fabs(a - 1.0) < 1e-8)) s_rot = 1;
+      }
+    } else {                                 // from global memory: a wave per column, coalesced (a thread per column walked d lines one by one)
+      for (int col = tid >> 6; col < d; col += (int)blockDim.x >> 6) {
+        double a = 0.0;
+        for (int r = tid & 63; r < d; r += 64) { const double v = V0[(size_t)col * d + r]; a += v * v; }
+        a = wave_sum(a);
+        if ((tid & 63) == 0 && !(fabs(a - 1.0) < 1e-8)) s_rot = 1;
+      }
     }
   }
   __syncthreads();
@@ -282,10 +294,12 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi(const double* __restrict
       const double* vcol = s_v + col * LD;
       for (int j = 0; j < d; ++j) v += (crow[j] * cscale) * vcol[j];
     } else if (warm) {
+      // C is symmetric BIT FOR BIT (k_cov forms C[i][j] and C[j][i] from the same products in the same order), so row `row` is read as
+      // column `row`: consecutive lanes, consecutive addresses (reading the row itself put every lane on a line of its own)
       v = 0.0;
-      const double* crow = C + (size_t)row * DP;
+      const double* ccol = C + row;
       const double* vcol = V0 + (size_t)col * d;
-      for (int j = 0; j < d; ++j) v += (crow[j] * cscale) * vcol[j];
+      for (int j = 0; j < d; ++j) v += (ccol[(size_t)j * DP] * cscale) * vcol[j];
     } else {
       v = C[(size_t)row * DP + col] * cscale;
     }
@@ -327,16 +341,16 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi(const double* __restrict
           double* gq = s_g + q * LD;
           // the lane's rows stay in registers between the dot products and the rotation (d <= 4 LP: 4 rows at most
           // on the fast path; longer columns take the second loop)
-          double xr[4], yr[4];
+          double xr[NT], yr[NT];
           double a = 0.0, b = 0.0, g = 0.0;
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
+          for (int t = 0; t < NT; ++t) {
             const int r = lane + t * LP;
             xr[t] = r < d ? gp[r] : 0.0;
             yr[t] = r < d ? gq[r] : 0.0;
             a += xr[t] * xr[t]; b += yr[t] * yr[t]; g += xr[t] * yr[t];
           }
-          for (int r = lane + 4 * LP; r < d; r += LP) {
+          for (int r = lane + NT * LP; r < d; r += LP) {
             double x = gp[r], y = gq[r];
             a += x * x; b += y * y; g += x * y;
           }
@@ -367,11 +381,11 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi(const double* __restrict
             if (cs == 123.456) s_rot = 2;      // (timing build only) keeps cs live before the stamp
             JSTAMP(ph_rot);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NT; ++u) {
               const int r = lane + u * LP;
               if (r < d) { gp[r] = cs * xr[u] - sn * yr[u]; gq[r] = sn * xr[u] + cs * yr[u]; }
             }
-            for (int r = lane + 4 * LP; r < d; r += LP) {
+            for (int r = lane + NT * LP; r < d; r += LP) {
               double x = gp[r], y = gq[r];
               gp[r] = cs * x - sn * y;
               gq[r] = sn * x + cs * y;
@@ -641,7 +655,8 @@ void launch_jacobi(hipStream_t s, const double* C, int d, int DP, const double* 
   static bool attr_set = false;
   if (!attr_set) {
     // 160 KB per work-group minus the kernel's static arrays (2.5 KB); d = 128 needs 132 KB of dynamic LDS
-    (void)hipFuncSetAttribute((const void*)k_jacobi, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_jacobi<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_jacobi<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     attr_set = true;
   }
   const int npairs = ((d + 1) & ~1) / 2;
@@ -649,7 +664,8 @@ void launch_jacobi(hipStream_t s, const double* C, int d, int DP, const double* 
   threads = (threads + 63) & ~63;
   if (threads < d) threads = (d + 63) & ~63;          // the selection step at the end uses one thread per component
   PcaSelect sel{n, var_threshold, n_components, comps, evr, k_dev, hm};
-  hipLaunchKernelGGL(k_jacobi, dim3(1, 1, zb.B), dim3(threads), lds, s, C, d, DP, V0, G, lam, sweeps, sel, zb.zs, zb.hzs);
+  if (d <= 64) hipLaunchKernelGGL(k_jacobi<4>, dim3(1, 1, zb.B), dim3(threads), lds, s, C, d, DP, V0, G, lam, sweeps, sel, zb.zs, zb.hzs);
+  else hipLaunchKernelGGL(k_jacobi<8>, dim3(1, 1, zb.B), dim3(threads), lds, s, C, d, DP, V0, G, lam, sweeps, sel, zb.zs, zb.hzs);
 }
 void launch_project(hipStream_t s, const double* X, const double* data_mean, const double* pca_mean,
                     const double* comps, const int* k_dev, int n, int d, double* Z, ZB zb) {

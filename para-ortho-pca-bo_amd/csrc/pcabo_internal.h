@@ -132,6 +132,28 @@ __device__ inline T* zrun(T* p, size_t stride, unsigned run) {
 }
 #define ZRUN(p) p = zrun(p, zs, blockIdx.z)
 
+// XCD-aware placement of a batched launch (grid (gx, gy, B), B runs of gx * gy tiles each).  Work-groups are dealt round-robin
+// over the 8 XCDs in dispatch order (x fastest), so the tiles of ONE run land on eight different L2s and every XCD fetches
+// the operand tiles those work-groups share (the block row L[J][.] of a look-back, the diagonal block of a panel, the L
+// tiles a column chunk of the root inverse walks) for itself.  The linear work-group id is read as (run, tile) such that all
+// tiles of a run have the same id % 8: one XCD, one L2 copy of the shared operands.  Placement only - every (run, tile)
+// pair is still visited exactly once, whatever the hardware does with the ids; runs beyond the last multiple of 8 (and
+// single contexts) keep the identity mapping.
+struct XcdTile { unsigned run, x, y; };
+#if defined(__HIPCC__)
+__device__ inline XcdTile xcd_tile() {
+  const unsigned gx = gridDim.x, gy = gridDim.y, T = gx * gy;
+  const unsigned lin = (blockIdx.z * gy + blockIdx.y) * gx + blockIdx.x, full = (gridDim.z & ~7u) * T;
+  XcdTile t;
+  if (lin < full) {
+    const unsigned slot = lin >> 3, tile = slot % T;
+    t.run = (slot / T) * 8u + (lin & 7u); t.x = tile % gx; t.y = tile / gx;
+  } else { t.run = blockIdx.z; t.x = blockIdx.x; t.y = blockIdx.y; }
+  return t;
+}
+#endif
+#define ZRUNX(p) p = zrun(p, zs, xt_.run)
+
 // Wave-wide sum without LDS traffic.  `__shfl_xor` compiles to ds_bpermute_b32 (two per double, each followed by an
 // lgkmcnt wait: ~100 cycles of dependent latency per step); in a kernel whose whole budget is ~15 us the reductions
 // were the largest single item.  DPP steps stay inside the VALU: quad_perm x2, row_half_mirror, row_mirror leave the

@@ -950,3 +950,34 @@ def test_acq_group_bits_are_pinned(native):
     assert set(got) == set(golden)
     for case in golden:
         assert got[case] == golden[case], case
+
+
+@pytest.mark.parametrize("n,k,B", [(450, 20, 34), (1050, 30, 17), (200, 6, 70), (450, 12, 136)])
+def test_oversubscribed_batch_factors_equal_the_single_context_bit_for_bit(native, n, k, B):
+    """launch_cholesky has two forms: one launch per panel (k_chol_step: single runs, small batches) and, once a batch holds more
+    tile rows than the chip has CUs (B * nblk > 256), look-backs + panel launches - over groups of two block columns up to 1 024
+    tile rows (k_chol_lookn, round 4: the row tiles L[I][p] read once per group), column by column beyond (k_chol_lookback); all
+    with XCD-aware tile placement.  Both accumulate a panel's products from zero
+    and subtract panels in ascending order, so a run's L, R and alpha must be the SAME BITS in a batch of any size and alone -
+    the invariant the batch drivers, the sharded runner and tests/golden/gp_factor_hashes.json rest on."""
+    from pcabo import _native as N
+    rng = np.random.default_rng(1000 * n + B)
+    Z = rng.uniform(0, 1, (B, n, k))
+    y = rng.normal(size=(B, n))
+    assert B * ((n + 63) // 64) > 256                        # the oversubscribed form is the one that runs
+    bt = N.Batch(B, max_n=n, max_d=k, max_q=64)
+    bt.gp_condition_begin(Z, y)
+    box = bt.acq_bounds()
+    _, status = bt.gp_wait_eval([box[b].mean(axis=0).reshape(1, -1).repeat(16, 0) for b in range(B)], [float(y[b].min()) for b in range(B)])
+    assert not status.any()
+    for b in sorted({0, 1, 7, B // 2, B - 2, B - 1}):       # (runs on both sides of the XCD placement's groups of eight)
+        c = bt.ctx[b]
+        c.n, c.k = n, k
+        got = c.gp_state()
+        one = N.Context(max_n=n, max_d=k, max_q=64)
+        one.gp_condition(y[b], Z=Z[b])
+        want = one.gp_state()
+        for f in ("L", "R", "alpha"):
+            assert np.array_equal(np.asarray(got[f]), np.asarray(want[f])), (b, f)
+        one.close()
+    bt.close()

@@ -147,7 +147,7 @@ def rocprof_summary():
     it, profiles/<round>/bench_steps20_kernel_stats.csv): the plain-launch acquisition kernel (one launch per round, what the
     profiled pass executes) and the resident one (what the timed region executes, one launch per optimize call)."""
     import csv
-    for rel in ("r03", "r02"):
+    for rel in ("r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", rel, "bench_steps20_kernel_stats.csv")
         if not os.path.exists(path):
             continue
@@ -206,10 +206,49 @@ def batch_per_gpu(device: int, rank: int, size: int, B: int = 30):
                     "exchanged with one all-gather after the timed region"}
 
 
+def device_lbfgsb_roofline(block: dict, runs_per_batch: int) -> dict:
+    """k_lbfgsb_group against the HBM peak, two ways, both stated: (a) from the KERNEL's time - the committed rocprofv3 kernel
+    statistics of a 30-run device-mode batch (profiles/<round>/batch30_device_kernel_stats.csv) with the algorithmic bytes that
+    same run reported (batch30_device_under_rocprof.json): `achieved` / `frac`; (b) over the wall time of this run's 4-batch block
+    (all phases of the iterations included): `block_*`.  Algorithmic bytes per evaluation of a restart group: 8 n (n + 1) + 16 n k
+    + 8 n (the triangles of R and of its transpose, the normalised points twice, alpha).  The bytes are served by the
+    L2 / Infinity Cache, not by HBM: FETCH / WRITE per launch from the separate --pmc passes are quoted beside them."""
+    import csv
+    out = {"kernel": "k_lbfgsb_group", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "block_runs_in_flight": 4 * runs_per_batch, "block_achieved": block["lbfgsb_algorithmic_bytes"] / block["seconds"] / 1e9,
+           "block_frac": block["lbfgsb_algorithmic_bytes"] / block["seconds"] / 1e9 / HBM_PEAK_GBS,
+           "block_group_evaluations": block["lbfgsb_group_evaluations"], "block_algorithmic_bytes": block["lbfgsb_algorithmic_bytes"],
+           "cache_level": "L2 / Infinity Cache resident (R, RT, ZnT of a run: <= 3.5 MB); HBM sees what the PMC passes count"}
+    for rel in ("r04", "r03"):
+        stats = os.path.join(ROOT, "profiles", rel, "batch30_device_kernel_stats.csv")
+        run = os.path.join(ROOT, "profiles", rel, "batch30_device_under_rocprof.json")
+        if not (os.path.exists(stats) and os.path.exists(run)):
+            continue
+        try:
+            row = next(r for r in csv.DictReader(open(stats)) if r["Name"].startswith("k_lbfgsb_group"))
+            meta = json.loads(open(run).read().strip().splitlines()[-1])
+            sec = float(row["TotalDurationNs"]) * 1e-9
+            out.update({"achieved": meta["lbfgsb_algorithmic_bytes"] / sec / 1e9, "frac": meta["lbfgsb_algorithmic_bytes"] / sec / 1e9 / HBM_PEAK_GBS,
+                        "kernel_launches": int(row["Calls"]), "kernel_avg_ms": float(row["AverageNs"]) * 1e-6,
+                        "kernel_share_of_gpu_time_percent": float(row["Percentage"]),
+                        "group_evaluations": meta["lbfgsb_group_evaluations"], "algorithmic_bytes": meta["lbfgsb_algorithmic_bytes"],
+                        "source": f"profiles/{rel}/batch30_device_kernel_stats.csv (rocprofv3 --kernel-trace --stats over tools/gpu_batch_clock.py 30 40 15 1 0 device)"})
+            pmc = os.path.join(ROOT, "profiles", rel, "pmc_device_lbfgsb.json")
+            if os.path.exists(pmc):
+                kk = json.load(open(pmc))["kernels"].get("k_lbfgsb_group")
+                if kk and kk["dispatches"]:
+                    out["traffic_per_launch"] = {"fetch_bytes": kk["fetch_bytes"] / kk["dispatches"], "write_bytes": kk["write_bytes"] / kk["dispatches"],
+                                                 "source": f"profiles/{rel}/pmc_device_lbfgsb.json (8-run batch; FETCH_SIZE x 2 per the gfx950 note, WRITE_SIZE)"}
+        except Exception as e:     # noqa: BLE001
+            out["kernel_time_error"] = str(e)
+        break
+    return out
+
+
 def nearest_pmc(n_mean: float):
     """PMC traffic of the acquisition kernel at the shape of the committed table that is closest to the mean n of the
     timed steps (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied)."""
-    for rel in ("r02", "r01"):
+    for rel in ("r04", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", rel, "pmc_traffic.json")
         try:
             pmc = json.load(open(path))
@@ -409,13 +448,7 @@ def main():
             # what the device-resident optimiser's evaluations move, algorithmically, against the chip's HBM peak: evaluations the
             # optimisers report x bytes of one evaluation at that iteration's (n, k), over the wall time of the whole block (all
             # phases of the iterations, not the kernel alone - an aggregate, beside `roofline` of the single run's kernel)
-            batch["roofline_device_lbfgsb"] = {
-                "kernel": "k_lbfgsb_group (4 x %d runs in flight)" % (2 * args.batch), "bound": "hbm", "peak": 8000.0, "unit": "GB/s",
-                "achieved": dev2["lbfgsb_algorithmic_bytes"] / dev2["seconds"] / 1e9,
-                "frac": dev2["lbfgsb_algorithmic_bytes"] / dev2["seconds"] / 1e9 / 8000.0,
-                "group_evaluations": dev2["lbfgsb_group_evaluations"], "algorithmic_bytes": dev2["lbfgsb_algorithmic_bytes"],
-                "note": "one CU streams ~32 GB/s per work-group whatever the cache level (profiles/r03/device_lbfgsb_phases_n449_30runs.txt, "
-                        "DESIGN.md 8b); the traffic is served by L2 / Infinity Cache (profiles/r03/pmc_device_lbfgsb.json)"}
+            batch["roofline_device_lbfgsb"] = device_lbfgsb_roofline(dev2, 2 * args.batch)
     if rank == 0 and size == 1 and not args.no_kchol_grid and not args.no_roofline:
         from pcabo import kchol_bench
         grid = kchol_bench.run(device, (1, 30), reps=3, big_batch=120)

@@ -123,21 +123,24 @@ __global__ __launch_bounds__(256) void k_chol_lookback(double* __restrict__ A, i
   for (int q = 0; q < 4; ++q)
 #pragma unroll
     for (int r = 0; r < 4; ++r) cold[q][r] = dst[(size_t)(16 * w + (l >> 4) + 4 * r) * ld + 16 * q + (l & 15)];
-  double pa[16], pb[16];
+  // 16 bytes per lane and load: a CU issues a wave's load instruction every ~11 ns whatever its width (the look-back's 128 eight-byte
+  // loads per step were 1.4 us of address path beside 1.7 us of MFMAs); LDS rows are 528 bytes apart: 16-byte aligned pairs
+  typedef double d2_t __attribute__((ext_vector_type(2)));
+  d2_t pa[8], pb[8];
   auto fetch = [&](int p) {
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int idx = tid + 256 * u, r = idx >> 6, c = idx & 63;
-      pa[u] = Arow[(size_t)r * ld + p * BS + c];
-      pb[u] = Brow[(size_t)r * ld + p * BS + c];          // (the same tile on the diagonal: an L2 hit)
+    for (int u = 0; u < 8; ++u) {
+      const int idx = tid + 256 * u, r = idx >> 5, c = (idx & 31) * 2;
+      pa[u] = *reinterpret_cast<const d2_t*>(Arow + (size_t)r * ld + p * BS + c);
+      pb[u] = *reinterpret_cast<const d2_t*>(Brow + (size_t)r * ld + p * BS + c);          // (the same tile on the diagonal: an L2 hit)
     }
   };
   auto put = [&]() {
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int idx = tid + 256 * u, r = idx >> 6, c = idx & 63;
-      s_a[r * TLD + c] = pa[u];
-      s_b[r * TLD + c] = pb[u];
+    for (int u = 0; u < 8; ++u) {
+      const int idx = tid + 256 * u, r = idx >> 5, c = (idx & 31) * 2;
+      *reinterpret_cast<d2_t*>(s_a + r * TLD + c) = pa[u];
+      *reinterpret_cast<d2_t*>(s_b + r * TLD + c) = pb[u];
     }
   };
   (void)diag;
@@ -212,22 +215,29 @@ __global__ __launch_bounds__(256 * NC) void k_chol_lookn(double* __restrict__ A,
 #pragma unroll
       for (int r = 0; r < 4; ++r) cold[q][r] = dst[(size_t)(16 * w + (l >> 4) + 4 * r) * ld + 16 * q + (l & 15)];
   }
-  constexpr int NA = 16 / NC;                          // elements of the row tile per thread
-  double pa[NA], pb[16];
+  typedef double d2_t __attribute__((ext_vector_type(2)));
+  constexpr int NA = 8 / NC;                           // 16-byte pieces of the row tile per thread
+  d2_t pa[NA], pb[8];
   auto fetch = [&](int p) {
 #pragma unroll
-    for (int u = 0; u < NA; ++u) { const int idx = tid + 256 * NC * u; pa[u] = Arow[(size_t)(idx >> 6) * ld + p * BS + (idx & 63)]; }
+    for (int u = 0; u < NA; ++u) {
+      const int idx = tid + 256 * NC * u;
+      pa[u] = *reinterpret_cast<const d2_t*>(Arow + (size_t)(idx >> 5) * ld + p * BS + (idx & 31) * 2);
+    }
     if (live) {
 #pragma unroll
-      for (int u = 0; u < 16; ++u) { const int idx = lt + 256 * u; pb[u] = Brow[(size_t)(idx >> 6) * ld + p * BS + (idx & 63)]; }
+      for (int u = 0; u < 8; ++u) {
+        const int idx = lt + 256 * u;
+        pb[u] = *reinterpret_cast<const d2_t*>(Brow + (size_t)(idx >> 5) * ld + p * BS + (idx & 31) * 2);
+      }
     }
   };
   auto put = [&]() {
 #pragma unroll
-    for (int u = 0; u < NA; ++u) { const int idx = tid + 256 * NC * u; s_a[(idx >> 6) * TLD + (idx & 63)] = pa[u]; }
+    for (int u = 0; u < NA; ++u) { const int idx = tid + 256 * NC * u; *reinterpret_cast<d2_t*>(s_a + (idx >> 5) * TLD + (idx & 31) * 2) = pa[u]; }
     if (live) {
 #pragma unroll
-      for (int u = 0; u < 16; ++u) { const int idx = lt + 256 * u; s_b[(idx >> 6) * TLD + (idx & 63)] = pb[u]; }
+      for (int u = 0; u < 8; ++u) { const int idx = lt + 256 * u; *reinterpret_cast<d2_t*>(s_b + (idx >> 5) * TLD + (idx & 31) * 2) = pb[u]; }
     }
   };
   fetch(p0);

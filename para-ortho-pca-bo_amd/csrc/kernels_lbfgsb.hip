@@ -1261,6 +1261,7 @@ __device__ __noinline__ void lb_formt(const LbLds L, int lane) {
 // lbfgsb.cpp: Lbfgsb::step (reverse communication), the state in LDS.  Returns the task.
 __device__ int lb_step(const LbLds L, int lane) {
   const int n = L.n;
+  LBT_BEGIN();                                         // (timing build: the step's own code between the routines, slots 41 ..)
   const double pgtol = 1e-5, factr = 1e7;
   if (ISR(I_TASK) >= LBFGSB_CONV_PG) return ISR(I_TASK);
   bool need_iteration_start = false, resume_linesearch = false;
@@ -1308,6 +1309,7 @@ __device__ int lb_step(const LbLds L, int lane) {
       // formt goes to the helper wave; the Cauchy search below waits for it where it first needs T.  (If it fails the search
       // returns with the failure set and the memory is reset there - the host resets it here and searches with an empty
       // memory: the same state either way, the search's first part depends on x, g and the bounds only)
+      LBT_NEXT(41);                                  // tests, r = g - r, r'r, scaling of d
       { LBT_BEGIN(); lb_matupd_a(L, rr, dr, lane); LBT_NEXT(6); }
       sti0(&ISC(I_HPEND), 1, lane);
       lb_help_post(L, LB_OP_FORMT, lane);               // (the rest of matupd, then formt)
@@ -1318,7 +1320,11 @@ __device__ int lb_step(const LbLds L, int lane) {
     if (need_iteration_start) {
       need_iteration_start = false;
       sti0(&ISC(I_IWORD), -1, lane);
+      LBT_NEXT(42);                                  // posts, flags in front of the Cauchy search
       { LBT_BEGIN(); lb_cauchy(L, lane); LBT_NEXT(0); }
+#ifdef PCABO_ACQ_TIMING
+      lbt_t0_ = wall_clock64();
+#endif
       lb_await_formt(L, lane);                          // (a search that returned before it needed T)
       if (ISR(I_INFO) != 0) { lb_reset_memory(L, lane); need_iteration_start = true; continue; }
       { LBT_BEGIN(); lb_freev(L, lane); LBT_NEXT(1); }
@@ -1334,12 +1340,22 @@ __device__ int lb_step(const LbLds L, int lane) {
         if (ISR(I_INFO) == 0) { LBT_BEGIN(); lb_subsm(L, lane); LBT_NEXT(4); }
         if (ISR(I_INFO) != 0) { lb_reset_memory(L, lane); need_iteration_start = true; continue; }
       }
+#ifdef PCABO_ACQ_TIMING
+      lbt_t0_ = wall_clock64();
+#endif
       for (int i = lane; i < n; i += 64) L.d()[i] = L.z()[i] - L.x()[i];
       sti0(&ISC(I_PHASE), 0, lane);
       LSYNC();
+      LBT_NEXT(43);                                  // d = z - x
     }
+#ifdef PCABO_ACQ_TIMING
+    lbt_t0_ = wall_clock64();
+#endif
     if (resume_linesearch) { resume_linesearch = false; sti0(&ISC(I_PHASE), 2, lane); LSYNC(); }
     { LBT_BEGIN(); lb_lnsrlb(L, lane); LBT_NEXT(5); }
+#ifdef PCABO_ACQ_TIMING
+    lbt_t0_ = wall_clock64();
+#endif
     if (ISR(I_INFO) != 0 || ISR(I_IBACK) >= 20) {
       for (int i = lane; i < n; i += 64) { L.x()[i] = L.t()[i]; L.g()[i] = L.r()[i]; }
       if (lane == 0) SC(S_F) = SR(S_FOLD);
@@ -1364,6 +1380,7 @@ __device__ int lb_step(const LbLds L, int lane) {
     lb_projgr(L, lane);
     if (lane == 0) { ISC(I_PHASE) = 3; ISC(I_TASK) = LBFGSB_NEW_X; }
     LSYNC();
+    LBT_NEXT(44);                                    // the tail of an accepted line search: iteration count, projected gradient
     return LBFGSB_NEW_X;
   }
 }
@@ -1907,6 +1924,7 @@ __global__ __launch_bounds__(LB_THREADS) void k_lbfgsb_group(
       }
     }
     __syncthreads();
+    LBT_NEXT(46);                                    // absorb: NaN check, f, cache copies, barrier
     if (!ISR(I_ACTIVE)) break;
   }
   __syncthreads();

@@ -30,7 +30,7 @@ names = {0: "cauchy", 1: "freev", 2: "formk", 3: "cmprlb", 4: "subsm", 5: "lnsrl
          14: "eval: contraction", 16: "step (advance, all of it)", 17: "evaluation (all of it)",
          18: "formk: shift + fill", 19: "formk: accum", 20: "formk: new column", 21: "formk: corrections", 22: "formk: assemble WN",
          23: "formk: dpofa 1", 24: "formk: solves", 25: "formk: products", 26: "formk: dpofa 2",
-         32: "cauchy: classify", 33: "cauchy: f1 + accum + copy", 34: "cauchy: wait for formt", 35: "cauchy: bmv + ddot", 36: "cauchy: breakpoint loop", 37: "lnsrlb: head (stpmx scan, copies / state load)", 38: "lnsrlb: g'd", 39: "lnsrlb: dcsrch + trial point", 40: "cauchy: breakpoints crossed (count)",
+         32: "cauchy: classify", 33: "cauchy: f1 + accum + copy", 34: "cauchy: wait for formt", 35: "cauchy: bmv + ddot", 36: "cauchy: breakpoint loop", 37: "lnsrlb: head (stpmx scan, copies / state load)", 38: "lnsrlb: g'd", 39: "lnsrlb: dcsrch + trial point", 40: "cauchy: breakpoints crossed (count)", 41: "step: head of an iteration (tests, r = g - r, r'r)", 42: "step: posts in front of cauchy", 43: "step: d = z - x", 44: "step: tail of an accepted search (projgr)", 46: "kernel: absorb + barrier",
          27: "subsm: scatter", 28: "subsm: accum", 29: "subsm: solves", 30: "subsm: update full", 31: "subsm: project"}
 have = hasattr(N.LIB, "pcabo_debug_lb_ticks")
 for rep in range(3):

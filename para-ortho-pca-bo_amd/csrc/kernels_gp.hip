@@ -100,12 +100,17 @@ __device__ inline void load_tile(const double* __restrict__ src, int ld, double*
 // L2 / Infinity-Cache bandwidth at ~3 TB/s with many runs side by side); operand tiles go through LDS with a leading
 // dimension of 66 doubles (conflict-free ds_read_b64), the next step's tiles travel in registers while the MFMAs of
 // the current one run.  The extra last work-group puts the previous panel's diagonal factor in place (see above).
-__global__ __launch_bounds__(256) void k_chol_lookback(double* __restrict__ A, int J, int nblk, int ld,
-                                                       const double* __restrict__ diag_scratch, size_t zs) {
+// (round 4) The operand tiles travel in HALVES of 32 columns: 35 KB of LDS and 155 registers per work-group instead of 68 KB and
+// 190, so THREE work-groups share a CU (12 waves) instead of two - while one waits for its loads or at a barrier, the others have
+// MFMAs to issue (120 runs at n = 1050: Cholesky 2 318 -> 2 209 us; four per CU would need 128 registers: 28 spills).  The products of a panel still accumulate from zero over ascending k (first half, then second half) before they
+// are subtracted: same bits.
+#define TLH 34                                       // leading dimension of a half tile (64 x 32): 272-byte rows, conflict-free reads
+__global__ __launch_bounds__(256, 3) void k_chol_lookback(double* __restrict__ A, int J, int nblk, int ld,
+                                                          const double* __restrict__ diag_scratch, size_t zs) {
   const XcdTile xt_ = xcd_tile();                    // (all tiles of a run on one XCD: they share the block row L[J][.])
   ZRUNX(A); ZRUNX(diag_scratch);
-  __shared__ __attribute__((aligned(16))) double s_a[BS * TLD];
-  __shared__ __attribute__((aligned(16))) double s_b[BS * TLD];
+  __shared__ __attribute__((aligned(16))) double s_a[BS * TLH];
+  __shared__ __attribute__((aligned(16))) double s_b[BS * TLH];
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
   if (xt_.x == gridDim.x - 1) {                      // panel J-1's diagonal factor: scratch -> its place
     double* Add = A + (size_t)((J - 1) * BS) * ld + (J - 1) * BS;
@@ -113,7 +118,6 @@ __global__ __launch_bounds__(256) void k_chol_lookback(double* __restrict__ A, i
     return;
   }
   const int I = J + (int)xt_.x;
-  const bool diag = I == J;
   double* dst = A + (size_t)(I * BS) * ld + J * BS;
   const double* Arow = A + (size_t)(I * BS) * ld;    // L[I][p] tiles
   const double* Brow = A + (size_t)(J * BS) * ld;    // L[J][p] tiles
@@ -123,50 +127,53 @@ __global__ __launch_bounds__(256) void k_chol_lookback(double* __restrict__ A, i
   for (int q = 0; q < 4; ++q)
 #pragma unroll
     for (int r = 0; r < 4; ++r) cold[q][r] = dst[(size_t)(16 * w + (l >> 4) + 4 * r) * ld + 16 * q + (l & 15)];
-  // 16 bytes per lane and load: a CU issues a wave's load instruction every ~11 ns whatever its width (the look-back's 128 eight-byte
-  // loads per step were 1.4 us of address path beside 1.7 us of MFMAs); LDS rows are 528 bytes apart: 16-byte aligned pairs
+  // 16 bytes per lane and load; a half tile is 64 rows x 16 pairs: 4 pairs per thread
   typedef double d2_t __attribute__((ext_vector_type(2)));
-  d2_t pa[8], pb[8];
-  auto fetch = [&](int p) {
+  d2_t pa[4], pb[4];
+  auto fetch = [&](int hs) {                         // hs = 2 p + half
+    const int col0 = (hs >> 1) * BS + (hs & 1) * 32;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int idx = tid + 256 * u, r = idx >> 5, c = (idx & 31) * 2;
-      pa[u] = *reinterpret_cast<const d2_t*>(Arow + (size_t)r * ld + p * BS + c);
-      pb[u] = *reinterpret_cast<const d2_t*>(Brow + (size_t)r * ld + p * BS + c);          // (the same tile on the diagonal: an L2 hit)
+    for (int u = 0; u < 4; ++u) {
+      const int idx = tid + 256 * u, r = idx >> 4, c = (idx & 15) * 2;
+      pa[u] = *reinterpret_cast<const d2_t*>(Arow + (size_t)r * ld + col0 + c);
+      pb[u] = *reinterpret_cast<const d2_t*>(Brow + (size_t)r * ld + col0 + c);          // (the same tile on the diagonal: an L2 hit)
     }
   };
   auto put = [&]() {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int idx = tid + 256 * u, r = idx >> 5, c = (idx & 31) * 2;
-      *reinterpret_cast<d2_t*>(s_a + r * TLD + c) = pa[u];
-      *reinterpret_cast<d2_t*>(s_b + r * TLD + c) = pb[u];
+    for (int u = 0; u < 4; ++u) {
+      const int idx = tid + 256 * u, r = idx >> 4, c = (idx & 15) * 2;
+      *reinterpret_cast<d2_t*>(s_a + r * TLH + c) = pa[u];
+      *reinterpret_cast<d2_t*>(s_b + r * TLH + c) = pb[u];
     }
   };
-  (void)diag;
   fetch(0);
-  for (int p = 0; p < J; ++p) {
+  double4_t acc[4];
+  for (int hs = 0; hs < 2 * J; ++hs) {
     // per panel: the 64-term products accumulate from zero and are then subtracted from the tile - the arithmetic (and the
     // bits) of a right-looking update applied panel by panel, without the tile leaving the registers in between
-    double4_t acc[4];
+    if ((hs & 1) == 0) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    __syncthreads();                                  // the previous step's MFMAs have read the LDS tiles
+      for (int q = 0; q < 4; ++q) acc[q] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    }
+    __syncthreads();                                  // the previous sub-step's MFMAs have read the LDS tiles
     put();
-    if (p + 1 < J) fetch(p + 1);
+    if (hs + 1 < 2 * J) fetch(hs + 1);
     __syncthreads();
-    for (int kk = 0; kk < BS; kk += 4) {
-      const double a = s_a[(16 * w + (l & 15)) * TLD + kk + (l >> 4)];
+    for (int kk = 0; kk < 32; kk += 4) {
+      const double a = s_a[(16 * w + (l & 15)) * TLH + kk + (l >> 4)];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const double bb = s_b[(16 * q + (l & 15)) * TLD + kk + (l >> 4)];     // B[k][j] = L[J-row j][k]
+        const double bb = s_b[(16 * q + (l & 15)) * TLH + kk + (l >> 4)];     // B[k][j] = L[J-row j][k]
         acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[q], 0, 0, 0);
       }
     }
+    if (hs & 1) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) cold[q][r] -= acc[q][r];
+        for (int r = 0; r < 4; ++r) cold[q][r] -= acc[q][r];
+    }
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q)

@@ -32,7 +32,7 @@ PARITY PIN STATUS
     a chain (the committed pca-experiment files come from an older revision of the reference that clipped
     candidates; their rows are not reproducible from the current code), and the random-restart heuristic of rows
     K-N (Sobol scrambling, `initialize_q_batch` temperature, arg-max over restarts: they select WHICH local optimum
-    is returned, and that is chaotic - DESIGN.md section 6).  These are restated from the published algorithms of
+    is returned, and that is chaotic - EXPERIMENTS.md section 6).  These are restated from the published algorithms of
     botorch 0.13 / gpytorch 1.14; sklearn, scipy and torch, which are present, are executed for real.  Every
     constant that comes from memory of the absent packages is a named module-level parameter below.
 

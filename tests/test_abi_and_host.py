@@ -316,3 +316,27 @@ def test_every_lhs_criterion_of_the_reference_surface():
     with pytest.raises(ValueError):
         LHS_sampler("optimal")
     assert np.array_equal(LHS_sampler("center", sample_zero=True)(3, 5)[0], np.zeros(3))
+
+
+def test_xcd_tile_placement_visits_every_tile_once():
+    """`xcd_tile()` (csrc/pcabo_internal.h) re-reads a batched launch's linear work-group id as (run, tile) so that all tiles of a run
+    share id % 8 - one XCD under round-robin dispatch.  Restated here: for any grid (gx, gy, B) the map is a bijection onto
+    (run, x, y), and within the groups of eight runs every tile of a run has the same id % 8."""
+    def xcd_tile(lin, gx, gy, B):
+        T = gx * gy
+        full = (B & ~7) * T
+        if lin < full:
+            slot = lin >> 3
+            tile = slot % T
+            return (slot // T) * 8 + (lin & 7), tile % gx, tile // gx
+        z, rem = divmod(lin, T)
+        return z, rem % gx, rem // gx
+    for gx, gy, B in ((17, 1, 120), (9, 1, 30), (1, 1, 7), (5, 5, 16), (18, 1, 8), (3, 2, 13), (68, 1, 120)):
+        seen = {}
+        for lin in range(gx * gy * B):
+            key = xcd_tile(lin, gx, gy, B)
+            assert key not in seen and key[0] < B and key[1] < gx and key[2] < gy
+            seen[key] = lin
+        assert len(seen) == gx * gy * B
+        for run in range(B & ~7):
+            assert len({seen[(run, x, y)] % 8 for x in range(gx) for y in range(gy)}) == 1

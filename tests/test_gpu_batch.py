@@ -121,7 +121,7 @@ def test_device_objectives_match_the_host_restatements(native):
 def test_batched_run_with_device_objectives(native):
     """The whole lock-step loop with the objectives on the device: f15/f16/f17 (BASELINE.json configs[2]) at d = 10, one
     batch.  Against the same batch with host objectives: same DoE, same first BO candidates; trajectories may part later
-    where a 1e-13 difference in f flips a rank (chaos), so the check is on the first iterations."""
+    where a 1e-13 difference in f flips a rank (chaos, EXPERIMENTS.md section 6), so the check is on the first iterations."""
     from pcabo.batchrun import BatchedPCABO
     runs = [(fid, inst) for fid in (15, 16, 17) for inst in (0, 1)]
     out = []

@@ -198,7 +198,7 @@ def _summarise(stats, name):
                                              np.median(vals), np.mean(np.array(vals) < 1e-3)))
     # Device optimiser vs ORACLE optimiser (each on its own f/g, which agree to ~1e-13): L-BFGS-B on 5k joint variables
     # stops on a relative f-reduction of 2.2e-9, i.e. on a flat optimum the end point is fixed to ~1e-4 only, and a
-    # line-search branch can flip on a 1e-14 difference.  In the late phase of the headline run
+    # line-search branch can flip on a 1e-14 difference (EXPERIMENTS.md section 6).  In the late phase of the headline run
     # (k = 8..16, many penalised points) that happens in about a third of the restart groups - measured on MI355X: counts
     # identical for 62 % (d=40, n = 120..449) / 70 % (d=20), end points: median 8e-7 / 6e-12, values: median 3e-11.  The optimiser itself is pinned
     # exactly above (scipy on the device surface); these bounds only catch a surface that has gone wrong.

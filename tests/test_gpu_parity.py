@@ -404,7 +404,7 @@ def test_free_running_run_replayed_by_oracle_d10(native):
     reproduces from the same state: candidates of all restarts, optimiser iteration counts, chosen point,
     objective value.  (Comparing two free-running trajectories directly is ill-posed: when several restarts
     reach the same acquisition optimum their values tie to ~1e-11 and arg-max is decided by rounding noise,
-    in the reference just as here)"""
+    in the reference just as here; see EXPERIMENTS.md section 6.)"""
     from Algorithms import PCA_BO
     torch.set_num_threads(4)
     iters = 15
@@ -704,7 +704,7 @@ def test_experiment_runner_quick_configuration(native, tmp_path):
 
 def test_vanilla_bo_final_results_distributed_like_the_reference_runs(native):
     """End-to-end statistical check against the reference's OWN committed runs (vanilla-experiment/, d=5, f15 and
-    f20, 30 instances each, budget 75): trajectories are chaotic, so the comparison is the
+    f20, 30 instances each, budget 75): trajectories are chaotic (EXPERIMENTS.md section 6), so the comparison is the
     distribution of the final best raw_y over the 30 instances - same seeds, same DoE.  Measured: medians 40.3 vs
     42.8 (f15) and 3.22 vs 2.98 (f20), Mann-Whitney p = 0.77 / 0.53."""
     import json, os

@@ -5,7 +5,7 @@
    no GPU, no HIP runtime) and run: a driver with a stub launcher, and the scipy comparison of tests/test_lbfgsb_vs_scipy.py once
    more through the ASan build of the entry points.
 2. The kernarg segment of every kernel in the built code objects stays below 3 968 bytes: round 2's abort under the tracer came
-   with a segment of exactly HIP's 4 096-byte maximum, and nothing guarded that bound.
+   with a segment of exactly HIP's 4 096-byte maximum (EXPERIMENTS.md section 5), and nothing guarded that bound.
 """
 import os
 import re

@@ -108,6 +108,6 @@ def test_first_divergence_of_lbfgsb_cpp_and_scipy_is_rounding(native, capsys, or
         small = [i for i in range(f, len(d) - 1) if d[i] < 1e-8]
         r["max_step_factor"] = max(d[i + 1] / max(d[i], 1e-16) for i in small)
         assert r["max_step_factor"] <= 300.0, (r["n"], r["group"], r["max_step_factor"])
-    # the late phase is where the counts part: at least one of the six runs does here
+    # the late phase is where the counts part (EXPERIMENTS.md section 6): at least one of the six runs does here
     parted = [r for r in rows if r["first"] is not None]
     assert parted, "no run of the committed late states parts: the fixture no longer shows the effect"

@@ -203,6 +203,10 @@ int pcabo_sobol_scramble(int64_t* state, const int64_t* ltm, int k);
  * botorch's map into the box, out[i*k + j] = lo[j] + rng[j] * u[i][j] (lo = rng = NULL: u itself).  state[k*30] after
  * pcabo_sobol_scramble, shift[k] = sum_b bit_b 2^b of the k x 30 shift bits (torch's `shift`). */
 int pcabo_sobol_draw(const int64_t* state, const int64_t* shift, int k, int n, const double* lo, const double* rng, double* out);
+/* The same for every run of a lock-step batch in one call: run r draws n points (n x ks[r]) into outs[r], mapped into the box
+ * [lo(k), hi(k)] found at boxes + r * box_stride (the packing of pcabo_batch_acq_bounds); states[r] == NULL skips run r. */
+int pcabo_sobol_draw_rows(const int64_t* const* states, const int64_t* const* shifts, const int* ks, int rows, int n,
+                          const double* boxes, long long box_stride, double* const* outs);
 /* torch's CPU generator restated for the host's pacing thread (csrc/host_entry.cpp): `blob` = the generator's state exactly as
  * torch.Generator.get_state() exports it (5056 bytes), read and ADVANCED in place - set_state(blob) afterwards leaves torch's
  * generator where torch's own call would have left it.

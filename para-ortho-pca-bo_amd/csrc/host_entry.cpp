@@ -5,9 +5,11 @@
 #include "../../include/pcabo.h"
 #include "lbfgsb.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 extern "C" {
@@ -106,6 +108,38 @@ int pcabo_sobol_draw(const int64_t* state, const int64_t* shift, int k, int n, c
 }
 
 
+// pcabo_sobol_draw for the runs of a lock-step batch in one call: run r's engine (states[r], shifts[r], ks[r] columns) draws n
+// points into outs[r] (n x ks[r], contiguous), mapped into the box whose corners lie in boxes + r * box_stride as [lo(k), hi(k)]
+// (the packing pcabo_batch_acq_bounds writes); rng = hi - lo is formed here, the subtraction the caller's numpy made.  A run with
+// states[r] == NULL is skipped.  Same numbers as `rows` calls of pcabo_sobol_draw.
+int pcabo_sobol_draw_rows(const int64_t* const* states, const int64_t* const* shifts, const int* ks, int rows, int n,
+                          const double* boxes, long long box_stride, double* const* outs) {
+  if (!states || !shifts || !ks || !boxes || !outs || rows < 1 || n < 1 || n > (1 << 30)) return PCABO_ERR_ARG;
+  for (int r = 0; r < rows; ++r)
+    if (states[r] && (ks[r] < 1 || !shifts[r] || !outs[r])) return PCABO_ERR_ARG;
+  auto some = [=](int r0, int r1) {
+    std::vector<double> rng;
+    for (int r = r0; r < r1; ++r) {
+      if (!states[r]) continue;
+      const int k = ks[r];
+      const double* lo = boxes + (size_t)r * box_stride;
+      rng.resize(k);
+      for (int j = 0; j < k; ++j) rng[j] = lo[k + j] - lo[j];
+      pcabo_sobol_draw(states[r], shifts[r], k, n, lo, rng.data(), outs[r]);       // (arguments checked above: cannot fail)
+    }
+  };
+  const int T = std::min(4, rows / 16);             // runs are independent: helper threads for a wide batch, as the pick below
+  if (T < 2) {
+    some(0, rows);
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(some, (int)((long long)rows * t / T), (int)((long long)rows * (t + 1) / T));
+    some(0, rows / T);
+    for (auto& x : th) x.join();
+  }
+  return PCABO_OK;
+}
+
 // ---- torch's CPU generator, restated (the host's pacing thread draws the reference's random numbers without torch calls) ----
 // The reference's restart heuristic draws from torch's global CPU generator: the Sobol scramble bits (torch.randint(2, ...)) and
 // botorch's initialize_q_batch -> torch.multinomial(weights, n, replacement=False) (behind PCA_BO.py:607-614).  With hundreds of
@@ -179,14 +213,14 @@ void multinomial_row(TorchMt* s, const double* w, int n, int n_pick, double* rat
 // permutation path on torch's generator - nothing was drawn here); 2 row skipped (blobs[r] == NULL).  The statistics are formed
 // in this file's order (Welford), not torch's: the weights can differ from a torch-formed row in the last bit, the picks - an
 // ordering of weights over independent exponential variates - do not (tests/test_abi_and_host.py compares 10 000 rows).
-int pcabo_boltzmann_pick_rows(void* const* blobs, const double* vals, int rows, int n, int n_pick, double eta, int64_t* out, int* flags) {
-  if (!blobs || !vals || !out || !flags || rows < 1 || n < 2 || n_pick < 1 || n_pick > n) return PCABO_ERR_ARG;
+namespace {
+// rows [r0, r1) of pcabo_boltzmann_pick_rows (a row touches its own generator, its own slice of out and its own flag only)
+void boltzmann_rows(void* const* blobs, const double* vals, int r0, int r1, int n, int n_pick, double eta, int64_t* out, int* flags) {
   std::vector<double> w((size_t)n), ratio((size_t)n);
   std::vector<int> best((size_t)n_pick);
-  for (int r = 0; r < rows; ++r) {
+  for (int r = r0; r < r1; ++r) {
     TorchMt* s = static_cast<TorchMt*>(blobs[r]);
     if (!s) { flags[r] = 2; continue; }
-    if (!s->seeded || s->left < 1 || s->left > 624 || s->next > 624) return PCABO_ERR_ARG;
     const double* v = vals + (size_t)r * n;
     double mean = 0.0, m2 = 0.0;
     int arg = 0;
@@ -211,6 +245,27 @@ int pcabo_boltzmann_pick_rows(void* const* blobs, const double* vals, int rows, 
     for (int j = 0; j < n_pick; ++j) has = has || o[j] == arg;
     if (!has) o[n_pick - 1] = arg;
     flags[r] = 0;
+  }
+}
+}  // namespace
+
+int pcabo_boltzmann_pick_rows(void* const* blobs, const double* vals, int rows, int n, int n_pick, double eta, int64_t* out, int* flags) {
+  if (!blobs || !vals || !out || !flags || rows < 1 || n < 2 || n_pick < 1 || n_pick > n) return PCABO_ERR_ARG;
+  for (int r = 0; r < rows; ++r) {
+    const TorchMt* s = static_cast<const TorchMt*>(blobs[r]);
+    if (s && (!s->seeded || s->left < 1 || s->left > 624 || s->next > 624)) return PCABO_ERR_ARG;
+  }
+  // the rows are independent (a generator each): a few helper threads for a wide batch - the caller is the ONE host thread that
+  // paces the device, and at 60+ runs this call was its largest single item
+  const int T = std::min(4, rows / 16);
+  if (T < 2) {
+    boltzmann_rows(blobs, vals, 0, rows, n, n_pick, eta, out, flags);
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t)
+      th.emplace_back(boltzmann_rows, blobs, vals, (int)((long long)rows * t / T), (int)((long long)rows * (t + 1) / T), n, n_pick, eta, out, flags);
+    boltzmann_rows(blobs, vals, 0, rows / T, n, n_pick, eta, out, flags);
+    for (auto& x : th) x.join();
   }
   return PCABO_OK;
 }

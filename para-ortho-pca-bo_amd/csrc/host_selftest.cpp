@@ -91,6 +91,80 @@ void test_sobol() {
   }
 }
 
+// torch's CPU generator restated (csrc/host_entry.cpp): state blobs of the published layout, the bit draws, the multinomial rows
+// and the Boltzmann pick - whose wide batches fan out over helper threads (tsan sees them); threaded picks = serial picks.
+void test_torch_rng() {
+  struct Blob { uint64_t seed; int32_t left, seeded; uint64_t next; uint64_t state[624]; unsigned char tail[32]; };
+  const int rows = 70, n = 512, n_pick = 10;
+  std::vector<Blob> blobs(rows), again;
+  std::vector<double> vals((size_t)rows * n);
+  for (int r = 0; r < rows; ++r) {
+    Lcg g(900 + r);
+    blobs[r].seed = 900 + r; blobs[r].left = 1 + (r * 37) % 624; blobs[r].seeded = 1; blobs[r].next = 624 - blobs[r].left;
+    for (auto& w : blobs[r].state) w = (uint64_t)(g.uni() * 4294967296.0);
+    for (auto& c : blobs[r].tail) c = 0;
+    for (int i = 0; i < n; ++i) vals[(size_t)r * n + i] = r == 5 ? 1.25 : 40.0 * g.uni() - 20.0;        // row 5: all equal
+  }
+  again = blobs;
+  std::vector<void*> ptr(rows);
+  for (int r = 0; r < rows; ++r) ptr[r] = &blobs[r];
+  ptr[7] = nullptr;                                                                                       // row 7: skipped
+  std::vector<int64_t> out((size_t)rows * n_pick, -1), out1((size_t)rows * n_pick, -1);
+  std::vector<int> flags(rows, -1), flags1(rows, -1);
+  CHECK(pcabo_boltzmann_pick_rows(ptr.data(), vals.data(), rows, n, n_pick, 1.0, out.data(), flags.data()) == PCABO_OK, "pick rows");
+  for (int r = 0; r < rows; ++r) {                            // one row per call: the serial path
+    void* p1 = r == 7 ? nullptr : (void*)&again[r];
+    CHECK(pcabo_boltzmann_pick_rows(&p1, vals.data() + (size_t)r * n, 1, n, n_pick, 1.0, out1.data() + (size_t)r * n_pick, flags1.data() + r) == PCABO_OK, "pick row %d", r);
+    CHECK(flags[r] == flags1[r] && flags[r] == (r == 7 ? 2 : r == 5 ? 1 : 0), "flag of row %d: %d / %d", r, flags[r], flags1[r]);
+    if (flags[r] != 0) continue;
+    for (int j = 0; j < n_pick; ++j) {
+      CHECK(out[(size_t)r * n_pick + j] == out1[(size_t)r * n_pick + j], "row %d pick %d differs between the threaded and the serial call", r, j);
+      CHECK(out[(size_t)r * n_pick + j] >= 0 && out[(size_t)r * n_pick + j] < n, "row %d pick %d out of range", r, j);
+    }
+    CHECK(blobs[r].left == again[r].left && blobs[r].next == again[r].next && blobs[r].state[0] == again[r].state[0], "generator of row %d", r);
+  }
+  std::vector<int64_t> bits(2000);
+  CHECK(pcabo_torch_randint2(&blobs[0], 2000, bits.data()) == PCABO_OK, "randint2");
+  for (int64_t b : bits) CHECK(b == 0 || b == 1, "bit %lld", (long long)b);
+  std::vector<double> w((size_t)3 * n);
+  Lcg g(77);
+  for (auto& v : w) v = 0.01 + g.uni();
+  void* three[3] = {&blobs[1], nullptr, &blobs[2]};
+  std::vector<int64_t> idx(3 * n_pick, -1);
+  CHECK(pcabo_torch_multinomial_rows(three, w.data(), 3, n, n_pick, idx.data()) == PCABO_OK, "multinomial rows");
+  for (int j = 0; j < n_pick; ++j) CHECK(idx[j] >= 0 && idx[j] < n && idx[n_pick + j] == -1 && idx[2 * n_pick + j] >= 0, "multinomial pick %d", j);
+  blobs[3].left = 900;
+  CHECK(pcabo_torch_randint2(&blobs[3], 4, bits.data()) == PCABO_ERR_ARG, "a broken blob accepted");
+}
+
+// pcabo_sobol_draw_rows: ragged k, a skipped run, the boxes in pcabo_batch_acq_bounds' packing - equal to the per-run calls
+void test_sobol_rows() {
+  const int rows = 37, n = 130, kmax = 36;          // (32 rows and more: the call fans out over helper threads)
+  int ks[rows];
+  for (int r = 0; r < rows; ++r) ks[r] = r == 0 ? 3 : r == 2 ? 1 : 1 + (r * 7) % 36;
+  std::vector<std::vector<int64_t>> st(rows), sh(rows);
+  std::vector<double> boxes((size_t)rows * 2 * kmax, NAN), out((size_t)rows * n * kmax, -7.0), one((size_t)n * kmax);
+  std::vector<const int64_t*> sp(rows), hp(rows);
+  std::vector<double*> op(rows);
+  for (int r = 0; r < rows; ++r) {
+    Lcg g(40 + r);
+    st[r].resize((size_t)ks[r] * 30); sh[r].resize(ks[r]);
+    for (auto& v : st[r]) v = (int64_t)(g.uni() * 1073741824.0);
+    for (auto& v : sh[r]) v = (int64_t)(g.uni() * 1073741824.0);
+    for (int j = 0; j < ks[r]; ++j) { boxes[(size_t)r * 2 * kmax + j] = -1.0 - j; boxes[(size_t)r * 2 * kmax + ks[r] + j] = 2.0 + r; }
+    sp[r] = r == 2 ? nullptr : st[r].data(); hp[r] = sh[r].data(); op[r] = out.data() + (size_t)r * n * kmax;
+  }
+  CHECK(pcabo_sobol_draw_rows(sp.data(), hp.data(), ks, rows, n, boxes.data(), 2 * kmax, op.data()) == PCABO_OK, "draw rows");
+  for (int r = 0; r < rows; ++r) {
+    if (r == 2) { CHECK(op[r][0] == -7.0, "a skipped run was written"); continue; }
+    std::vector<double> rng(ks[r]);
+    for (int j = 0; j < ks[r]; ++j) rng[j] = boxes[(size_t)r * 2 * kmax + ks[r] + j] - boxes[(size_t)r * 2 * kmax + j];
+    CHECK(pcabo_sobol_draw(st[r].data(), sh[r].data(), ks[r], n, boxes.data() + (size_t)r * 2 * kmax, rng.data(), one.data()) == PCABO_OK, "draw");
+    for (int i = 0; i < n * ks[r]; ++i) CHECK(one[i] == op[r][i], "run %d element %d", r, i);
+    if (ks[r] < kmax) CHECK(op[r][(size_t)n * ks[r]] == -7.0, "write behind the points of run %d", r);
+  }
+}
+
 void test_plan() {
   std::vector<int> plan(LB_PLAN_INTS + 64, 0x5a5a5a5a);        // guard words behind the plan: they must stay
   for (int NP = 64; NP <= LB_MAXNP; NP += 64) {
@@ -197,6 +271,8 @@ int main(int argc, char** argv) {
   const int workers = argc > 1 ? std::atoi(argv[1]) : 4;
   test_minimize();
   test_sobol();
+  test_sobol_rows();
+  test_torch_rng();
   test_plan();
   test_gang_pool(1, 3);
   test_gang_pool(workers, 11);

@@ -48,7 +48,7 @@ EXPORTS = [
     "pcabo_gp_condition_end", "pcabo_gp_condition_end_eval", "pcabo_wpca_gp_condition_begin", "pcabo_wpca_results",
     "pcabo_acq_bounds",
     "pcabo_acq_eval", "pcabo_logei", "pcabo_optimize_acqf", "pcabo_inverse_map", "pcabo_get_gp_state",
-    "pcabo_get_gram", "pcabo_lbfgsb_minimize", "pcabo_lbfgsb_set_vector_kernels", "pcabo_lbfgsb_set_sum_order", "pcabo_sobol_scramble", "pcabo_sobol_draw", "pcabo_torch_randint2", "pcabo_torch_multinomial_rows", "pcabo_boltzmann_pick_rows", "pcabo_set_profiling",
+    "pcabo_get_gram", "pcabo_lbfgsb_minimize", "pcabo_lbfgsb_set_vector_kernels", "pcabo_lbfgsb_set_sum_order", "pcabo_sobol_scramble", "pcabo_sobol_draw", "pcabo_sobol_draw_rows", "pcabo_torch_randint2", "pcabo_torch_multinomial_rows", "pcabo_boltzmann_pick_rows", "pcabo_set_profiling",
     "pcabo_get_profile", "pcabo_get_profile_calibration", "pcabo_reset_profile",
     "pcabo_batch_create", "pcabo_batch_destroy", "pcabo_batch_last_error", "pcabo_batch_ctx",
     "pcabo_batch_wpca_gp_condition_begin", "pcabo_batch_wpca_results", "pcabo_batch_acq_bounds",
@@ -110,6 +110,7 @@ def _load() -> C.CDLL:
     lib.pcabo_get_gram.argtypes = [vp, vp]
     lib.pcabo_sobol_scramble.argtypes = [vp, vp, C.c_int]
     lib.pcabo_sobol_draw.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp]
+    lib.pcabo_sobol_draw_rows.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_longlong, vp]
     lib.pcabo_set_profiling.argtypes = [vp, C.c_int]
     lib.pcabo_get_profile.argtypes = [vp, C.c_int, dp, C.POINTER(C.c_int64), dp, dp]
     lib.pcabo_reset_profile.argtypes = [vp]
@@ -525,7 +526,7 @@ class Batch:
                  "evr": evr[b, :rc_], "k": int(k[b]), "Z": None} for b in range(B)]
 
     def acq_bounds(self):
-        buf = np.zeros((self.B, 2 * self.max_d))
+        buf = self.acq_bounds_packed = np.zeros((self.B, 2 * self.max_d))     # (kept: sobol_draw_rows reads the boxes from it)
         self._chk(LIB.pcabo_batch_acq_bounds(self._h, _ptr(buf)))
         return [buf[b, : 2 * int(self.k[b])].reshape(2, int(self.k[b])).copy() for b in range(self.B)]
 
@@ -702,6 +703,30 @@ def sobol_draw(state: np.ndarray, shift: np.ndarray, n: int, lo=None, rng=None, 
     if rc != 0:
         raise PcaboError(rc, "pcabo_sobol_draw: bad argument")
     return out
+
+
+def sobol_draw_rows(engines, n: int, boxes: np.ndarray, outbuf: np.ndarray):
+    """`sobol_draw` for the runs of a batch in one native call (pcabo_sobol_draw_rows): engines[b] (objects with .k, .state, .shift;
+    None = skip) draws n points into `outbuf[b, :n*k_b]`, mapped into the box packed in `boxes[b]` as [lo(k_b), hi(k_b)]
+    (Batch.acq_bounds_packed).  Returns the list of (n, k_b) views into `outbuf` (None for skipped runs)."""
+    B = len(engines)
+    assert boxes.dtype == np.float64 and boxes.flags.c_contiguous and boxes.shape[0] == B
+    assert outbuf.dtype == np.float64 and outbuf.flags.c_contiguous and outbuf.shape[0] == B
+    ks = np.zeros(B, dtype=np.int32)
+    st, sh, ou = (C.c_void_p * B)(), (C.c_void_p * B)(), (C.c_void_p * B)()
+    base, stride = outbuf.ctypes.data, outbuf.strides[0]
+    views = [None] * B
+    for b, e in enumerate(engines):
+        if e is None:
+            continue
+        k = ks[b] = e.k
+        assert 2 * k <= boxes.shape[1] and n * k <= outbuf.shape[1] and e.state.dtype == np.int64 and e.shift.dtype == np.int64
+        st[b], sh[b], ou[b] = e.state.ctypes.data, e.shift.ctypes.data, base + b * stride
+        views[b] = outbuf[b, : n * k].reshape(n, k)
+    rc = LIB.pcabo_sobol_draw_rows(st, sh, _ptr(ks), B, int(n), _ptr(boxes), boxes.strides[0] // 8, ou)
+    if rc != 0:
+        raise PcaboError(rc, "pcabo_sobol_draw_rows: bad argument")
+    return views
 
 
 def comm_unique_id() -> bytes:

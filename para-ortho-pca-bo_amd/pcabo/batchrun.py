@@ -288,11 +288,9 @@ class BatchedPCABO:
             if engines[b] is None:
                 engines[b] = _init.scrambled_sobol_engine(res[b]["k"], self._tg[b])
             self.k_prev[b] = res[b]["k"]
-            kb = res[b]["k"]
-            raw[b] = _init.draw_sobol(bounds[b], self.raw_samples, engines[b],
-                                      out=rawbuf[b, : self.raw_samples * kb].reshape(self.raw_samples, kb))
         for b in range(B):
             draw(b)
+        raw = _native.sobol_draw_rows(engines, self.raw_samples, bt.acq_bounds_packed, rawbuf)       # all runs' points, one call
         best_f = [self.current_best[b] for b in range(B)]
         for b in range(B):
             bt.ctx[b].match_best_f_dtype(best_f[b])
@@ -476,6 +474,7 @@ class BatchedVanillaBO(BatchedPCABO):
         d = self.dimension
         self._identity = np.vstack([np.zeros(d), np.ones(d)])
         self._boxes = [np.ascontiguousarray(self.bounds[b].T, dtype=np.float64) for b in range(self.B)]     # 2 x d each
+        self._boxes_packed = np.ascontiguousarray(np.stack([bx.ravel() for bx in self._boxes]))             # B x [lo(d), hi(d)]
         self.k_prev = [d] * self.B
 
     def _iteration_steps(self):
@@ -494,12 +493,9 @@ class BatchedVanillaBO(BatchedPCABO):
         # device conditions the GPs
         built, self._engines_ahead = self._engines_ahead, {}
         bounds = self._boxes
-        raw = [None] * B
         rawbuf = bt.raw_row_buffer(self.raw_samples)
-        for b in range(B):
-            engine = built[b][1] if b in built else _init.scrambled_sobol_engine(d, self._tg[b])
-            raw[b] = _init.draw_sobol(bounds[b], self.raw_samples, engine,
-                                      out=rawbuf[b, : self.raw_samples * d].reshape(self.raw_samples, d))
+        engines = [built[b][1] if b in built else _init.scrambled_sobol_engine(d, self._tg[b]) for b in range(B)]
+        raw = _native.sobol_draw_rows(engines, self.raw_samples, self._boxes_packed, rawbuf)
         best_f = [self.current_best[b] for b in range(B)]
         for b in range(B):
             bt.ctx[b].match_best_f_dtype(best_f[b])

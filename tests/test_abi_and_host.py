@@ -140,6 +140,32 @@ def test_sobol_helpers_equal_the_real_torch_engine_bit_for_bit():
     del g2
 
 
+def test_sobol_rows_call_equals_the_per_run_calls_bit_for_bit():
+    """pcabo_sobol_draw_rows (all runs of a lock-step batch in one call, boxes in the packing of pcabo_batch_acq_bounds, points
+    straight into the rows the scoring launch packs) against one pcabo_sobol_draw per run; ragged k, a skipped run."""
+    import torch
+    from pcabo import initializers as I, _native as N
+    ks = [3, 40, 1, 17, 36, 40] + [1 + (7 * b) % 40 for b in range(34)]      # (32 runs and more: the call fans out over threads)
+    kmax, n = 40, 512
+    gens = [torch.Generator().manual_seed(70 + b) for b in range(len(ks))]
+    engines = [I.scrambled_sobol_engine(k, g) for k, g in zip(ks, gens)]
+    engines[2] = None
+    boxes = np.full((len(ks), 2 * kmax), np.nan)
+    want = []
+    for b, k in enumerate(ks):
+        lo, hi = np.linspace(-3, 1, k) * (b + 1), np.linspace(1.5, 7, k) + b
+        boxes[b, :k], boxes[b, k: 2 * k] = lo, hi
+        want.append(None if engines[b] is None else I.draw_sobol(np.vstack([lo, hi]), n, engines[b]))
+    out = np.full((len(ks), n * kmax), -7.0)
+    views = N.sobol_draw_rows(engines, n, boxes, out)
+    for b, k in enumerate(ks):
+        if engines[b] is None:
+            assert views[b] is None and np.all(out[b] == -7.0)
+        else:
+            assert views[b].shape == (n, k) and np.array_equal(views[b], want[b]) and np.shares_memory(views[b], out)
+            assert np.all(out[b, n * k:] == -7.0)
+
+
 def test_gc_guard_is_reference_counted_and_undone():
     """pcabo/gcguard.py: freeze + raised young-generation threshold while at least one run is open, everything back to
     what it was afterwards (nested runs: the outermost leave restores)."""

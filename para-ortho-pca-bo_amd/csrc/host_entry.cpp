@@ -128,7 +128,7 @@ int pcabo_sobol_draw_rows(const int64_t* const* states, const int64_t* const* sh
       pcabo_sobol_draw(states[r], shifts[r], k, n, lo, rng.data(), outs[r]);       // (arguments checked above: cannot fail)
     }
   };
-  const int T = std::min(4, rows / 16);             // runs are independent: helper threads for a wide batch, as the pick below
+  const int T = std::min(4, rows / 8);             // runs are independent: helper threads for a wide batch, as the pick below
   if (T < 2) {
     some(0, rows);
   } else {
@@ -257,7 +257,7 @@ int pcabo_boltzmann_pick_rows(void* const* blobs, const double* vals, int rows, 
   }
   // the rows are independent (a generator each): a few helper threads for a wide batch - the caller is the ONE host thread that
   // paces the device, and at 60+ runs this call was its largest single item
-  const int T = std::min(4, rows / 16);
+  const int T = std::min(4, rows / 8);
   if (T < 2) {
     boltzmann_rows(blobs, vals, 0, rows, n, n_pick, eta, out, flags);
   } else {

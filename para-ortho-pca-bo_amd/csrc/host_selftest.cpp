@@ -139,7 +139,7 @@ void test_torch_rng() {
 
 // pcabo_sobol_draw_rows: ragged k, a skipped run, the boxes in pcabo_batch_acq_bounds' packing - equal to the per-run calls
 void test_sobol_rows() {
-  const int rows = 37, n = 130, kmax = 36;          // (32 rows and more: the call fans out over helper threads)
+  const int rows = 37, n = 130, kmax = 36;          // (16 rows and more: the call fans out over helper threads)
   int ks[rows];
   for (int r = 0; r < rows; ++r) ks[r] = r == 0 ? 3 : r == 2 ? 1 : 1 + (r * 7) % 36;
   std::vector<std::vector<int64_t>> st(rows), sh(rows);

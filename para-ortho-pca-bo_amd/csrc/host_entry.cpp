@@ -12,6 +12,25 @@
 #include <thread>
 #include <vector>
 
+namespace {
+// fn(r0, r1) over [0, rows) on up to four threads (the caller's included); a thread that cannot be started (std::system_error)
+// leaves its range to the caller - no exception crosses the C boundary.
+template <class F>
+void fan_out_rows(int rows, F fn) {
+  const int T = std::min(4, rows / 8);
+  if (T < 2) { fn(0, rows); return; }
+  std::vector<std::thread> th;
+  std::vector<int> mine;                              // ranges the caller runs itself
+  for (int t = 1; t < T; ++t) {
+    const int r0 = (int)((long long)rows * t / T), r1 = (int)((long long)rows * (t + 1) / T);
+    try { th.emplace_back(fn, r0, r1); } catch (...) { mine.push_back(r0); mine.push_back(r1); }
+  }
+  fn(0, rows / T);
+  for (size_t i = 0; i + 1 < mine.size(); i += 2) fn(mine[i], mine[i + 1]);
+  for (auto& x : th) x.join();
+}
+}  // namespace
+
 extern "C" {
 
 int pcabo_lbfgsb_minimize(int nvar, double* x, const double* lower, const double* upper, pcabo_fg_callback fg,
@@ -128,15 +147,7 @@ int pcabo_sobol_draw_rows(const int64_t* const* states, const int64_t* const* sh
       pcabo_sobol_draw(states[r], shifts[r], k, n, lo, rng.data(), outs[r]);       // (arguments checked above: cannot fail)
     }
   };
-  const int T = std::min(4, rows / 8);             // runs are independent: helper threads for a wide batch, as the pick below
-  if (T < 2) {
-    some(0, rows);
-  } else {
-    std::vector<std::thread> th;
-    for (int t = 1; t < T; ++t) th.emplace_back(some, (int)((long long)rows * t / T), (int)((long long)rows * (t + 1) / T));
-    some(0, rows / T);
-    for (auto& x : th) x.join();
-  }
+  fan_out_rows(rows, some);                         // runs are independent: helper threads for a wide batch, as the pick below
   return PCABO_OK;
 }
 
@@ -257,16 +268,7 @@ int pcabo_boltzmann_pick_rows(void* const* blobs, const double* vals, int rows, 
   }
   // the rows are independent (a generator each): a few helper threads for a wide batch - the caller is the ONE host thread that
   // paces the device, and at 60+ runs this call was its largest single item
-  const int T = std::min(4, rows / 8);
-  if (T < 2) {
-    boltzmann_rows(blobs, vals, 0, rows, n, n_pick, eta, out, flags);
-  } else {
-    std::vector<std::thread> th;
-    for (int t = 1; t < T; ++t)
-      th.emplace_back(boltzmann_rows, blobs, vals, (int)((long long)rows * t / T), (int)((long long)rows * (t + 1) / T), n, n_pick, eta, out, flags);
-    boltzmann_rows(blobs, vals, 0, rows / T, n, n_pick, eta, out, flags);
-    for (auto& x : th) x.join();
-  }
+  fan_out_rows(rows, [=](int r0, int r1) { boltzmann_rows(blobs, vals, r0, r1, n, n_pick, eta, out, flags); });
   return PCABO_OK;
 }
 

@@ -51,12 +51,27 @@ class _NoBar:
     def close(self): pass
 
 
+DEVICE_BATCHES_AT_ONCE = 8       # lock-step batches of the device-resident optimiser one host thread interleaves at most
+
+
 def device_batch_plan(n_runs: int):
-    """Batches for the device-resident optimiser: (runs per batch, batches advancing at once) - up to four batches of at least
-    30 runs at a time, none larger than 120 runs (45 -> 1 x 45; 90 -> 3 x 30; 600 -> 8 x 75, four at a time)."""
+    """Batches for the device-resident optimiser of ONE dimension: (runs per batch, batches advancing at once) - up to four batches
+    of at least 30 runs at a time, none larger than 120 runs (45 -> 1 x 45; 90 -> 3 x 30; 600 -> 8 x 75, four at a time).  The
+    runner lets the groups of different dimensions advance together up to DEVICE_BATCHES_AT_ONCE batches (_run_batched)."""
     nb = min(4, max(1, n_runs // 30))
     rounds = -(-n_runs // (120 * nb))
     return -(-n_runs // (nb * rounds)), nb
+
+
+def merge_batch_groups(groups, at_once: int):
+    """Neighbouring groups of batches joined while a joined group holds at most `at_once` batches (order kept, no batch split)."""
+    merged = []
+    for g in groups:
+        if merged and len(merged[-1]) + len(g) <= at_once:
+            merged[-1] = merged[-1] + list(g)
+        else:
+            merged.append(list(g))
+    return merged
 
 
 def resolve_arithmetic_mode(batch_acq_kernel: str, batched: int, dim: int, runs_of_dim_in_experiment: int, budget: int) -> str:
@@ -203,16 +218,17 @@ class ExperimentRunner:
         from pcabo.iohlog import LoggedProblem
         mine = self._my_runs()
         groups = []                          # lists of (dim, runs of one batch, kernel): the batches of a list advance together
+        device_groups = []                   # the same for the device-resident optimiser, merged across dimensions below
         for dim in sorted({r[1] for r in mine}, key=self.dimensions.index):
             cell = [r for r in mine if r[1] == dim]
             kernel = self.arithmetic_modes[dim]              # (a property of the experiment, not of this rank's share)
             if kernel == "device" and self.batch_acq_kernel == "auto":
-                # the optimiser on the device: up to FOUR batches of >= 30 runs interleaved on one host thread (bigger batches win,
-                # more than four at once do not: DESIGN.md section 7).  How this rank groups its runs changes no number: within a
+                # the optimiser on the device: up to four batches of >= 30 runs of a dimension interleaved on one host thread (bigger
+                # batches win: DESIGN.md section 7), the dimensions' groups merged below.  How this rank groups its runs changes no number: within a
                 # mode a run is bit-identical in any batch (tests/test_gpu_batch.py, tests/test_gpu_device_lbfgsb.py)
                 per, nb = device_batch_plan(len(cell))
                 parts = [cell[i:i + per] for i in range(0, len(cell), per)]
-                groups += [[(dim, part, kernel) for part in parts[i:i + nb]] for i in range(0, len(parts), nb)]
+                device_groups += [[(dim, part, kernel) for part in parts[i:i + nb]] for i in range(0, len(parts), nb)]
                 continue
             # the runs of a dimension are divided EVENLY over a multiple of `side_by_side` batches of about `batched` runs
             # (a lone last batch would advance with nothing beside it; larger batches amortise the rounds of the slowest
@@ -220,6 +236,11 @@ class ExperimentRunner:
             parts = split_evenly(cell, self.batched, self.side_by_side)
             groups += [[(dim, part, kernel) for part in parts[i:i + self.side_by_side]]
                        for i in range(0, len(parts), self.side_by_side)]
+        # device mode: the groups of different dimensions advance TOGETHER while they fit DEVICE_BATCHES_AT_ONCE batches on the one
+        # host thread - with several hundred runs in flight the CUs decide (a work-group per restart group holds a CU), and more
+        # queued launches fill the gaps the slowest groups of a batch leave (one MI355X, f15 d = 40: 240 runs as 4 x 60 5 400 it/s,
+        # 480 runs as 8 x 60 6 830; EXPERIMENTS.md R4.4)
+        groups += merge_batch_groups(device_groups, DEVICE_BATCHES_AT_ONCE)
         import torch
         saved_threads = torch.get_num_threads()      # (see BatchedPCABO.start: the loop's small tensor operations and torch's
         if saved_threads > 4:                        # intra-op pool at the machine's core count do not get along)

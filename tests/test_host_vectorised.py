@@ -58,6 +58,20 @@ def test_row_wise_argsort_gives_the_ranks_of_the_1d_calls():
                 assert np.array_equal(np.argsort(np.argsort(fb)) + 1, r2[b]), (t, b)
 
 
+def test_device_groups_of_different_dimensions_merge_up_to_eight_batches():
+    """ExperimentRunner._run_batched: the device-mode groups of the dimensions advance together while they fit
+    DEVICE_BATCHES_AT_ONCE batches; order kept, no batch split, nothing lost."""
+    from Algorithms.Experiment.ExperimentRunner import merge_batch_groups, DEVICE_BATCHES_AT_ONCE
+    assert DEVICE_BATCHES_AT_ONCE == 8
+    a, b, c = [("d20", i) for i in range(4)], [("d40", i) for i in range(4)], [("d10", i) for i in range(3)]
+    assert merge_batch_groups([a, b], 8) == [a + b]                        # configs[3]: 4 x 75 + 4 x 75 in one group
+    assert merge_batch_groups([a, b, c], 8) == [a + b, c]
+    assert merge_batch_groups([c, a, b], 8) == [c + a, b]
+    assert merge_batch_groups([a, b], 4) == [a, b] and merge_batch_groups([], 8) == []
+    nine = [("x", i) for i in range(9)]
+    assert merge_batch_groups([nine, a], 8) == [nine, a]                   # (a group is never split)
+
+
 def test_device_batch_plan_covers_every_run_in_bounded_batches():
     """ExperimentRunner's "auto" mode: up to four batches of >= 30 runs at a time, none above 120 runs, nothing left over."""
     from Algorithms.Experiment.ExperimentRunner import device_batch_plan

@@ -2,6 +2,7 @@
 (`ExperimentRunner(batched=30)`: the 30 instances of a (function, dimension) cell advance in lock-step) and print one
 JSON line: runs, BO iterations, wall seconds, aggregate BO iterations/s, per-dimension breakdown, IOHprofiler files written.
     python tools/gpu_run_config.py 2 [batched] [side_by_side] [acq_kernel]     # configs[2]: f15/f16/f17 x d in {10, 20, 40} x 30 runs
+    python tools/gpu_run_config.py 3 75 4 auto together     # one runner call for all dimensions
     python tools/gpu_run_config.py 3      # configs[3] on one GPU: f15-f24 x d in {20, 40} x 30 runs (the N = 1 point)"""
 import json, os, sys, tempfile, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # read by the HIP runtime at its first call: a Batch uses a stream per worker thread
@@ -18,14 +19,15 @@ torch.set_num_threads(4)
 root = tempfile.mkdtemp(prefix="pcabo_cfg%d_" % which)
 per_dim = {}
 t_all = time.perf_counter()
-for dim in dims:                       # one runner call per dimension so that each gets its own clock
-    er = ExperimentRunner(algorithms=["pca"], dimensions=[dim], problem_ids=fids, num_runs=30, root_dir=root,
-                          experiment_name=f"experiment-d{dim}", progress=False, batched=batched, side_by_side=side_by_side, batch_acq_kernel=acq_kernel)
+together = len(sys.argv) > 5 and sys.argv[5] == "together"     # ONE runner call for all dimensions (the product's way: device-mode batches of different dimensions advance together)
+for dim in ([dims] if together else dims):                       # else one runner call per dimension so that each gets its own clock
+    er = ExperimentRunner(algorithms=["pca"], dimensions=dim if together else [dim], problem_ids=fids, num_runs=30, root_dir=root,
+                          experiment_name="experiment-all" if together else f"experiment-d{dim}", progress=False, batched=batched, side_by_side=side_by_side, batch_acq_kernel=acq_kernel)
     t0 = time.perf_counter()
     er.run_experiment()
     dt = time.perf_counter() - t0
     its = sum(r["iterations"] for r in er.results)
-    per_dim[dim] = {"runs": len(er.results), "bo_iterations": its, "seconds": dt, "bo_iterations_per_s": its / dt,
+    per_dim["all" if together else dim] = {"runs": len(er.results), "bo_iterations": its, "seconds": dt, "bo_iterations_per_s": its / dt,
                     "runs_stopped_early": [(f["problem_id"], f["instance"], f["n"]) for f in er.failed_runs],
                     "best_by_function": {str(f): min(r["best"] for r in er.results if r["problem_id"] == f) for f in fids}}
     print(f"d={dim}: {len(er.results)} runs, {its} BO iterations in {dt:.1f} s = {its / dt:.0f} it/s", file=sys.stderr, flush=True)

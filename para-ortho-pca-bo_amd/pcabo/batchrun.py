@@ -113,7 +113,6 @@ class BatchedPCABO:
         self._torch_threads, self._saved_torch_threads = torch_threads, None
         self._gc_freeze, self._gc_entered = bool(gc_freeze), False
         self._noise_ahead = {}
-        self._cooperative = False          # set by run_interleaved while several batches share its thread
         self._noise_next = None            # (B, n + 1, d) block the pool threads fill for the next iteration
         # likewise the scrambled Sobol engines of the next iteration (torch's two randint draws per run, 0.06 ms each and
         # serial under the interpreter lock): built by one pool thread with THIS iteration's k as the guess while the main
@@ -237,10 +236,6 @@ class BatchedPCABO:
         # same permutation, ties included (checked on 6 000 rows with repeated values; the bit-for-bit tests compare whole runs)
         ranks = np.argsort(np.argsort(-F if self.maximization else F, axis=1), axis=1).astype(np.int64) + 1
         ahead, self._noise_ahead = self._noise_ahead, {}
-        if self._cooperative:             # other batches share this host thread: their turn while a pool thread still draws
-            jobs = {id(f.job): f.job for f in ahead.values()}
-            while any(not j.done() for j in jobs.values()):
-                yield "host wait"
         # (all blocks drawn ahead: the pool threads have written them into _noise_next themselves - no copy on this thread)
         noise = self._noise_next if (len(ahead) == B and self._noise_next is not None and self._noise_next.shape == (B, n, d)) \
             else np.empty((B, n, d))
@@ -359,8 +354,6 @@ class BatchedPCABO:
             outs, status = bt.optimize_acqf(ics, bounds, best_f, self.maximization, self.acq_code, batch_limit=5, maxiter=200)
         if engines_job is not None:
             # botorch's retry below draws from a run's generator: a run that needs it takes its generator back first
-            while self._cooperative and not engines_job.done():
-                yield "host wait"
             built = engines_job.result()
             for b in list(built):
                 if status[b] != 0 or outs[b][3]:
@@ -545,8 +538,6 @@ class BatchedVanillaBO(BatchedPCABO):
         else:
             outs, status = bt.optimize_acqf(ics, bounds, best_f, self.maximization, self.acq_code, batch_limit=5, maxiter=200)
         if engines_job is not None:
-            while self._cooperative and not engines_job.done():
-                yield "host wait"
             built = engines_job.result()
             for b in list(built):
                 if status[b] != 0 or outs[b][3]:          # botorch's retry draws from the run's generator first
@@ -656,10 +647,7 @@ def run_interleaved(runners: Sequence["BatchedPCABO"], started: bool = False) ->
         for r in runners:
             r.start()
     steps = {id(r): None for r in runners}
-    last: dict = {}
     live = list(runners)
-    for r in runners:                     # with company a batch hands the thread on instead of blocking on its pool threads
-        r._cooperative = len(runners) > 1
     stats = LAST_INTERLEAVE_STATS
     stats.clear()
     stats.update({"host_busy_seconds": 0.0, "resumptions": 0, "segments": {}})
@@ -682,10 +670,6 @@ def run_interleaved(runners: Sequence["BatchedPCABO"], started: bool = False) ->
                     steps[id(r)] = None
                     where = "end"
                 dt = perf_counter() - t0
-                spin = where == "host wait" and last.get(id(r)) == "host wait"      # a look at a pool job, nothing done
-                last[id(r)] = where
-                if spin:
-                    continue
                 stats["host_busy_seconds"] += dt
                 stats["resumptions"] += 1
                 seg = stats["segments"].setdefault(where, [0.0, 0])
@@ -693,8 +677,6 @@ def run_interleaved(runners: Sequence["BatchedPCABO"], started: bool = False) ->
                 seg[1] += 1
         stats["wall_seconds"] = perf_counter() - t_start
     finally:
-        for r in runners:
-            r._cooperative = False
         for g in steps.values():
             if g is not None:
                 g.close()

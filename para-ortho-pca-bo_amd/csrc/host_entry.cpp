@@ -9,27 +9,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
-#include <thread>
 #include <vector>
-
-namespace {
-// fn(r0, r1) over [0, rows) on up to four threads (the caller's included); a thread that cannot be started (std::system_error)
-// leaves its range to the caller - no exception crosses the C boundary.
-template <class F>
-void fan_out_rows(int rows, F fn) {
-  const int T = std::min(4, rows / 8);
-  if (T < 2) { fn(0, rows); return; }
-  std::vector<std::thread> th;
-  std::vector<int> mine;                              // ranges the caller runs itself
-  for (int t = 1; t < T; ++t) {
-    const int r0 = (int)((long long)rows * t / T), r1 = (int)((long long)rows * (t + 1) / T);
-    try { th.emplace_back(fn, r0, r1); } catch (...) { mine.push_back(r0); mine.push_back(r1); }
-  }
-  fn(0, rows / T);
-  for (size_t i = 0; i + 1 < mine.size(); i += 2) fn(mine[i], mine[i + 1]);
-  for (auto& x : th) x.join();
-}
-}  // namespace
 
 extern "C" {
 
@@ -136,18 +116,15 @@ int pcabo_sobol_draw_rows(const int64_t* const* states, const int64_t* const* sh
   if (!states || !shifts || !ks || !boxes || !outs || rows < 1 || n < 1 || n > (1 << 30)) return PCABO_ERR_ARG;
   for (int r = 0; r < rows; ++r)
     if (states[r] && (ks[r] < 1 || !shifts[r] || !outs[r])) return PCABO_ERR_ARG;
-  auto some = [=](int r0, int r1) {
-    std::vector<double> rng;
-    for (int r = r0; r < r1; ++r) {
-      if (!states[r]) continue;
-      const int k = ks[r];
-      const double* lo = boxes + (size_t)r * box_stride;
-      rng.resize(k);
-      for (int j = 0; j < k; ++j) rng[j] = lo[k + j] - lo[j];
-      pcabo_sobol_draw(states[r], shifts[r], k, n, lo, rng.data(), outs[r]);       // (arguments checked above: cannot fail)
-    }
-  };
-  fan_out_rows(rows, some);                         // runs are independent: helper threads for a wide batch, as the pick below
+  std::vector<double> rng;
+  for (int r = 0; r < rows; ++r) {
+    if (!states[r]) continue;
+    const int k = ks[r];
+    const double* lo = boxes + (size_t)r * box_stride;
+    rng.resize(k);
+    for (int j = 0; j < k; ++j) rng[j] = lo[k + j] - lo[j];
+    pcabo_sobol_draw(states[r], shifts[r], k, n, lo, rng.data(), outs[r]);       // (arguments checked above: cannot fail)
+  }
   return PCABO_OK;
 }
 
@@ -225,7 +202,7 @@ void multinomial_row(TorchMt* s, const double* w, int n, int n_pick, double* rat
 // in this file's order (Welford), not torch's: the weights can differ from a torch-formed row in the last bit, the picks - an
 // ordering of weights over independent exponential variates - do not (tests/test_abi_and_host.py compares 10 000 rows).
 namespace {
-// rows [r0, r1) of pcabo_boltzmann_pick_rows (a row touches its own generator, its own slice of out and its own flag only)
+// rows [r0, r1) of pcabo_boltzmann_pick_rows
 void boltzmann_rows(void* const* blobs, const double* vals, int r0, int r1, int n, int n_pick, double eta, int64_t* out, int* flags) {
   std::vector<double> w((size_t)n), ratio((size_t)n);
   std::vector<int> best((size_t)n_pick);
@@ -266,9 +243,7 @@ int pcabo_boltzmann_pick_rows(void* const* blobs, const double* vals, int rows, 
     const TorchMt* s = static_cast<const TorchMt*>(blobs[r]);
     if (s && (!s->seeded || s->left < 1 || s->left > 624 || s->next > 624)) return PCABO_ERR_ARG;
   }
-  // the rows are independent (a generator each): a few helper threads for a wide batch - the caller is the ONE host thread that
-  // paces the device, and at 60+ runs this call was its largest single item
-  fan_out_rows(rows, [=](int r0, int r1) { boltzmann_rows(blobs, vals, r0, r1, n, n_pick, eta, out, flags); });
+  boltzmann_rows(blobs, vals, 0, rows, n, n_pick, eta, out, flags);
   return PCABO_OK;
 }
 

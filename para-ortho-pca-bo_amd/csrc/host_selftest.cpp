@@ -92,7 +92,7 @@ void test_sobol() {
 }
 
 // torch's CPU generator restated (csrc/host_entry.cpp): state blobs of the published layout, the bit draws, the multinomial rows
-// and the Boltzmann pick - whose wide batches fan out over helper threads (tsan sees them); threaded picks = serial picks.
+// and the Boltzmann pick; all rows in one call = one call per row.
 void test_torch_rng() {
   struct Blob { uint64_t seed; int32_t left, seeded; uint64_t next; uint64_t state[624]; unsigned char tail[32]; };
   const int rows = 70, n = 512, n_pick = 10;
@@ -112,13 +112,13 @@ void test_torch_rng() {
   std::vector<int64_t> out((size_t)rows * n_pick, -1), out1((size_t)rows * n_pick, -1);
   std::vector<int> flags(rows, -1), flags1(rows, -1);
   CHECK(pcabo_boltzmann_pick_rows(ptr.data(), vals.data(), rows, n, n_pick, 1.0, out.data(), flags.data()) == PCABO_OK, "pick rows");
-  for (int r = 0; r < rows; ++r) {                            // one row per call: the serial path
+  for (int r = 0; r < rows; ++r) {                            // one row per call
     void* p1 = r == 7 ? nullptr : (void*)&again[r];
     CHECK(pcabo_boltzmann_pick_rows(&p1, vals.data() + (size_t)r * n, 1, n, n_pick, 1.0, out1.data() + (size_t)r * n_pick, flags1.data() + r) == PCABO_OK, "pick row %d", r);
     CHECK(flags[r] == flags1[r] && flags[r] == (r == 7 ? 2 : r == 5 ? 1 : 0), "flag of row %d: %d / %d", r, flags[r], flags1[r]);
     if (flags[r] != 0) continue;
     for (int j = 0; j < n_pick; ++j) {
-      CHECK(out[(size_t)r * n_pick + j] == out1[(size_t)r * n_pick + j], "row %d pick %d differs between the threaded and the serial call", r, j);
+      CHECK(out[(size_t)r * n_pick + j] == out1[(size_t)r * n_pick + j], "row %d pick %d differs between the all-rows call and the one-row call", r, j);
       CHECK(out[(size_t)r * n_pick + j] >= 0 && out[(size_t)r * n_pick + j] < n, "row %d pick %d out of range", r, j);
     }
     CHECK(blobs[r].left == again[r].left && blobs[r].next == again[r].next && blobs[r].state[0] == again[r].state[0], "generator of row %d", r);
@@ -139,7 +139,7 @@ void test_torch_rng() {
 
 // pcabo_sobol_draw_rows: ragged k, a skipped run, the boxes in pcabo_batch_acq_bounds' packing - equal to the per-run calls
 void test_sobol_rows() {
-  const int rows = 37, n = 130, kmax = 36;          // (16 rows and more: the call fans out over helper threads)
+  const int rows = 37, n = 130, kmax = 36;          // (more rows than a small batch)
   int ks[rows];
   for (int r = 0; r < rows; ++r) ks[r] = r == 0 ? 3 : r == 2 ? 1 : 1 + (r * 7) % 36;
   std::vector<std::vector<int64_t>> st(rows), sh(rows);

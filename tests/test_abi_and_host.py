@@ -145,7 +145,7 @@ def test_sobol_rows_call_equals_the_per_run_calls_bit_for_bit():
     straight into the rows the scoring launch packs) against one pcabo_sobol_draw per run; ragged k, a skipped run."""
     import torch
     from pcabo import initializers as I, _native as N
-    ks = [3, 40, 1, 17, 36, 40] + [1 + (7 * b) % 40 for b in range(34)]      # (16 runs and more: the call fans out over threads)
+    ks = [3, 40, 1, 17, 36, 40] + [1 + (7 * b) % 40 for b in range(34)]      # (a wide batch)
     kmax, n = 40, 512
     gens = [torch.Generator().manual_seed(70 + b) for b in range(len(ks))]
     engines = [I.scrambled_sobol_engine(k, g) for k, g in zip(ks, gens)]

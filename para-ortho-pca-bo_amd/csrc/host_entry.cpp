@@ -143,12 +143,14 @@ struct TorchMt {
 inline uint32_t mt_twist(uint64_t u, uint64_t v) {
   return (uint32_t)((((uint32_t)u & 0x80000000u) | ((uint32_t)v & 0x7fffffffu)) >> 1) ^ (((uint32_t)v & 1u) ? 0x9908b0dfu : 0u);
 }
-inline void mt_next_state(TorchMt* s) {
-  const int N = 624, M = 397;
-  uint64_t* p = s->state;
-  for (int j = N - M + 1; --j; ++p) *p = (uint32_t)p[M] ^ mt_twist(p[0], p[1]);
-  for (int j = M; --j; ++p) *p = (uint32_t)p[M - N] ^ mt_twist(p[0], p[1]);
-  *p = (uint32_t)p[M - N] ^ mt_twist(p[0], s->state[0]);
+// (index form, blocks shorter than the recurrence's reach of N - M = 227 words: no iteration of a block reads what the block writes
+// except st[i + 1] of its last element, read before it is written - the compiler may vectorise)
+__attribute__((optimize("O3"))) inline void mt_next_state(TorchMt* s) {
+  constexpr int N = 624, M = 397;
+  uint64_t* __restrict__ st = s->state;
+  for (int i = 0; i < N - M; ++i) st[i] = (uint32_t)st[i + M] ^ mt_twist(st[i], st[i + 1]);
+  for (int i = N - M; i < N - 1; ++i) st[i] = (uint32_t)st[i + M - N] ^ mt_twist(st[i], st[i + 1]);
+  st[N - 1] = (uint32_t)st[M - 1] ^ mt_twist(st[N - 1], st[0]);
   s->left = N;
   s->next = 0;
 }
@@ -161,6 +163,17 @@ inline uint32_t mt_draw(TorchMt* s) {
   y ^= (y >> 18);
   return y;
 }
+// the low bit of the tempered words w[0 .. m)
+__attribute__((optimize("O3"))) inline void mt_temper_bits(const uint64_t* w, int64_t m, int64_t* out) {
+  for (int64_t i = 0; i < m; ++i) {
+    uint32_t y = (uint32_t)w[i];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    out[i] = (int64_t)(y & 1u);
+  }
+}
 }  // namespace
 
 // torch.randint(2, (count,), generator=g): one 32-bit draw per element, value = draw % 2 (int64 out).
@@ -168,7 +181,25 @@ int pcabo_torch_randint2(void* blob, int64_t count, int64_t* out) {
   if (!blob || !out || count < 0) return PCABO_ERR_ARG;
   TorchMt* s = static_cast<TorchMt*>(blob);
   if (!s->seeded || s->left < 1 || s->left > 624 || s->next > 624) return PCABO_ERR_ARG;
-  for (int64_t i = 0; i < count; ++i) out[i] = (int64_t)(mt_draw(s) & 1u);
+  // whole runs of state words at a time (the tempering of a run is a loop without dependencies: the compiler vectorises it);
+  // the bookkeeping is mt_draw's: a fresh state serves N draws, `left` stays N after the first of them
+  while (count > 0) {
+    int64_t take;
+    if (s->left == 1) {
+      mt_next_state(s);
+      take = count < 624 ? count : 624;
+      mt_temper_bits(s->state + s->next, take, out);
+      s->next += (uint64_t)take;
+      s->left = 624 - (int32_t)(take - 1);
+    } else {
+      take = count < s->left - 1 ? count : s->left - 1;
+      mt_temper_bits(s->state + s->next, take, out);
+      s->next += (uint64_t)take;
+      s->left -= (int32_t)take;
+    }
+    out += take;
+    count -= take;
+  }
   return PCABO_OK;
 }
 

@@ -199,7 +199,7 @@ def batch_per_gpu(device: int, rank: int, size: int, B: int = 30):
             "seconds": dt, "aggregate_bo_iterations_per_s": total / dt, "bo_iterations": total,
             "per_rank": [{"bo_iterations_per_s": p[0], "seconds": p[1], "runs": int(p[2]), "cores_in_affinity_mask": int(p[3]),
                           "torch_threads": int(p[4]), "failed_runs": int(p[5])} for p in per_rank],
-            "host_threads_per_rank": "one Python thread interleaves up to four device-mode batches; 8 pool threads draw the next "
+            "host_threads_per_rank": "one Python thread interleaves up to eight device-mode batches (four per dimension); 8 pool threads draw the next "
                                      "iteration's noise blocks and Sobol engines; no gang workers in device mode",
             "backend": D.backend_name(), "rccl_ranks": D.ranks_seen(),
             "note": "whole runs incl. DoE and IOHprofiler files; no data-path collective; the per-rank figures above were "
